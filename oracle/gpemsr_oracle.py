@@ -1,0 +1,505 @@
+"""CPU oracle for the GPEMSR stage-3 super-resolution forward.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``gpemsr_amd/`` may import this file;
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg use it, and there only as the checker / the reported CPU baseline.
+
+What this is: a *functional* pure-torch restatement (NCHW, CPU, fp32 or fp64)
+of the reference network, driven directly by a flat ``state_dict`` in the
+reference's key layout.  It never imports anything from ``/root/reference``.
+All paths cited below are relative to
+``/root/reference/GPEMSR-CREMI/GPEMSR/``.
+
+Parity pinning (see DESIGN.md "Oracle"):
+  * first-party arithmetic (model/GPEMSR.py, blocks.py, indexer.py, codebook.py,
+    decoder.py, VGG.py slicing) is PINNED: ``oracle/gen_golden.py`` imports the
+    unmodified reference modules in the build container and
+    ``tests/test_oracle_golden.py`` checks this file against the tensors it
+    dumped (``tests/golden/*.npz``).
+  * third-party arithmetic that is absent from the reference tree
+    (basicsr ``ResidualBlockNoBN``/``DCNv2Pack``/``SpyNet``/``flow_warp``,
+    torchvision ``vgg19``/``deform_conv2d``; no version is pinned by the
+    reference -- it has no requirements file) is restated here from the public
+    basicsr-1.4.x / torchvision definitions.  **Parity unpinned** at that
+    boundary: the golden vectors were produced with import shims
+    (``oracle/ref_shims``) that are themselves restatements.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------
+def _lrelu(x: Tensor) -> Tensor:
+    # LeakyReLU(0.1) everywhere in GPEMSR/POD/ThreeDA: model/GPEMSR.py:96,168,321
+    return F.leaky_relu(x, 0.1)
+
+
+def _conv(sd: SD, name: str, x: Tensor, stride: int = 1, padding: Optional[int] = None) -> Tensor:
+    w = sd[name + ".weight"]
+    b = sd.get(name + ".bias")
+    if padding is None:
+        padding = w.shape[-1] // 2
+    return F.conv2d(x, w.to(x.dtype), None if b is None else b.to(x.dtype), stride, padding)
+
+
+def _convT(sd: SD, name: str, x: Tensor) -> Tensor:
+    # nn.ConvTranspose2d(cin, cout, 3, 2, 1, 1): model/GPEMSR.py:252-254, model/blocks.py:35
+    return F.conv_transpose2d(x, sd[name + ".weight"].to(x.dtype), sd[name + ".bias"].to(x.dtype),
+                              stride=2, padding=1, output_padding=1)
+
+
+def _bilinear(x: Tensor, scale: float) -> Tensor:
+    return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=False)
+
+
+def _count_seq(sd: SD, prefix: str) -> int:
+    """Number of children ``prefix.{i}`` present in the state dict."""
+    idx = set()
+    plen = len(prefix) + 1
+    for k in sd:
+        if k.startswith(prefix + "."):
+            head = k[plen:].split(".", 1)[0]
+            if head.isdigit():
+                idx.add(int(head))
+    return (max(idx) + 1) if idx else 0
+
+
+# --------------------------------------------------------------------------
+# third-party restatements (basicsr / torchvision) -- parity unpinned
+# --------------------------------------------------------------------------
+def resblock_nobn(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    """basicsr ``ResidualBlockNoBN``: x + conv2(relu(conv1(x))), res_scale 1.
+    Call sites: model/GPEMSR.py:239,243,256,259,262,265,302."""
+    return x + _conv(sd, prefix + ".conv2", F.relu(_conv(sd, prefix + ".conv1", x)))
+
+
+def resblocks_nobn(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    for i in range(_count_seq(sd, prefix)):
+        x = resblock_nobn(sd, f"{prefix}.{i}", x)
+    return x
+
+
+def flow_warp(x: Tensor, flow_nhw2: Tensor) -> Tensor:
+    """basicsr ``flow_warp`` (bilinear, border padding, align_corners=True).
+    flow[...,0] is the x displacement, flow[...,1] the y displacement."""
+    _, _, h, w = x.shape
+    gy, gx = torch.meshgrid(torch.arange(h, dtype=x.dtype), torch.arange(w, dtype=x.dtype), indexing="ij")
+    vx = gx.unsqueeze(0) + flow_nhw2[..., 0]
+    vy = gy.unsqueeze(0) + flow_nhw2[..., 1]
+    vx = 2.0 * vx / max(w - 1, 1) - 1.0
+    vy = 2.0 * vy / max(h - 1, 1) - 1.0
+    grid = torch.stack((vx, vy), dim=3)
+    return F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=True)
+
+
+_SPY_MEAN = (0.485, 0.456, 0.406)
+_SPY_STD = (0.229, 0.224, 0.225)
+
+
+def spynet_basic_module(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    # 7x7 convs 8-32-64-32-16-2, ReLU between (keys .basic_module.{0,2,4,6,8})
+    for j, idx in enumerate((0, 2, 4, 6, 8)):
+        x = _conv(sd, f"{prefix}.basic_module.{idx}", x, 1, 3)
+        if j < 4:
+            x = F.relu(x)
+    return x
+
+
+def spynet(sd: SD, prefix: str, ref: Tensor, supp: Tensor) -> Tensor:
+    """basicsr ``SpyNet.forward(ref, supp)``; called at model/GPEMSR.py:99-100
+    with ref = bilinear x4 of the neighbour frame, supp = bilinear x4 of the centre."""
+    h, w = ref.shape[2], ref.shape[3]
+    w_floor = int(math.floor(math.ceil(w / 32.0) * 32.0))
+    h_floor = int(math.floor(math.ceil(h / 32.0) * 32.0))
+    ref = F.interpolate(ref, size=(h_floor, w_floor), mode="bilinear", align_corners=False)
+    supp = F.interpolate(supp, size=(h_floor, w_floor), mode="bilinear", align_corners=False)
+
+    mean = sd.get(prefix + ".mean")
+    std = sd.get(prefix + ".std")
+    if mean is None:
+        mean = torch.tensor(_SPY_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(_SPY_STD).view(1, 3, 1, 1)
+    mean = mean.to(ref.dtype)
+    std = std.to(ref.dtype)
+    refs = [(ref - mean) / std]      # a 1-channel frame broadcasts to 3 channels
+    supps = [(supp - mean) / std]
+    for _ in range(5):
+        refs.insert(0, F.avg_pool2d(refs[0], 2, 2, count_include_pad=False))
+        supps.insert(0, F.avg_pool2d(supps[0], 2, 2, count_include_pad=False))
+    flow = refs[0].new_zeros(refs[0].shape[0], 2, refs[0].shape[2] // 2, refs[0].shape[3] // 2)
+    for level in range(len(refs)):
+        up = F.interpolate(flow, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
+        if up.shape[2] != refs[level].shape[2]:
+            up = F.pad(up, [0, 0, 0, 1], mode="replicate")
+        if up.shape[3] != refs[level].shape[3]:
+            up = F.pad(up, [0, 1, 0, 0], mode="replicate")
+        inp = torch.cat([refs[level], flow_warp(supps[level], up.permute(0, 2, 3, 1)), up], 1)
+        flow = spynet_basic_module(sd, f"{prefix}.basic_module.{level}", inp) + up
+    flow = F.interpolate(flow, size=(h, w), mode="bilinear", align_corners=False)
+    flow = flow.clone()
+    flow[:, 0] *= float(w) / float(w_floor)
+    flow[:, 1] *= float(h) / float(h_floor)
+    return flow
+
+
+def deform_conv2d_v2(x: Tensor, offset: Tensor, mask: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    """torchvision ``deform_conv2d`` semantics for k3 s1 p1 d1 (modulated):
+    offset channel g*2K+2k = dy, +1 = dx; mask channel g*K+k; out-of-image
+    bilinear corners contribute zero."""
+    B, C, H, W = x.shape
+    K = 9
+    G = offset.shape[1] // (2 * K)
+    cg = C // G
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=x.dtype), torch.arange(W, dtype=x.dtype), indexing="ij")
+    cols = x.new_zeros(B, C, K, H, W)
+    xf = x.reshape(B, C, H * W)
+    for g in range(G):
+        xg = xf[:, g * cg:(g + 1) * cg]                     # [B,cg,HW]
+        for k in range(K):
+            ky, kx = k // 3, k % 3
+            py = ys + (ky - 1) + offset[:, g * 2 * K + 2 * k]        # [B,H,W]
+            px = xs + (kx - 1) + offset[:, g * 2 * K + 2 * k + 1]
+            m = mask[:, g * K + k]
+            y0 = torch.floor(py)
+            x0 = torch.floor(px)
+            ly, lx = py - y0, px - x0
+            val = x.new_zeros(B, cg, H, W)
+            for (yy, wy) in ((y0, 1 - ly), (y0 + 1, ly)):
+                for (xx, wx) in ((x0, 1 - lx), (x0 + 1, lx)):
+                    ok = (yy >= 0) & (yy <= H - 1) & (xx >= 0) & (xx <= W - 1)
+                    idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long().reshape(B, 1, H * W)
+                    v = torch.gather(xg, 2, idx.expand(B, cg, H * W)).reshape(B, cg, H, W)
+                    val = val + v * (wy * wx * ok.to(x.dtype)).unsqueeze(1)
+            cols[:, g * cg:(g + 1) * cg, k] = val * m.unsqueeze(1)
+    out = torch.einsum("bckhw,ock->bohw", cols, weight.to(x.dtype).reshape(weight.shape[0], C, K))
+    return out + bias.to(x.dtype).view(1, -1, 1, 1)
+
+
+def dcn_v2_pack(sd: SD, prefix: str, x: Tensor, feat: Tensor) -> Tensor:
+    """basicsr ``DCNv2Pack.forward(x, feat)``; call sites model/GPEMSR.py:115,122,131,138."""
+    out = _conv(sd, prefix + ".conv_offset", feat)
+    o1, o2, m = torch.chunk(out, 3, dim=1)
+    offset = torch.cat((o1, o2), dim=1)
+    return deform_conv2d_v2(x, offset, torch.sigmoid(m), sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def vgg_relu1_2(sd: SD, prefix: str, x3: Tensor) -> Tensor:
+    """torchvision vgg19.features[0:4] = ``slice1`` of model/VGG.py:20-21."""
+    h = F.relu(_conv(sd, prefix + ".slice1.0", x3))
+    return F.relu(_conv(sd, prefix + ".slice1.2", h))
+
+
+# --------------------------------------------------------------------------
+# VQGAN prior (first-party; pinned by the golden vectors)
+# --------------------------------------------------------------------------
+def gn(sd: SD, name: str, x: Tensor) -> Tensor:
+    # model/blocks.py:5-6  GroupNorm(32, eps=1e-6, affine)
+    return F.group_norm(x, 32, sd[name + ".weight"].to(x.dtype), sd[name + ".bias"].to(x.dtype), eps=1e-6)
+
+
+def vq_resblock(sd: SD, p: str, x: Tensor) -> Tensor:
+    # model/blocks.py:8-29
+    h = F.relu(gn(sd, p + ".block.1", _conv(sd, p + ".block.0", x)))
+    h = F.relu(gn(sd, p + ".block.4", _conv(sd, p + ".block.3", h)))
+    if (p + ".channel_up.weight") in sd:
+        return _conv(sd, p + ".channel_up", x) + h
+    return x + h
+
+
+def nonlocal_block(sd: SD, p: str, x: Tensor) -> Tensor:
+    # model/blocks.py:61-83
+    h_ = gn(sd, p + ".gn", x)
+    q = _conv(sd, p + ".q", h_)
+    k = _conv(sd, p + ".k", h_)
+    v = _conv(sd, p + ".v", h_)
+    b, c, h, w = q.shape
+    q = q.reshape(b, c, h * w).permute(0, 2, 1)
+    k = k.reshape(b, c, h * w)
+    v = v.reshape(b, c, h * w)
+    attn = torch.bmm(q, k) * (int(c) ** (-0.5))
+    attn = F.softmax(attn, dim=2).permute(0, 2, 1)
+    a = torch.bmm(v, attn).reshape(b, c, h, w)
+    return x + _conv(sd, p + ".proj_out", a)
+
+
+def _vq_layer(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Dispatch one child of a VQGAN nn.Sequential by the keys it owns."""
+    if (p + ".block.0.weight") in sd:
+        return vq_resblock(sd, p, x)
+    if (p + ".downblock.weight") in sd:            # model/blocks.py:41-47
+        return _conv(sd, p + ".downblock", x, 2, 1)
+    if (p + ".upblock.weight") in sd:              # model/blocks.py:32-38
+        return _convT(sd, p + ".upblock", x)
+    if (p + ".gn.weight") in sd:
+        return nonlocal_block(sd, p, x)
+    if (p + ".weight") in sd:                      # bare conv (1x1 or 3x3)
+        return _conv(sd, p, x)
+    raise KeyError(p)
+
+
+def indexer_logits(sd: SD, p: str, x: Tensor) -> Tensor:
+    """model/indexer.py:98-102 (Indexer8) / :51-55 (Indexer16) -> logits [B,h,w,1024]."""
+    h = F.relu(_conv(sd, p + ".input_layer.0", x))
+    for i in range(_count_seq(sd, p + ".feat_extract")):
+        h = _vq_layer(sd, f"{p}.feat_extract.{i}", h)
+    for i in range(_count_seq(sd, p + ".output_layer")):
+        h = _vq_layer(sd, f"{p}.output_layer.{i}", h)
+    return F.linear(h.permute(0, 2, 3, 1), sd[p + ".embedding.weight"].to(x.dtype), sd[p + ".embedding.bias"].to(x.dtype))
+
+
+def codebook_lookup(sd: SD, p: str, logits: Tensor, forced_idx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """model/codebook.py:34-43: softmax -> topk(1) == argmax of the logits."""
+    B, H, W, C = logits.shape
+    idx = torch.argmax(logits.reshape(B * H * W, C), dim=1) if forced_idx is None else forced_idx.reshape(-1)
+    zq = sd[p + ".embedding.weight"].to(logits.dtype)[idx].view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+    return zq, idx
+
+
+def decoder_multi_scale(sd: SD, p: str, z: Tensor, num_res_blocks: int = 1) -> List[Tensor]:
+    """model/decoder.py:40-57 with use_non_local=True."""
+    x = z
+    for i in range(_count_seq(sd, p + ".input_layer")):
+        x = _vq_layer(sd, f"{p}.input_layer.{i}", x)
+    n = _count_seq(sd, p + ".feat_extract")
+    feats = []
+    x = _vq_layer(sd, f"{p}.feat_extract.0", x)          # NonLocalBlock
+    for i in range(n - 1):
+        x = _vq_layer(sd, f"{p}.feat_extract.{i + 1}", x)
+        if (i - num_res_blocks + 1) % (num_res_blocks + 1) == 0:
+            feats.append(x)
+    feats.append(_conv(sd, p + ".output_layer", x))
+    return feats
+
+
+def ref_extract(sd: SD, p: str, x: Tensor, num_res_blocks: int = 1,
+                forced_idx: Optional[Tensor] = None, trace: Optional[dict] = None) -> List[Tensor]:
+    """model/vqgan_indexer.py:87-91."""
+    logits = indexer_logits(sd, p + ".indexer", x)
+    zq, idx = codebook_lookup(sd, p + ".codebook", logits, forced_idx)
+    if trace is not None:
+        trace["logits"] = logits
+        trace["code_idx"] = idx
+    return decoder_multi_scale(sd, p + ".decoder", zq, num_res_blocks)
+
+
+# --------------------------------------------------------------------------
+# GPEMSR-specific stages (first-party; pinned)
+# --------------------------------------------------------------------------
+def patch_cosine(a: Tensor, b: Tensor) -> Tensor:
+    """model/GPEMSR.py:14-60,387-395: cosine similarity of co-located 16x16xC
+    patches (stride 16; reflection 'same' padding only when the size is not a
+    multiple of 16).  Returns [B,1,ceil(H/16),ceil(W/16)]."""
+    def unfold(t):
+        B, C, H, W = t.shape
+        oh, ow = (H + 15) // 16, (W + 15) // 16
+        pr = max(0, (oh - 1) * 16 + 16 - H)
+        pc = max(0, (ow - 1) * 16 + 16 - W)
+        pt, pl = int(pr / 2.0), int(pc / 2.0)
+        if pr or pc:
+            t = F.pad(t, (pl, pc - pl, pt, pr - pt), mode="reflect")
+        return F.normalize(F.unfold(t, 16, stride=16), dim=1), oh, ow
+    ua, oh, ow = unfold(a)
+    ub, _, _ = unfold(b)
+    return torch.sum(ua * ub, dim=1, keepdim=True).view(a.shape[0], 1, oh, ow)
+
+
+def pod_align(sd: SD, p: str, nbr: List[Tensor], ref: List[Tensor], nbr_frame: Tensor, ref_frame: Tensor,
+              dedup_spynet: bool = True) -> Tensor:
+    """POD.forward, model/GPEMSR.py:98-140.  The reference evaluates SpyNet
+    twice with identical arguments (:99-100); the results are identical, so the
+    oracle evaluates it once unless ``dedup_spynet`` is False."""
+    up_n, up_r = _bilinear(nbr_frame, 4), _bilinear(ref_frame, 4)
+    flow1 = spynet(sd, p + ".spynet", up_n, up_r)
+    flow2 = flow1 if dedup_spynet else spynet(sd, p + ".spynet", up_n, up_r)
+    L1_f1 = _conv(sd, p + ".flowdsconv0_1", flow1, 4, 1)
+    L1_f2 = _conv(sd, p + ".flowdsconv0_2", flow2, 4, 1)
+    L2_f1 = _conv(sd, p + ".flowdsconv1_1", L1_f1, 2, 1)
+    L2_f2 = _conv(sd, p + ".flowdsconv1_2", L1_f2, 2, 1)
+    L3_f1 = _conv(sd, p + ".flowdsconv2_1", L2_f1, 2, 1)
+    L3_f2 = _conv(sd, p + ".flowdsconv2_2", L2_f2, 2, 1)
+    nf2, rf2 = _bilinear(nbr_frame, 0.5), _bilinear(ref_frame, 0.5)
+    nf3, rf3 = _bilinear(nf2, 0.5), _bilinear(rf2, 0.5)
+
+    L3_off = torch.cat([nbr[2], ref[2], L3_f1, L3_f2, nf3, rf3], 1)
+    L3_off = _lrelu(_conv(sd, p + ".L3_offset_conv1", L3_off))
+    L3_off = _lrelu(_conv(sd, p + ".L3_offset_conv2", L3_off))
+    L3_fea = _lrelu(dcn_v2_pack(sd, p + ".L3_dcnpack", nbr[2], L3_off))
+
+    L2_off = torch.cat([nbr[1], ref[1], L2_f1, L2_f2, nf2, rf2], 1)
+    L2_off = _lrelu(_conv(sd, p + ".L2_offset_conv1", L2_off))
+    L3_off = _bilinear(L3_off, 2)
+    L2_off = _lrelu(_conv(sd, p + ".L2_offset_conv2", torch.cat([L2_off, L3_off * 2], 1)))
+    L2_off = _lrelu(_conv(sd, p + ".L2_offset_conv3", L2_off))
+    L2_fea = dcn_v2_pack(sd, p + ".L2_dcnpack", nbr[1], L2_off)
+    L3_fea = _bilinear(L3_fea, 2)
+    L2_fea = _lrelu(_conv(sd, p + ".L2_fea_conv", torch.cat([L2_fea, L3_fea], 1)))
+
+    L1_off = torch.cat([nbr[0], ref[0], L1_f1, L1_f2, nbr_frame, ref_frame], 1)
+    L1_off = _lrelu(_conv(sd, p + ".L1_offset_conv1", L1_off))
+    L2_off = _bilinear(L2_off, 2)
+    L1_off = _lrelu(_conv(sd, p + ".L1_offset_conv2", torch.cat([L1_off, L2_off * 2], 1)))
+    L1_off = _lrelu(_conv(sd, p + ".L1_offset_conv3", L1_off))
+    L1_fea = dcn_v2_pack(sd, p + ".L1_dcnpack", nbr[0], L1_off)
+    L2_fea = _bilinear(L2_fea, 2)
+    L1_fea = _conv(sd, p + ".L1_fea_conv", torch.cat([L1_fea, L2_fea], 1))
+
+    off = torch.cat([L1_fea, ref[0]], 1)
+    off = _lrelu(_conv(sd, p + ".cas_offset_conv1", off))
+    off = _lrelu(_conv(sd, p + ".cas_offset_conv2", off))
+    return _lrelu(dcn_v2_pack(sd, p + ".cas_dcnpack", L1_fea, off))
+
+
+def three_da(sd: SD, p: str, aligned: Tensor, center: int) -> Tensor:
+    """ThreeDA.forward, model/GPEMSR.py:172-222."""
+    b, t, c, h, w = aligned.shape
+    emb_ref = _conv(sd, p + ".temporal_attn1", aligned[:, center].clone())
+    emb = _conv(sd, p + ".temporal_attn2", aligned.reshape(-1, c, h, w)).view(b, t, -1, h, w)
+    corr = torch.stack([torch.sum(emb[:, i] * emb_ref, 1) for i in range(t)], dim=1)   # b,t,h,w
+    prob = torch.sigmoid(corr).unsqueeze(2).expand(b, t, c, h, w).reshape(b, -1, h, w)
+    af = aligned.reshape(b, -1, h, w) * prob
+
+    def conv3d(name, x5):   # nn.Conv3d(t, t, 1): mixes the frame axis
+        wgt = sd[name + ".weight"].to(x5.dtype).view(t, t)
+        return torch.einsum("ij,bjchw->bichw", wgt, x5) + sd[name + ".bias"].to(x5.dtype).view(1, t, 1, 1, 1)
+
+    feat = _lrelu(_conv(sd, p + ".feat_fusion", af))
+    f1 = _lrelu(conv3d(p + ".conv3D_1", af.view(b, t, -1, h, w)))
+    f1 = _lrelu(_conv(sd, p + ".conv3D_fusion_1", f1.reshape(b, -1, h, w)))
+    f2 = _lrelu(conv3d(p + ".conv3D_2", af.view(b, t, -1, h, w)))
+    f2 = _lrelu(_conv(sd, p + ".conv3D_fusion_2", f2.reshape(b, -1, h, w)))
+    feat = feat + f1
+    f3 = _conv(sd, p + ".conv2D_fusion_3", feat)
+
+    attn = _lrelu(_conv(sd, p + ".spatial_attn1", af))
+    amax, aavg = F.max_pool2d(attn, 3, 2, 1), F.avg_pool2d(attn, 3, 2, 1)
+    attn = _lrelu(_conv(sd, p + ".spatial_attn2", torch.cat([amax, aavg], 1)))
+    lvl = _lrelu(_conv(sd, p + ".spatial_attn_l1", attn))
+    lmax, lavg = F.max_pool2d(lvl, 3, 2, 1), F.avg_pool2d(lvl, 3, 2, 1)
+    lvl = _lrelu(_conv(sd, p + ".spatial_attn_l2", torch.cat([lmax, lavg], 1)))
+    lvl = _lrelu(_conv(sd, p + ".spatial_attn_l3", lvl))
+    lvl = _bilinear(lvl, 2)
+    attn = _lrelu(_conv(sd, p + ".spatial_attn3", attn)) + lvl
+    attn = _lrelu(_conv(sd, p + ".spatial_attn4", attn))
+    attn = _bilinear(attn, 2)
+    attn = _conv(sd, p + ".spatial_attn5", attn)
+    attn_add = _conv(sd, p + ".spatial_attn_add2", _lrelu(_conv(sd, p + ".spatial_attn_add1", attn)))
+    attn = torch.sigmoid(attn)
+    return feat * attn * 2 + attn_add + f2 + f3
+
+
+def gpemsr_forward(sd: SD, x: Tensor, scale: int = 8, num_res_blocks_dec: int = 1,
+                   forced_idx: Optional[Tensor] = None, trace: Optional[dict] = None,
+                   as_written: bool = False) -> Tuple[Tensor, Tensor]:
+    """GPEMSR.forward, model/GPEMSR.py:323-456.
+
+    x: [B,N,1,H,W] in [0,1].  Returns (out [B,1,sH,sW], ref_img [B,N,1,sH,sW]).
+    ``as_written`` re-evaluates SpyNet twice like the reference (:99-100); the
+    unused VGG slices 2-5 (model/VGG.py:37-44) never influence the outputs and
+    are not evaluated either way.
+    ``forced_idx`` teacher-forces the codebook indices (argmax is discontinuous).
+    """
+    sd = {k: v for k, v in sd.items()}
+    B, N, C, H, W = x.shape
+    center = N // 2
+    t = trace if trace is not None else {}
+    xf = x.reshape(-1, C, H, W)
+    x_center = x[:, center].contiguous()
+
+    L1 = _lrelu(_conv(sd, "conv_first", xf))
+    L1 = resblocks_nobn(sd, "feature_extraction", L1)
+    t["L1_fea"] = L1
+
+    L2 = _lrelu(_convT(sd, "reffea_L2_conv1", L1))
+    L3 = _lrelu(_convT(sd, "reffea_L3_conv1", L2))
+    if scale == 16:
+        L4 = _lrelu(_convT(sd, "reffea_L4_conv1", L3))
+    ref_x16, ref_x8, ref_x4, ref_x2, ref_img = ref_extract(sd, "refmodel", xf, num_res_blocks_dec, forced_idx, t)
+    t["ref_x8"], t["ref_x2"], t["ref_img"] = ref_x8, ref_x2, ref_img
+    up_lr = _bilinear(xf, scale)
+    fa = vgg_relu1_2(sd, "vgg", ref_img.expand(-1, 3, -1, -1))
+    fb = vgg_relu1_2(sd, "vgg", up_lr.expand(-1, 3, -1, -1))
+    mask = patch_cosine(fa, fb)
+    t["mask_cos"] = mask
+    mask = mask.view(B * N, 1, H if scale == 16 else H // 2, W if scale == 16 else W // 2)
+    mask = _lrelu(_conv(sd, "refmaskconv1", mask))
+    mask = _lrelu(_conv(sd, "refmaskconv2", mask))
+    mask = _lrelu(_conv(sd, "refmaskconv3", mask))
+    mask = torch.sigmoid(mask)
+    t["mask"] = mask
+
+    if scale == 16:   # :361-376
+        r2 = _conv(sd, "reffusionconv1", torch.cat((L4, ref_x2), 1))
+        r2 = resblocks_nobn(sd, "fusion_fea_block1", r2) * _bilinear(mask, 8)
+        r2 = _conv(sd, "down_fea_conv1", r2, 2, 1)
+        r4 = _conv(sd, "reffusionconv2", torch.cat((L3, ref_x4, r2), 1))
+        r4 = resblocks_nobn(sd, "fusion_fea_block2", r4) * _bilinear(mask, 4)
+        r4 = _conv(sd, "down_fea_conv2", torch.cat((r4, r2), 1), 2, 1)
+        r8 = _conv(sd, "reffusionconv3", torch.cat((L2, ref_x8, r4), 1))
+        r8 = resblocks_nobn(sd, "fusion_fea_block3", r8) * _bilinear(mask, 2)
+        r8 = _conv(sd, "down_fea_conv3", torch.cat((r8, r4), 1), 2, 1)
+        r16 = _conv(sd, "reffusionconv4", torch.cat((L1, ref_x16, r8), 1))
+        r16 = resblocks_nobn(sd, "fusion_fea_block4", r16) * mask
+        L1 = _conv(sd, "reduce_dim_conv", torch.cat((r16, r8, L1), 1))
+    else:             # :402-415
+        r2 = _conv(sd, "reffusionconv1", torch.cat((L3, ref_x2), 1))
+        r2 = resblocks_nobn(sd, "fusion_fea_block1", r2) * _bilinear(mask, 8)
+        r2 = _conv(sd, "down_fea_conv1", r2, 2, 1)
+        r4 = _conv(sd, "reffusionconv2", torch.cat((L2, ref_x4, r2), 1))
+        r4 = resblocks_nobn(sd, "fusion_fea_block2", r4) * _bilinear(mask, 4)
+        r4 = _conv(sd, "down_fea_conv2", torch.cat((r4, r2), 1), 2, 1)
+        r8 = _conv(sd, "reffusionconv3", torch.cat((L1, ref_x8, r4), 1))
+        r8 = resblocks_nobn(sd, "fusion_fea_block3", r8) * _bilinear(mask, 2)
+        L1 = _conv(sd, "reduce_dim_conv", torch.cat((r8, r4, L1), 1))
+    t["L1_fused"] = L1
+
+    L2 = _lrelu(_conv(sd, "fea_L2_conv1", L1, 2, 1))
+    L2 = _lrelu(_conv(sd, "fea_L2_conv2", L2))
+    L3 = _lrelu(_conv(sd, "fea_L3_conv1", L2, 2, 1))
+    L3 = _lrelu(_conv(sd, "fea_L3_conv2", L3))
+    L1v = L1.view(B, N, -1, H, W)
+    L2v = L2.view(B, N, -1, H // 2, W // 2)
+    L3v = L3.view(B, N, -1, H // 4, W // 4)
+    ref_l = [L1v[:, center].clone(), L2v[:, center].clone(), L3v[:, center].clone()]
+    aligned = []
+    for i in range(N):
+        nbr_l = [L1v[:, i].clone(), L2v[:, i].clone(), L3v[:, i].clone()]
+        aligned.append(pod_align(sd, "align_module", nbr_l, ref_l, x[:, i], x_center, dedup_spynet=not as_written))
+    aligned = torch.stack(aligned, dim=1)
+    t["aligned"] = aligned
+    fea = three_da(sd, "ThreeDA", aligned, center)
+    t["fused"] = fea
+    out = resblocks_nobn(sd, "recon_trunk", fea)
+    out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv1", out), 2))
+    out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv2", out), 2))
+    out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv3", out), 2))
+    if scale == 16:
+        out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv4", out), 2))
+    out = _lrelu(_conv(sd, "HRconv", out))
+    out = _conv(sd, "conv_last", out)
+    out = out + _bilinear(x_center, scale)
+    return out, ref_img.view(B, N, C, H * scale, W * scale)
+
+
+# --------------------------------------------------------------------------
+# image-space metric helpers (util/util.py:139-163, 253-260)
+# --------------------------------------------------------------------------
+def tensor2img_u8(t: Tensor):
+    import numpy as np
+    a = t.squeeze().float().cpu().clamp(0, 1).numpy()
+    return (a * 255.0).round().astype(np.uint8)
+
+
+def psnr_u8(a, b) -> float:
+    import numpy as np
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float("inf") if mse == 0 else 20 * math.log10(255.0 / math.sqrt(mse))
