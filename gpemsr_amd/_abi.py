@@ -1,0 +1,94 @@
+"""ctypes binding of libgpemsr_hip.so (include/gpemsr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  (Build it with ``python -m gpemsr_amd.build``
+or ``__graft_entry__.build()``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgpemsr_hip.so")
+_lib = None
+
+MAX_SRC = 4
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_LRELU_SIGMOID = 0, 1, 2, 3, 4
+
+# every symbol include/gpemsr_hip.h declares (checked by tests/test_abi_cpu.py)
+SYMBOLS = [
+    "gpemsr_abi_version", "gpemsr_last_error", "gpemsr_device_info", "gpemsr_conv2d", "gpemsr_conv2d_direct",
+    "gpemsr_groupnorm_stats", "gpemsr_groupnorm_apply", "gpemsr_softmax_rows", "gpemsr_argmax_rows",
+    "gpemsr_gather_rows", "gpemsr_bilinear", "gpemsr_avgpool2", "gpemsr_pool3s2_maxavg", "gpemsr_spynet_prep",
+    "gpemsr_dcn_columns", "gpemsr_patch_cosine", "gpemsr_temporal_gate", "gpemsr_frame_mix_lrelu",
+    "gpemsr_threeda_combine", "gpemsr_tensor2img_u8", "gpemsr_copy_channels", "gpemsr_copy_images",
+]
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ld", C.c_int32), ("c", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("nsrc", C.c_int32),
+        ("src", Src * MAX_SRC),
+        ("src_image_stride", C.c_int64 * MAX_SRC),
+        ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("transposed", C.c_int32),
+        ("weight", C.c_void_p), ("weight_image_stride", C.c_int64),
+        ("bias", C.c_void_p), ("act", C.c_int32),
+        ("residual", C.c_void_p), ("res_ld", C.c_int32),
+        ("pixmul", C.c_void_p), ("pixel_shuffle", C.c_int32),
+        ("out", C.c_void_p), ("out_ld", C.c_int32),
+    ]
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"gpemsr_amd: HIP kernel library not found at {_LIB_PATH}. Build it first "
+            "(python -m gpemsr_amd.build). There is no CPU fallback for the product path.")
+    lib = C.CDLL(_LIB_PATH)
+    lib.gpemsr_last_error.restype = C.c_char_p
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise RuntimeError(f"gpemsr_amd: {_LIB_PATH} does not export {s}")
+    v = lib.gpemsr_abi_version()
+    if v != 1:
+        raise RuntimeError(f"gpemsr_amd: ABI version {v} != 1")
+    p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    lib.gpemsr_conv2d.argtypes = [C.POINTER(ConvDesc), p]
+    lib.gpemsr_conv2d_direct.argtypes = [p, i32, i32, i32, i32, i32, p, p, i32, i32, i32, i32, p, i32, p, i32, p]
+    lib.gpemsr_groupnorm_stats.argtypes = [p, i32, i32, i32, i32, i32, f32, p, i32, p, p]
+    lib.gpemsr_groupnorm_apply.argtypes = [p, i32, i32, i32, i32, i32, p, p, p, i32, p, i32, p, i32, p]
+    lib.gpemsr_softmax_rows.argtypes = [p, i64, i32, p]
+    lib.gpemsr_argmax_rows.argtypes = [p, i64, i32, p, p]
+    lib.gpemsr_gather_rows.argtypes = [p, i32, p, i64, p, i32, p]
+    lib.gpemsr_bilinear.argtypes = [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, i32, p]
+    lib.gpemsr_avgpool2.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
+    lib.gpemsr_pool3s2_maxavg.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
+    lib.gpemsr_spynet_prep.argtypes = [p, p, p, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), p, p, p]
+    lib.gpemsr_dcn_columns.argtypes = [p, i32, i32, i32, i32, i32, p, i32, i32, p, p]
+    lib.gpemsr_patch_cosine.argtypes = [p, p, i32, i32, i32, i32, p, p]
+    lib.gpemsr_temporal_gate.argtypes = [p, p, p, i32, i32, i32, i32, p, p]
+    lib.gpemsr_frame_mix_lrelu.argtypes = [p, i64, i32, i32, p, p, p, p]
+    lib.gpemsr_threeda_combine.argtypes = [p, p, p, p, p, i64, p, p]
+    lib.gpemsr_tensor2img_u8.argtypes = [p, i64, p, p]
+    lib.gpemsr_copy_channels.argtypes = [p, i32, p, i32, i64, i32, p]
+    lib.gpemsr_copy_images.argtypes = [p, p, i64, i64, i32, i32, i32, p]
+    lib.gpemsr_device_info.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gpemsr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"gpemsr_amd: {what} failed (code {rc}): {msg}")

@@ -1,0 +1,140 @@
+// Direct (VALU) convolution for layers whose channel counts are too small for the
+// matrix pipe: cout <= 16.  HBM/L2-bound byte work, so the design goal is
+// coalesced float4 traffic, not MFMA:
+//   * "vec" kernel (cin in {16,64}, ld%4==0): LPP = cin/4 lanes cooperate on one
+//     output pixel, each lane owns 4 input channels (one float4 per tap, so a
+//     wave reads whole 64..256-B pixel rows), the cross-channel sum is finished
+//     with wavefront shuffles (__shfl_xor over the LPP lanes).
+//   * scalar kernel (anything else, e.g. the 2->16 stride-4 flow conv): one thread
+//     per (pixel, cout).
+// Weights are read in the packed [tap][cout][cin_pad8] layout of gpemsr_conv2d
+// (cin padded to a multiple of 8) and cached in LDS.
+// Replaces: model/GPEMSR.py:70-75 (flowdsconv*), :250 (refmaskconv3), :318 (conv_last),
+// decoder.output_layer (model/decoder.py:33), SpyNet's last 16->2 7x7 conv.
+#include "common.h"
+
+namespace gpemsr {
+
+struct DirectParams {
+  const float* x; int n, h, w, ld, cin, cin_pad;
+  const float* weight; const float* bias; int cout, ksize, stride, pad, oh, ow;
+  int act; const float* residual; int res_ld; float* out; int out_ld;
+  long long npix;
+};
+
+template <int LPP, int COUT>
+__global__ __launch_bounds__(256) void conv_direct_vec_kernel(DirectParams P) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];   // [tap][COUT][cin_pad]
+  const int ntap = P.ksize * P.ksize;
+  for (int i = threadIdx.x; i < ntap * P.cout * P.cin_pad; i += 256) wsm[i] = P.weight[i];
+  __syncthreads();
+  const int sub = threadIdx.x % LPP;
+  const long long per_iter = (long long)gridDim.x * (256 / LPP);
+  const long long niter = (P.npix + per_iter - 1) / per_iter;
+  for (long long it = 0; it < niter; ++it) {
+    // every lane runs every iteration (the shuffles below need full participation)
+    const long long pix = it * per_iter + (long long)blockIdx.x * (256 / LPP) + threadIdx.x / LPP;
+    const bool valid = pix < P.npix;
+    const long long pp = valid ? pix : 0;
+    const int ox = (int)(pp % P.ow);
+    const int oy = (int)((pp / P.ow) % P.oh);
+    const int img = (int)(pp / ((long long)P.ow * P.oh));
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int ky = 0; ky < P.ksize; ++ky) {
+      const int iy = oy * P.stride - P.pad + ky;
+      if (iy < 0 || iy >= P.h) continue;
+      for (int kx = 0; kx < P.ksize; ++kx) {
+        const int ix = ox * P.stride - P.pad + kx;
+        if (ix < 0 || ix >= P.w) continue;
+        const float4 v = *reinterpret_cast<const float4*>(P.x + (((long long)img * P.h + iy) * P.w + ix) * P.ld + 4 * sub);
+        const float* wp = wsm + (ky * P.ksize + kx) * P.cout * P.cin_pad + 4 * sub;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          if (co < P.cout) {
+            const float4 wv = *reinterpret_cast<const float4*>(wp + co * P.cin_pad);
+            acc[co] = fmaf(v.x, wv.x, acc[co]); acc[co] = fmaf(v.y, wv.y, acc[co]);
+            acc[co] = fmaf(v.z, wv.z, acc[co]); acc[co] = fmaf(v.w, wv.w, acc[co]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+      for (int m = LPP / 2; m >= 1; m >>= 1) acc[co] += __shfl_xor(acc[co], m);
+    if (valid) {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+        if (co < P.cout && (co % LPP) == sub) {
+          float v = apply_act(acc[co] + (P.bias ? P.bias[co] : 0.f), P.act);
+          if (P.residual) v += P.residual[pix * P.res_ld + co];
+          P.out[pix * P.out_ld + co] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_direct_scalar_kernel(DirectParams P) {
+  const long long total = P.npix * P.cout;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int co = (int)(e % P.cout);
+    const long long pix = e / P.cout;
+    const int ox = (int)(pix % P.ow);
+    const int oy = (int)((pix / P.ow) % P.oh);
+    const int img = (int)(pix / ((long long)P.ow * P.oh));
+    float acc = 0.f;
+    for (int ky = 0; ky < P.ksize; ++ky) {
+      const int iy = oy * P.stride - P.pad + ky;
+      if (iy < 0 || iy >= P.h) continue;
+      for (int kx = 0; kx < P.ksize; ++kx) {
+        const int ix = ox * P.stride - P.pad + kx;
+        if (ix < 0 || ix >= P.w) continue;
+        const float* xp = P.x + (((long long)img * P.h + iy) * P.w + ix) * P.ld;
+        const float* wp = P.weight + ((long long)(ky * P.ksize + kx) * P.cout + co) * P.cin_pad;
+        for (int ci = 0; ci < P.cin; ++ci) acc = fmaf(xp[ci], wp[ci], acc);
+      }
+    }
+    float v = apply_act(acc + (P.bias ? P.bias[co] : 0.f), P.act);
+    if (P.residual) v += P.residual[pix * P.res_ld + co];
+    P.out[pix * P.out_ld + co] = v;
+  }
+}
+
+}  // namespace gpemsr
+
+using namespace gpemsr;
+
+extern "C" int gpemsr_conv2d_direct(const float* x, int n, int h, int w, int ld, int cin,
+                                    const float* weight, const float* bias, int cout, int ksize, int stride,
+                                    int act, const float* residual, int res_ld, float* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && weight && out, "conv2d_direct: null pointer");
+  GP_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && cout <= 16, "conv2d_direct: bad geometry (cout<=16)");
+  GP_REQUIRE(ksize >= 1 && ksize <= 7 && (ksize & 1), "conv2d_direct: ksize=%d", ksize);
+  GP_REQUIRE(stride == 1 || stride == 2 || stride == 4, "conv2d_direct: stride=%d", stride);
+  DirectParams P{};
+  P.x = x; P.n = n; P.h = h; P.w = w; P.ld = ld; P.cin = cin; P.cin_pad = (cin + 7) / 8 * 8;
+  P.weight = weight; P.bias = bias; P.cout = cout; P.ksize = ksize; P.stride = stride; P.pad = ksize / 2;
+  P.oh = (h + 2 * P.pad - ksize) / stride + 1; P.ow = (w + 2 * P.pad - ksize) / stride + 1;
+  P.act = act; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
+  P.npix = (long long)n * P.oh * P.ow;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (cin == 16 || cin == 64);
+  const size_t lds = (size_t)ksize * ksize * cout * P.cin_pad * sizeof(float);
+  if (vec_ok && lds <= 60 * 1024) {
+    const int lpp = cin / 4;
+    const long long groups = (P.npix + (256 / lpp) - 1) / (256 / lpp);
+    const int grid = (int)(groups < 8192 ? groups : 8192);
+#define GP_LAUNCH_VEC(L, C) hipLaunchKernelGGL((conv_direct_vec_kernel<L, C>), dim3(grid), dim3(256), lds, st, P)
+    if (lpp == 16) { if (cout == 1) GP_LAUNCH_VEC(16, 1); else if (cout <= 2) GP_LAUNCH_VEC(16, 2); else GP_LAUNCH_VEC(16, 16); }
+    else           { if (cout == 1) GP_LAUNCH_VEC(4, 1);  else if (cout <= 2) GP_LAUNCH_VEC(4, 2);  else GP_LAUNCH_VEC(4, 16); }
+#undef GP_LAUNCH_VEC
+    return check_launch("conv_direct_vec_kernel");
+  }
+  const long long total = P.npix * cout;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(conv_direct_scalar_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, P);
+  return check_launch("conv_direct_scalar_kernel");
+}

@@ -1,0 +1,417 @@
+"""Device-side forward of the stage-3 GPEMSR network on the HIP kernel library.
+
+This is the host logic above the C ABI: it owns the packed weights and issues
+the kernel sequence for ``GPEMSR.forward`` (reference:
+/root/reference/GPEMSR-CREMI/GPEMSR/model/GPEMSR.py:323-456 and the modules it
+calls).  The structure mirrors the reference stage by stage; what changes is how
+each stage is executed:
+
+  * activations are NHWC float32 and channel concatenations are never
+    materialised (multi-source convolutions);
+  * the 5 slices of every tile are batched through the per-frame front half
+    (features, VQGAN prior, VGG mask, MPF) in frame chunks, and the 5 POD
+    alignments of every tile are batched as 5*B "pairs" instead of a Python loop;
+  * SpyNet is evaluated once per pair (the reference evaluates it twice with
+    identical arguments, :99-100) and only VGG slice1 is evaluated (slices 2-5
+    are dead in the forward, model/VGG.py:37-44);
+  * PixelShuffle, residual adds, LeakyReLU/ReLU/sigmoid, the mask multiply and
+    the bilinear base add are epilogues of the producing convolution.
+
+torch is used for allocation and stream plumbing only; there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
+from .packing import pack_conv, pack_convT, pack_dcn, pack_linear, pack_vgg_first
+
+_SPY_MEAN = (0.485, 0.456, 0.406)
+_SPY_STD = (0.229, 0.224, 0.225)
+
+
+def _seq_len(sd, prefix: str) -> int:
+    idx, plen = set(), len(prefix) + 1
+    for k in sd:
+        if k.startswith(prefix + "."):
+            head = k[plen:].split(".", 1)[0]
+            if head.isdigit():
+                idx.add(int(head))
+    return (max(idx) + 1) if idx else 0
+
+
+class Engine:
+    def __init__(self, sd: Dict[str, torch.Tensor], device, scale: int, nframes: int = 5, groups: int = 8,
+                 nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 20, tile_chunk: int = 4):
+        assert scale in (8, 16)
+        assert nf == 64, "kernels are specialised for nf=64 (every shipped option file)"
+        self.sd = sd
+        self.dev = device
+        self.scale, self.N, self.groups, self.nf = scale, nframes, groups, nf
+        self.center = nframes // 2
+        self.dec_nrb = dec_num_res_blocks
+        self.frame_chunk, self.tile_chunk = frame_chunk, tile_chunk
+        self.pc: Dict[str, ops.PackedConv] = {}
+        self.par: Dict[str, torch.Tensor] = {}
+        self._pack_all()
+
+    # ------------------------------------------------------------------ packing
+    def _pack_all(self):
+        sd, dev, nf = self.sd, self.dev, self.nf
+        splits = {
+            "reffusionconv1": (nf, 64), "reffusionconv2": (nf, 128, nf), "down_fea_conv2": (nf, nf),
+            "reffusionconv3": (nf, 256, 2 * nf), "down_fea_conv3": (nf, 2 * nf), "reffusionconv4": (nf, 512, 3 * nf),
+            "reduce_dim_conv": (nf, 3 * nf, nf) if self.scale == 16 else (nf, 2 * nf, nf),
+            "align_module.L3_offset_conv1": (nf, nf, 32, 2), "align_module.L2_offset_conv1": (nf, nf, 32, 2),
+            "align_module.L1_offset_conv1": (nf, nf, 32, 2), "align_module.L2_offset_conv2": (nf, nf),
+            "align_module.L1_offset_conv2": (nf, nf), "align_module.L2_fea_conv": (nf, nf),
+            "align_module.L1_fea_conv": (nf, nf), "align_module.cas_offset_conv1": (nf, nf),
+        }
+        ps = {"upconv1", "upconv2", "upconv3", "upconv4"}
+        for k, w in sd.items():
+            if not k.endswith(".weight"):
+                continue
+            name = k[:-7]
+            if name.startswith("refmodel.encoder.") or name.startswith("vgg.slice") and not name.startswith("vgg.slice1."):
+                continue                                   # never evaluated in the stage-3 forward
+            b = sd.get(name + ".bias")
+            if w.dim() == 4 and name.endswith("dcnpack"):
+                self.pc[name] = pack_dcn(w, b, dev)
+            elif w.dim() == 4 and (name.startswith("reffea_L") or name.endswith(".upblock")):
+                self.pc[name] = pack_convT(w, b, dev)
+            elif name == "vgg.slice1.0":
+                self.pc[name] = pack_vgg_first(w, b, dev)
+            elif w.dim() == 4 and name.endswith((".q",)) and ".feat_extract." in name:
+                c = w.shape[0]
+                self.pc[name] = pack_conv(w, b, dev, scale=float(int(c) ** (-0.5)))   # fold C^-1/2 (blocks.py:76)
+            elif w.dim() == 4:
+                self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
+            elif w.dim() == 2 and name.endswith("indexer.embedding"):
+                self.pc[name] = pack_linear(w, b, dev)
+            elif w.dim() == 2 and name.endswith("codebook.embedding"):
+                self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
+            elif w.dim() == 5:                             # ThreeDA.conv3D_{1,2}: [t,t,1,1,1]
+                self.par[k] = w.detach().to(torch.float32).reshape(w.shape[0], w.shape[1]).contiguous().to(dev)
+                self.par[name + ".bias"] = b.detach().to(torch.float32).contiguous().to(dev)
+            elif w.dim() == 1:                             # GroupNorm affine
+                self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
+                self.par[name + ".bias"] = b.detach().to(torch.float32).contiguous().to(dev)
+        m, s = sd.get("align_module.spynet.mean"), sd.get("align_module.spynet.std")
+        self.spy_mean = tuple(float(v) for v in m.flatten()) if m is not None else _SPY_MEAN
+        self.spy_std = tuple(float(v) for v in s.flatten()) if s is not None else _SPY_STD
+
+    # ------------------------------------------------------------------ helpers
+    def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
+        return ops.conv2d(srcs, self.pc[name], act, **kw)
+
+    def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:
+        """basicsr ResidualBlockNoBN chain; ``pixmul`` multiplies the output of the LAST block
+        (the MPF mask, model/GPEMSR.py:403)."""
+        n = _seq_len(self.sd, prefix)
+        for i in range(n):
+            t = self.conv(x, f"{prefix}.{i}.conv1", ACT_RELU)
+            x = self.conv(t, f"{prefix}.{i}.conv2", ACT_NONE, residual=x, pixmul=pixmul if i == n - 1 else None)
+        return x
+
+    # ------------------------------------------------------------------ VQGAN prior
+    def vq_resblock(self, x: Act, p: str) -> Act:
+        t = self.conv(x, p + ".block.0")
+        ops.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
+        u = self.conv(t, p + ".block.3")
+        skip = self.conv(x, p + ".channel_up") if (p + ".channel_up") in self.pc else x
+        return ops.groupnorm_relu(u, self.par[p + ".block.4.weight"], self.par[p + ".block.4.bias"], True, residual=skip, out=u)
+
+    def nonlocal_block(self, x: Act, p: str) -> Act:
+        """model/blocks.py:61-83 with the score matrix materialised per frame chunk."""
+        n, h, w, c = x.n, x.h, x.w, x.c
+        T = h * w
+        if T % 32 != 0 or c % 32 != 0:
+            raise RuntimeError(f"gpemsr_amd: non-local block needs latent tokens ({T}) and channels ({c}) to be multiples of 32")
+        hn = ops.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
+        q = self.conv(hn, p + ".q")                       # already scaled by C^-1/2
+        k = self.conv(hn, p + ".k")
+        gh, gw = (T // 16, 16) if T % 16 == 0 else (T, 1)
+        # V^T[c][j] = sum_c' Wv[c][c'] hn[j][c']  (bias folded into the PV product: softmax rows sum to 1)
+        wv = self.pc[p + ".v"]
+        vT = self._vt(wv.w, hn, n, c, T)
+        out = ops.new_act(n, h, w, c, device=self.dev)
+        fc = max(1, min(n, (1 << 30) // (T * T * 4)))      # frames per score-matrix chunk (<= 1 GiB)
+        for f0 in range(0, n, fc):
+            m = min(fc, n - f0)
+            qa = q.images(f0, m).reshape_hw(gh, gw)
+            S = ops.conv2d([qa], ops.PackedConv(k.images(f0, m).buf, None, 1, T, (c,), 32), ACT_NONE,
+                           weight_image_stride=T * c)
+            ops.softmax_rows_(S.buf, m * T, T)
+            ops.conv2d([S], ops.PackedConv(vT.images(f0, m).buf, wv.b, 1, c, (T,), 32), ACT_NONE,
+                       weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw))
+        return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
+
+    def _vt(self, wv_packed: torch.Tensor, hn: Act, n: int, c: int, T: int) -> Act:
+        vT = ops.new_act(n, c // 16, 16, T, device=self.dev)
+        a = Act(wv_packed, n, c // 16, 16, c, c, 0)        # n "images" that all alias the one [C][C] weight matrix
+        ops.conv2d([a], ops.PackedConv(hn.buf, None, 1, T, (c,), 32), ACT_NONE, weight_image_stride=T * c,
+                   src_image_stride=[0], out=vT)
+        return vT
+
+    def vq_layer(self, x: Act, p: str) -> Act:
+        if (p + ".block.0") in self.pc:
+            return self.vq_resblock(x, p)
+        if (p + ".downblock") in self.pc:
+            return self.conv(x, p + ".downblock", stride=2)
+        if (p + ".upblock") in self.pc:
+            return self.conv(x, p + ".upblock")
+        if (p + ".q") in self.pc:
+            return self.nonlocal_block(x, p)
+        if p in self.pc:
+            return self.conv(x, p)
+        raise KeyError(p)
+
+    def indexer_logits(self, xf: Act) -> Act:
+        p = "refmodel.indexer"
+        h = self.conv(xf, p + ".input_layer.0", ACT_RELU)
+        for i in range(_seq_len(self.sd, p + ".feat_extract")):
+            h = self.vq_layer(h, f"{p}.feat_extract.{i}")
+        for i in range(_seq_len(self.sd, p + ".output_layer")):
+            h = self.vq_layer(h, f"{p}.output_layer.{i}")
+        return self.conv(h, p + ".embedding")              # nn.Linear on NHWC == 1x1 conv (indexer.py:100)
+
+    def ref_extract(self, xf: Act, forced_idx: Optional[torch.Tensor], trace: Optional[dict]) -> List[Act]:
+        logits = self.indexer_logits(xf)
+        idx = ops.argmax_rows(logits) if forced_idx is None else forced_idx.to(torch.int32).contiguous()
+        if trace is not None:
+            trace.setdefault("logits", []).append(logits.torch().clone())
+            trace.setdefault("code_idx", []).append(idx.clone())
+        x = ops.gather_rows(self.par["refmodel.codebook.embedding.weight"], idx, logits.n, logits.h, logits.w)
+        del logits
+        p = "refmodel.decoder"
+        for i in range(_seq_len(self.sd, p + ".input_layer")):
+            x = self.vq_layer(x, f"{p}.input_layer.{i}")
+        n_fe = _seq_len(self.sd, p + ".feat_extract")
+        feats = []
+        x = self.vq_layer(x, f"{p}.feat_extract.0")
+        nrb = self.dec_nrb
+        for i in range(n_fe - 1):
+            x = self.vq_layer(x, f"{p}.feat_extract.{i + 1}")
+            if (i - nrb + 1) % (nrb + 1) == 0:
+                feats.append(x)
+        feats.append(self.conv(x, p + ".output_layer"))
+        return feats
+
+    # ------------------------------------------------------------------ mask
+    def vgg_mask(self, ref_img: Act, up_lr: Act) -> Act:
+        """model/GPEMSR.py:386-395 for a chunk of frames -> cosine map [n,sH/16,sW/16,1]."""
+        n = ref_img.n
+        out = ops.new_act(n, ref_img.h // 16, ref_img.w // 16, 1, device=self.dev)
+        per = max(1, (1 << 30) // (ref_img.h * ref_img.w * 64 * 4))
+        for i0 in range(0, n, per):
+            m = min(per, n - i0)
+            fa = self.conv(self.conv(ref_img.images(i0, m), "vgg.slice1.0", ACT_RELU), "vgg.slice1.2", ACT_RELU)
+            fb = self.conv(self.conv(up_lr.images(i0, m), "vgg.slice1.0", ACT_RELU), "vgg.slice1.2", ACT_RELU)
+            o = ops.patch_cosine(fa, fb)
+            ops.copy_channels(o, out.images(i0, m))
+        return out
+
+    # ------------------------------------------------------------------ per-frame front half
+    def front(self, xf: Act, forced_idx, trace) -> Dict[str, Act]:
+        s, H, W = self.scale, xf.h, xf.w
+        L1 = self.conv(xf, "conv_first", ACT_LRELU)
+        L1 = self.resblocks_nobn(L1, "feature_extraction")
+        if trace is not None:
+            trace.setdefault("L1_fea", []).append(L1.nchw())
+        Lr2 = self.conv(L1, "reffea_L2_conv1", ACT_LRELU)
+        Lr3 = self.conv(Lr2, "reffea_L3_conv1", ACT_LRELU)
+        Lr4 = self.conv(Lr3, "reffea_L4_conv1", ACT_LRELU) if s == 16 else None
+        ref_x16, ref_x8, ref_x4, ref_x2, ref_img = self.ref_extract(xf, forced_idx, trace)
+        up_lr = ops.bilinear(xf, s * H, s * W)
+        mask = self.vgg_mask(ref_img, up_lr)
+        del up_lr
+        if trace is not None:
+            trace.setdefault("mask_cos", []).append(mask.nchw())
+        mask = self.conv(mask, "refmaskconv1", ACT_LRELU)
+        mask = self.conv(mask, "refmaskconv2", ACT_LRELU)
+        mask = self.conv(mask, "refmaskconv3", ACT_LRELU_SIGMOID)
+        mh, mw = mask.h, mask.w
+        if s == 16:
+            fine, mid, coarse = Lr4, Lr3, Lr2
+        else:
+            fine, mid, coarse = Lr3, Lr2, L1
+        r2 = self.conv([fine, ref_x2], "reffusionconv1")
+        r2 = self.resblocks_nobn(r2, "fusion_fea_block1", pixmul=ops.bilinear(mask, mh * 8, mw * 8))
+        r2 = self.conv(r2, "down_fea_conv1", stride=2)
+        r4 = self.conv([mid, ref_x4, r2], "reffusionconv2")
+        r4 = self.resblocks_nobn(r4, "fusion_fea_block2", pixmul=ops.bilinear(mask, mh * 4, mw * 4))
+        r4 = self.conv([r4, r2], "down_fea_conv2", stride=2)
+        r8 = self.conv([coarse, ref_x8, r4], "reffusionconv3")
+        r8 = self.resblocks_nobn(r8, "fusion_fea_block3", pixmul=ops.bilinear(mask, mh * 2, mw * 2))
+        if s == 16:
+            r8 = self.conv([r8, r4], "down_fea_conv3", stride=2)
+            r16 = self.conv([L1, ref_x16, r8], "reffusionconv4")
+            r16 = self.resblocks_nobn(r16, "fusion_fea_block4", pixmul=mask)
+            L1 = self.conv([r16, r8, L1], "reduce_dim_conv")
+        else:
+            L1 = self.conv([r8, r4, L1], "reduce_dim_conv")
+        L2 = self.conv(self.conv(L1, "fea_L2_conv1", ACT_LRELU, stride=2), "fea_L2_conv2", ACT_LRELU)
+        L3 = self.conv(self.conv(L2, "fea_L3_conv1", ACT_LRELU, stride=2), "fea_L3_conv2", ACT_LRELU)
+        return {"L1": L1, "L2": L2, "L3": L3, "ref_img": ref_img}
+
+    # ------------------------------------------------------------------ SpyNet + POD
+    def spynet(self, ref: Act, supp: Act) -> Act:
+        """basicsr SpyNet.forward(ref, supp) on 1-channel frames -> flow [n,h,w,2] (x,y)."""
+        h, w = ref.h, ref.w
+        hf, wf = ((h + 31) // 32) * 32, ((w + 31) // 32) * 32
+        if (hf, wf) != (h, w):
+            ref, supp = ops.bilinear(ref, hf, wf), ops.bilinear(supp, hf, wf)
+        rp, sp = [ref], [supp]
+        for _ in range(5):
+            rp.insert(0, ops.avgpool2(rp[0])); sp.insert(0, ops.avgpool2(sp[0]))
+        flow = None
+        p = "align_module.spynet.basic_module"
+        for lvl in range(6):
+            up, inp = ops.spynet_prep(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std)
+            t = self.conv(inp, f"{p}.{lvl}.basic_module.0", ACT_RELU)
+            t = self.conv(t, f"{p}.{lvl}.basic_module.2", ACT_RELU)
+            t = self.conv(t, f"{p}.{lvl}.basic_module.4", ACT_RELU)
+            t = self.conv(t, f"{p}.{lvl}.basic_module.6", ACT_RELU)
+            flow = self.conv(t, f"{p}.{lvl}.basic_module.8", ACT_NONE, residual=up)
+        if (hf, wf) != (h, w):
+            out = ops.new_act(flow.n, h, w, 2, device=self.dev)
+            ops.bilinear(flow.slice(0, 1), h, w, mul=float(w) / float(wf), out=out.slice(0, 1))
+            ops.bilinear(flow.slice(1, 1), h, w, mul=float(h) / float(hf), out=out.slice(1, 1))
+            flow = out
+        return flow
+
+    def dcn(self, x: Act, feat: Act, name: str, act: int) -> Act:
+        om = self.conv(feat, name + ".conv_offset", force_mfma=True)
+        col = ops.dcn_columns(x, om, self.groups)
+        return self.conv(col, name, act)
+
+    def pod(self, nbr: List[Act], ref: List[Act], nbr_frame: Act, ref_frame: Act, trace) -> Act:
+        """POD.forward (model/GPEMSR.py:98-140) for P = 5*B' (neighbour, centre) pairs at once."""
+        p = "align_module"
+        P, H, W = nbr_frame.n, nbr_frame.h, nbr_frame.w
+        flow = self.spynet(ops.bilinear(nbr_frame, 4 * H, 4 * W), ops.bilinear(ref_frame, 4 * H, 4 * W))
+        if trace is not None:
+            trace.setdefault("flow", []).append(flow.nchw())
+        fl1 = ops.new_act(P, H, W, 32, device=self.dev)
+        self.conv(flow, p + ".flowdsconv0_1", stride=4, out=fl1.slice(0, 16))
+        self.conv(flow, p + ".flowdsconv0_2", stride=4, out=fl1.slice(16, 16))
+        fl2 = ops.new_act(P, H // 2, W // 2, 32, device=self.dev)
+        self.conv(fl1.slice(0, 16), p + ".flowdsconv1_1", stride=2, out=fl2.slice(0, 16))
+        self.conv(fl1.slice(16, 16), p + ".flowdsconv1_2", stride=2, out=fl2.slice(16, 16))
+        fl3 = ops.new_act(P, H // 4, W // 4, 32, device=self.dev)
+        self.conv(fl2.slice(0, 16), p + ".flowdsconv2_1", stride=2, out=fl3.slice(0, 16))
+        self.conv(fl2.slice(16, 16), p + ".flowdsconv2_2", stride=2, out=fl3.slice(16, 16))
+        fr1 = ops.new_act(P, H, W, 2, device=self.dev)
+        ops.copy_channels(nbr_frame, fr1.slice(0, 1)); ops.copy_channels(ref_frame, fr1.slice(1, 1))
+        fr2 = ops.bilinear(fr1, H // 2, W // 2)
+        fr3 = ops.bilinear(fr2, H // 4, W // 4)
+
+        o3 = self.conv([nbr[2], ref[2], fl3, fr3], p + ".L3_offset_conv1", ACT_LRELU)
+        o3 = self.conv(o3, p + ".L3_offset_conv2", ACT_LRELU)
+        f3 = self.dcn(nbr[2], o3, p + ".L3_dcnpack", ACT_LRELU)
+
+        o2 = self.conv([nbr[1], ref[1], fl2, fr2], p + ".L2_offset_conv1", ACT_LRELU)
+        o3u = ops.bilinear(o3, o3.h * 2, o3.w * 2, mul=2.0)
+        o2 = self.conv([o2, o3u], p + ".L2_offset_conv2", ACT_LRELU)
+        o2 = self.conv(o2, p + ".L2_offset_conv3", ACT_LRELU)
+        f2 = self.dcn(nbr[1], o2, p + ".L2_dcnpack", ACT_NONE)
+        f3u = ops.bilinear(f3, f3.h * 2, f3.w * 2)
+        f2 = self.conv([f2, f3u], p + ".L2_fea_conv", ACT_LRELU)
+
+        o1 = self.conv([nbr[0], ref[0], fl1, fr1], p + ".L1_offset_conv1", ACT_LRELU)
+        o2u = ops.bilinear(o2, o2.h * 2, o2.w * 2, mul=2.0)
+        o1 = self.conv([o1, o2u], p + ".L1_offset_conv2", ACT_LRELU)
+        o1 = self.conv(o1, p + ".L1_offset_conv3", ACT_LRELU)
+        f1 = self.dcn(nbr[0], o1, p + ".L1_dcnpack", ACT_NONE)
+        f2u = ops.bilinear(f2, f2.h * 2, f2.w * 2)
+        f1 = self.conv([f1, f2u], p + ".L1_fea_conv", ACT_NONE)
+
+        off = self.conv([f1, ref[0]], p + ".cas_offset_conv1", ACT_LRELU)
+        off = self.conv(off, p + ".cas_offset_conv2", ACT_LRELU)
+        return self.dcn(f1, off, p + ".cas_dcnpack", ACT_LRELU)
+
+    # ------------------------------------------------------------------ ThreeDA
+    def three_da(self, aligned: Act, B: int) -> Act:
+        """ThreeDA.forward (model/GPEMSR.py:172-222); aligned is [B*N,h,w,c], frame-major per tile."""
+        p, N = "ThreeDA", self.N
+        centre = ops.copy_images(aligned, B, 1, N, self.center)
+        emb_ref = self.conv(centre, p + ".temporal_attn1")
+        emb = self.conv(aligned, p + ".temporal_attn2")
+        af = ops.temporal_gate(aligned, emb, emb_ref, B, N)
+        m1 = ops.frame_mix_lrelu(af, N, self.par[p + ".conv3D_1.weight"], self.par[p + ".conv3D_1.bias"])
+        f1 = self.conv(m1, p + ".conv3D_fusion_1", ACT_LRELU)
+        m2 = ops.frame_mix_lrelu(af, N, self.par[p + ".conv3D_2.weight"], self.par[p + ".conv3D_2.bias"])
+        f2 = self.conv(m2, p + ".conv3D_fusion_2", ACT_LRELU)
+        feat = self.conv(af, p + ".feat_fusion", ACT_LRELU, residual=f1)
+        f3 = self.conv(feat, p + ".conv2D_fusion_3")
+        attn = self.conv(af, p + ".spatial_attn1", ACT_LRELU)
+        attn = self.conv(ops.pool3s2_maxavg(attn), p + ".spatial_attn2", ACT_LRELU)
+        lvl = self.conv(attn, p + ".spatial_attn_l1", ACT_LRELU)
+        lvl = self.conv(ops.pool3s2_maxavg(lvl), p + ".spatial_attn_l2", ACT_LRELU)
+        lvl = self.conv(lvl, p + ".spatial_attn_l3", ACT_LRELU)
+        lvl = ops.bilinear(lvl, lvl.h * 2, lvl.w * 2)
+        attn = self.conv(attn, p + ".spatial_attn3", ACT_LRELU, residual=lvl)
+        attn = self.conv(attn, p + ".spatial_attn4", ACT_LRELU)
+        attn = ops.bilinear(attn, attn.h * 2, attn.w * 2)
+        attn = self.conv(attn, p + ".spatial_attn5")
+        add = self.conv(self.conv(attn, p + ".spatial_attn_add1", ACT_LRELU), p + ".spatial_attn_add2")
+        return ops.threeda_combine(feat, attn, add, f2, f3)
+
+    # ------------------------------------------------------------------ whole forward
+    def forward(self, x: torch.Tensor, forced_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):
+        if not x.is_cuda:
+            raise RuntimeError("gpemsr_amd: forward needs a device (cuda/HIP) tensor; there is no CPU path")
+        B, N, C, H, W = x.shape
+        assert N == self.N and C == 1, "expected [B, nframes, 1, H, W]"
+        s = self.scale
+        if s == 8:
+            assert H % 8 == 0 and W % 8 == 0, "x8: LR height/width must be multiples of 8"
+        else:
+            assert H % 4 == 0 and W % 4 == 0, "x16: LR height/width must be multiples of 4"
+        x = x.to(torch.float32).contiguous()
+        xa = Act(x, B * N, H, W, 1, 1, 0)
+        nfr = B * N
+        L1 = ops.new_act(nfr, H, W, 64, device=self.dev)
+        L2 = ops.new_act(nfr, H // 2, W // 2, 64, device=self.dev)
+        L3 = ops.new_act(nfr, H // 4, W // 4, 64, device=self.dev)
+        ref_img = torch.empty(B, N, C, H * s, W * s, dtype=torch.float32, device=self.dev)
+        ref_act = Act(ref_img, nfr, H * s, W * s, 1, 1, 0)
+        lat = (H // 2) * (W // 2) if s == 8 else H * W
+        for f0 in range(0, nfr, self.frame_chunk):
+            m = min(self.frame_chunk, nfr - f0)
+            fi = None if forced_idx is None else forced_idx.reshape(-1)[f0 * lat:(f0 + m) * lat]
+            r = self.front(xa.images(f0, m), fi, trace)
+            ops.copy_channels(r["L1"], L1.images(f0, m)); ops.copy_channels(r["L2"], L2.images(f0, m))
+            ops.copy_channels(r["L3"], L3.images(f0, m)); ops.copy_channels(r["ref_img"], ref_act.images(f0, m))
+            del r
+        if trace is not None:
+            trace["L1_fused"] = L1.nchw()
+        out = torch.empty(B, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
+        out_act = Act(out, B, H * s, W * s, 1, 1, 0)
+        for b0 in range(0, B, self.tile_chunk):
+            bm = min(self.tile_chunk, B - b0)
+            P = bm * N
+            nbr = [L1.images(b0 * N, P), L2.images(b0 * N, P), L3.images(b0 * N, P)]
+            ref = [ops.copy_images(t, P, N, N, b0 * N + self.center) for t in (L1, L2, L3)]
+            nbr_frame = xa.images(b0 * N, P)
+            ref_frame = ops.copy_images(xa, P, N, N, b0 * N + self.center)
+            aligned = self.pod(nbr, ref, nbr_frame, ref_frame, trace)
+            if trace is not None:
+                trace.setdefault("aligned", []).append(aligned.nchw().view(bm, N, 64, H, W))
+            fea = self.three_da(aligned, bm)
+            if trace is not None:
+                trace.setdefault("fused", []).append(fea.nchw())
+            o = self.resblocks_nobn(fea, "recon_trunk")
+            o = self.conv(o, "upconv1", ACT_LRELU)
+            o = self.conv(o, "upconv2", ACT_LRELU)
+            o = self.conv(o, "upconv3", ACT_LRELU)
+            if s == 16:
+                o = self.conv(o, "upconv4", ACT_LRELU)
+            o = self.conv(o, "HRconv", ACT_LRELU)
+            xc = ops.copy_images(xa, bm, 1, N, b0 * N + self.center)
+            base = ops.bilinear(xc, H * s, W * s)
+            self.conv(o, "conv_last", ACT_NONE, residual=base, out=out_act.images(b0, bm))
+        return out, ref_img

@@ -1,0 +1,127 @@
+"""Drop-in host module for the reference's ``model.GPEMSR.GPEMSR``.
+
+Same constructor arguments, same ``forward(x[B,N,1,H,W]) -> (out[B,1,sH,sW],
+ref_img[B,N,1,sH,sW])``, same state-dict key layout / ``load_state_dict(strict=True)``
+behaviour and ``requires_grad`` flags as
+/root/reference/GPEMSR-CREMI/GPEMSR/model/GPEMSR.py:225-456 (callers:
+output_GPEMSR.py:36-52, train_stage3.py:123-141) -- but the forward runs on the
+hand-written HIP kernels of libgpemsr_hip.so (gpemsr_amd/engine.py), on a
+cuda/HIP device only.  There is no CPU fallback: calling forward without a GPU or
+without the built library raises.
+"""
+from __future__ import annotations
+
+import os
+from collections import namedtuple
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .arch import param_specs
+from .synth import synth_tensor
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, trainable: bool, is_buffer: bool):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    if is_buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=trainable))
+
+
+class GPEMSR(nn.Module):
+    """See module docstring.  Extra (optional) keyword arguments, all defaulted so the
+    reference call sites work unchanged:
+      init_seed    seed of the deterministic synthetic initialisation used until a
+                   checkpoint is loaded (the reference's files are Google-Drive only);
+      frame_chunk / tile_chunk   batching granularity of the two halves of the forward.
+    """
+
+    def __init__(self, ref_path_G, ref_path_Indexer, argref, nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10,
+                 w_ref=True, ref_fusion_feat_RBs=3, align_mode='POD', fusion_mode='ThreeDA', mode='16to1', scale=16,
+                 init_seed: int = 0, frame_chunk: int = 20, tile_chunk: int = 4):
+        super().__init__()
+        if not (w_ref and align_mode == 'POD' and fusion_mode == 'ThreeDA'):
+            raise NotImplementedError("gpemsr_amd implements the shipped configuration: w_ref=True, POD, ThreeDA")
+        if (scale, mode) not in ((8, '8to1'), (16, '16to1')):
+            raise ValueError('scale is wrong!')                      # model/GPEMSR.py:286-287
+        self.nf, self.center, self.scale = nf, nframes // 2, scale
+        self.nframes, self.groups = nframes, groups
+        self.w_ref, self.align_mode, self.fusion_mode, self.mode = w_ref, align_mode, fusion_mode, mode
+        self._dec_nrb = int(argref["Decoder"]["num_resblock_per_scale"])
+        self._chunks = (frame_chunk, tile_chunk)
+        self._specs = param_specs(argref=argref, nf=nf, nframes=nframes, groups=groups, front_RBs=front_RBs,
+                                  back_RBs=back_RBs, w_ref=w_ref, ref_fusion_feat_RBs=ref_fusion_feat_RBs,
+                                  align_mode=align_mode, fusion_mode=fusion_mode, mode=mode, scale=scale)
+        for name, spec in self._specs.items():
+            _register(self, name, synth_tensor(name, spec, init_seed), spec.trainable, spec.is_buffer)
+        self._engine = None
+        # the reference loads the frozen prior at construction (model/GPEMSR.py:275-276, 283-284)
+        if ref_path_G is not None and os.path.exists(str(ref_path_G)):
+            self.refmodel.load_state_dict(torch.load(ref_path_G, map_location="cpu"), strict=False)
+        if ref_path_Indexer is not None and os.path.exists(str(ref_path_Indexer)):
+            self.refmodel.indexer.load_state_dict(torch.load(ref_path_Indexer, map_location="cpu"), strict=True)
+
+    # -- weight lifecycle: any change of the parameters invalidates the packed copies
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = dict(state_dict)
+        if strict:   # tolerate checkpoints written by a basicsr without the spynet mean/std buffers
+            for k in ("align_module.spynet.mean", "align_module.spynet.std"):
+                if k not in sd and k in self._specs:
+                    sd[k] = self.state_dict()[k]
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self._engine = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode: bool = True):      # train() == eval(): no BatchNorm/Dropout in the network
+        return super().train(mode)
+
+    def _get_engine(self, device):
+        if self._engine is None or self._engine.dev != device:
+            from . import _abi
+            from .engine import Engine
+            _abi.load()                        # fail loudly if the HIP library is missing
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._engine = Engine(sd, device, self.scale, self.nframes, self.groups, self.nf, self._dec_nrb,
+                                  frame_chunk=self._chunks[0], tile_chunk=self._chunks[1])
+        return self._engine
+
+    def forward(self, x, forced_code_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):
+        if not x.is_cuda:
+            raise RuntimeError("gpemsr_amd.GPEMSR.forward: input must live on a cuda/HIP device "
+                               "(the MI355X kernel path is the only path)")
+        with torch.no_grad():
+            return self._get_engine(x.device).forward(x, forced_code_idx, trace)
+
+    @property
+    def vgg_features(self):
+        return _VGGFeatures(self)
+
+
+VggOutputs = namedtuple("VggOutputs", ['relu1_2', 'relu2_2', 'relu3_4', 'relu4_4', 'relu5_4'])
+
+
+class _VGGFeatures:
+    """``model.vgg`` lookalike (model/VGG.py:34-52): relu1_2 through the HIP conv kernels.
+    Slices 2-5 are only needed by the stage-3 contextual loss (train_stage3.py:352-355), which is
+    listed as 'next' in DESIGN.md; they raise until that row is built."""
+
+    def __init__(self, owner: GPEMSR):
+        self.owner = owner
+
+    def relu1_2(self, x1: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        eng = self.owner._get_engine(x1.device)
+        a = ops.from_nchw(x1.to(torch.float32))
+        f = eng.conv(eng.conv(a, "vgg.slice1.0", ops.ACT_RELU), "vgg.slice1.2", ops.ACT_RELU)
+        return f.nchw()

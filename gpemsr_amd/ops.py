@@ -1,0 +1,300 @@
+"""Python-side operator wrappers over the C ABI (include/gpemsr_hip.h).
+
+Activations are ``Act`` objects: float32 NHWC device memory owned by a torch
+tensor (torch is used only as allocator / stream provider), possibly a channel
+slice of a wider buffer (``ld`` > ``c``), which is how ``torch.cat(dim=1)`` in
+the reference becomes free here.  Every function enqueues HIP kernels on the
+current torch stream and returns immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _abi
+from ._abi import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, ACT_SIGMOID  # noqa: F401
+
+
+class Act:
+    """NHWC float32 activation view: channels [off, off+c) of ``buf`` [n,h,w,ld]."""
+    __slots__ = ("buf", "n", "h", "w", "c", "ld", "off")
+
+    def __init__(self, buf: torch.Tensor, n: int, h: int, w: int, c: int, ld: int, off: int = 0):
+        self.buf, self.n, self.h, self.w, self.c, self.ld, self.off = buf, n, h, w, c, ld, off
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + 4 * self.off
+
+    @property
+    def pixels(self) -> int:
+        return self.n * self.h * self.w
+
+    def slice(self, c0: int, c: int) -> "Act":
+        assert 0 <= c0 and c0 + c <= self.c
+        return Act(self.buf, self.n, self.h, self.w, c, self.ld, self.off + c0)
+
+    def images(self, i0: int, cnt: int) -> "Act":
+        """Sub-range of images [i0, i0+cnt) (shares memory)."""
+        assert 0 <= i0 and i0 + cnt <= self.n
+        flat = self.buf.view(-1)
+        start = i0 * self.h * self.w * self.ld
+        return Act(flat[start:start + cnt * self.h * self.w * self.ld], cnt, self.h, self.w, self.c, self.ld, self.off)
+
+    def reshape_hw(self, h: int, w: int) -> "Act":
+        assert h * w == self.h * self.w
+        return Act(self.buf, self.n, h, w, self.c, self.ld, self.off)
+
+    def regroup(self, n: int) -> "Act":
+        """View [n0,h,w,..] as n images of (n0/n)*h rows (pixel order unchanged)."""
+        assert self.n % n == 0
+        return Act(self.buf, n, (self.n // n) * self.h, self.w, self.c, self.ld, self.off)
+
+    def torch(self) -> torch.Tensor:
+        """[n,h,w,c] torch view (for tests / boundary)."""
+        assert self.off + self.c <= self.ld
+        v = self.buf.view(-1)[: self.n * self.h * self.w * self.ld].view(self.n, self.h, self.w, self.ld)
+        return v[..., self.off:self.off + self.c]
+
+    def nchw(self) -> torch.Tensor:
+        return self.torch().permute(0, 3, 1, 2).contiguous()
+
+
+def new_act(n: int, h: int, w: int, c: int, ld: Optional[int] = None, device=None) -> Act:
+    ld = c if ld is None else ld
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return Act(torch.empty(n * h * w * ld, dtype=torch.float32, device=dev), n, h, w, c, ld, 0)
+
+
+def from_nhwc(t: torch.Tensor) -> Act:
+    assert t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous()
+    n, h, w, c = t.shape
+    return Act(t, n, h, w, c, c, 0)
+
+
+def from_nchw(t: torch.Tensor) -> Act:
+    """NCHW -> NHWC (copy unless C == 1)."""
+    assert t.dim() == 4
+    if t.shape[1] == 1:
+        t = t.contiguous()
+        return Act(t, t.shape[0], t.shape[2], t.shape[3], 1, 1, 0)
+    return from_nhwc(t.permute(0, 2, 3, 1).contiguous())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(*acts):
+    for a in acts:
+        if a is not None and not a.buf.is_cuda:
+            raise RuntimeError("gpemsr_amd ops need device (cuda/HIP) memory; there is no CPU path")
+
+
+@dataclass
+class PackedConv:
+    """Weights repacked for gpemsr_conv2d: w [tap][cout][cin_pad] (cin padded per source to CK)."""
+    w: torch.Tensor
+    b: Optional[torch.Tensor]
+    ksize: int
+    cout: int
+    splits: tuple
+    ck: int
+    transposed: bool = False
+    pixel_shuffle: bool = False
+
+    @property
+    def cin(self) -> int:
+        return sum(self.splits)
+
+
+def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
+           pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
+           src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False) -> Act:
+    lib = _abi.load()
+    if isinstance(srcs, Act):
+        srcs = [srcs]
+    _require_gpu(*srcs)
+    assert len(srcs) == len(pc.splits) and all(s.c == c for s, c in zip(srcs, pc.splits)), \
+        f"source channels {[s.c for s in srcs]} != packed splits {pc.splits}"
+    s0 = srcs[0]
+    n, h, w = s0.n, s0.h, s0.w
+    k = pc.ksize
+    if pc.transposed:
+        oh, ow = 2 * h, 2 * w
+    else:
+        oh, ow = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    OH, OW, oc = (2 * oh, 2 * ow, pc.cout // 4) if pc.pixel_shuffle else (oh, ow, pc.cout)
+    if out is None:
+        out = new_act(n, OH, OW, oc, device=s0.buf.device)
+    assert (out.n, out.h, out.w, out.c) == (n, OH, OW, oc), f"out geometry {(out.n, out.h, out.w, out.c)} != {(n, OH, OW, oc)}"
+    use_direct = (not force_mfma and pc.cout <= 16 and len(srcs) == 1 and k >= 3 and pc.ck == 8 and not pc.transposed
+                  and not pc.pixel_shuffle and pixmul is None and weight_image_stride == 0 and src_image_stride is None)
+    if stride == 4:
+        assert use_direct, "stride 4 is only available through the direct kernel"
+    if use_direct:
+        _abi.check(lib.gpemsr_conv2d_direct(s0.ptr, n, h, w, s0.ld, s0.c, pc.w.data_ptr(),
+                                            pc.b.data_ptr() if pc.b is not None else None, pc.cout, k, stride, act,
+                                            residual.ptr if residual is not None else None,
+                                            residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()),
+                   "conv2d_direct")
+        return out
+    d = _abi.ConvDesc()
+    d.n, d.h, d.w, d.nsrc = n, h, w, len(srcs)
+    for i, s in enumerate(srcs):
+        assert (s.n, s.h, s.w) == (n, h, w) or (src_image_stride is not None)
+        d.src[i].ptr, d.src[i].ld, d.src[i].c = s.ptr, s.ld, s.c
+        d.src_image_stride[i] = -1 if src_image_stride is None else int(src_image_stride[i])
+    d.cout, d.ksize, d.stride, d.transposed = pc.cout, k, stride, int(pc.transposed)
+    d.weight, d.weight_image_stride = pc.w.data_ptr(), int(weight_image_stride)
+    d.bias = pc.b.data_ptr() if pc.b is not None else None
+    d.act = act
+    if residual is not None:
+        assert (residual.n, residual.h, residual.w, residual.c) == (n, OH, OW, oc)
+        d.residual, d.res_ld = residual.ptr, residual.ld
+    if pixmul is not None:
+        assert pixmul.c == 1 and pixmul.ld == 1 and (pixmul.n, pixmul.h, pixmul.w) == (n, OH, OW)
+        d.pixmul = pixmul.ptr
+    d.pixel_shuffle = int(pc.pixel_shuffle)
+    d.out, d.out_ld = out.ptr, out.ld
+    _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
+    return out
+
+
+def groupnorm_relu(x: Act, gamma: torch.Tensor, beta: torch.Tensor, relu: bool = True, residual: Optional[Act] = None,
+                   out: Optional[Act] = None, groups: int = 32, eps: float = 1e-6) -> Act:
+    lib = _abi.load()
+    _require_gpu(x)
+    hw = x.h * x.w
+    parts = max(1, min(64, hw // 64))
+    ws = torch.empty(x.n * parts * x.c * 2 + x.n * groups * 2, dtype=torch.float32, device=x.buf.device)
+    mr = ws[x.n * parts * x.c * 2:]
+    _abi.check(lib.gpemsr_groupnorm_stats(x.ptr, x.n, hw, x.c, x.ld, groups, eps, ws.data_ptr(), parts, mr.data_ptr(),
+                                          _stream()), "groupnorm_stats")
+    if out is None:
+        out = new_act(x.n, x.h, x.w, x.c, device=x.buf.device)
+    _abi.check(lib.gpemsr_groupnorm_apply(x.ptr, x.n, hw, x.c, x.ld, groups, mr.data_ptr(), gamma.data_ptr(),
+                                          beta.data_ptr(), int(relu), residual.ptr if residual is not None else None,
+                                          residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()),
+               "groupnorm_apply")
+    return out
+
+
+def softmax_rows_(x: torch.Tensor, rows: int, cols: int):
+    _abi.check(_abi.load().gpemsr_softmax_rows(x.data_ptr(), rows, cols, _stream()), "softmax_rows")
+
+
+def argmax_rows(x: Act) -> torch.Tensor:
+    assert x.ld == x.c
+    idx = torch.empty(x.pixels, dtype=torch.int32, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_argmax_rows(x.ptr, x.pixels, x.c, idx.data_ptr(), _stream()), "argmax_rows")
+    return idx
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, n: int, h: int, w: int) -> Act:
+    dim = table.shape[1]
+    out = new_act(n, h, w, dim, device=table.device)
+    _abi.check(_abi.load().gpemsr_gather_rows(table.data_ptr(), dim, idx.data_ptr(), n * h * w, out.ptr, out.ld, _stream()),
+               "gather_rows")
+    return out
+
+
+def bilinear(x: Act, oh: int, ow: int, align_corners: bool = False, mul: float = 1.0, out: Optional[Act] = None) -> Act:
+    _require_gpu(x)
+    if out is None:
+        out = new_act(x.n, oh, ow, x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_bilinear(x.ptr, x.n, x.h, x.w, x.c, x.ld, oh, ow, int(align_corners), mul, out.ptr,
+                                           out.ld, _stream()), "bilinear")
+    return out
+
+
+def avgpool2(x: Act) -> Act:
+    out = new_act(x.n, x.h // 2, x.w // 2, x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_avgpool2(x.ptr, x.n, x.h, x.w, x.c, x.ld, out.ptr, out.ld, _stream()), "avgpool2")
+    return out
+
+
+def pool3s2_maxavg(x: Act) -> Act:
+    oh, ow = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
+    out = new_act(x.n, oh, ow, 2 * x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_pool3s2_maxavg(x.ptr, x.n, x.h, x.w, x.c, x.ld, out.ptr, out.ld, _stream()), "pool3s2")
+    return out
+
+
+def spynet_prep(ref: Act, supp: Act, flow_coarse: Optional[Act], mean3, std3):
+    assert ref.c == 1 and ref.ld == 1 and supp.c == 1 and supp.ld == 1
+    up = new_act(ref.n, ref.h, ref.w, 2, device=ref.buf.device)
+    inp = new_act(ref.n, ref.h, ref.w, 8, device=ref.buf.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    s = (C.c_float * 3)(*[float(v) for v in std3])
+    if flow_coarse is not None:
+        assert flow_coarse.ld == 2 and flow_coarse.h * 2 == ref.h and flow_coarse.w * 2 == ref.w
+    _abi.check(_abi.load().gpemsr_spynet_prep(ref.ptr, supp.ptr, flow_coarse.ptr if flow_coarse is not None else None,
+                                              ref.n, ref.h, ref.w, m, s, up.ptr, inp.ptr, _stream()), "spynet_prep")
+    return up, inp
+
+
+def dcn_columns(x: Act, om: Act, groups: int) -> Act:
+    col = new_act(x.n, x.h, x.w, 9 * x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_dcn_columns(x.ptr, x.n, x.h, x.w, x.c, x.ld, om.ptr, om.ld, groups, col.ptr, _stream()),
+               "dcn_columns")
+    return col
+
+
+def patch_cosine(a: Act, b: Act) -> Act:
+    assert a.ld == a.c and b.ld == b.c
+    out = new_act(a.n, a.h // 16, a.w // 16, 1, device=a.buf.device)
+    _abi.check(_abi.load().gpemsr_patch_cosine(a.ptr, b.ptr, a.n, a.h, a.w, a.c, out.ptr, _stream()), "patch_cosine")
+    return out
+
+
+def temporal_gate(aligned: Act, emb: Act, emb_ref: Act, b: int, t: int) -> Act:
+    """aligned/emb: [b*t,h,w,c]; emb_ref: [b,h,w,c] -> af [b,h,w,t*c]."""
+    assert aligned.ld == aligned.c and emb.ld == emb.c and emb_ref.ld == emb_ref.c
+    af = new_act(b, aligned.h, aligned.w, t * aligned.c, device=aligned.buf.device)
+    _abi.check(_abi.load().gpemsr_temporal_gate(aligned.ptr, emb.ptr, emb_ref.ptr, b, t, aligned.h * aligned.w, aligned.c,
+                                                af.ptr, _stream()), "temporal_gate")
+    return af
+
+
+def frame_mix_lrelu(af: Act, t: int, m: torch.Tensor, bias: torch.Tensor) -> Act:
+    assert af.ld == af.c and af.c % t == 0
+    out = new_act(af.n, af.h, af.w, af.c, device=af.buf.device)
+    _abi.check(_abi.load().gpemsr_frame_mix_lrelu(af.ptr, af.pixels, t, af.c // t, m.data_ptr(), bias.data_ptr(), out.ptr,
+                                                  _stream()), "frame_mix")
+    return out
+
+
+def threeda_combine(feat: Act, attn: Act, attn_add: Act, f2: Act, f3: Act) -> Act:
+    for a in (feat, attn, attn_add, f2, f3):
+        assert a.ld == a.c
+    out = new_act(feat.n, feat.h, feat.w, feat.c, device=feat.buf.device)
+    _abi.check(_abi.load().gpemsr_threeda_combine(feat.ptr, attn.ptr, attn_add.ptr, f2.ptr, f3.ptr, feat.pixels * feat.c,
+                                                  out.ptr, _stream()), "threeda_combine")
+    return out
+
+
+def tensor2img_u8(x: torch.Tensor) -> torch.Tensor:
+    """util/util.py:145-163 on device: clamp -> *255 -> round-half-even -> uint8 (same shape)."""
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _abi.check(_abi.load().gpemsr_tensor2img_u8(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "tensor2img")
+    return out
+
+
+def copy_channels(src: Act, dst: Act):
+    assert src.pixels == dst.pixels and src.c == dst.c
+    _abi.check(_abi.load().gpemsr_copy_channels(src.ptr, src.ld, dst.ptr, dst.ld, src.pixels, src.c, _stream()),
+               "copy_channels")
+
+
+def copy_images(src: Act, n_dst: int, div: int, mul: int, add: int) -> Act:
+    """dst image j = src image (j // div) * mul + add (dense NHWC images, ld == c)."""
+    assert src.ld == src.c and src.off == 0
+    dst = new_act(n_dst, src.h, src.w, src.c, device=src.buf.device)
+    _abi.check(_abi.load().gpemsr_copy_images(src.ptr, dst.ptr, n_dst, src.h * src.w * src.c, div, mul, add, _stream()),
+               "copy_images")
+    return dst

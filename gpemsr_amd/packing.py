@@ -1,0 +1,75 @@
+"""Weight repacking: reference state-dict layouts -> the kernel-native layout of
+gpemsr_conv2d ([tap][cout][cin_pad], cin fastest, cin padded per concat source to
+the kernel's channel chunk: 8 for k>=3, 32 for 1x1).  Done once at load time.
+
+Reference layouts (model/GPEMSR.py, model/blocks.py): Conv2d OIHW; ConvTranspose2d
+[Cin,Cout,3,3]; Linear [out,in]; DCNv2Pack.weight [Cout,Cin,3,3]."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from .ops import PackedConv
+
+
+def _pad_split(w_tco: torch.Tensor, splits: Sequence[int], ck: int) -> torch.Tensor:
+    """w_tco: [tap][cout][cin] -> cin padded per split to a multiple of ck."""
+    pieces, off = [], 0
+    for c in splits:
+        piece = w_tco[:, :, off:off + c]
+        pad = (-c) % ck
+        if pad:
+            piece = torch.cat([piece, piece.new_zeros(piece.shape[0], piece.shape[1], pad)], dim=2)
+        pieces.append(piece)
+        off += c
+    assert off == w_tco.shape[2], (off, w_tco.shape)
+    return torch.cat(pieces, dim=2).contiguous()
+
+
+def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, splits: Optional[Sequence[int]] = None,
+              pixel_shuffle: bool = False, scale: float = 1.0) -> PackedConv:
+    cout, cin, kh, kw = w.shape
+    assert kh == kw
+    ck = 32 if kh == 1 else 8
+    splits = tuple(splits) if splits is not None else (cin,)
+    wt = w.detach().to(torch.float32).permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
+    bb = None if b is None else b.detach().to(torch.float32).clone()
+    if scale != 1.0:
+        wt = wt * scale
+        bb = None if bb is None else bb * scale
+    if pixel_shuffle:
+        # PixelShuffle(2): out[c', 2y+i, 2x+j] = in[4c'+2i+j, y, x]; regroup rows as (2i+j)*C/4 + c'
+        cq = cout // 4
+        perm = torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)
+        wt = wt[:, perm]
+        bb = None if bb is None else bb[perm]
+    packed = _pad_split(wt, splits, ck).to(device)
+    return PackedConv(packed, None if bb is None else bb.contiguous().to(device), kh, cout, splits, ck,
+                      transposed=False, pixel_shuffle=pixel_shuffle)
+
+
+def pack_convT(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
+    cin, cout, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    wt = w.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(9, cout, cin)
+    return PackedConv(_pad_split(wt, (cin,), 8).to(device), b.detach().to(torch.float32).contiguous().to(device), 3, cout,
+                      (cin,), 8, transposed=True)
+
+
+def pack_linear(w: torch.Tensor, b: Optional[torch.Tensor], device) -> PackedConv:
+    return pack_conv(w.reshape(w.shape[0], w.shape[1], 1, 1), b, device)
+
+
+def pack_dcn(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
+    """DCN contraction as a 1x1 conv over the tap-major column tensor [9*cin]."""
+    cout, cin, kh, kw = w.shape
+    wt = w.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(1, cout, kh * kw * cin)
+    return PackedConv(_pad_split(wt, (kh * kw * cin,), 32).to(device), b.detach().to(torch.float32).contiguous().to(device),
+                      1, cout, (kh * kw * cin,), 32)
+
+
+def pack_vgg_first(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
+    """vgg conv1_1 applied to a 1-channel image expanded to 3 identical channels
+    (model/GPEMSR.py:386,390) == a 1->64 conv with the weights summed over Cin."""
+    return pack_conv(w.detach().to(torch.float32).sum(dim=1, keepdim=True), b, device)

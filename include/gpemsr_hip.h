@@ -1,0 +1,166 @@
+/* gpemsr_hip.h -- C ABI of libgpemsr_hip.so, the MI355X (gfx950) kernel library
+ * behind the GPEMSR stage-3 super-resolution forward.
+ *
+ * The reference (jtshou/GPEMSR) has no FFI: every op on its hot path is a
+ * PyTorch ATen call (or basicsr/torchvision op) issued from
+ *   GPEMSR-CREMI/GPEMSR/model/GPEMSR.py:323-456  (GPEMSR.forward)
+ * Each entry point below replaces the ATen/third-party call(s) named in its
+ * comment; the Python host (gpemsr_amd/) binds them with ctypes and a reference
+ * maintainer would bind them the same way.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer; activations are float32 NHWC
+ *    ([n][h][w][c], c fastest) with an explicit per-pixel stride `ld`
+ *    (elements) so a tensor can be a channel slice of a wider buffer
+ *    (this is how torch.cat along C is made free);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued, nothing
+ *    synchronises, nothing allocates (graph-capture safe);
+ *  - return value 0 = success; otherwise a negative GPEMSR_E* code and
+ *    gpemsr_last_error() describes it.  No exceptions cross the ABI.
+ *  - the library owns no memory; the caller owns inputs, outputs, workspaces.
+ */
+#ifndef GPEMSR_HIP_H
+#define GPEMSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPEMSR_ABI_VERSION 1
+
+enum { GPEMSR_OK = 0, GPEMSR_EINVAL = -1, GPEMSR_ELAUNCH = -2, GPEMSR_EUNSUPPORTED = -3 };
+
+/* activation applied to (acc + bias) */
+enum {
+  GPEMSR_ACT_NONE = 0,
+  GPEMSR_ACT_RELU = 1,          /* basicsr ResidualBlockNoBN, VGG, SpyNet, VQGAN blocks */
+  GPEMSR_ACT_LRELU = 2,         /* LeakyReLU(0.1): model/GPEMSR.py:96,168,321 */
+  GPEMSR_ACT_SIGMOID = 3,
+  GPEMSR_ACT_LRELU_SIGMOID = 4  /* sigmoid(lrelu(x)): model/GPEMSR.py:398-399 */
+};
+
+int gpemsr_abi_version(void);
+const char* gpemsr_last_error(void);
+/* name, CU count, total HBM bytes of the current device (diagnostics for bench.py) */
+int gpemsr_device_info(char* name, int name_len, int* cu_count, int64_t* hbm_bytes);
+
+/* ---------------------------------------------------------------------------
+ * Convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32, LDS-staged halo)
+ * replaces: F.conv2d / nn.Conv2d (k in {1,3,7}, stride in {1,2}, pad k/2),
+ *           nn.ConvTranspose2d(k3,s2,p1,op1)  (model/GPEMSR.py:252-254, blocks.py:35),
+ *           nn.Linear and torch.bmm (as 1x1 convs with per-image weights:
+ *           blocks.py:75,80; indexer.py:100), nn.PixelShuffle(2) fused into the
+ *           store (model/GPEMSR.py:442-448), torch.cat along C (multi-source input),
+ *           residual adds and the mask multiply of the MPF (model/GPEMSR.py:403-411).
+ * ------------------------------------------------------------------------- */
+#define GPEMSR_MAX_SRC 4
+
+typedef struct {
+  const float* ptr;  /* NHWC base of this source */
+  int32_t ld;        /* elements between consecutive pixels */
+  int32_t c;         /* channels taken from this source */
+} gpemsr_src_t;
+
+typedef struct {
+  int32_t n, h, w;                 /* input images, height, width */
+  int32_t nsrc;
+  gpemsr_src_t src[GPEMSR_MAX_SRC];/* virtual concat along C, in order */
+  int64_t src_image_stride[GPEMSR_MAX_SRC]; /* elements between images; 0 = shared by all n; <0 = dense (h*w*ld) */
+  int32_t cout;
+  int32_t ksize;                   /* 1, 3 or 7 */
+  int32_t stride;                  /* 1 or 2 (ignored when transposed) */
+  int32_t transposed;              /* 1 = ConvTranspose2d(k=3,s=2,p=1,op=1): out is 2h x 2w */
+  const float* weight;             /* packed [tap][cout][cin_total], tap = ky*k+kx, cin fastest */
+  int64_t weight_image_stride;     /* elements; 0 = one weight set for all images (normal conv) */
+  const float* bias;               /* [cout] or NULL */
+  int32_t act;                     /* GPEMSR_ACT_* */
+  const float* residual;           /* added after act; same geometry as out; NULL = none */
+  int32_t res_ld;
+  const float* pixmul;             /* [n][oh][ow] multiplier applied last; NULL = none */
+  int32_t pixel_shuffle;           /* 1: store as PixelShuffle(2); weight rows pre-permuted so that
+                                      cout index = (2*i+j)*(cout/4)+c ; out is [n][2oh][2ow][cout/4] */
+  float* out;
+  int32_t out_ld;
+} gpemsr_conv_desc;
+
+int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream);
+
+/* Direct (VALU) convolution for tiny channel counts: cout <= 16, any k<=7, stride 1/2/4.
+ * replaces: POD.flowdsconv* (model/GPEMSR.py:70-75,101-106), SpyNet's last 16->2 conv,
+ * conv_last / decoder.output_layer / refmaskconv3 (cout = 1).  weight layout as above. */
+int gpemsr_conv2d_direct(const float* x, int n, int h, int w, int ld, int cin,
+                         const float* weight, const float* bias, int cout, int ksize, int stride,
+                         int act, const float* residual, int res_ld, float* out, int out_ld, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * GroupNorm(32, eps) statistics + fused apply (+ReLU, +residual)
+ * replaces: model/blocks.py:5-6,13-28  (Normalize -> ReLU, and x + block(x))
+ * stats: ws must hold n*parts*c*2 floats; mean_rstd gets [n][groups][2].
+ * ------------------------------------------------------------------------- */
+int gpemsr_groupnorm_stats(const float* x, int n, int hw, int c, int ld, int groups, float eps,
+                           float* ws, int parts, float* mean_rstd, void* stream);
+int gpemsr_groupnorm_apply(const float* x, int n, int hw, int c, int ld, int groups, const float* mean_rstd,
+                           const float* gamma, const float* beta, int relu,
+                           const float* residual, int res_ld, float* out, int out_ld, void* stream);
+
+/* row softmax in place: x[rows][cols] (blocks.py:77), row argmax -> int32 (codebook.py:38-40,
+ * ties -> lowest index) and row gather out[r] = table[idx[r]] (codebook.py:41). */
+int gpemsr_softmax_rows(float* x, int64_t rows, int cols, void* stream);
+int gpemsr_argmax_rows(const float* x, int64_t rows, int cols, int32_t* idx, void* stream);
+int gpemsr_gather_rows(const float* table, int dim, const int32_t* idx, int64_t rows, float* out, int out_ld,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Resampling
+ * ------------------------------------------------------------------------- */
+/* F.interpolate(mode='bilinear'): out = mul * bilinear(x).  align_corners 0/1.
+ * replaces model/GPEMSR.py:99,107-110,119,123,128,132,211,215,385,403-411,451-455 */
+int gpemsr_bilinear(const float* x, int n, int h, int w, int c, int ld, int oh, int ow, int align_corners,
+                    float mul, float* out, int out_ld, void* stream);
+/* F.avg_pool2d(2,2) (SpyNet pyramid) */
+int gpemsr_avgpool2(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld, void* stream);
+/* MaxPool2d(3,2,1) and AvgPool2d(3,2,1) (count_include_pad) written side by side:
+ * out[..., 0:c] = max, out[..., c:2c] = avg  == torch.cat([max, avg], 1)  (model/GPEMSR.py:201-204) */
+int gpemsr_pool3s2_maxavg(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld, void* stream);
+/* One SpyNet level input (basicsr SpyNet.process): up = 2*bilinear_x2(flow, align_corners=True)
+ * (zeros when flow == NULL), inp = cat[norm(ref), flow_warp(norm(supp), up, border), up] (8 ch).
+ * ref/supp are the 1-channel raw pyramids; mean3/std3 are HOST pointers to the three
+ * ImageNet mean/std constants that basicsr broadcasts over the (1-channel) input. */
+int gpemsr_spynet_prep(const float* ref, const float* supp, const float* flow_coarse, int n, int h, int w,
+                       const float* mean3, const float* std3, float* up_flow, float* inp8, void* stream);
+/* Modulated deformable sampling (torchvision deform_conv2d, k3 p1): builds the column tensor
+ * col[n][h][w][9*c] (tap-major) from x and the raw conv_offset output `om` ([.., 3*groups*9]:
+ * chunk 0,1 -> offsets (basicsr DCNv2Pack cat(o1,o2)), chunk 2 -> mask logits). */
+int gpemsr_dcn_columns(const float* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
+                       float* col, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * GPEMSR-specific fused elementwise / reductions
+ * ------------------------------------------------------------------------- */
+/* model/GPEMSR.py:387-395: cosine similarity of co-located 16x16xC patches. a,b: [n][h][w][c]. */
+int gpemsr_patch_cosine(const float* a, const float* b, int n, int h, int w, int c, float* out, void* stream);
+/* ThreeDA temporal gating (model/GPEMSR.py:179-187): af[b][h][w][t*c] = aligned * sigmoid(sum_c emb*emb_ref) */
+int gpemsr_temporal_gate(const float* aligned, const float* emb, const float* emb_ref, int b, int t, int hw, int c,
+                         float* af, void* stream);
+/* nn.Conv3d(t,t,1) over the frame axis + LeakyReLU (model/GPEMSR.py:191,193) on af[b][hw][t*c] */
+int gpemsr_frame_mix_lrelu(const float* af, int64_t pixels, int t, int c, const float* m, const float* bias,
+                           float* out, void* stream);
+/* model/GPEMSR.py:219-221: out = feat*sigmoid(attn)*2 + attn_add + f2 + f3 */
+int gpemsr_threeda_combine(const float* feat, const float* attn, const float* attn_add, const float* f2,
+                           const float* f3, int64_t count, float* out, void* stream);
+/* util/util.py:145-163 tensor2img: clamp[0,1] -> *255 -> round-half-even -> uint8 */
+int gpemsr_tensor2img_u8(const float* x, int64_t count, uint8_t* out, void* stream);
+/* strided channel copy (assembling small concat buffers): dst[p][0:c] = src[p][0:c] */
+int gpemsr_copy_channels(const float* src, int src_ld, float* dst, int dst_ld, int64_t pixels, int c, void* stream);
+
+/* image regrouping: dst image j = src image (j / div) * mul + add  (elems_per_image % 4 == 0).
+ * replaces the x[:, i] / [:, center].clone() indexing of model/GPEMSR.py:325,427-437,175. */
+int gpemsr_copy_images(const float* src, float* dst, int64_t n_dst, int64_t elems_per_image, int div, int mul, int add,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPEMSR_HIP_H */

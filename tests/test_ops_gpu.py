@@ -1,0 +1,341 @@
+"""Known-answer tests of every C-ABI op against torch CPU functional ops
+(none exist upstream, so the build authors them).  All calls go
+through ctypes -> libgpemsr_hip.so; tolerances are fp32-accumulation level."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _to_act(x_nchw, dev, ld=None, off=0):
+    """NCHW cpu tensor -> Act on device, optionally embedded in a wider buffer."""
+    from gpemsr_amd import ops
+    n, c, h, w = x_nchw.shape
+    ld = c if ld is None else ld
+    buf = torch.full((n, h, w, ld), 7.0)
+    buf[..., off:off + c] = x_nchw.permute(0, 2, 3, 1)
+    return ops.Act(buf.to(dev).contiguous(), n, h, w, c, ld, off)
+
+
+def _close(got, want, tol=2e-5, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    ref = max(want.abs().max().item(), 1e-6)
+    assert err <= tol * ref + 1e-6, f"{what}: max err {err:.3e} vs ref max {ref:.3e}"
+
+
+CONV_CASES = [
+    # (n, cins, cout, k, stride, h, w, act, residual, pixmul)
+    (2, (64,), 64, 3, 1, 16, 16, 1, True, False),
+    (1, (1,), 64, 3, 1, 24, 40, 2, False, False),
+    (2, (64, 64), 64, 3, 1, 17, 19, 0, True, True),
+    (1, (64, 128, 64), 64, 3, 1, 16, 32, 0, False, False),
+    (1, (64, 64, 32, 2), 64, 3, 1, 8, 8, 2, False, False),
+    (1, (64,), 216, 3, 1, 16, 16, 0, False, False),
+    (2, (64,), 64, 3, 2, 32, 32, 2, False, False),
+    (1, (256,), 512, 3, 2, 16, 16, 0, False, False),
+    (1, (128,), 256, 3, 1, 16, 16, 0, False, False),
+    (1, (8,), 32, 7, 1, 32, 32, 1, False, False),
+    (1, (32,), 64, 7, 1, 16, 48, 1, False, False),
+    (1, (64,), 32, 7, 1, 9, 11, 1, False, False),
+    (2, (512,), 512, 1, 1, 8, 8, 0, True, False),
+    (1, (64, 128, 64), 64, 1, 1, 16, 16, 0, False, False),
+    (1, (320,), 64, 1, 1, 12, 20, 2, False, False),
+    (1, (512,), 1024, 1, 1, 8, 8, 0, False, False),
+    (1, (64,), 20, 3, 1, 16, 16, 3, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_mfma(case):
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv
+    n, cins, cout, k, stride, h, w, act, use_res, use_mul = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _rand(n, cin, h, w, seed=1)
+    wt = _rand(cout, cin, k, k, seed=2, scale=1.0 / np.sqrt(cin * k * k))
+    b = _rand(cout, seed=3, scale=0.1)
+    want = F.conv2d(x, wt, b, stride, k // 2)
+    if act == 1:
+        want = F.relu(want)
+    elif act == 2:
+        want = F.leaky_relu(want, 0.1)
+    elif act == 3:
+        want = torch.sigmoid(want)
+    oh, ow = want.shape[2:]
+    res = _rand(n, cout, oh, ow, seed=4) if use_res else None
+    mul = torch.rand(n, 1, oh, ow, generator=torch.Generator().manual_seed(5)) if use_mul else None
+    if res is not None:
+        want = want + res
+    if mul is not None:
+        want = want * mul
+    srcs, off = [], 0
+    for i, c in enumerate(cins):      # each source lives in its own (sometimes wider) buffer
+        pad = 8 if (i % 2 == 1 and c % 4 == 0) else 0
+        srcs.append(_to_act(x[:, off:off + c], dev, ld=c + pad, off=pad // 2 if pad else 0))
+        off += c
+    pc = pack_conv(wt, b, dev, cins)
+    out = ops.conv2d(srcs, pc, act, stride=stride, residual=_to_act(res, dev) if use_res else None,
+                     pixmul=_to_act(mul, dev) if use_mul else None, force_mfma=True)
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, what=f"conv {case}")
+
+
+def test_conv2d_output_slice_and_images():
+    """out may be a channel slice of a wider buffer (free torch.cat of producers)."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv
+    dev = _dev()
+    x = _rand(3, 64, 16, 16, seed=11)
+    wt = _rand(64, 64, 3, 3, seed=12, scale=0.05)
+    b = _rand(64, seed=13)
+    want = F.conv2d(x, wt, b, 1, 1)
+    big = ops.new_act(3, 16, 16, 160, device=dev)
+    big.buf.fill_(-3.0)
+    ops.conv2d([_to_act(x, dev)], pack_conv(wt, b, dev), 0, out=big.slice(32, 64))
+    torch.cuda.synchronize()
+    t = big.torch().cpu()
+    _close(t[..., 32:96].permute(0, 3, 1, 2), want, what="slice out")
+    assert float(t[..., :32].min()) == -3.0 and float(t[..., 96:].max()) == -3.0
+    sub = big.slice(32, 64).images(1, 2)
+    _close(sub.nchw(), want[1:3], what="images view")
+
+
+def test_conv_transpose():
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_convT
+    dev = _dev()
+    for (n, cin, cout, h, w, act) in [(2, 64, 64, 16, 16, 2), (1, 512, 256, 8, 8, 0), (1, 64, 64, 9, 21, 0), (1, 128, 64, 16, 16, 0)]:
+        x = _rand(n, cin, h, w, seed=21)
+        wt = _rand(cin, cout, 3, 3, seed=22, scale=1.0 / np.sqrt(cin * 2.25))
+        b = _rand(cout, seed=23, scale=0.1)
+        want = F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1)
+        if act == 2:
+            want = F.leaky_relu(want, 0.1)
+        out = ops.conv2d([_to_act(x, dev)], pack_convT(wt, b, dev), act)
+        torch.cuda.synchronize()
+        _close(out.nchw(), want, what=f"convT {(n, cin, cout, h, w)}")
+
+
+def test_pixel_shuffle_fused():
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv
+    dev = _dev()
+    x = _rand(2, 64, 12, 20, seed=31)
+    wt = _rand(256, 64, 3, 3, seed=32, scale=0.05)
+    b = _rand(256, seed=33, scale=0.1)
+    want = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, wt, b, 1, 1), 2), 0.1)
+    out = ops.conv2d([_to_act(x, dev)], pack_conv(wt, b, dev, pixel_shuffle=True), ops.ACT_LRELU)
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, what="pixel shuffle")
+
+
+def test_batched_weight_gemm():
+    """torch.bmm as a 1x1 conv with per-image weights (attention products)."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    n, T, Cc = 3, 64, 96
+    q = _rand(n, T, Cc, seed=41)
+    k = _rand(n, T, Cc, seed=42)
+    want = torch.bmm(q, k.transpose(1, 2))                       # [n,T,T]
+    qa = ops.Act(q.to(dev).contiguous(), n, T // 16, 16, Cc, Cc, 0)
+    kd = k.to(dev).contiguous()
+    S = ops.conv2d([qa], ops.PackedConv(kd, None, 1, T, (Cc,), 32), 0, weight_image_stride=T * Cc)
+    torch.cuda.synchronize()
+    _close(S.torch().reshape(n, T, T), want, what="bmm")
+    # shared A (image stride 0) with per-image weights
+    a = _rand(32, Cc, seed=43)
+    want2 = torch.einsum("ic,njc->nij", a, k)
+    aa = ops.Act(a.to(dev).contiguous(), n, 2, 16, Cc, Cc, 0)
+    o2 = ops.new_act(n, 2, 16, T, device=dev)
+    ops.conv2d([aa], ops.PackedConv(kd, None, 1, T, (Cc,), 32), 0, weight_image_stride=T * Cc, src_image_stride=[0], out=o2)
+    torch.cuda.synchronize()
+    _close(o2.torch().reshape(n, 32, T), want2, what="shared-A bmm")
+
+
+DIRECT_CASES = [(2, 64, 1, 3, 1, 32, 32), (1, 16, 2, 7, 1, 16, 24), (1, 2, 16, 3, 4, 64, 64), (2, 16, 16, 3, 2, 16, 16),
+                (1, 64, 1, 3, 1, 7, 9)]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES)
+def test_conv2d_direct(case):
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv
+    n, cin, cout, k, stride, h, w = case
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=51)
+    wt = _rand(cout, cin, k, k, seed=52, scale=1.0 / np.sqrt(cin * k * k))
+    b = _rand(cout, seed=53, scale=0.1)
+    want = F.leaky_relu(F.conv2d(x, wt, b, stride, k // 2), 0.1)
+    res = _rand(*want.shape, seed=54)
+    want = want + res
+    out = ops.conv2d([_to_act(x, dev, ld=cin + (16 if cin % 4 == 0 else 0))], pack_conv(wt, b, dev), ops.ACT_LRELU, stride=stride,
+                     residual=_to_act(res, dev))
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, what=f"direct {case}")
+
+
+def test_groupnorm_relu_residual():
+    from gpemsr_amd import ops
+    dev = _dev()
+    for (n, c, h, w) in [(2, 64, 16, 16), (1, 512, 8, 8), (3, 128, 32, 32), (1, 256, 16, 16)]:
+        x = _rand(n, c, h, w, seed=61) * 3 + 0.7
+        g, b = _rand(c, seed=62) + 1.5, _rand(c, seed=63)
+        res = _rand(n, c, h, w, seed=64)
+        want = F.relu(F.group_norm(x.double(), 32, g.double(), b.double(), eps=1e-6)).float() + res
+        out = ops.groupnorm_relu(_to_act(x, dev), g.to(dev), b.to(dev), True, residual=_to_act(res, dev))
+        torch.cuda.synchronize()
+        _close(out.nchw(), want, tol=1e-5, what=f"groupnorm {(n, c, h, w)}")
+        want2 = F.group_norm(x, 32, g, b, eps=1e-6)
+        a = _to_act(x, dev)
+        ops.groupnorm_relu(a, g.to(dev), b.to(dev), False, out=a)
+        torch.cuda.synchronize()
+        _close(a.nchw(), want2, tol=1e-5, what="groupnorm in place")
+
+
+def test_softmax_argmax_gather():
+    from gpemsr_amd import ops, _abi
+    dev = _dev()
+    for cols in (64, 256, 4096):
+        x = _rand(37, cols, seed=71) * 6
+        d = x.to(dev).contiguous()
+        ops.softmax_rows_(d, 37, cols)
+        torch.cuda.synchronize()
+        _close(d, F.softmax(x, dim=1), tol=1e-5, what="softmax")
+    x = _rand(1001, 1024, seed=72)
+    x[5, 100] = x[5, 900] = 9.0          # tie -> lowest index
+    x[6, 1023] = 10.0
+    a = ops.Act(x.to(dev).contiguous(), 1, 1001, 1, 1024, 1024, 0)
+    idx = ops.argmax_rows(a)
+    torch.cuda.synchronize()
+    assert torch.equal(idx.cpu().long(), torch.argmax(x, dim=1))
+    assert int(idx[5]) == 100 and int(idx[6]) == 1023
+    table = _rand(1024, 512, seed=73)
+    g = ops.gather_rows(table.to(dev), idx, 1, 1001, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(g.torch().reshape(1001, 512).cpu(), table[idx.cpu().long()])
+
+
+def test_bilinear_and_pools():
+    from gpemsr_amd import ops
+    dev = _dev()
+    x = _rand(2, 5, 12, 20, seed=81)
+    for s in (2, 4, 8, 0.5):
+        want = F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False)
+        out = ops.bilinear(_to_act(x, dev, ld=8, off=2), want.shape[2], want.shape[3])
+        torch.cuda.synchronize()
+        _close(out.nchw(), want, tol=1e-5, what=f"bilinear x{s}")
+    want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
+    out = ops.bilinear(_to_act(x, dev), 24, 40, align_corners=True, mul=2.0)
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, tol=1e-5, what="bilinear align_corners")
+    want = F.interpolate(x, size=(32, 64), mode="bilinear", align_corners=False)
+    out = ops.bilinear(_to_act(x, dev), 32, 64)
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, tol=1e-5, what="bilinear to size")
+    _close(ops.avgpool2(_to_act(x, dev)).nchw(), F.avg_pool2d(x, 2, 2), tol=1e-6, what="avgpool2")
+    x = _rand(2, 64, 13, 16, seed=82)
+    want = torch.cat([F.max_pool2d(x, 3, 2, 1), F.avg_pool2d(x, 3, 2, 1)], 1)
+    _close(ops.pool3s2_maxavg(_to_act(x, dev)).nchw(), want, tol=1e-6, what="pool3s2")
+
+
+def test_spynet_prep_matches_basicsr_level():
+    """One SpyNet level input vs the restated basicsr math (oracle.flow_warp)."""
+    from gpemsr_amd import ops
+    from oracle import gpemsr_oracle as orc
+    dev = _dev()
+    n, h, w = 2, 16, 32
+    ref, supp = torch.rand(n, 1, h, w, generator=torch.Generator().manual_seed(91)), torch.rand(n, 1, h, w, generator=torch.Generator().manual_seed(92))
+    flow = _rand(n, 2, h // 2, w // 2, seed=93) * 3
+    mean = torch.tensor(orc._SPY_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(orc._SPY_STD).view(1, 3, 1, 1)
+    up = F.interpolate(flow, scale_factor=2, mode="bilinear", align_corners=True) * 2.0
+    want = torch.cat([(ref - mean) / std, orc.flow_warp((supp - mean) / std, up.permute(0, 2, 3, 1)), up], 1)
+    u, inp = ops.spynet_prep(_to_act(ref, dev), _to_act(supp, dev), _to_act(flow, dev), orc._SPY_MEAN, orc._SPY_STD)
+    torch.cuda.synchronize()
+    _close(u.nchw(), up, tol=1e-5, what="up flow")
+    _close(inp.nchw(), want, tol=2e-5, what="spynet level input")
+    u0, inp0 = ops.spynet_prep(_to_act(ref, dev), _to_act(supp, dev), None, orc._SPY_MEAN, orc._SPY_STD)
+    torch.cuda.synchronize()
+    want0 = torch.cat([(ref - mean) / std, (supp - mean) / std, torch.zeros(n, 2, h, w)], 1)
+    _close(inp0.nchw(), want0, tol=1e-5, what="spynet level 0")
+
+
+def test_dcn_matches_torchvision_semantics():
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_dcn
+    from oracle import gpemsr_oracle as orc
+    dev = _dev()
+    n, c, h, w = 2, 64, 12, 16
+    x = _rand(n, c, h, w, seed=101)
+    feat = _rand(n, c, h, w, seed=102)
+    sd = {"d.weight": _rand(64, 64, 3, 3, seed=103, scale=0.05), "d.bias": _rand(64, seed=104, scale=0.1),
+          "d.conv_offset.weight": _rand(216, 64, 3, 3, seed=105, scale=0.08), "d.conv_offset.bias": _rand(216, seed=106)}
+    want = orc.dcn_v2_pack(sd, "d", x, feat)
+    om = ops.conv2d([_to_act(feat, dev)], pack_conv(sd["d.conv_offset.weight"], sd["d.conv_offset.bias"], dev), 0)
+    col = ops.dcn_columns(_to_act(x, dev), om, 8)
+    out = ops.conv2d([col], pack_dcn(sd["d.weight"], sd["d.bias"], dev), 0)
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, tol=3e-5, what="dcn")
+    # large offsets exercise the out-of-image rule
+    sd["d.conv_offset.bias"] = _rand(216, seed=107) * 12
+    want = orc.dcn_v2_pack(sd, "d", x, feat)
+    om = ops.conv2d([_to_act(feat, dev)], pack_conv(sd["d.conv_offset.weight"], sd["d.conv_offset.bias"], dev), 0)
+    out = ops.conv2d([ops.dcn_columns(_to_act(x, dev), om, 8)], pack_dcn(sd["d.weight"], sd["d.bias"], dev), 0)
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, tol=3e-5, what="dcn big offsets")
+
+
+def test_patch_cosine_and_threeda_pieces():
+    from gpemsr_amd import ops
+    from oracle import gpemsr_oracle as orc
+    dev = _dev()
+    a, b = torch.rand(2, 64, 32, 48, generator=torch.Generator().manual_seed(111)), torch.rand(2, 64, 32, 48, generator=torch.Generator().manual_seed(112))
+    out = ops.patch_cosine(_to_act(a, dev), _to_act(b, dev))
+    torch.cuda.synchronize()
+    _close(out.nchw(), orc.patch_cosine(a, b), tol=1e-5, what="patch cosine")
+    B, T, c, h, w = 2, 5, 64, 8, 12
+    al, emb, er = _rand(B * T, c, h, w, seed=113), _rand(B * T, c, h, w, seed=114) * 0.3, _rand(B, c, h, w, seed=115)
+    corr = torch.sigmoid((emb.view(B, T, c, h, w) * er.unsqueeze(1)).sum(2))          # B,T,h,w
+    want = (al.view(B, T, c, h, w) * corr.unsqueeze(2)).reshape(B, T * c, h, w)
+    af = ops.temporal_gate(_to_act(al, dev), _to_act(emb, dev), _to_act(er, dev), B, T)
+    torch.cuda.synchronize()
+    _close(af.nchw(), want, tol=1e-5, what="temporal gate")
+    m, bias = _rand(T, T, seed=116), _rand(T, seed=117)
+    want2 = F.leaky_relu(torch.einsum("ij,bjchw->bichw", m, want.view(B, T, c, h, w)) + bias.view(1, T, 1, 1, 1), 0.1).reshape(B, T * c, h, w)
+    fm = ops.frame_mix_lrelu(af, T, m.to(dev), bias.to(dev))
+    torch.cuda.synchronize()
+    _close(fm.nchw(), want2, tol=1e-5, what="frame mix")
+    f = [_rand(B, c, h, w, seed=120 + i) for i in range(5)]
+    want3 = f[0] * torch.sigmoid(f[1]) * 2 + f[2] + f[3] + f[4]
+    out = ops.threeda_combine(*[_to_act(t, dev) for t in f])
+    torch.cuda.synchronize()
+    _close(out.nchw(), want3, tol=1e-5, what="threeda combine")
+
+
+def test_tensor2img_and_copies():
+    from gpemsr_amd import ops
+    dev = _dev()
+    x = torch.cat([torch.linspace(-0.2, 1.2, 4001), torch.tensor([0.5 / 255, 1.5 / 255, 2.5 / 255, 126.5 / 255])])
+    want = (x.clamp(0, 1).numpy() * 255.0).round().astype(np.uint8)
+    got = ops.tensor2img_u8(x.to(dev)).cpu().numpy()
+    assert np.array_equal(got, want)
+    src = _rand(10, 3, 4, 8, seed=131)
+    a = _to_act(src, dev)
+    d = ops.copy_images(a, 4, 2, 5, 3)          # dst j <- src (j//2)*5+3
+    torch.cuda.synchronize()
+    assert torch.equal(d.nchw().cpu(), src[[3, 3, 8, 8]])
