@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: output megapixels/s of the 8x EMSR stage-3 forward
+(5-slice 1x128x128 LR windows -> 1024x1024 HR tiles) on 1/2/4/8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one pass of the hot path over one batch of synthetic tiles: at N=1 the
+workload is BASELINE.json configs[1] (batch = 16 tiles, fp32, forward only); at N>1
+every rank runs the same 16 tiles/GPU (weak scaling) and the step ends with the RCCL
+all-gather of the HR output slabs (the north_star's only exchange step).  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with the
+`roofline` (conv implicit-GEMM kernel: algorithmic FLOPs / HIP-event time, against the
+fp32 matrix peak) and `cpu_baseline` (the CPU oracle timed on the host cores) objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+ESSENTIAL_GFLOP_PER_TILE = {8: 5901.7, 16: 4882.3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tiles", type=int, default=16, help="tiles (5-slice windows) per GPU per step")
+    ap.add_argument("--lr", type=int, default=128)
+    ap.add_argument("--scale", type=int, default=8, choices=(8, 16))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-lr", type=int, default=128, help="LR size of the CPU-oracle sample tile")
+    ap.add_argument("--layer-report", type=str, default="", help="write a per-layer conv timing table to this file")
+    args = ap.parse_args()
+
+    from gpemsr_amd import dist as gdist, ops
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+
+    rank, world, local = gdist.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{args.scale}.yml"))
+    model = build_model(opt, load_prior_files=False).eval().to(dev)
+    B, s, lr = args.tiles, args.scale, args.lr
+    x = synth_lr_tiles(B, 5, lr, lr, seed=1000 + rank, kind="uniform").to(dev)     # resident in HBM before timing
+
+    def step():
+        out, _ = gdist.forward_sharded(model, x, rank, world, already_local=True, gather=True)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert out.shape[0] == B * world
+
+    mp_per_step = world * B * (lr * s) * (lr * s) / 1e6
+    value = mp_per_step * args.steps / dt
+    summ = prof.summary()
+    conv = summ.get("conv_mfma", {"launches": 0, "ms": 0.0, "flops": 0.0})
+    achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+    alg_gflop_tile = conv["flops"] / 1e9 / (args.steps * B) if args.steps * B else 0.0
+    roofline = {
+        "bound": "mfma", "kernel": "conv_mfma_kernel (implicit-GEMM conv/GEMM family, v_mfma_f32_32x32x2_f32)",
+        "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+        "launches_per_step": conv["launches"] // max(args.steps, 1),
+        "avg_launch_us": round(1e3 * conv["ms"] / max(conv["launches"], 1), 2),
+        "algorithmic_gflop_per_tile_in_kernel": round(alg_gflop_tile, 1),
+        "essential_gflop_per_tile_survey": ESSENTIAL_GFLOP_PER_TILE[s],
+        "kernel_time_share_of_step": round(conv["ms"] * 1e-3 / dt, 3),
+        "whole_path_tflops_essential": round(ESSENTIAL_GFLOP_PER_TILE[s] * B * args.steps / dt / 1e3, 2),
+    }
+    if args.layer_report and rank == 0:
+        rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
+        with open(args.layer_report, "w") as f:
+            f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\n")
+            for (kern, tag), d in rows:
+                tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0
+                f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{tf:.1f}\n")
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample of the same workload: ONE 5-slice window through the CPU oracle on the host cores
+        from oracle import gpemsr_oracle as orc
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        xc = x[:1].cpu() if args.cpu_lr == lr else synth_lr_tiles(1, 5, args.cpu_lr, args.cpu_lr, seed=1000)
+        with torch.no_grad():
+            orc.gpemsr_forward(sd, synth_lr_tiles(1, 5, 16, 16, seed=1), scale=s)      # warm-up (tiny tile)
+            t1 = time.perf_counter()
+            o_cpu, _ = orc.gpemsr_forward(sd, xc, scale=s)
+            cdt = time.perf_counter() - t1
+        cpu_mp = (args.cpu_lr * s) ** 2 / 1e6 / cdt
+        cpu_baseline = {"value": round(cpu_mp, 5), "unit": "output megapixels/s", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": f"1 window [1,5,1,{args.cpu_lr},{args.cpu_lr}] -> {args.cpu_lr * s}^2, one pass "
+                                  f"({cdt:.1f} s) of oracle/gpemsr_oracle.py (torch CPU fp32; SpyNet de-duplicated, VGG slice1 only)"}
+        if args.cpu_lr == lr:
+            err = float((out[:1].cpu() - o_cpu).abs().max() / o_cpu.abs().max())
+            cpu_baseline["gpu_vs_cpu_rel_err_free_running"] = round(err, 6)
+
+    if rank == 0:
+        line = {
+            "metric": "output megapixels/sec, 8x EMSR 128->1024 tiles" if s == 8 else "output megapixels/sec, 16x EMSR 64->1024 tiles",
+            "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{s}x EMSR stage-3 forward, batch={B} synthetic 5x1x{lr}x{lr} LR windows per GPU -> "
+                                   f"{lr * s}x{lr * s} HR tiles, fp32 (BASELINE.json configs[1])",
+                       "tiles_per_gpu": B, "global_tiles": B * world, "lr": lr, "scale": s,
+                       "weights": "deterministic synthetic init (reference checkpoints are not redistributable)",
+                       "parallelism": f"tiles sharded over {world} GPU(s), RCCL all-gather of HR slabs" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,12 +87,14 @@ __global__ __launch_bounds__(256) void spynet_prep_kernel(const float* ref, cons
     const int yq = (int)((e / w) % h);
     const int img = (int)(e / ((long long)w * h));
     float fx = 0.f, fy = 0.f;
-    if (fc) {   // bilinear x2, align_corners=True, then *2
-      const float sh = ch2 > 1 ? (float)(ch2 - 1) / (float)(h - 1) : 0.f;
-      const float sw = cw2 > 1 ? (float)(cw2 - 1) / (float)(w - 1) : 0.f;
+    if (fc) {   // bilinear x2 (align_corners=True) of the [h/2][w/2] flow, *2, replicate-padded to h x w
+      const int uh = 2 * ch2, uw = 2 * cw2;
+      const float sh = uh > 1 ? (float)(ch2 - 1) / (float)(uh - 1) : 0.f;
+      const float sw = uw > 1 ? (float)(cw2 - 1) / (float)(uw - 1) : 0.f;
+      const int yu = yq < uh ? yq : uh - 1, xu = xq < uw ? xq : uw - 1;   // F.pad(..., mode='replicate')
       int y0, y1, x0, x1; float ly, lx;
-      src_index(yq, sh, 1, ch2, y0, y1, ly);
-      src_index(xq, sw, 1, cw2, x0, x1, lx);
+      src_index(yu, sh, 1, ch2, y0, y1, ly);
+      src_index(xu, sw, 1, cw2, x0, x1, lx);
       const float* b = fc + (long long)img * ch2 * cw2 * 2;
       const float hy = 1.f - ly, hx = 1.f - lx;
 #define GP_F(yy, xx, k) b[((long long)(yy) * cw2 + (xx)) * 2 + (k)]
@@ -185,7 +187,7 @@ extern "C" int gpemsr_bilinear(const float* x, int n, int h, int w, int c, int l
 }
 
 extern "C" int gpemsr_avgpool2(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld, void* stream) {
-  GP_REQUIRE(x && out && h % 2 == 0 && w % 2 == 0, "avgpool2: needs even h,w");
+  GP_REQUIRE(x && out && h >= 2 && w >= 2, "avgpool2: bad args");   // odd sizes floor like F.avg_pool2d
   hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((long long)n * (h / 2) * (w / 2) * c)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, n, h, w, c, ld, out, out_ld);
   return check_launch("avgpool2");
@@ -202,7 +204,7 @@ extern "C" int gpemsr_pool3s2_maxavg(const float* x, int n, int h, int w, int c,
 extern "C" int gpemsr_spynet_prep(const float* ref, const float* supp, const float* flow_coarse, int n, int h, int w,
                                   const float* mean3, const float* std3, float* up_flow, float* inp8, void* stream) {
   GP_REQUIRE(ref && supp && up_flow && inp8 && mean3 && std3, "spynet_prep: null pointer");
-  GP_REQUIRE(h % 2 == 0 && w % 2 == 0 && h >= 2 && w >= 2, "spynet_prep: needs even h,w (got %d x %d)", h, w);
+  GP_REQUIRE(h >= 2 && w >= 2, "spynet_prep: level smaller than 2x2 (got %d x %d); basicsr SpyNet needs inputs >= 64 px", h, w);
   GP_REQUIRE((reinterpret_cast<uintptr_t>(inp8) & 15) == 0, "spynet_prep: inp8 alignment");
   // mean3/std3 are HOST pointers (3 floats each): constants of the basicsr SpyNet buffers
   hipLaunchKernelGGL(spynet_prep_kernel, dim3(grid_for((long long)n * h * w)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),

@@ -1,0 +1,75 @@
+"""Multi-GPU inference: one process per GPU, tiles sharded contiguously over ranks
+(tiles are fully independent in the forward: no BatchNorm, per-sample GroupNorm,
+per-frame attention -- SURVEY 8(e)), weights replicated, and ONE collective per
+step: an all-gather of the HR output slabs (4 MiB per tile in fp32) over
+RCCL/xGMI (``backend='nccl'`` is RCCL on ROCm; ``gloo`` for the CPU tests).
+The reference has no multi-GPU inference (output_GPEMSR.py is single-process);
+this is the north_star's new capability."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """Returns (rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of `total` tiles owned by `rank` (remainder spread over the first ranks)."""
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def all_gather_slabs(local: torch.Tensor, world: int) -> torch.Tensor:
+    """All-gather equally sized per-rank slabs [b,1,H,W] -> [world*b,1,H,W] (rank-major = tile order)."""
+    if world == 1:
+        return local
+    local = local.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out
+
+
+def all_gather_ragged(local: torch.Tensor, total: int, rank: int, world: int) -> torch.Tensor:
+    """All-gather when `total` is not divisible by `world`: pad to the largest shard, gather, trim."""
+    if world == 1:
+        return local
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    g = all_gather_slabs(pad, world).view(world, mx, *local.shape[1:])
+    return torch.cat([g[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def forward_sharded(model, x_all_or_local: torch.Tensor, rank: int, world: int, already_local: bool = False,
+                    gather: bool = True):
+    """Run the stage-3 forward on this rank's tiles and (optionally) all-gather the SR slabs.
+    x: [B,N,1,H,W]; returns (out_all [B,1,sH,sW] on every rank, ref_img_local)."""
+    B = x_all_or_local.shape[0] * (world if already_local else 1)
+    if already_local:
+        x = x_all_or_local
+    else:
+        lo, hi = shard_range(B, rank, world)
+        x = x_all_or_local[lo:hi]
+    out, ref = model(x)
+    if not gather or world == 1:
+        return out, ref
+    if B % world == 0:
+        return all_gather_slabs(out, world), ref
+    return all_gather_ragged(out, B, rank, world), ref

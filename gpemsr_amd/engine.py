@@ -105,7 +105,7 @@ class Engine:
 
     # ------------------------------------------------------------------ helpers
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
-        return ops.conv2d(srcs, self.pc[name], act, **kw)
+        return ops.conv2d(srcs, self.pc[name], act, tag=name, **kw)
 
     def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:
         """basicsr ResidualBlockNoBN chain; ``pixmul`` multiplies the output of the LAST block
@@ -143,17 +143,17 @@ class Engine:
             m = min(fc, n - f0)
             qa = q.images(f0, m).reshape_hw(gh, gw)
             S = ops.conv2d([qa], ops.PackedConv(k.images(f0, m).buf, None, 1, T, (c,), 32), ACT_NONE,
-                           weight_image_stride=T * c)
+                           weight_image_stride=T * c, tag=p + ".qk")
             ops.softmax_rows_(S.buf, m * T, T)
             ops.conv2d([S], ops.PackedConv(vT.images(f0, m).buf, wv.b, 1, c, (T,), 32), ACT_NONE,
-                       weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw))
+                       weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw), tag=p + ".pv")
         return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
 
     def _vt(self, wv_packed: torch.Tensor, hn: Act, n: int, c: int, T: int) -> Act:
         vT = ops.new_act(n, c // 16, 16, T, device=self.dev)
         a = Act(wv_packed, n, c // 16, 16, c, c, 0)        # n "images" that all alias the one [C][C] weight matrix
         ops.conv2d([a], ops.PackedConv(hn.buf, None, 1, T, (c,), 32), ACT_NONE, weight_image_stride=T * c,
-                   src_image_stride=[0], out=vT)
+                   src_image_stride=[0], out=vT, tag="nonlocal.vT")
         return vT
 
     def vq_layer(self, x: Act, p: str) -> Act:
@@ -405,12 +405,20 @@ class Engine:
             if trace is not None:
                 trace.setdefault("fused", []).append(fea.nchw())
             o = self.resblocks_nobn(fea, "recon_trunk")
+            if trace is not None:
+                trace.setdefault("recon", []).append(o.nchw())
             o = self.conv(o, "upconv1", ACT_LRELU)
+            if trace is not None:
+                trace.setdefault("up1", []).append(o.nchw())
             o = self.conv(o, "upconv2", ACT_LRELU)
             o = self.conv(o, "upconv3", ACT_LRELU)
             if s == 16:
                 o = self.conv(o, "upconv4", ACT_LRELU)
+            if trace is not None:
+                trace.setdefault("up_last", []).append(o.nchw())
             o = self.conv(o, "HRconv", ACT_LRELU)
+            if trace is not None:
+                trace.setdefault("hr", []).append(o.nchw())
             xc = ops.copy_images(xa, bm, 1, N, b0 * N + self.center)
             base = ops.bilinear(xc, H * s, W * s)
             self.conv(o, "conv_last", ACT_NONE, residual=base, out=out_act.images(b0, bm))

@@ -84,6 +84,35 @@ def from_nchw(t: torch.Tensor) -> Act:
     return from_nhwc(t.permute(0, 2, 3, 1).contiguous())
 
 
+class LaunchProfiler:
+    """Per-launch HIP-event timing of the conv kernels (bench.py roofline leg).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.items = []
+
+    def run(self, kernel: str, tag: str, flops: float, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.items.append((kernel, tag, flops, s, e))
+
+    def summary(self, by_tag: bool = False):
+        torch.cuda.synchronize()
+        out = {}
+        for kernel, tag, flops, s, e in self.items:
+            key = (kernel, tag) if by_tag else kernel
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+        return out
+
+
+PROFILER: Optional[LaunchProfiler] = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -113,7 +142,7 @@ class PackedConv:
 
 def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
            pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
-           src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False) -> Act:
+           src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "") -> Act:
     lib = _abi.load()
     if isinstance(srcs, Act):
         srcs = [srcs]
@@ -135,12 +164,20 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
                   and not pc.pixel_shuffle and pixmul is None and weight_image_stride == 0 and src_image_stride is None)
     if stride == 4:
         assert use_direct, "stride 4 is only available through the direct kernel"
+    # algorithmic FLOPs of this launch (2*MAC, un-padded channel counts)
+    taps = 9.0 / 4.0 if pc.transposed else float(k * k)
+    flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps
     if use_direct:
-        _abi.check(lib.gpemsr_conv2d_direct(s0.ptr, n, h, w, s0.ld, s0.c, pc.w.data_ptr(),
-                                            pc.b.data_ptr() if pc.b is not None else None, pc.cout, k, stride, act,
-                                            residual.ptr if residual is not None else None,
-                                            residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()),
-                   "conv2d_direct")
+        def _go():
+            _abi.check(lib.gpemsr_conv2d_direct(s0.ptr, n, h, w, s0.ld, s0.c, pc.w.data_ptr(),
+                                                pc.b.data_ptr() if pc.b is not None else None, pc.cout, k, stride, act,
+                                                residual.ptr if residual is not None else None,
+                                                residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()),
+                       "conv2d_direct")
+        if PROFILER is not None:
+            PROFILER.run("conv_direct", tag, flops, _go)
+        else:
+            _go()
         return out
     d = _abi.ConvDesc()
     d.n, d.h, d.w, d.nsrc = n, h, w, len(srcs)
@@ -160,7 +197,10 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
         d.pixmul = pixmul.ptr
     d.pixel_shuffle = int(pc.pixel_shuffle)
     d.out, d.out_ld = out.ptr, out.ld
-    _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
+    if PROFILER is not None:
+        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"))
+    else:
+        _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
     return out
 
 
@@ -231,7 +271,7 @@ def spynet_prep(ref: Act, supp: Act, flow_coarse: Optional[Act], mean3, std3):
     m = (C.c_float * 3)(*[float(v) for v in mean3])
     s = (C.c_float * 3)(*[float(v) for v in std3])
     if flow_coarse is not None:
-        assert flow_coarse.ld == 2 and flow_coarse.h * 2 == ref.h and flow_coarse.w * 2 == ref.w
+        assert flow_coarse.ld == 2 and flow_coarse.h == ref.h // 2 and flow_coarse.w == ref.w // 2
     _abi.check(_abi.load().gpemsr_spynet_prep(ref.ptr, supp.ptr, flow_coarse.ptr if flow_coarse is not None else None,
                                               ref.n, ref.h, ref.w, m, s, up.ptr, inp.ptr, _stream()), "spynet_prep")
     return up, inp

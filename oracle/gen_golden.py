@@ -45,7 +45,7 @@ SUB_TARGET = 60_000
 
 
 def store(arrs: dict, name: str, t: torch.Tensor):
-    a = t.detach().cpu().numpy()
+    a = t.detach().cpu().numpy().copy()      # copy: the reference's tensor2img clamps its input IN PLACE
     if a.size > MAX_FULL:
         stride = int(np.ceil(a.size / SUB_TARGET))
         arrs[name + "__sub"] = np.ascontiguousarray(a.reshape(-1)[::stride])
@@ -148,7 +148,7 @@ def run_case(scale: int, lr: int, batch: int, kind: str, tag: str, model, sd):
         store(arrs, k, cap[k])
     # image-space golden (util/util.py:139-163,253-260) through the reference's own helpers
     import util.util as rutil
-    img = rutil.tensor2img(out[0:1])
+    img = rutil.tensor2img(out[0:1].clone())
     arrs["out_u8"] = img
     arrs["psnr_vs_base"] = np.array(rutil.calculate_psnr(
         img, rutil.tensor2img(torch.nn.functional.interpolate(x[0:1, 2], scale_factor=scale, mode="bilinear",

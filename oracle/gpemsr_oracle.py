@@ -479,12 +479,16 @@ def gpemsr_forward(sd: SD, x: Tensor, scale: int = 8, num_res_blocks_dec: int = 
     fea = three_da(sd, "ThreeDA", aligned, center)
     t["fused"] = fea
     out = resblocks_nobn(sd, "recon_trunk", fea)
+    t["recon"] = out
     out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv1", out), 2))
+    t["up1"] = out
     out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv2", out), 2))
     out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv3", out), 2))
     if scale == 16:
         out = _lrelu(F.pixel_shuffle(_conv(sd, "upconv4", out), 2))
+    t["up_last"] = out
     out = _lrelu(_conv(sd, "HRconv", out))
+    t["hr"] = out
     out = _conv(sd, "conv_last", out)
     out = out + _bilinear(x_center, scale)
     return out, ref_img.view(B, N, C, H * scale, W * scale)
