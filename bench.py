@@ -30,6 +30,18 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 ESSENTIAL_GFLOP_PER_TILE = {8: 5901.7, 16: 4882.3}
 
 
+def effective_cores() -> int:
+    """Host cores this process may actually use: min(affinity, cgroup v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,7 +125,7 @@ def main():
         # bounded sample of the same workload: ONE 5-slice window through the CPU oracle on the host cores
         from oracle import gpemsr_oracle as orc
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cores = os.cpu_count() or 1
+        cores = effective_cores()
         torch.set_num_threads(cores)
         xc = x[:1].cpu() if args.cpu_lr == lr else synth_lr_tiles(1, 5, args.cpu_lr, args.cpu_lr, seed=1000)
         with torch.no_grad():

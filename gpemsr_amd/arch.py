@@ -176,11 +176,12 @@ def param_specs(argref: dict, nf: int = 64, nframes: int = 5, groups: int = 8, f
         s.conv("fea_L2_conv1", nf, nf, 3); s.conv("fea_L2_conv2", nf, nf, 3)
         s.conv("fea_L3_conv1", nf, nf, 3); s.conv("fea_L3_conv2", nf, nf, 3)
         p = "align_module"
+        # state_dict order: a module's own buffers precede its children
+        s[p + ".spynet.mean"] = ParamSpec((1, 3, 1, 1), "buf_mean", False, True)
+        s[p + ".spynet.std"] = ParamSpec((1, 3, 1, 1), "buf_std", False, True)
         for lvl in range(6):
             for idx, (ci, co) in zip((0, 2, 4, 6, 8), ((8, 32), (32, 64), (64, 32), (32, 16), (16, 2))):
                 s.conv(f"{p}.spynet.basic_module.{lvl}.basic_module.{idx}", ci, co, 7, False)
-        s[p + ".spynet.mean"] = ParamSpec((1, 3, 1, 1), "buf_mean", False, True)
-        s[p + ".spynet.std"] = ParamSpec((1, 3, 1, 1), "buf_std", False, True)
         s.conv(p + ".flowdsconv0_1", 2, 16, 3); s.conv(p + ".flowdsconv0_2", 2, 16, 3)
         for n in ("flowdsconv1_1", "flowdsconv1_2", "flowdsconv2_1", "flowdsconv2_2"):
             s.conv(f"{p}.{n}", 16, 16, 3)

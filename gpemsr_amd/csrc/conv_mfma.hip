@@ -354,3 +354,6 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
     return launch<32, 128>(P, lds, st);
   }
 }
+
+// The Python binding (gpemsr_amd/_abi.py) mirrors this struct field by field.
+static_assert(sizeof(gpemsr_conv_desc) == 208, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");

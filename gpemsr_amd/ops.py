@@ -160,7 +160,8 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
     if out is None:
         out = new_act(n, OH, OW, oc, device=s0.buf.device)
     assert (out.n, out.h, out.w, out.c) == (n, OH, OW, oc), f"out geometry {(out.n, out.h, out.w, out.c)} != {(n, OH, OW, oc)}"
-    use_direct = (not force_mfma and pc.cout <= 16 and len(srcs) == 1 and k >= 3 and pc.ck == 8 and not pc.transposed
+    use_direct = (not force_mfma and pc.cout <= 16 and (pc.cout <= 2 or pc.cin <= 16) and len(srcs) == 1 and k >= 3
+                  and pc.ck == 8 and not pc.transposed
                   and not pc.pixel_shuffle and pixmul is None and weight_image_stride == 0 and src_image_stride is None)
     if stride == 4:
         assert use_direct, "stride 4 is only available through the direct kernel"

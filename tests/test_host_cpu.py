@@ -1,0 +1,176 @@
+"""CPU: host logic -- architecture inventory vs the reference manifest, synthetic weights,
+drop-in module behaviour, weight packing, option files, sharding helpers, C-ABI surface."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _opt(scale):
+    from gpemsr_amd.config import load_options
+    return load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{scale}.yml"))
+
+
+@pytest.mark.parametrize("scale", [8, 16])
+def test_param_specs_match_reference_manifest(scale, golden_dir):
+    """Key names, shapes, parameter counts == the reference model's state_dict (565 / 575 tensors)."""
+    from gpemsr_amd.arch import param_specs
+    man = json.load(open(os.path.join(golden_dir, f"state_manifest_x{scale}.json")))
+    net = _opt(scale)["network"]
+    specs = param_specs(scale=scale, **{k: v for k, v in net.items() if k not in ("ref_path_G", "ref_path_Indexer")})
+    assert [k for k, _ in man["keys"]] == list(specs.keys())            # same ORDER as the reference too
+    for k, shp in man["keys"]:
+        assert list(specs[k].shape) == shp, k
+    n_params = sum(int(np.prod(s.shape)) for s in specs.values() if not s.is_buffer)
+    n_train = sum(int(np.prod(s.shape)) for s in specs.values() if s.trainable)
+    assert (n_params, n_train) == (man["n_params"], man["n_trainable"])
+    assert man["n_tensors"] == (565 if scale == 8 else 575)
+
+
+def test_synthetic_weights_are_deterministic():
+    from gpemsr_amd.arch import ParamSpec
+    from gpemsr_amd.synth import synth_lr_tiles, synth_tensor
+    t = synth_tensor("recon_trunk.3.conv1.weight", ParamSpec((64, 64, 3, 3), "conv_w", True), 0)
+    assert hashlib.sha256(t.numpy().tobytes()).hexdigest()[:16] == hashlib.sha256(
+        synth_tensor("recon_trunk.3.conv1.weight", ParamSpec((64, 64, 3, 3), "conv_w", True), 0).numpy().tobytes()).hexdigest()[:16]
+    assert not torch.equal(t, synth_tensor("recon_trunk.4.conv1.weight", ParamSpec((64, 64, 3, 3), "conv_w", True), 0))
+    assert abs(float(t.std()) - 1.4 / np.sqrt(576)) < 0.01
+    x = synth_lr_tiles(2, 5, 16, 16, seed=3)
+    assert x.shape == (2, 5, 1, 16, 16) and 0 <= float(x.min()) and float(x.max()) < 1
+    assert torch.equal(x, synth_lr_tiles(2, 5, 16, 16, seed=3))
+
+
+def test_module_is_a_drop_in(golden_dir):
+    from gpemsr_amd.config import build_model
+    from gpemsr_amd.synth import synth_state_dict
+    m = build_model(_opt(8), load_prior_files=False)
+    sd = m.state_dict()
+    man = json.load(open(os.path.join(golden_dir, "state_manifest_x8.json")))
+    assert list(sd.keys()) == [k for k, _ in man["keys"]]
+    frozen = [k for k, p in m.named_parameters() if not p.requires_grad]
+    assert all(k.startswith(("vgg.", "refmodel.", "align_module.spynet.")) for k in frozen)
+    assert all(p.requires_grad for k, p in m.named_parameters() if not k.startswith(("vgg.", "refmodel.", "align_module.spynet.")))
+    # strict load of a full stage-3 dict (output_GPEMSR.py:52), tolerant of missing spynet mean/std buffers only
+    sd2 = synth_state_dict(m._specs, seed=7)
+    m.load_state_dict(sd2, strict=True)
+    assert torch.equal(m.state_dict()["conv_first.weight"], sd2["conv_first.weight"])
+    sd3 = {k: v for k, v in sd2.items() if not k.endswith(("spynet.mean", "spynet.std"))}
+    m.load_state_dict(sd3, strict=True)
+    bad = dict(sd2); bad.pop("HRconv.bias")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+    assert m.eval() is m and m.train() is m
+    with pytest.raises(RuntimeError, match="cuda/HIP"):
+        m(torch.rand(1, 5, 1, 16, 16))                      # no CPU fallback, by design
+    with pytest.raises(ValueError):
+        from gpemsr_amd.model import GPEMSR
+        GPEMSR(None, None, _opt(8)["network"]["argref"], mode="8to1", scale=4)
+
+
+def test_option_files_accepted_like_the_reference():
+    for scale in (8, 16):
+        o = _opt(scale)
+        assert o["scale"] == scale and o["dataset"]["N_frames"] == 5
+        for k in ("save_path", "pretrain_path"):
+            assert k in o
+        net = o["network"]
+        assert net["mode"] == f"{scale}to1" and net["ref_fusion_feat_RBs"] == 1
+        assert ("Indexer16" if scale == 16 else "Indexer8") in net["argref"]
+    from gpemsr_amd.config import dict_to_nonedict
+    nd = dict_to_nonedict({"a": {"b": 1}})
+    assert nd["zzz"] is None and nd["a"]["nope"] is None and nd["a"]["b"] == 1
+
+
+def _unpack_conv(pc, splits):
+    """Inverse of packing: [tap][cout][cin_pad] -> OIHW (drops the per-source zero padding)."""
+    k = pc.ksize
+    w = pc.w.cpu()
+    pieces, off = [], 0
+    for c in splits:
+        cp = -(-c // pc.ck) * pc.ck
+        pieces.append(w[:, :, off:off + c]); off += cp
+        assert float(w[:, :, off - (cp - c):off].abs().sum()) == 0.0
+    w = torch.cat(pieces, dim=2)
+    return w.reshape(k, k, pc.cout, -1).permute(2, 3, 0, 1).contiguous()
+
+
+def test_weight_packing_layouts():
+    from gpemsr_amd.packing import pack_conv, pack_convT, pack_dcn, pack_vgg_first
+    g = torch.Generator().manual_seed(0)
+    w, b = torch.randn(64, 162, 3, 3, generator=g), torch.randn(64, generator=g)
+    pc = pack_conv(w, b, "cpu", (64, 64, 32, 2))
+    assert pc.w.shape == (9, 64, 64 + 64 + 32 + 8) and pc.ck == 8
+    assert torch.equal(_unpack_conv(pc, (64, 64, 32, 2)), w)
+    w1 = torch.randn(64, 320, 1, 1, generator=g)
+    assert pack_conv(w1, None, "cpu").w.shape == (1, 64, 320) and pack_conv(w1, None, "cpu").ck == 32
+    # pixel shuffle: conv with permuted rows, stored as (2i+j)*C/4 + c, equals F.pixel_shuffle of the plain conv
+    wp, bp = torch.randn(16, 8, 3, 3, generator=g), torch.randn(16, generator=g)
+    x = torch.randn(1, 8, 5, 6, generator=g)
+    pcp = pack_conv(wp, bp, "cpu", pixel_shuffle=True)
+    y = F.conv2d(x, _unpack_conv(pcp, (8,)), pcp.b, 1, 1)             # [1,16,5,6] in permuted row order
+    cq = 4
+    shuffled = torch.zeros(1, cq, 10, 12)
+    for q in range(4):
+        shuffled[:, :, (q >> 1)::2, (q & 1)::2] = y[:, q * cq:(q + 1) * cq]
+    assert torch.allclose(shuffled, F.pixel_shuffle(F.conv2d(x, wp, bp, 1, 1), 2), atol=1e-6)
+    # transposed conv: [Cin,Cout,3,3] -> [tap][cout][cin]
+    wt = torch.randn(8, 16, 3, 3, generator=g)
+    pt = pack_convT(wt, torch.zeros(16), "cpu")
+    assert pt.transposed and torch.equal(pt.w[4], wt[:, :, 1, 1].t())
+    # DCN: tap-major column order
+    wd = torch.randn(64, 64, 3, 3, generator=g)
+    pd = pack_dcn(wd, torch.zeros(64), "cpu")
+    assert pd.w.shape == (1, 64, 576) and torch.equal(pd.w[0, :, 5 * 64:6 * 64], wd[:, :, 1, 2])
+    # VGG conv1_1 on three identical channels == 1-channel conv with summed weights
+    wv, bv = torch.randn(64, 3, 3, 3, generator=g), torch.randn(64, generator=g)
+    img = torch.rand(1, 1, 7, 7, generator=g)
+    a = F.conv2d(img.expand(-1, 3, -1, -1), wv, bv, 1, 1)
+    c = F.conv2d(img, _unpack_conv(pack_vgg_first(wv, bv, "cpu"), (1,)), bv, 1, 1)
+    assert torch.allclose(a, c, atol=1e-5)
+
+
+def test_shard_ranges_cover_everything():
+    from gpemsr_amd.dist import shard_range
+    for total in (1, 7, 16, 128, 130):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The built shared object loads without a GPU and exports every function include/gpemsr_hip.h declares."""
+    from gpemsr_amd import _abi
+    hdr = open(os.path.join(ROOT, "include", "gpemsr_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(gpemsr_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(_abi.SYMBOLS), (set(declared) ^ set(_abi.SYMBOLS))
+    if not os.path.exists(_abi.lib_path()):
+        from gpemsr_amd.build import build_library
+        build_library()
+    lib = ctypes.CDLL(_abi.lib_path())
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.gpemsr_abi_version() == 1
+    lib.gpemsr_last_error.restype = ctypes.c_char_p
+    assert lib.gpemsr_conv2d(None, None) == -1 and b"null descriptor" in lib.gpemsr_last_error()   # validation only, no compute
+    assert ctypes.sizeof(_abi.ConvDesc) == 208        # matches the C struct layout (static_assert in conv_mfma.hip)
+
+
+def test_image_helpers_match_reference_semantics(golden_dir):
+    from gpemsr_amd.imgutil import calculate_psnr, tensor2img
+    d = np.load(os.path.join(golden_dir, "x8_lr16_b1_uniform.npz"))
+    u8 = tensor2img(torch.from_numpy(d["out"]))
+    assert np.array_equal(u8, d["out_u8"])
+    assert calculate_psnr(u8, u8) == float("inf")
+    x = torch.tensor([[0.5 / 255, 1.5 / 255, 2.5 / 255, -1.0, 2.0]])
+    assert tensor2img(x).tolist() == [0, 2, 2, 0, 255]      # round-half-even, clamp

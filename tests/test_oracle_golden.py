@@ -1,0 +1,116 @@
+"""CPU: the oracle (oracle/gpemsr_oracle.py) against the golden vectors that
+oracle/gen_golden.py captured from the UNMODIFIED reference modules
+(/root/reference/GPEMSR-CREMI/GPEMSR/model/*.py imported behind shims).  This is the
+pin of the oracle; the GPU parity tests then compare the HIP path with both."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _load(golden_dir, tag):
+    return np.load(os.path.join(golden_dir, tag + ".npz"))
+
+
+def _weights(scale):
+    from gpemsr_amd.arch import param_specs
+    from gpemsr_amd.config import load_options
+    from gpemsr_amd.synth import synth_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    opt = load_options(os.path.join(root, "option", f"output_GPEMSR_x{scale}.yml"))
+    kw = {k: v for k, v in opt["network"].items() if k not in ("ref_path_G", "ref_path_Indexer")}
+    return synth_state_dict(param_specs(scale=scale, **kw), seed=0)
+
+
+def _check(got, d, name, tol):
+    if name in d.files:
+        want, g = d[name], got.detach().numpy()
+    else:
+        stride = int(d[name + "__stride"][0])
+        want, g = d[name + "__sub"], got.detach().numpy().reshape(-1)[::stride]
+    err = np.abs(g.reshape(want.shape).astype(np.float64) - want).max()
+    assert err <= tol * np.abs(want).max(), f"{name}: {err:.3e}"
+
+
+@pytest.mark.parametrize("tag", ["x8_lr16_b1_uniform", "x16_lr16_b1_smooth"])
+def test_oracle_reproduces_reference(tag, golden_dir):
+    from oracle import gpemsr_oracle as orc
+    d = _load(golden_dir, tag)
+    scale = int(d["scale"])
+    sd = _weights(scale)
+    tr = {}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out, ref_img = orc.gpemsr_forward(sd, torch.from_numpy(d["x"]), scale=scale, trace=tr)
+    assert np.array_equal(tr["code_idx"].numpy(), d["code_idx"]), "codebook indices differ from the reference"
+    for name, t in (("L1_fea", tr["L1_fea"]), ("logits", tr["logits"]), ("mask_cos", tr["mask_cos"]),
+                    ("L1_fused", tr["L1_fused"]), ("aligned", tr["aligned"]), ("fused", tr["fused"]),
+                    ("ref_img", ref_img), ("out", out)):
+        _check(t, d, name, 1e-5)
+    # image space (util/util.py:139-163, 253-260)
+    u8 = orc.tensor2img_u8(out[0:1])
+    diff = np.abs(u8.astype(np.int32) - d["out_u8"].astype(np.int32))      # 1e-7 float noise may flip a .5 rounding
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    base = torch.nn.functional.interpolate(torch.from_numpy(d["x"])[0:1, 2], scale_factor=scale, mode="bilinear", align_corners=False)
+    assert abs(orc.psnr_u8(u8, orc.tensor2img_u8(base)) - float(d["psnr_vs_base"])) < 1e-3
+
+
+def test_oracle_as_written_equals_deduplicated(golden_dir):
+    """Evaluating SpyNet twice (model/GPEMSR.py:99-100) changes nothing."""
+    from oracle import gpemsr_oracle as orc
+    d = _load(golden_dir, "x8_lr16_b1_uniform")
+    sd = _weights(8)
+    x = torch.from_numpy(d["x"])
+    with torch.no_grad():
+        a, _ = orc.gpemsr_forward(sd, x, scale=8, as_written=True)
+        b, _ = orc.gpemsr_forward(sd, x, scale=8, as_written=False)
+    assert torch.equal(a, b)
+
+
+def test_oracle_teacher_forcing_and_fp64(golden_dir):
+    """forced indices reproduce the free-running result; fp64 evaluation bounds the fp32 noise."""
+    from oracle import gpemsr_oracle as orc
+    d = _load(golden_dir, "x8_lr16_b1_uniform")
+    sd = _weights(8)
+    x = torch.from_numpy(d["x"])
+    idx = torch.from_numpy(d["code_idx"]).long()
+    with torch.no_grad():
+        a, _ = orc.gpemsr_forward(sd, x, scale=8, forced_idx=idx)
+        b, _ = orc.gpemsr_forward({k: v.double() for k, v in sd.items()}, x.double(), scale=8, forced_idx=idx)
+    _check(a, d, "out", 1e-5)
+    assert float((a.double() - b).abs().max() / b.abs().max()) < 1e-4      # fp32 vs fp64 evaluation of the same graph
+
+
+def test_deform_conv_restatements_agree():
+    """Two independent restatements of torchvision.ops.deform_conv2d (gather form in the oracle,
+    grid_sample form in the import shim) agree, including far out-of-image offsets."""
+    import sys
+    from oracle import gpemsr_oracle as orc
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "ref_shims")
+    sys.path.insert(0, shim)
+    try:
+        import importlib
+        tv_ops = importlib.import_module("torchvision.ops")
+    finally:
+        sys.path.remove(shim)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 9, 11, generator=g)
+    off = torch.randn(2, 144, 9, 11, generator=g) * 4
+    mask = torch.rand(2, 72, 9, 11, generator=g)
+    w, b = torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g)
+    a = orc.deform_conv2d_v2(x, off, mask, w, b)
+    c = tv_ops.deform_conv2d(x, off, w, b, 1, 1, 1, mask)
+    assert float((a - c).abs().max()) < 1e-4
+    for m in [m for m in list(sys.modules) if m.split(".")[0] == "torchvision"]:
+        del sys.modules[m]
+
+
+def test_gen_report_is_clean(golden_dir):
+    rep = json.load(open(os.path.join(golden_dir, "gen_report.json")))
+    assert len(rep) == 3
+    for r in rep:
+        assert r["idx_agree"] == 1.0
+        for k in ("out", "ref_img", "L1_fea", "logits", "mask_cos", "L1_fused", "aligned", "fused"):
+            assert r[k] < 1e-5, (r["case"], k, r[k])
