@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Inference entry point -- drop-in for the reference's ``output_GPEMSR.py``:
+
+    python output_GPEMSR.py -opt option/output_GPEMSR_x8.yml
+
+Same CLI, same option-file keys, same outputs (``save_path/{k}.png``, 8-bit grayscale,
+k = 0..n-1 over the LQ volume; the first/last two slices use replicated neighbours exactly
+as /root/reference/GPEMSR-CREMI/GPEMSR/output_GPEMSR.py:54-84,98-128), but the model is
+``gpemsr_amd.GPEMSR`` running on the MI355X HIP kernels.  Differences, all additive:
+  * PNG I/O uses Pillow when OpenCV is not installed (same uint8 data either way);
+  * ``tile_batch`` (option key) > 1 batches several 5-slice windows per forward call;
+  * with several ranks (torchrun), windows are sharded over GPUs (gpemsr_amd.dist);
+  * ``synthetic_weights_if_missing: true`` lets the script run without the authors'
+    Google-Drive checkpoints (deterministic synthetic weights) -- for smoke runs only.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import os.path as osp
+import sys
+
+import numpy as np
+import torch
+
+ROOT = osp.dirname(osp.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gpemsr_amd import dist as gdist                      # noqa: E402
+from gpemsr_amd.config import build_model, dict_to_nonedict, load_options   # noqa: E402
+from gpemsr_amd.imgutil import tensor2img                 # noqa: E402
+
+
+def read_img(path: str) -> np.ndarray:
+    """data/util.py:75-88: uint8 image -> float32 HWC in [0,1] (grayscale -> HxWx1)."""
+    try:
+        import cv2
+        img = cv2.imread(path, cv2.IMREAD_UNCHANGED)
+    except ImportError:
+        from PIL import Image
+        img = np.array(Image.open(path))
+    img = img.astype(np.float32) / 255.
+    if img.ndim == 2:
+        img = np.expand_dims(img, axis=2)
+    if img.shape[2] > 3:
+        img = img[:, :, :3]
+    return img
+
+
+def save_img(img: np.ndarray, path: str):
+    try:
+        import cv2
+        cv2.imwrite(path, img)
+    except ImportError:
+        from PIL import Image
+        Image.fromarray(img).save(path)
+
+
+def seek_path(idx, dir_path, center):            # output_GPEMSR.py:216-222
+    cur = center + idx
+    p = osp.join(dir_path, str(cur) + '.png')
+    if osp.exists(p):
+        return p
+    return seek_path(idx - 1, dir_path, center)
+
+
+class CREMIWindows:
+    """The val-phase behaviour of the reference's CREMIDataset (output_GPEMSR.py:132-214):
+    item i = the N-slice LQ window centred on the (i + N//2)-th GT slice."""
+
+    def __init__(self, opt):
+        self.N = opt['N_frames']
+        self.LQ_root = opt['dataroot_LQ']
+        ids = sorted(int(f[:-4]) for f in os.listdir(opt['dataroot_GT']) if f.endswith('.png'))
+        half = (self.N - 1) // 2
+        self.centres = ids[half:len(ids) - half] if half else ids
+        self.offsets = list(range(-half, half + 1))
+
+    def __len__(self):
+        return len(self.centres)
+
+    def __getitem__(self, i):
+        c = self.centres[i]
+        frames = [read_img(seek_path(o, self.LQ_root, c)) for o in self.offsets]
+        lq = np.stack(frames, axis=0)                                     # N,H,W,1
+        return torch.from_numpy(np.ascontiguousarray(np.transpose(lq, (0, 3, 1, 2)))).float()   # N,1,H,W
+
+
+def build_windows(ds: CREMIWindows):
+    """All 5-slice windows of the volume in output order (edge replication as the reference)."""
+    first, last = ds[0], ds[len(ds) - 1]
+    wins = [first[[0, 0, 0, 1, 2]], first[[0, 0, 1, 2, 3]]]               # slices 0 and 1
+    wins += [ds[i] for i in range(len(ds))]
+    n = last.shape[0]
+    wins += [last[[n - 4, n - 3, n - 2, n - 1, n - 1]], last[[n - 3, n - 2, n - 1, n - 1, n - 1]]]
+    return wins
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-opt', type=str, required=True, help='Path to option YAML file.')
+    parser.add_argument('--local_rank', type=int, default=os.getenv('LOCAL_RANK', -1))
+    args = parser.parse_args()
+    opt = load_options(args.opt)
+    im_path_SR, scale = opt['save_path'], opt['scale']
+    os.makedirs(im_path_SR, exist_ok=True)
+    dataset_dict = dict(opt['dataset']); dataset_dict['scale'] = scale
+    ds = CREMIWindows(dict_to_nonedict(dataset_dict))
+    assert ds.N == 5, "the edge handling of the reference script is written for N_frames = 5"
+
+    rank, world, local = gdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise RuntimeError("output_GPEMSR.py (gpemsr_amd) needs an MI355X / HIP device: there is no CPU path")
+    torch.cuda.set_device(max(local, 0))
+    device = torch.device("cuda", max(local, 0))
+    model = build_model(opt).eval().to(device)
+    pretrain_path = opt['pretrain_path']
+    if pretrain_path and osp.exists(pretrain_path):
+        model.load_state_dict(torch.load(pretrain_path, map_location="cpu"), strict=True)   # output_GPEMSR.py:52
+    elif not opt.get('synthetic_weights_if_missing', False):
+        raise FileNotFoundError(pretrain_path)
+    elif rank == 0:
+        print(f"[gpemsr_amd] {pretrain_path} not found: using deterministic synthetic weights", file=sys.stderr)
+
+    wins = build_windows(ds)
+    lo, hi = gdist.shard_range(len(wins), rank, world)
+    tb = int(opt.get('tile_batch', 1) or 1)
+    with torch.no_grad():
+        for b0 in range(lo, hi, tb):
+            b1 = min(hi, b0 + tb)
+            LQ = torch.stack(wins[b0:b1], dim=0).to(device)              # [b,5,1,H,W]
+            SR, _ = model(LQ)
+            for j in range(b1 - b0):
+                save_img(tensor2img(SR[j]), osp.join(im_path_SR, '{}.png'.format(b0 + j)))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -174,3 +174,24 @@ def test_image_helpers_match_reference_semantics(golden_dir):
     assert calculate_psnr(u8, u8) == float("inf")
     x = torch.tensor([[0.5 / 255, 1.5 / 255, 2.5 / 255, -1.0, 2.0]])
     assert tensor2img(x).tolist() == [0, 2, 2, 0, 255]      # round-half-even, clamp
+
+
+def test_cli_window_order_matches_reference_edges(tmp_path):
+    """output_GPEMSR.py:54-128: slices 0,1 and n-2,n-1 use replicated neighbours; files are 0..n-1."""
+    from PIL import Image
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cli", os.path.join(ROOT, "output_GPEMSR.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    n = 9
+    for d in ("GT", "LQ"):
+        os.makedirs(tmp_path / d)
+        for i in range(n):
+            Image.fromarray(np.full((8, 8), i * 10, dtype=np.uint8)).save(tmp_path / d / f"{i}.png")
+    ds = cli.CREMIWindows({"N_frames": 5, "dataroot_GT": str(tmp_path / "GT"), "dataroot_LQ": str(tmp_path / "LQ")})
+    assert len(ds) == n - 4
+    wins = cli.build_windows(ds)
+    ids = [[int(round(float(w[j, 0, 0, 0]) * 255 / 10)) for j in range(5)] for w in wins]
+    assert ids[0] == [0, 0, 0, 1, 2] and ids[1] == [0, 0, 1, 2, 3]
+    assert ids[2] == [0, 1, 2, 3, 4] and ids[n - 3] == [n - 5, n - 4, n - 3, n - 2, n - 1]
+    assert ids[n - 2] == [n - 4, n - 3, n - 2, n - 1, n - 1] and ids[n - 1] == [n - 3, n - 2, n - 1, n - 1, n - 1]
+    assert len(wins) == n and wins[0].shape == (5, 1, 8, 8) and wins[0].dtype == torch.float32
