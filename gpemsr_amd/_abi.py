@@ -9,7 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgpemsr_hip.so")
+_LIB_PATH = os.environ.get("GPEMSR_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                               "libgpemsr_hip.so")   # env override: A/B kernel builds
 _lib = None
 
 MAX_SRC = 4

@@ -226,10 +226,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
   __syncthreads();   // tap table visible
   prefetch(0);
   for (int stage = 0; stage < nstages; ++stage) {
+#ifdef GP_EXP_NO_RESTAGE
+    if (stage == 0) {
+#endif
     __syncthreads();           // everyone done reading the previous stage
     commit(stage);
     __syncthreads();
     if (stage + 1 < nstages) prefetch(stage + 1);
+#ifdef GP_EXP_NO_RESTAGE
+    }
+#endif
     const int grp = stage % ngroups;
     for (int tt = 0; tt < tpg; ++tt) {
       const int tg = grp * tpg + tt;
@@ -268,6 +274,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef GP_EXP_NO_EPILOGUE
+        if (r != 0) { asm volatile("" ::"v"(acc[mt][nt][r])); continue; }
+#endif
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int p = wm * PM + mt * 32 + row;
         const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
