@@ -1,33 +1,52 @@
-// Implicit-GEMM convolution on the CDNA4 f32 matrix pipe (v_mfma_f32_32x32x2_f32).
+// Implicit-GEMM convolution on the CDNA4 f32 matrix pipe (v_mfma_f32_32x32x2_f32).   [v2]
 //
 // One workgroup (4 waves) produces an 8x16-pixel x BN-channel output tile:
 //   D[pixel][cout] = sum_{tap} sum_{cin} In[pixel*stride + tap][cin] * W[tap][cout][cin]
-// The K loop runs over (cin chunk of CK channels) x (tap group).  Per chunk the
-// input halo tile ((8-1)*s+k) x ((16-1)*s+k) x CK is staged ONCE in LDS and every
-// tap of the filter reads it at a shifted offset (k*k-fold reuse out of LDS, no
-// im2col in HBM).  The weight slice [taps][BN][CK] of the chunk is staged beside
-// it.  Global loads of stage s+1 are issued into registers before the MFMAs of
-// stage s, and written to LDS after them (register-staged pipeline).
+// K loop = (cin chunk of CK channels) x (tap group).  Per chunk the input halo tile
+// ((8-1)*s+kh) x ((16-1)*s+kw) x CK is staged ONCE in LDS and every tap reads it at a shifted
+// offset (k*k-fold reuse out of LDS, no im2col in HBM); the weight slice [taps][BN][CK] of the
+// stage sits beside it.  Both are double-buffered: stage s+1 is written to the other buffer
+// before the MFMAs of stage s and the global loads of stage s+2 are in flight in registers
+// during them -- ONE barrier per stage.  Inside a stage the tap loop is software-pipelined
+// (fragments of tap t+1 are read from LDS while the MFMAs of tap t issue) and tap offsets are
+// scalar arithmetic.
 //
 // MFMA operand maps (guide section 3): A[i = lane&31][k = lane>>5], B[k][j = lane&31],
-// D col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel).  A lane
-// reads one float4 of A and B per tap: element e is k-step e, in which lane half h
+// D col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel).  A lane reads one
+// float4 of A and of B per tap (ds_read_b128): element e is k-step e, in which lane half h
 // supplies channel 4h+e of the chunk -- A and B agree, so the k order is free.
 //
-// The same kernel evaluates ConvTranspose2d(k3,s2,p1,op1) as four sub-pixel phases
-// (blockIdx carries the phase; phase (py,px) has (1+py)*(1+px) taps), fuses
-// PixelShuffle(2) into the store, reads a virtual channel-concat of up to four
-// sources, and serves torch.bmm / nn.Linear as 1x1 convolutions with per-image
-// weights.  Replaces the ATen conv/bmm calls under model/GPEMSR.py:323-456.
+// Epilogue: accumulators go through LDS ([pixel][BN+4]) and leave as coalesced float4 rows
+// with bias / activation / residual / per-pixel multiplier applied; PixelShuffle(2) and the
+// transposed convolution only change the (pixel, channel) -> address map of that store.
+//
+// ConvTranspose2d(k3,s2,p1,op1) is evaluated as a 2x2-tap convolution with 4*Cout
+// "phase-stacked" output channels (n' = (co/32)*128 + q*32 + co%32, q = 2*py+px): tap (dy,dx)
+// only feeds the phases with py>=dy, px>=dx, so each wave owns all four phases of 32 channels
+// and skips the zero (tap, phase) blocks through a per-tap N-tile mask: 9 MFMA blocks per 4
+// output pixels = the true FLOP count, balanced across waves.
+//
+// Staging comes in two flavours.  DMA (the fast one, used whenever every source has
+// c % CK == 0 and 16-B aligned rows): global_load_lds_dwordx4 writes the LDS images directly
+// (1 KiB per wave-instruction, no VGPR round trip, no ds_write; out-of-image halo pixels and
+// channels past cout read a 16-B zero constant).  The LDS images are therefore lane-linear;
+// the 128-B rows of the 1x1/GEMM case are XOR-swizzled on the SOURCE address and on the read
+// (guide rule 21) so ds_read_b128 stays conflict-free.  The register-staged flavour (global ->
+// VGPR -> ds_write, zero-padding by predication) serves 1/2/34-channel sources.
+//
+// Replaces the ATen conv / conv_transpose / bmm / linear calls under model/GPEMSR.py:323-456.
 #include "common.h"
 
 namespace gpemsr {
 
+__device__ float4 g_zero16;          // 16 zero bytes: DMA source of every padded / out-of-range slot
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TILE_H = 8, TILE_W = 16;
-constexpr int MAX_TAPS = 49;
-constexpr int A_LOADS = 5;   // float4 per thread per A stage (561 halo px * 2 / 256 -> 5)
+constexpr int A_LOADS = 5;   // float4 per thread per A stage (17*33 halo px * 2 / 256 -> 5)
+
+enum { STORE_PLAIN = 0, STORE_PIXSHUF = 1, STORE_CONVT = 2 };
 
 struct ConvParams {
   const float* src[GPEMSR_MAX_SRC];
@@ -37,42 +56,42 @@ struct ConvParams {
   int vec[GPEMSR_MAX_SRC];
   int nsrc;
   int n, h, w;            // input geometry
-  int oh, ow;             // conv grid (per phase for transposed)
+  int oh, ow;             // conv grid
   int OH, OW;             // stored output geometry
-  int cin_pad, cout;
-  int ksize, stride, pad, transposed;
+  int cin_pad, cout;      // cout = GEMM N (4*Cout for the transposed form)
+  int kh, kw, stride, pad;
   const float* weight; long long w_img_stride;
   const float* bias; int act;
   const float* residual; int res_ld;
   const float* pixmul;
-  int pixel_shuffle;
+  int store_mode, cq;     // cq: channels per sub-pixel group (PIXSHUF)
   float* out; int out_ld;
-  int tiles_x, tiles_y, tiles_n, nphase;
+  int out_vec, res_vec;
+  int tiles_x, tiles_y, tiles_n;
   int halo_h, halo_w;
-  int ntaps, taps_per_group, ngroups;
+  int tpg_h, tpg_w, ngroups;      // taps of one stage: tpg_h x tpg_w (rows x cols of the filter)
+  int a_buf_floats, b_buf_floats;
+  int na, nb;                     // DMA slots (float4 per thread) per A / B stage
   int nblocks;
 };
 
-template <int CK, int BN>
+template <int CK, int BN, int WM, int WN, bool MASKED, bool DMA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
-  constexpr int WN = (BN >= 64) ? 2 : 1;
-  constexpr int WM = 4 / WN;
   constexpr int PM = 128 / WM;        // pixels per wave
   constexpr int MT = PM / 32;
   constexpr int WNT = BN / WN;        // couts per wave
   constexpr int NT = WNT / 32;
-  constexpr int APIX = (CK == 8) ? 8 : CK + 4;   // floats per halo pixel in LDS
+  constexpr int APIX = (CK == 8 || DMA) ? CK : CK + 4;   // floats per halo pixel in LDS (DMA images are unpadded)
+  constexpr bool SWZ = DMA && CK == 32;                  // XOR-swizzled 128-B rows
   constexpr int BPIX = APIX;
   constexpr int V4 = CK / 4;          // float4 per pixel per chunk
   constexpr int KJ = CK / 8;          // 8-channel groups per chunk
-  constexpr int B_LOADS = (CK == 8) ? (9 * BN * V4 + 255) / 256 : (BN * V4 + 255) / 256;  // CK=32 is 1x1 only
+  constexpr int MAXTPG = (CK == 32) ? 1 : (BN == 128 ? 4 : 7);
+  constexpr int B_LOADS = (MAXTPG * BN * V4 + 255) / 256;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* tap_dy = reinterpret_cast<int*>(smem);
-  int* tap_dx = tap_dy + 64;
-  int* tap_w = tap_dx + 64;
-  float* As = smem + 192;
-  float* Bs = As + ((P.halo_h * P.halo_w * APIX + 3) & ~3);
+  float* const As0 = smem;
+  float* const Bs0 = smem + 2 * P.a_buf_floats;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -90,55 +109,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
   const int tn = t % P.tiles_n; t /= P.tiles_n;
   const int tx = t % P.tiles_x; t /= P.tiles_x;
   const int ty = t % P.tiles_y; t /= P.tiles_y;
-  const int phase = t % P.nphase; t /= P.nphase;
   const int img = t;
-  const int py = phase >> 1, px = phase & 1;
   const int oy0 = ty * TILE_H, ox0 = tx * TILE_W, n0 = tn * BN;
-
-  // ---- tap table: (dy,dx) in halo coordinates, weight tap index ----
-  int ntaps = P.ntaps;
-  if (P.transposed) ntaps = (1 + py) * (1 + px);
-  if (tid < MAX_TAPS) {
-    int dy = 0, dx = 0, wt = 0;
-    if (!P.transposed) {
-      dy = tid / P.ksize; dx = tid % P.ksize; wt = tid;
-    } else {
-      // out(2i+py, 2j+px) = sum_{ky,kx} in(i+dy, j+dx) W[ky][kx] with 2*dy = py+1-ky
-      const int ay = tid / (1 + px), ax = tid % (1 + px);
-      const int ky = py ? (ay ? 2 : 0) : 1, kx = px ? (ax ? 2 : 0) : 1;
-      dy = py ? (ay ? 0 : 1) : 0; dx = px ? (ax ? 0 : 1) : 0;
-      wt = ky * 3 + kx;
-    }
-    tap_dy[tid] = dy; tap_dx[tid] = dx; tap_w[tid] = wt;
-  }
-  const int S = P.transposed ? 1 : P.stride;
-  const int iy0 = P.transposed ? oy0 : oy0 * S - P.pad;
-  const int ix0 = P.transposed ? ox0 : ox0 * S - P.pad;
+  const int S = P.stride;
+  const int iy0 = oy0 * S - P.pad, ix0 = ox0 * S - P.pad;
   const int halo_px = P.halo_h * P.halo_w;
+  const int tpg = P.tpg_h * P.tpg_w;
 
-  // ---- per-thread A staging slots (independent of the stage) ----
+  // ---- per-thread staging slots (independent of the stage) ----
+  // register path: a_pix/a_lds/a_ch + b_goff/b_lds ; DMA path: byte offsets a_boff/b_boff (INVALID -> zero source)
   int a_pix[A_LOADS];      // pixel index inside the image, or -1
   int a_lds[A_LOADS];      // LDS float offset, or -1
+  int a_ch[A_LOADS];       // channel offset of the float4 inside the chunk
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
     const int e = tid + i * 256;
-    a_pix[i] = -1; a_lds[i] = -1;
+    a_pix[i] = -1; a_lds[i] = -1; a_ch[i] = 0;
     if (e < halo_px * V4) {
-      const int hp = e / V4, j = e % V4;
+      const int hp = e / V4, pc = e % V4;
+      const int j = SWZ ? (pc ^ (hp & 7)) : pc;           // logical 16-B chunk held at physical chunk pc
       const int hy = hp / P.halo_w, hx = hp % P.halo_w;
       const int iy = iy0 + hy, ix = ix0 + hx;
-      a_lds[i] = hp * APIX + 4 * j;
+      a_lds[i] = hp * APIX + 4 * pc; a_ch[i] = 4 * j;
       if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) a_pix[i] = iy * P.w + ix;
     }
   }
-  // per-lane A fragment pixel offsets (floats) for each M tile
+  int b_goff[B_LOADS];     // float offset of the float4 inside the weight tensor (stage offset excluded), or -1
+  int b_lds[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int e = tid + i * 256;
+    b_goff[i] = -1; b_lds[i] = -1;
+    if (e < tpg * BN * V4) {
+      const int row = e / V4, pc = e % V4;
+      const int j = SWZ ? (pc ^ (row & 7)) : pc;
+      const int tt = row / BN, nn = row % BN;
+      b_lds[i] = row * BPIX + 4 * pc;
+      if (n0 + nn < P.cout) b_goff[i] = (tt * P.cout + n0 + nn) * P.cin_pad + 4 * j;
+    }
+  }
+  // per-lane fragment offsets (floats)
   int a_frag[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    a_frag[mt] = (((p >> 4) * S) * P.halo_w + (p & 15) * S) * APIX + 4 * lh;
+    a_frag[mt] = (((p >> 4) * S) * P.halo_w + (p & 15) * S) * APIX + (SWZ ? 0 : 4 * lh);
   }
-  const int b_frag = (wn * WNT + li) * BPIX + 4 * lh;
+  const int b_frag = (wn * WNT + li) * BPIX + (SWZ ? 0 : 4 * lh);
+  const int swz_x = li & 7;            // SWZ: row & 7 of this lane's A and B rows (tile bases are multiples of 8)
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -148,35 +166,39 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  // ---- stage enumeration: chunk-major, tap-group-minor ----
+  // ---- stage enumeration (chunk-major, tap-group-minor), advanced incrementally ----
   int nchunks = 0;
   for (int s = 0; s < P.nsrc; ++s) nchunks += (P.c[s] + CK - 1) / CK;
-  const int ngroups = P.transposed ? 1 : P.ngroups;
-  const int tpg = P.transposed ? ntaps : P.taps_per_group;
+  const int ngroups = P.ngroups;
   const int nstages = nchunks * ngroups;
   const float* wbase = P.weight + (long long)img * P.w_img_stride;
+  const int grp_stride = tpg * P.cout * P.cin_pad;     // weight floats between tap groups
 
+  // state of the NEXT stage to be fetched
+  int f_src = 0, f_c0 = 0, f_cpad = 0, f_grp = 0, f_chunk = 0, f_stage = 0;
   float4 ra[A_LOADS];
   float4 rb[B_LOADS];
 
-  auto prefetch = [&](int stage) {
-    const int chunk = stage / ngroups, grp = stage % ngroups;
-    int s = 0, c0 = chunk * CK, cpad = 0;
-    while (s < P.nsrc - 1 && c0 >= ((P.c[s] + CK - 1) / CK) * CK) {
-      const int cp = ((P.c[s] + CK - 1) / CK) * CK;
-      c0 -= cp; cpad += cp; ++s;
+  auto advance = [&]() {
+    ++f_stage;
+    if (++f_grp == ngroups) {
+      f_grp = 0; ++f_chunk; f_c0 += CK;
+      const int cp = ((P.c[f_src] + CK - 1) / CK) * CK;
+      if (f_c0 >= cp && f_src + 1 < P.nsrc) { f_c0 = 0; f_cpad += cp; ++f_src; }
     }
-    if (grp == 0) {
-      const float* sp = P.src[s] + (long long)img * P.img_stride[s];
-      const int ld = P.ld[s], cs = P.c[s];
+  };
+  auto fetch = [&]() {      // register path: global -> registers for the next stage
+    if (f_grp == 0) {
+      const float* sp = P.src[f_src] + (long long)img * P.img_stride[f_src];
+      const int ld = P.ld[f_src], cs = P.c[f_src];
+      const bool vec = P.vec[f_src] != 0;
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a_pix[i] >= 0) {
-          const int j = (a_lds[i] % APIX) >> 2;
-          const int cc = c0 + 4 * j;
+          const int cc = f_c0 + a_ch[i];
           const float* gp = sp + (long long)a_pix[i] * ld + cc;
-          if (P.vec[s] && cc + 3 < cs) {
+          if (vec && cc + 3 < cs) {
             v = *reinterpret_cast<const float4*>(gp);
           } else {
             if (cc + 0 < cs) v.x = gp[0];
@@ -188,115 +210,211 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
         ra[i] = v;
       }
     }
-    const int nb4 = tpg * BN * V4;
+    const float* wp = wbase + (long long)f_grp * grp_stride + f_cpad + f_c0;
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-      const int e = tid + i * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < nb4) {
-        const int tt = e / (BN * V4), rem = e % (BN * V4);
-        const int nn = rem / V4, j = rem % V4;
-        if (n0 + nn < P.cout) {
-          const int wt = tap_w[grp * tpg + tt];
-          v = *reinterpret_cast<const float4*>(wbase + ((long long)wt * P.cout + n0 + nn) * P.cin_pad + cpad + c0 + 4 * j);
-        }
-      }
+      if (b_goff[i] >= 0) v = *reinterpret_cast<const float4*>(wp + b_goff[i]);
       rb[i] = v;
     }
+    advance();
   };
-  auto commit = [&](int stage) {
-    const int grp = stage % ngroups;
+  auto commit = [&](int chunk, int grp, int stage) {   // register path: registers -> the LDS buffers of that stage
     if (grp == 0) {
+      float* A = As0 + (chunk & 1) * P.a_buf_floats;
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i)
-        if (a_lds[i] >= 0) *reinterpret_cast<float4*>(As + a_lds[i]) = ra[i];
+        if (a_lds[i] >= 0) *reinterpret_cast<float4*>(A + a_lds[i]) = ra[i];
     }
-    const int nb4 = tpg * BN * V4;
+    float* B = Bs0 + (stage & 1) * P.b_buf_floats;
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      if (b_lds[i] >= 0) *reinterpret_cast<float4*>(B + b_lds[i]) = rb[i];
+  };
+  // DMA path: the next stage's images go global -> LDS directly.  Lane l of wave w, slot i, lands at
+  // image byte 16 * (i*256 + 64*w + l): the images are linear in the slot index by construction.
+  auto dma_issue = [&]() {
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const char* zsrc = reinterpret_cast<const char*>(&g_zero16);
+    if (f_grp == 0) {
+      const char* sp = reinterpret_cast<const char*>(P.src[f_src] + (long long)img * P.img_stride[f_src] + f_c0);
+      const unsigned pixb = (unsigned)P.ld[f_src] * 4u;
+      float* A = As0 + (f_chunk & 1) * P.a_buf_floats + wave * 256;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        if (i < P.na) {
+          const char* gp = (a_pix[i] >= 0) ? sp + (size_t)((unsigned)a_pix[i] * pixb + 4u * (unsigned)a_ch[i]) : zsrc;
+          __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(A + i * 1024), 16, 0, 0);
+        }
+      }
+    }
+    const char* wp = reinterpret_cast<const char*>(wbase + (long long)f_grp * grp_stride + f_cpad + f_c0);
+    float* B = Bs0 + (f_stage & 1) * P.b_buf_floats + wave * 256;
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-      const int e = tid + i * 256;
-      if (e < nb4) {
-        const int tt = e / (BN * V4), rem = e % (BN * V4);
-        const int nn = rem / V4, j = rem % V4;
-        *reinterpret_cast<float4*>(Bs + (tt * BN + nn) * BPIX + 4 * j) = rb[i];
+      if (i < P.nb) {
+        const char* gp = (b_goff[i] >= 0) ? wp + (size_t)((unsigned)b_goff[i] * 4u) : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(B + i * 1024), 16, 0, 0);
       }
     }
+    advance();
   };
 
-  __syncthreads();   // tap table visible
-  prefetch(0);
+  // ---- prologue ----
+  if (DMA) {
+    dma_issue();
+  } else {
+    fetch();
+    commit(0, 0, 0);
+    if (nstages > 1) fetch();
+  }
+  __syncthreads();
+
+  int chunk = 0, grp = 0;
   for (int stage = 0; stage < nstages; ++stage) {
-#ifdef GP_EXP_NO_RESTAGE
-    if (stage == 0) {
+    int nchunk = chunk, ngrp = grp + 1;
+    if (ngrp == ngroups) { ngrp = 0; ++nchunk; }
+    if (DMA) {
+      if (stage + 1 < nstages) dma_issue();               // stage+1 lands in the other buffers during the MFMAs below
+    } else {
+      // stage+1 -> the other LDS buffers (its loads were issued a whole stage ago)
+#ifndef GP_EXP_NO_COMMIT
+      if (stage + 1 < nstages) commit(nchunk, ngrp, stage + 1);
 #endif
-    __syncthreads();           // everyone done reading the previous stage
-    commit(stage);
-    __syncthreads();
-    if (stage + 1 < nstages) prefetch(stage + 1);
-#ifdef GP_EXP_NO_RESTAGE
+#ifndef GP_EXP_NO_FETCH
+      if (stage + 2 < nstages) fetch();                   // stage+2 in flight during the MFMAs below
+#endif
     }
-#endif
-    const int grp = stage % ngroups;
-    for (int tt = 0; tt < tpg; ++tt) {
-      const int tg = grp * tpg + tt;
-      const int aoff = (tap_dy[tg] * P.halo_w + tap_dx[tg]) * APIX;
-      const float* bp = Bs + tt * BN * BPIX + b_frag;
+
+    const float* A = As0 + (chunk & 1) * P.a_buf_floats;
+    const float* B = Bs0 + (stage & 1) * P.b_buf_floats + b_frag;
+    // tap loop, software pipelined by two
+    const int ky0 = grp * P.tpg_h;
+    const int nsteps = tpg * KJ;
+    float4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+    int s_ky = 0, s_kx = 0, s_kj = 0;                   // coordinates of the NEXT step to load
+    auto load_step = [&](float4 (&fa)[MT], float4 (&fb)[NT], unsigned& mask) {
+      const int tt = s_ky * P.tpg_w + s_kx;
+      // SWZ: this lane's 16-B chunk (2*kj + lh) of a 128-B row sits at physical chunk (2*kj + lh) ^ (row & 7)
+      const int koff = SWZ ? 4 * (((2 * s_kj + lh) ^ swz_x)) : 8 * s_kj;
+      const int aoff = ((ky0 + s_ky) * P.halo_w + s_kx) * APIX + koff;
 #pragma unroll
-      for (int kj = 0; kj < KJ; ++kj) {
-        float4 a[MT], b[NT];
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const float4*>(A + a_frag[mt] + aoff);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(As + a_frag[mt] + aoff + 8 * kj);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(bp + nt * 32 * BPIX + 8 * kj);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
-          }
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const float4*>(B + (tt * BN + nt * 32) * BPIX + koff);
+      if (MASKED) {     // transposed form: tap (dy,dx) feeds phases q = 2py+px with py >= dy, px >= dx
+        mask = s_ky ? (s_kx ? 0x8u : 0xCu) : (s_kx ? 0xAu : 0xFu);
+      } else {
+        mask = 0xFu;
       }
+      if (++s_kj == KJ) { s_kj = 0; if (++s_kx == P.tpg_w) { s_kx = 0; ++s_ky; } }
+    };
+    auto mma_step = [&](const float4 (&fa)[MT], const float4 (&fb)[NT], unsigned mask) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (MASKED && !((mask >> nt) & 1u)) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].x, fb[nt].x, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].y, fb[nt].y, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].z, fb[nt].z, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt].w, fb[nt].w, acc[mt][nt], 0, 0, 0);
+        }
+      }
+    };
+    unsigned m0 = 0xF, m1 = 0xF;
+    load_step(fa0, fb0, m0);
+    int st = 0;
+    for (; st + 1 < nsteps; st += 2) {
+      load_step(fa1, fb1, m1);
+      mma_step(fa0, fb0, m0);
+      if (st + 2 < nsteps) load_step(fa0, fb0, m0);
+      mma_step(fa1, fb1, m1);
     }
+    if (st < nsteps) mma_step(fa0, fb0, m0);
+    __syncthreads();     // (a) every wave finished reading this stage's buffers, (b) stage+1's writes/DMA are visible
+    chunk = nchunk; grp = ngrp;
   }
 
-  // ---- epilogue: bias, activation, residual, pixel multiplier, (shuffled) store ----
-  const int cq = P.cout >> 2;
+  // ---- epilogue: accumulators -> LDS [pixel][EW+4] (64 output columns per pass) -> coalesced rows ----
+  constexpr int EW = BN < 64 ? BN : 64;
+  constexpr int EPIX = EW + 4;
+  constexpr int NPASS = BN / EW;
+  constexpr int NV = EW / 4;
+  float* E = smem;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int nidx = n0 + wn * WNT + nt * 32 + li;
-    if (nidx >= P.cout) continue;
-    const float bv = P.bias ? P.bias[nidx] : 0.f;
-    int ch = nidx, sy = 0, sx = 0;
-    if (P.pixel_shuffle) { const int q = nidx / cq; ch = nidx - q * cq; sy = q >> 1; sx = q & 1; }
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (pass > 0) __syncthreads();                       // previous pass fully read out
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col0 = wn * WNT + nt * 32;               // first column of this wave's N tile inside the block tile
+      if (col0 / EW != pass) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#ifdef GP_EXP_NO_EPILOGUE
-        if (r != 0) { asm volatile("" ::"v"(acc[mt][nt][r])); continue; }
-#endif
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int p = wm * PM + mt * 32 + row;
-        const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-        if (oy >= P.oh || ox >= P.ow) continue;
-        int Y = oy, X = ox;
-        if (P.transposed) { Y = 2 * oy + py; X = 2 * ox + px; }
-        else if (P.pixel_shuffle) { Y = 2 * oy + sy; X = 2 * ox + sx; }
-        const long long opix = ((long long)img * P.OH + Y) * P.OW + X;
-        float v = apply_act(acc[mt][nt][r] + bv, P.act);
-        if (P.residual) v += P.residual[opix * P.res_ld + ch];
-        if (P.pixmul) v *= P.pixmul[opix];
-        P.out[opix * P.out_ld + ch] = v;
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          E[(wm * PM + mt * 32 + row) * EPIX + (col0 - pass * EW) + li] = acc[mt][nt][r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 128 * NV; e += 256) {
+      const int p = e / NV, j = e % NV;
+      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
+      const int nidx = n0 + pass * EW + 4 * j;
+      if (oy >= P.oh || ox >= P.ow || nidx >= P.cout) continue;
+      int Y = oy, X = ox, ch = nidx, bidx = nidx;
+      if (P.store_mode == STORE_PIXSHUF) {          // bias was permuted with the weight rows
+        const int q = nidx / P.cq; ch = nidx - q * P.cq; Y = 2 * oy + (q >> 1); X = 2 * ox + (q & 1);
+      } else if (P.store_mode == STORE_CONVT) {     // bias is per true output channel
+        const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); bidx = ch;
+        Y = 2 * oy + (q >> 1); X = 2 * ox + (q & 1);
+      }
+      const long long opix = ((long long)img * P.OH + Y) * P.OW + X;
+      const float4 a4 = *reinterpret_cast<const float4*>(E + p * EPIX + 4 * j);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      const int nvalid = (P.cout - nidx) < 4 ? (P.cout - nidx) : 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nvalid) v[k] = apply_act(v[k] + (P.bias ? P.bias[bidx + k] : 0.f), P.act);
+      if (P.residual) {
+        const float* rp = P.residual + opix * P.res_ld + ch;
+        if (P.res_vec && nvalid == 4) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rp);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (k < nvalid) v[k] += rp[k];
+        }
+      }
+      if (P.pixmul) {
+        const float m = P.pixmul[opix];
+        v[0] *= m; v[1] *= m; v[2] *= m; v[3] *= m;
+      }
+      float* op = P.out + opix * P.out_ld + ch;
+      if (P.out_vec && nvalid == 4) {
+        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < nvalid) op[k] = v[k];
       }
     }
   }
 }
 
-template <int CK, int BN>
+template <int CK, int BN, int WM, int WN, bool MASKED, bool DMA>
 static int launch(const ConvParams& P, size_t lds_bytes, hipStream_t st) {
-  hipLaunchKernelGGL((conv_mfma_kernel<CK, BN>), dim3(P.nblocks), dim3(256), lds_bytes, st, P);
+  auto kfn = conv_mfma_kernel<CK, BN, WM, WN, MASKED, DMA>;
+  if (lds_bytes > 64 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return fail(GPEMSR_ELAUNCH, "conv2d: cannot raise the dynamic LDS limit");
+      attr_done = true;
+    }
+  }
+  hipLaunchKernelGGL(kfn, dim3(P.nblocks), dim3(256), lds_bytes, st, P);
   return check_launch("conv_mfma_kernel");
 }
 
@@ -312,9 +430,10 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   GP_REQUIRE(d->weight && d->out, "conv2d: null weight/out");
   ConvParams P{};
   const bool tr = d->transposed != 0;
-  if (tr) GP_REQUIRE(d->ksize == 3 && !d->pixel_shuffle, "conv2d: transposed needs k=3, no pixel_shuffle");
+  if (tr) GP_REQUIRE(d->ksize == 3 && !d->pixel_shuffle && d->cout % 32 == 0 && !d->pixmul,
+                     "conv2d: transposed needs k=3, cout%%32==0, no pixel_shuffle/pixmul");
   else GP_REQUIRE(d->stride == 1 || d->stride == 2, "conv2d: stride=%d unsupported (use conv2d_direct)", d->stride);
-  if (d->pixel_shuffle) GP_REQUIRE(d->cout % 4 == 0 && d->stride == 1, "conv2d: pixel_shuffle needs cout%%4==0, stride 1");
+  if (d->pixel_shuffle) GP_REQUIRE(d->cout % 16 == 0 && d->stride == 1, "conv2d: pixel_shuffle needs cout%%16==0, stride 1");
   const int CK = (d->ksize == 1) ? 32 : 8;
   int cin_pad = 0;
   for (int s = 0; s < d->nsrc; ++s) {
@@ -326,42 +445,69 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   }
   GP_REQUIRE((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0 && d->weight_image_stride % 4 == 0, "conv2d: weight must be 16B aligned");
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w;
-  P.cin_pad = cin_pad; P.cout = d->cout; P.ksize = d->ksize;
-  P.stride = tr ? 1 : d->stride; P.pad = d->ksize / 2; P.transposed = tr;
+  P.cin_pad = cin_pad;
   P.weight = d->weight; P.w_img_stride = d->weight_image_stride; P.bias = d->bias; P.act = d->act;
-  P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul; P.pixel_shuffle = d->pixel_shuffle;
+  P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;
   P.out = d->out; P.out_ld = d->out_ld;
-  if (tr) { P.oh = d->h; P.ow = d->w; P.OH = 2 * d->h; P.OW = 2 * d->w; P.nphase = 4;
-            P.halo_h = TILE_H + 1; P.halo_w = TILE_W + 1; P.ntaps = 4; P.taps_per_group = 4; P.ngroups = 1; }
-  else {
+  P.out_vec = (d->out_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
+  P.res_vec = d->residual && (d->res_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->residual) & 15) == 0);
+  int BN;
+  if (tr) {
+    // phase-stacked 2x2-tap form; weight = [4 taps (dy,dx)][4*Cout][cin_pad] (gpemsr_amd/packing.py::pack_convT)
+    P.kh = P.kw = 2; P.stride = 1; P.pad = 0; P.cout = 4 * d->cout;
+    P.oh = d->h; P.ow = d->w; P.OH = 2 * d->h; P.OW = 2 * d->w;
+    P.store_mode = STORE_CONVT; P.cq = d->cout;
+    P.tpg_h = 2; P.tpg_w = 2; P.ngroups = 1; BN = 128;
+  } else {
+    P.kh = P.kw = d->ksize; P.stride = d->stride; P.pad = d->ksize / 2; P.cout = d->cout;
     P.oh = (d->h + 2 * P.pad - d->ksize) / P.stride + 1;
     P.ow = (d->w + 2 * P.pad - d->ksize) / P.stride + 1;
-    P.OH = d->pixel_shuffle ? 2 * P.oh : P.oh; P.OW = d->pixel_shuffle ? 2 * P.ow : P.ow; P.nphase = 1;
-    P.halo_h = (TILE_H - 1) * P.stride + d->ksize; P.halo_w = (TILE_W - 1) * P.stride + d->ksize;
-    P.ntaps = d->ksize * d->ksize;
-    P.taps_per_group = d->ksize == 7 ? 7 : P.ntaps; P.ngroups = P.ntaps / P.taps_per_group;
+    P.store_mode = d->pixel_shuffle ? STORE_PIXSHUF : STORE_PLAIN; P.cq = d->cout / 4;
+    P.OH = d->pixel_shuffle ? 2 * P.oh : P.oh; P.OW = d->pixel_shuffle ? 2 * P.ow : P.ow;
+    BN = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
+    GP_REQUIRE(!(d->ksize == 7 && BN == 128), "conv2d: 7x7 with cout > 64 unsupported");
+    if (d->ksize == 1) { P.tpg_h = 1; P.tpg_w = 1; P.ngroups = 1; }
+    else { P.tpg_h = 1; P.tpg_w = d->ksize; P.ngroups = d->ksize; }   // one filter row per stage (small LDS images -> more blocks per CU)
   }
-  const int BN = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
-  P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TILE_H); P.tiles_n = cdiv(d->cout, BN);
-  const long long nb = (long long)d->n * P.nphase * P.tiles_y * P.tiles_x * P.tiles_n;
+  P.halo_h = (TILE_H - 1) * P.stride + P.kh; P.halo_w = (TILE_W - 1) * P.stride + P.kw;
+  P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TILE_H); P.tiles_n = cdiv(P.cout, BN);
+  const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d: grid too large");
   P.nblocks = (int)nb;
-  const int APIX = CK == 8 ? 8 : CK + 4;
   GP_REQUIRE(P.halo_h * P.halo_w * (CK / 4) <= A_LOADS * 256, "conv2d: halo too large");
-  const size_t a_floats = ((size_t)P.halo_h * P.halo_w * APIX + 3) & ~(size_t)3;
-  const size_t b_floats = (size_t)P.taps_per_group * BN * APIX;
-  const size_t lds = (192 + a_floats + b_floats) * sizeof(float);
-  GP_REQUIRE(lds <= 160 * 1024 - 256, "conv2d: LDS %zu too large", lds);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (CK == 8) {
-    if (BN == 32) return launch<8, 32>(P, lds, st);
-    if (BN == 64) return launch<8, 64>(P, lds, st);
-    return launch<8, 128>(P, lds, st);
+  // DMA staging needs: every source 16-B aligned rows with c % CK == 0 (no partial chunks), 32-bit byte offsets
+  bool dma = true;
+  for (int s = 0; s < d->nsrc; ++s)
+    dma = dma && P.vec[s] && (P.c[s] % CK == 0) && ((long long)d->h * d->w * P.ld[s] * 4 < (1ll << 32));
+  dma = dma && ((long long)P.kh * P.kw * P.cout * P.cin_pad * 4 < (1ll << 32));
+  const int tpg = P.tpg_h * P.tpg_w;
+  P.na = cdiv((long long)P.halo_h * P.halo_w * (CK / 4), 256);
+  P.nb = cdiv((long long)tpg * BN * (CK / 4), 256);
+  if (dma) {
+    P.a_buf_floats = P.na * 1024;           // linear images, padded to whole 1-KiB wave pieces
+    P.b_buf_floats = P.nb * 1024;
   } else {
-    if (BN == 32) return launch<32, 32>(P, lds, st);
-    if (BN == 64) return launch<32, 64>(P, lds, st);
-    return launch<32, 128>(P, lds, st);
+    const int APIX = CK == 8 ? 8 : CK + 4;
+    P.a_buf_floats = (P.halo_h * P.halo_w * APIX + 3) & ~3;
+    P.b_buf_floats = tpg * BN * APIX;
   }
+  size_t lds_floats = 2 * (size_t)(P.a_buf_floats + P.b_buf_floats);
+  const size_t epi_floats = 128 * (size_t)((BN < 64 ? BN : 64) + 4);
+  if (epi_floats > lds_floats) lds_floats = epi_floats;
+  const size_t lds = lds_floats * sizeof(float);
+  GP_REQUIRE(lds <= 160 * 1024, "conv2d: LDS %zu too large", lds);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define GP_LAUNCH(CKv, BNv, WMv, WNv, MK) (dma ? launch<CKv, BNv, WMv, WNv, MK, true>(P, lds, st) : launch<CKv, BNv, WMv, WNv, MK, false>(P, lds, st))
+  if (tr) return GP_LAUNCH(8, 128, 4, 1, true);
+  if (CK == 8) {
+    if (BN == 32) return GP_LAUNCH(8, 32, 4, 1, false);
+    if (BN == 64) return GP_LAUNCH(8, 64, 2, 2, false);
+    return GP_LAUNCH(8, 128, 2, 2, false);
+  }
+  if (BN == 32) return GP_LAUNCH(32, 32, 4, 1, false);
+  if (BN == 64) return GP_LAUNCH(32, 64, 2, 2, false);
+  return GP_LAUNCH(32, 128, 2, 2, false);
+#undef GP_LAUNCH
 }
 
 // The Python binding (gpemsr_amd/_abi.py) mirrors this struct field by field.

@@ -50,10 +50,23 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, splits: Option
 
 
 def pack_convT(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
+    """ConvTranspose2d(k3,s2,p1,op1) [Cin,Cout,3,3] -> the kernel's phase-stacked 2x2-tap form
+    [tap = 2*dy+dx][n' = (co//32)*128 + q*32 + co%32][cin_pad], q = 2*py+px:
+        out(2i+py, 2j+px) = sum_{dy<=py, dx<=px} in(i+dy, j+dx) . W[:, :, py+1-2dy, px+1-2dx]
+    (rows of phases that a tap does not feed stay zero and are skipped by the kernel's tap mask)."""
     cin, cout, kh, kw = w.shape
-    assert kh == 3 and kw == 3
-    wt = w.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(9, cout, cin)
-    return PackedConv(_pad_split(wt, (cin,), 8).to(device), b.detach().to(torch.float32).contiguous().to(device), 3, cout,
+    assert kh == 3 and kw == 3 and cout % 32 == 0
+    wf = w.detach().to(torch.float32).cpu()
+    out = torch.zeros(4, 4 * cout, cin, dtype=torch.float32)
+    co = torch.arange(cout)
+    for dy in range(2):
+        for dx in range(2):
+            for py in range(dy, 2):
+                for px in range(dx, 2):
+                    q = 2 * py + px
+                    rows = (co // 32) * 128 + q * 32 + (co % 32)
+                    out[2 * dy + dx, rows] = wf[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()
+    return PackedConv(_pad_split(out, (cin,), 8).to(device), b.detach().to(torch.float32).contiguous().to(device), 3, cout,
                       (cin,), 8, transposed=True)
 
 

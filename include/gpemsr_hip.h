@@ -72,7 +72,9 @@ typedef struct {
   int32_t ksize;                   /* 1, 3 or 7 */
   int32_t stride;                  /* 1 or 2 (ignored when transposed) */
   int32_t transposed;              /* 1 = ConvTranspose2d(k=3,s=2,p=1,op=1): out is 2h x 2w */
-  const float* weight;             /* packed [tap][cout][cin_total], tap = ky*k+kx, cin fastest */
+  const float* weight;             /* packed [tap][cout][cin_pad], tap = ky*k+kx, cin fastest, cin padded per source to 8
+                                      (k>=3) or 32 (k=1).  transposed: [tap = 2*dy+dx][n' = (co/32)*128 + q*32 + co%32][cin_pad],
+                                      q = 2*py+px, the phase-stacked 2x2-tap form (gpemsr_amd/packing.py::pack_convT) */
   int64_t weight_image_stride;     /* elements; 0 = one weight set for all images (normal conv) */
   const float* bias;               /* [cout] or NULL */
   int32_t act;                     /* GPEMSR_ACT_* */

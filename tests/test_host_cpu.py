@@ -121,10 +121,18 @@ def test_weight_packing_layouts():
     for q in range(4):
         shuffled[:, :, (q >> 1)::2, (q & 1)::2] = y[:, q * cq:(q + 1) * cq]
     assert torch.allclose(shuffled, F.pixel_shuffle(F.conv2d(x, wp, bp, 1, 1), 2), atol=1e-6)
-    # transposed conv: [Cin,Cout,3,3] -> [tap][cout][cin]
-    wt = torch.randn(8, 16, 3, 3, generator=g)
-    pt = pack_convT(wt, torch.zeros(16), "cpu")
-    assert pt.transposed and torch.equal(pt.w[4], wt[:, :, 1, 1].t())
+    # transposed conv: phase-stacked 2x2-tap form reproduces F.conv_transpose2d
+    wt, bt = torch.randn(8, 32, 3, 3, generator=g), torch.randn(32, generator=g)
+    pt = pack_convT(wt, bt, "cpu")
+    assert pt.transposed and pt.w.shape == (4, 128, 8)
+    xt = torch.randn(1, 8, 5, 7, generator=g)
+    xp = F.pad(xt, (0, 1, 0, 1))                                  # in(i+1, j+1) beyond the image is zero
+    stacked = sum(torch.einsum("nc,bchw->bnhw", pt.w[2 * dy + dx], xp[:, :, dy:dy + 5, dx:dx + 7])
+                  for dy in range(2) for dx in range(2))          # [1,128,5,7]
+    yt = torch.zeros(1, 32, 10, 14)
+    for q in range(4):
+        yt[:, :, (q >> 1)::2, (q & 1)::2] = stacked[:, q * 32:(q + 1) * 32]
+    assert torch.allclose(yt + bt.view(1, -1, 1, 1), F.conv_transpose2d(xt, wt, bt, stride=2, padding=1, output_padding=1), atol=1e-5)
     # DCN: tap-major column order
     wd = torch.randn(64, 64, 3, 3, generator=g)
     pd = pack_dcn(wd, torch.zeros(64), "cpu")
