@@ -1,9 +1,9 @@
 // Implicit-GEMM convolution on the CDNA4 f32 matrix pipe (v_mfma_f32_32x32x2_f32).   [v2]
 //
-// One workgroup (4 waves) produces an 8x16-pixel x BN-channel output tile:
+// One workgroup (4 waves) produces a 4x32-pixel x BN-channel output tile:
 //   D[pixel][cout] = sum_{tap} sum_{cin} In[pixel*stride + tap][cin] * W[tap][cout][cin]
 // K loop = (cin chunk of CK channels) x (tap group).  Per chunk the input halo tile
-// ((8-1)*s+kh) x ((16-1)*s+kw) x CK is staged ONCE in LDS and every tap reads it at a shifted
+// ((4-1)*s+kh) x ((32-1)*s+kw) x CK is staged ONCE in LDS and every tap reads it at a shifted
 // offset (k*k-fold reuse out of LDS, no im2col in HBM); the weight slice [taps][BN][CK] of the
 // stage sits beside it.  Both are double-buffered: stage s+1 is written to the other buffer
 // before the MFMAs of stage s and the global loads of stage s+2 are in flight in registers
@@ -39,11 +39,10 @@
 
 namespace gpemsr {
 
-__device__ float4 g_zero16;          // 16 zero bytes: DMA source of every padded / out-of-range slot
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TILE_H = 8, TILE_W = 16;
+constexpr int TILE_W = 32;                // a 32-pixel MFMA tile is one contiguous tile row: conflict-free A fragment reads
 constexpr int A_LOADS = 5;   // float4 per thread per A stage (17*33 halo px * 2 / 256 -> 5)
 
 enum { STORE_PLAIN = 0, STORE_PIXSHUF = 1, STORE_CONVT = 2 };
@@ -72,12 +71,44 @@ struct ConvParams {
   int tpg_h, tpg_w, ngroups;      // taps of one stage: tpg_h x tpg_w (rows x cols of the filter)
   int a_buf_floats, b_buf_floats;
   int na, nb;                     // DMA slots (float4 per thread) per A / B stage
+  int ring;                       // DMA: weight images in a 3-deep ring, counted vmcnt (needs ngroups >= 2 or not; see kernel)
   int nblocks;
 };
 
-template <int CK, int BN, int WM, int WN, bool MASKED, bool DMA>
+// One LDS-DMA piece: lane l's 16 bytes at (base + voff) land at LDS byte (lds_addr + 16*l); base and lds_addr are
+// wave-uniform (SGPRs), voff is the lane's 32-bit byte offset; lanes masked off by EXEC write nothing.
+// Issued through inline asm ON PURPOSE: hipcc treats a builtin LDS-DMA as a pending LDS store and drains it with
+// s_waitcnt vmcnt(0) before the next ds_read, which serialises the pipeline; an asm DMA is outside its wait-count
+// bookkeeping (guide 5.7 item 1), so the counted waits below (wait_vmcnt + s_barrier) are the ONLY ordering.
+__device__ __forceinline__ void glds16(unsigned voff, const void* base, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+
+// s_waitcnt vmcnt(n) with a wave-uniform runtime n (the instruction needs an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+  }
+}
+
+template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
-  constexpr int PM = 128 / WM;        // pixels per wave
+  constexpr int NPIX = TH * TILE_W;   // output pixels per workgroup (TH x 32)
+  constexpr int PM = NPIX / WM;       // pixels per wave
   constexpr int MT = PM / 32;
   constexpr int WNT = BN / WN;        // couts per wave
   constexpr int NT = WNT / 32;
@@ -110,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
   const int tx = t % P.tiles_x; t /= P.tiles_x;
   const int ty = t % P.tiles_y; t /= P.tiles_y;
   const int img = t;
-  const int oy0 = ty * TILE_H, ox0 = tx * TILE_W, n0 = tn * BN;
+  const int oy0 = ty * TH, ox0 = tx * TILE_W, n0 = tn * BN;
   const int S = P.stride;
   const int iy0 = oy0 * S - P.pad, ix0 = ox0 * S - P.pad;
   const int halo_px = P.halo_h * P.halo_w;
@@ -153,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    a_frag[mt] = (((p >> 4) * S) * P.halo_w + (p & 15) * S) * APIX + (SWZ ? 0 : 4 * lh);
+    a_frag[mt] = (((p / TILE_W) * S) * P.halo_w + (p % TILE_W) * S) * APIX + (SWZ ? 0 : 4 * lh);
   }
   const int b_frag = (wn * WNT + li) * BPIX + (SWZ ? 0 : 4 * lh);
   const int swz_x = li & 7;            // SWZ: row & 7 of this lane's A and B rows (tile bases are multiples of 8)
@@ -233,50 +264,87 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
   };
   // DMA path: the next stage's images go global -> LDS directly.  Lane l of wave w, slot i, lands at
   // image byte 16 * (i*256 + 64*w + l): the images are linear in the slot index by construction.
-  auto dma_issue = [&]() {
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const char* zsrc = reinterpret_cast<const char*>(&g_zero16);
-    if (f_grp == 0) {
-      const char* sp = reinterpret_cast<const char*>(P.src[f_src] + (long long)img * P.img_stride[f_src] + f_c0);
-      const unsigned pixb = (unsigned)P.ld[f_src] * 4u;
-      float* A = As0 + (f_chunk & 1) * P.a_buf_floats + wave * 256;
+  // DMA path.  Lane l of wave w, slot i lands at image byte 16*(i*256 + 64*w + l): the images are linear in the slot
+  // index by construction.  Slots that never receive data (out-of-image halo pixels, rows past cout, the padding of
+  // the last 1-KiB piece) are zeroed ONCE below and their lanes stay masked off in every DMA.
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem) + (unsigned)wave * 1024u);   // wave's 1-KiB piece of slot 0
+  const int nbuf_b = DMA ? 3 : 2;
+  if (DMA) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < A_LOADS; ++i) {
-        if (i < P.na) {
-          const char* gp = (a_pix[i] >= 0) ? sp + (size_t)((unsigned)a_pix[i] * pixb + 4u * (unsigned)a_ch[i]) : zsrc;
-          __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(A + i * 1024), 16, 0, 0);
-        }
-      }
-    }
-    const char* wp = reinterpret_cast<const char*>(wbase + (long long)f_grp * grp_stride + f_cpad + f_c0);
-    float* B = Bs0 + (f_stage & 1) * P.b_buf_floats + wave * 256;
+    for (int i = 0; i < A_LOADS; ++i)
+      if (i < P.na && a_pix[i] < 0)
+        for (int bsel = 0; bsel < 2; ++bsel) *reinterpret_cast<float4*>(As0 + bsel * P.a_buf_floats + (tid + i * 256) * 4) = z;
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      if (i < P.nb) {
-        const char* gp = (b_goff[i] >= 0) ? wp + (size_t)((unsigned)b_goff[i] * 4u) : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)gp, (lptr_t)(B + i * 1024), 16, 0, 0);
-      }
-    }
-    advance();
+    for (int i = 0; i < B_LOADS; ++i)
+      if (i < P.nb && b_goff[i] < 0)
+        for (int bsel = 0; bsel < 3; ++bsel) *reinterpret_cast<float4*>(Bs0 + bsel * P.b_buf_floats + (tid + i * 256) * 4) = z;
+  }
+  // DMA instructions THIS WAVE really issues per image: a slot whose 64 lanes are all masked off is branched over
+  // (s_cbranch_execz), so the counted waits must not include it.
+  int na_w = 0, nb_w = 0;
+  if (DMA) {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) na_w += (i < P.na && __ballot(a_pix[i] >= 0) != 0ull) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) nb_w += (i < P.nb && __ballot(b_goff[i] >= 0) != 0ull) ? 1 : 0;
+  }
+  auto dma_b = [&]() -> int {                   // weight image of the fetch state's stage -> ring slot f_stage % 3
+    const float* wp = wbase + (long long)f_grp * grp_stride + f_cpad + f_c0;
+    const unsigned lb = lds0 + (unsigned)(2 * P.a_buf_floats + (f_stage % nbuf_b) * P.b_buf_floats) * 4u;
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      if (i < P.nb && b_goff[i] >= 0) glds16((unsigned)b_goff[i] * 4u, wp, lb + i * 4096u);
+    return nb_w;
   };
 
   // ---- prologue ----
+  // ring mode (DMA only): the fetch state runs TWO stages ahead for the weight images; the activation image of
+  // chunk c+1 is issued during the FIRST stage of chunk c.  a_next_* is a second fetch cursor for the A images.
+  int an_src = 0, an_c0 = 0, an_chunk = 0;      // chunk whose A image is issued next (ring mode)
+  auto a_cursor_advance = [&]() {
+    ++an_chunk; an_c0 += CK;
+    const int cp = ((P.c[an_src] + CK - 1) / CK) * CK;
+    if (an_c0 >= cp && an_src + 1 < P.nsrc) { an_c0 = 0; ++an_src; }
+  };
+  auto dma_a_cursor = [&]() -> int {            // activation image of chunk an_chunk -> A buffer an_chunk & 1
+    const float* sp = P.src[an_src] + (long long)img * P.img_stride[an_src] + an_c0;
+    const unsigned pixb = (unsigned)P.ld[an_src] * 4u;
+    const unsigned la = lds0 + (unsigned)((an_chunk & 1) * P.a_buf_floats) * 4u;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+      if (i < P.na && a_pix[i] >= 0) glds16((unsigned)a_pix[i] * pixb + 4u * (unsigned)a_ch[i], sp, la + i * 4096u);
+    a_cursor_advance();
+    return na_w;
+  };
   if (DMA) {
-    dma_issue();
+    dma_a_cursor();                              // A(0)
+    dma_b(); advance();                          // B(0)
+    int infl = 0;
+    if (nstages > 1) { infl = dma_b(); advance(); }   // B(1) may stay in flight
+    wait_vmcnt(infl);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero-fill ds_writes above
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   } else {
     fetch();
     commit(0, 0, 0);
     if (nstages > 1) fetch();
+    __syncthreads();
   }
-  __syncthreads();
 
   int chunk = 0, grp = 0;
   for (int stage = 0; stage < nstages; ++stage) {
     int nchunk = chunk, ngrp = grp + 1;
     if (ngrp == ngroups) { ngrp = 0; ++nchunk; }
+    int issued = 0;                                       // ring mode: DMA instructions issued during this stage
     if (DMA) {
-      if (stage + 1 < nstages) dma_issue();               // stage+1 lands in the other buffers during the MFMAs below
+      // order: A(chunk+1) first, then B(stage+2).  At the end of the stage we wait until only THIS stage's issues
+      // (minus the A image when the next stage already needs it, i.e. ngroups == 1) may still be in flight.
+      int a_issued = 0;
+      if (grp == 0 && an_chunk < nchunks) a_issued = dma_a_cursor();
+      if (stage + 2 < nstages) { issued = dma_b(); advance(); }
+      if (ngroups > 1) issued += a_issued;
     } else {
       // stage+1 -> the other LDS buffers (its loads were issued a whole stage ago)
 #ifndef GP_EXP_NO_COMMIT
@@ -288,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
     }
 
     const float* A = As0 + (chunk & 1) * P.a_buf_floats;
-    const float* B = Bs0 + (stage & 1) * P.b_buf_floats + b_frag;
+    const float* B = Bs0 + (stage % nbuf_b) * P.b_buf_floats + b_frag;
     // tap loop, software pipelined by two
     const int ky0 = grp * P.tpg_h;
     const int nsteps = tpg * KJ;
@@ -333,36 +401,52 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
       mma_step(fa1, fb1, m1);
     }
     if (st < nsteps) mma_step(fa0, fb0, m0);
-    __syncthreads();     // (a) every wave finished reading this stage's buffers, (b) stage+1's writes/DMA are visible
+    if (DMA) {
+      // everything issued BEFORE this stage has landed (this wave's part); the barrier makes all waves' parts visible
+      // and guarantees every wave is done reading the buffers the next stage's DMA will overwrite.
+      wait_vmcnt(issued);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");        // no LDS read of the next stage may be hoisted above the barrier
+    } else {
+      __syncthreads();   // (a) every wave finished reading this stage's buffers, (b) stage+1's writes/DMA are visible
+    }
     chunk = nchunk; grp = ngrp;
   }
 
   // ---- epilogue: accumulators -> LDS [pixel][EW+4] (64 output columns per pass) -> coalesced rows ----
   constexpr int EW = BN < 64 ? BN : 64;
   constexpr int EPIX = EW + 4;
-  constexpr int NPASS = BN / EW;
+  constexpr int NCP = BN / EW;         // column passes
+  constexpr int NPP = NPIX / 128;      // pixel passes (128 pixels per pass)
   constexpr int NV = EW / 4;
   float* E = smem;
+  if (DMA) __syncthreads();
 #pragma unroll
-  for (int pass = 0; pass < NPASS; ++pass) {
+  for (int pass = 0; pass < NCP * NPP; ++pass) {
+    const int cpass = pass % NCP, ppass = pass / NCP;
     if (pass > 0) __syncthreads();                       // previous pass fully read out
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col0 = wn * WNT + nt * 32;               // first column of this wave's N tile inside the block tile
-      if (col0 / EW != pass) continue;
+      if (col0 / EW != cpass) continue;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        const int prow0 = wm * PM + mt * 32;             // first pixel of this M tile inside the block tile
+        if (prow0 / 128 != ppass) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          E[(wm * PM + mt * 32 + row) * EPIX + (col0 - pass * EW) + li] = acc[mt][nt][r];
+          E[(prow0 - ppass * 128 + row) * EPIX + (col0 - cpass * EW) + li] = acc[mt][nt][r];
         }
+      }
     }
     __syncthreads();
     for (int e = tid; e < 128 * NV; e += 256) {
-      const int p = e / NV, j = e % NV;
-      const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
-      const int nidx = n0 + pass * EW + 4 * j;
+      const int pl = e / NV, j = e % NV;
+      const int p = ppass * 128 + pl;
+      const int oy = oy0 + p / TILE_W, ox = ox0 + p % TILE_W;
+      const int nidx = n0 + cpass * EW + 4 * j;
       if (oy >= P.oh || ox >= P.ow || nidx >= P.cout) continue;
       int Y = oy, X = ox, ch = nidx, bidx = nidx;
       if (P.store_mode == STORE_PIXSHUF) {          // bias was permuted with the weight rows
@@ -372,7 +456,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
         Y = 2 * oy + (q >> 1); X = 2 * ox + (q & 1);
       }
       const long long opix = ((long long)img * P.OH + Y) * P.OW + X;
-      const float4 a4 = *reinterpret_cast<const float4*>(E + p * EPIX + 4 * j);
+      const float4 a4 = *reinterpret_cast<const float4*>(E + pl * EPIX + 4 * j);
       float v[4] = {a4.x, a4.y, a4.z, a4.w};
       const int nvalid = (P.cout - nidx) < 4 ? (P.cout - nidx) : 4;
 #pragma unroll
@@ -403,9 +487,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
   }
 }
 
-template <int CK, int BN, int WM, int WN, bool MASKED, bool DMA>
+template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA>
 static int launch(const ConvParams& P, size_t lds_bytes, hipStream_t st) {
-  auto kfn = conv_mfma_kernel<CK, BN, WM, WN, MASKED, DMA>;
+  auto kfn = conv_mfma_kernel<CK, BN, WM, WN, TH, MASKED, DMA>;
   if (lds_bytes > 64 * 1024) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -469,8 +553,10 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
     if (d->ksize == 1) { P.tpg_h = 1; P.tpg_w = 1; P.ngroups = 1; }
     else { P.tpg_h = 1; P.tpg_w = d->ksize; P.ngroups = d->ksize; }   // one filter row per stage (small LDS images -> more blocks per CU)
   }
-  P.halo_h = (TILE_H - 1) * P.stride + P.kh; P.halo_w = (TILE_W - 1) * P.stride + P.kw;
-  P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TILE_H); P.tiles_n = cdiv(P.cout, BN);
+  // 8x32-pixel blocks (every wave owns 64 pixels x all couts) for stride-1 k>=3 convs with cout <= 64; 4x32 otherwise
+  const int TH = (!tr && d->ksize == 3 && BN <= 64 && P.stride == 1) ? 8 : 4;   // (7x7: the LDS images would allow 1 block/CU)
+  P.halo_h = (TH - 1) * P.stride + P.kh; P.halo_w = (TILE_W - 1) * P.stride + P.kw;
+  P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d: grid too large");
   P.nblocks = (int)nb;
@@ -491,22 +577,24 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
     P.a_buf_floats = (P.halo_h * P.halo_w * APIX + 3) & ~3;
     P.b_buf_floats = tpg * BN * APIX;
   }
-  size_t lds_floats = 2 * (size_t)(P.a_buf_floats + P.b_buf_floats);
+  P.ring = dma ? 1 : 0;
+  size_t lds_floats = 2 * (size_t)P.a_buf_floats + (size_t)(P.ring ? 3 : 2) * P.b_buf_floats;
   const size_t epi_floats = 128 * (size_t)((BN < 64 ? BN : 64) + 4);
   if (epi_floats > lds_floats) lds_floats = epi_floats;
   const size_t lds = lds_floats * sizeof(float);
   GP_REQUIRE(lds <= 160 * 1024, "conv2d: LDS %zu too large", lds);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define GP_LAUNCH(CKv, BNv, WMv, WNv, MK) (dma ? launch<CKv, BNv, WMv, WNv, MK, true>(P, lds, st) : launch<CKv, BNv, WMv, WNv, MK, false>(P, lds, st))
-  if (tr) return GP_LAUNCH(8, 128, 4, 1, true);
+#define GP_LAUNCH(CKv, BNv, WMv, WNv, THv, MK) \
+  (dma ? launch<CKv, BNv, WMv, WNv, THv, MK, true>(P, lds, st) : launch<CKv, BNv, WMv, WNv, THv, MK, false>(P, lds, st))
+  if (tr) return GP_LAUNCH(8, 128, 4, 1, 4, true);
   if (CK == 8) {
-    if (BN == 32) return GP_LAUNCH(8, 32, 4, 1, false);
-    if (BN == 64) return GP_LAUNCH(8, 64, 2, 2, false);
-    return GP_LAUNCH(8, 128, 2, 2, false);
+    if (BN == 32) return TH == 8 ? GP_LAUNCH(8, 32, 4, 1, 8, false) : GP_LAUNCH(8, 32, 4, 1, 4, false);
+    if (BN == 64) return TH == 8 ? GP_LAUNCH(8, 64, 4, 1, 8, false) : GP_LAUNCH(8, 64, 2, 2, 4, false);
+    return GP_LAUNCH(8, 128, 2, 2, 4, false);
   }
-  if (BN == 32) return GP_LAUNCH(32, 32, 4, 1, false);
-  if (BN == 64) return GP_LAUNCH(32, 64, 2, 2, false);
-  return GP_LAUNCH(32, 128, 2, 2, false);
+  if (BN == 32) return GP_LAUNCH(32, 32, 4, 1, 4, false);
+  if (BN == 64) return GP_LAUNCH(32, 64, 2, 2, 4, false);
+  return GP_LAUNCH(32, 128, 2, 2, 4, false);
 #undef GP_LAUNCH
 }
 

@@ -133,7 +133,7 @@ class Engine:
         hn = ops.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
         q = self.conv(hn, p + ".q")                       # already scaled by C^-1/2
         k = self.conv(hn, p + ".k")
-        gh, gw = (T // 16, 16) if T % 16 == 0 else (T, 1)
+        gh, gw = T // 32, 32                               # GEMM rows as 32-wide "images" (the conv tile is 4x32 pixels)
         # V^T[c][j] = sum_c' Wv[c][c'] hn[j][c']  (bias folded into the PV product: softmax rows sum to 1)
         wv = self.pc[p + ".v"]
         vT = self._vt(wv.w, hn, n, c, T)
@@ -150,8 +150,8 @@ class Engine:
         return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
 
     def _vt(self, wv_packed: torch.Tensor, hn: Act, n: int, c: int, T: int) -> Act:
-        vT = ops.new_act(n, c // 16, 16, T, device=self.dev)
-        a = Act(wv_packed, n, c // 16, 16, c, c, 0)        # n "images" that all alias the one [C][C] weight matrix
+        vT = ops.new_act(n, c // 32, 32, T, device=self.dev)
+        a = Act(wv_packed, n, c // 32, 32, c, c, 0)        # n "images" that all alias the one [C][C] weight matrix
         ops.conv2d([a], ops.PackedConv(hn.buf, None, 1, T, (c,), 32), ACT_NONE, weight_image_stride=T * c,
                    src_image_stride=[0], out=vT, tag="nonlocal.vT")
         return vT

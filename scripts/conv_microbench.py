@@ -23,7 +23,7 @@ SHAPES = [  # name, n, cin, cout, k, stride, h, w, kind, residual
     ("up256_ps", 16, 64, 256, 3, 1, 512, 512, "ps", False),
     ("convT64_512", 20, 64, 64, 3, 1, 512, 512, "convT", False),
     ("down_s2", 20, 64, 64, 3, 2, 512, 512, "conv", False),
-    ("attn_qk", 4, 512, 4096, 1, 1, 256, 16, "bmm", False),
+    ("attn_qk", 4, 512, 4096, 1, 1, 128, 32, "bmm", False),
 ]
 print(f"{'shape':14s} {'ms':>8s} {'TFLOP/s':>8s}")
 for name, n, cin, cout, k, stride, h, w, kind, use_res in SHAPES:

@@ -339,3 +339,36 @@ def test_tensor2img_and_copies():
     d = ops.copy_images(a, 4, 2, 5, 3)          # dst j <- src (j//2)*5+3
     torch.cuda.synchronize()
     assert torch.equal(d.nchw().cpu(), src[[3, 3, 8, 8]])
+
+
+STABILITY_CASES = [(20, 64, 64, 3, 1, 128, 128), (8, 256, 256, 3, 1, 128, 128), (4, 32, 64, 7, 1, 256, 256),
+                   (8, 512, 512, 1, 1, 64, 64), (8, 64, 64, 3, 2, 256, 256), (3, 64, 216, 3, 1, 100, 76),
+                   (2, 64, 32, 3, 1, 130, 94), (4, 64, 64, 0, 1, 128, 128)]
+
+
+@pytest.mark.parametrize("case", STABILITY_CASES)
+def test_conv_large_grids_are_bit_stable(case):
+    """Race screen for the LDS-DMA pipeline (counted vmcnt + raw barriers): production-sized grids (every CU holds
+    several co-resident workgroups, ragged tiles, masked DMA lanes) must be correct AND bit-identical run to run."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_convT
+    n, cin, cout, k, stride, h, w = case
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=201)
+    if k == 0:
+        wt, b = _rand(cin, cout, 3, 3, seed=202, scale=0.05), _rand(cout, seed=203)
+        pc, want = pack_convT(wt, b, dev), F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1)
+    else:
+        wt, b = _rand(cout, cin, k, k, seed=202, scale=1.0 / np.sqrt(cin * k * k)), _rand(cout, seed=203)
+        pc, want = pack_conv(wt, b, dev), F.conv2d(x, wt, b, stride, k // 2)
+    xa = ops.from_nchw(x.to(dev))
+    ref = None
+    for _ in range(5):
+        out = ops.conv2d([xa], pc, 0, stride=stride if k else 1)
+        torch.cuda.synchronize()
+        o = out.torch().clone()
+        if ref is None:
+            ref = o
+            _close(out.nchw(), want, tol=1e-5, what=f"large conv {case}")
+        else:
+            assert torch.equal(o, ref), f"non-deterministic result for {case}"
