@@ -106,7 +106,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvParams P) {
   constexpr int NPIX = TH * TILE_W;   // output pixels per workgroup (TH x 32)
   constexpr int PM = NPIX / WM;       // pixels per wave
   constexpr int MT = PM / 32;
@@ -422,9 +422,57 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
   constexpr int NV = EW / 4;
   float* E = smem;
   if (DMA) __syncthreads();
-#pragma unroll
+  constexpr int ITER = (128 * NV) / 256;      // readout float4 per thread per pass (8 for 64 columns, 4 for 32)
+  constexpr int PSTEP = 256 / NV;             // pixels between a thread's consecutive items
+  const int ej = tid % NV, ep0 = tid / NV;    // this thread's float4 column and first pixel of every pass
+  // per-image bases (wave-uniform) + 32-bit in-image pixel indices keep the item state small
+  const long long img_pix0 = (long long)img * P.OH * P.OW;
+  const float* res_img = P.residual ? P.residual + img_pix0 * P.res_ld : nullptr;
+  const float* mul_img = P.pixmul ? P.pixmul + img_pix0 : nullptr;
+  float* out_img = P.out + img_pix0 * P.out_ld;
+#pragma unroll 1
   for (int pass = 0; pass < NCP * NPP; ++pass) {
     const int cpass = pass % NCP, ppass = pass / NCP;
+    // ---- (1) addresses of this pass's items; residual / multiplier loads are issued BEFORE the LDS round trip ----
+    const int nidx = n0 + cpass * EW + 4 * ej;
+    int ch = nidx, bidx = nidx, sy = 0, sx = 0;
+    if (P.store_mode == STORE_PIXSHUF) {          // bias was permuted with the weight rows
+      const int q = nidx / P.cq; ch = nidx - q * P.cq; sy = q >> 1; sx = q & 1;
+    } else if (P.store_mode == STORE_CONVT) {     // bias is per true output channel
+      const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); bidx = ch; sy = q >> 1; sx = q & 1;
+    }
+    const int nvalid = (P.cout - nidx) < 4 ? (P.cout - nidx) : 4;      // <= 0: this thread's columns are past cout
+    const bool full = nvalid == 4;
+    int opix[ITER];                                                     // pixel index inside the image, or -1
+    float4 rres[ITER];
+    float rmul[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int p = ppass * 128 + ep0 + it * PSTEP;
+      const int oy = oy0 + p / TILE_W, ox = ox0 + p % TILE_W;
+      opix[it] = -1; rres[it] = make_float4(0.f, 0.f, 0.f, 0.f); rmul[it] = 1.f;
+      if (oy < P.oh && ox < P.ow && nvalid > 0) {
+        const int Y = P.store_mode == STORE_PLAIN ? oy : 2 * oy + sy, X = P.store_mode == STORE_PLAIN ? ox : 2 * ox + sx;
+        opix[it] = Y * P.OW + X;
+        if (P.residual) {
+          const float* rp = res_img + (long long)opix[it] * P.res_ld + ch;
+          if (P.res_vec && full) rres[it] = *reinterpret_cast<const float4*>(rp);
+          else {
+            if (nvalid > 0) rres[it].x = rp[0];
+            if (nvalid > 1) rres[it].y = rp[1];
+            if (nvalid > 2) rres[it].z = rp[2];
+            if (nvalid > 3) rres[it].w = rp[3];
+          }
+        }
+        if (P.pixmul) rmul[it] = mul_img[opix[it]];
+      }
+    }
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k < nvalid) bv[k] = P.bias[bidx + k];
+    }
+    // ---- (2) this pass's accumulator columns / pixel rows -> LDS ----
     if (pass > 0) __syncthreads();                       // previous pass fully read out
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -442,42 +490,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams P) {
       }
     }
     __syncthreads();
-    for (int e = tid; e < 128 * NV; e += 256) {
-      const int pl = e / NV, j = e % NV;
-      const int p = ppass * 128 + pl;
-      const int oy = oy0 + p / TILE_W, ox = ox0 + p % TILE_W;
-      const int nidx = n0 + cpass * EW + 4 * j;
-      if (oy >= P.oh || ox >= P.ow || nidx >= P.cout) continue;
-      int Y = oy, X = ox, ch = nidx, bidx = nidx;
-      if (P.store_mode == STORE_PIXSHUF) {          // bias was permuted with the weight rows
-        const int q = nidx / P.cq; ch = nidx - q * P.cq; Y = 2 * oy + (q >> 1); X = 2 * ox + (q & 1);
-      } else if (P.store_mode == STORE_CONVT) {     // bias is per true output channel
-        const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); bidx = ch;
-        Y = 2 * oy + (q >> 1); X = 2 * ox + (q & 1);
-      }
-      const long long opix = ((long long)img * P.OH + Y) * P.OW + X;
-      const float4 a4 = *reinterpret_cast<const float4*>(E + pl * EPIX + 4 * j);
+    // ---- (3) coalesced rows: bias, activation, residual, multiplier, store ----
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (opix[it] < 0) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(E + (ep0 + it * PSTEP) * EPIX + 4 * ej);
       float v[4] = {a4.x, a4.y, a4.z, a4.w};
-      const int nvalid = (P.cout - nidx) < 4 ? (P.cout - nidx) : 4;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k < nvalid) v[k] = apply_act(v[k] + (P.bias ? P.bias[bidx + k] : 0.f), P.act);
-      if (P.residual) {
-        const float* rp = P.residual + opix * P.res_ld + ch;
-        if (P.res_vec && nvalid == 4) {
-          const float4 r4 = *reinterpret_cast<const float4*>(rp);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) if (k < nvalid) v[k] += rp[k];
-        }
-      }
-      if (P.pixmul) {
-        const float m = P.pixmul[opix];
-        v[0] *= m; v[1] *= m; v[2] *= m; v[3] *= m;
-      }
-      float* op = P.out + opix * P.out_ld + ch;
-      if (P.out_vec && nvalid == 4) {
+      for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k] + bv[k], P.act);
+      v[0] += rres[it].x; v[1] += rres[it].y; v[2] += rres[it].z; v[3] += rres[it].w;
+      v[0] *= rmul[it]; v[1] *= rmul[it]; v[2] *= rmul[it]; v[3] *= rmul[it];
+      float* op = out_img + (long long)opix[it] * P.out_ld + ch;
+      if (P.out_vec && full) {
         *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
