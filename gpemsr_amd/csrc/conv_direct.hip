@@ -103,9 +103,55 @@ __global__ __launch_bounds__(256) void conv_direct_scalar_kernel(DirectParams P)
   }
 }
 
+// 1 -> COUT (multiple of 64... here any multiple of 4) 3x3 stride-1 "stem" convolution: HBM-write-bound (4*COUT bytes out per
+// 4 bytes in).  One lane per (pixel, 4 output channels): the 3x3 input neighbourhood is 9 cached scalar loads shared by
+// the 16 lanes of a pixel, weights sit in LDS as [tap][cout], the store is a coalesced float4 (256 B per pixel).
+// Used for VGG conv1_1 on the 1-channel 1024^2 images (model/GPEMSR.py:386,390), conv_first, refmaskconv1, indexer stem.
+__global__ __launch_bounds__(256) void conv_stem1_kernel(const float* x, int n, int h, int w, const float* weight, const float* bias,
+                                                         int cout, int cin_pad, int act, float* out, int out_ld) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];   // [9][cout] then bias[cout]
+  for (int i = threadIdx.x; i < 9 * cout; i += 256) wsm[i] = weight[((long long)(i / cout) * cout + (i % cout)) * cin_pad];
+  for (int i = threadIdx.x; i < cout; i += 256) wsm[9 * cout + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int c4 = cout >> 2;
+  const long long total = (long long)n * h * w * c4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e % c4);
+    const long long pix = e / c4;
+    const int ox = (int)(pix % w), oy = (int)((pix / w) % h);
+    const long long img = pix / ((long long)w * h);
+    const float* xp = x + img * h * w;
+    float4 acc = *reinterpret_cast<const float4*>(wsm + 9 * cout + 4 * j);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy - 1 + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox - 1 + kx;
+        const float v = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? xp[(long long)iy * w + ix] : 0.f;
+        const float4 wv = *reinterpret_cast<const float4*>(wsm + (ky * 3 + kx) * cout + 4 * j);
+        acc.x = fmaf(v, wv.x, acc.x); acc.y = fmaf(v, wv.y, acc.y); acc.z = fmaf(v, wv.z, acc.z); acc.w = fmaf(v, wv.w, acc.w);
+      }
+    }
+    acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
+    *reinterpret_cast<float4*>(out + pix * out_ld + 4 * j) = acc;
+  }
+}
+
 }  // namespace gpemsr
 
 using namespace gpemsr;
+
+extern "C" int gpemsr_conv2d_stem1(const float* x, int n, int h, int w, const float* weight, const float* bias, int cout,
+                                   int act, float* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && weight && out && n > 0 && h > 0 && w > 0, "conv2d_stem1: bad args");
+  GP_REQUIRE(cout % 4 == 0 && cout <= 512 && out_ld % 4 == 0 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0), "conv2d_stem1: cout/out alignment");
+  const long long total = (long long)n * h * w * (cout / 4);
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(conv_stem1_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), (size_t)10 * cout * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), x, n, h, w, weight, bias, cout, 8, act, out, out_ld);
+  return check_launch("conv_stem1_kernel");
+}
 
 extern "C" int gpemsr_conv2d_direct(const float* x, int n, int h, int w, int ld, int cin,
                                     const float* weight, const float* bias, int cout, int ksize, int stride,

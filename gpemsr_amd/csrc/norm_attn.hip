@@ -37,22 +37,29 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int hw,
   }
 }
 
-// stage 2: one thread per (image, group): mean, rstd (biased variance, eps inside sqrt)
-__global__ void gn_final_kernel(const float* ws, int n, int hw, int c, int groups, int parts, float eps, float* mr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// stage 2: one wave per (image, group): lanes stride over the parts x channels-per-group partials, fixed-order
+// double-precision shuffle reduction (deterministic); mean, rstd (biased variance, eps inside the sqrt)
+__global__ __launch_bounds__(256) void gn_final_kernel(const float* ws, int n, int hw, int c, int groups, int parts, float eps, float* mr) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n * groups) return;
+  const int lane = threadIdx.x & 63;
   const int img = i / groups, g = i % groups, cpg = c / groups;
   double s = 0, q = 0;
-  for (int p = 0; p < parts; ++p) {
-    const float* o = ws + (((long long)img * parts + p) * c + g * cpg) * 2;
-    for (int k = 0; k < cpg; ++k) { s += o[2 * k]; q += o[2 * k + 1]; }
+  for (int e = lane; e < parts * cpg; e += 64) {
+    const int p = e / cpg, k = e % cpg;
+    const float* o = ws + (((long long)img * parts + p) * c + g * cpg + k) * 2;
+    s += o[0]; q += o[1];
   }
-  const double cnt = (double)hw * cpg;
-  const double mean = s / cnt;
-  double var = q / cnt - mean * mean;
-  if (var < 0) var = 0;
-  mr[2 * i] = (float)mean;
-  mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m); q += __shfl_xor(q, m); }
+  if (lane == 0) {
+    const double cnt = (double)hw * cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0) var = 0;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, long long total4, int hw, int c, int ld, int groups,
@@ -183,7 +190,7 @@ extern "C" int gpemsr_groupnorm_stats(const float* x, int n, int hw, int c, int 
   GP_REQUIRE(c % groups == 0 && ld % 4 == 0 && parts >= 1, "groupnorm_stats: bad groups/ld/parts");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gn_partial_kernel, dim3(parts, n), dim3(256), 0, st, x, hw, c, ld, parts, ws);
-  hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(n * groups, 64)), dim3(64), 0, st, ws, n, hw, c, groups, parts, eps, mean_rstd);
+  hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(n * groups, 4)), dim3(256), 0, st, ws, n, hw, c, groups, parts, eps, mean_rstd);
   return check_launch("groupnorm_stats");
 }
 

@@ -165,6 +165,18 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
                   and not pc.pixel_shuffle and pixmul is None and weight_image_stride == 0 and src_image_stride is None)
     if stride == 4:
         assert use_direct, "stride 4 is only available through the direct kernel"
+    use_stem = (not force_mfma and len(srcs) == 1 and s0.c == 1 and s0.ld == 1 and k == 3 and stride == 1 and pc.ck == 8
+                and pc.cout % 4 == 0 and pc.cout > 16 and not pc.transposed and not pc.pixel_shuffle and pixmul is None
+                and residual is None and weight_image_stride == 0 and src_image_stride is None and out.ld % 4 == 0)
+    if use_stem:
+        def _go_stem():
+            _abi.check(lib.gpemsr_conv2d_stem1(s0.ptr, n, h, w, pc.w.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
+                                               pc.cout, act, out.ptr, out.ld, _stream()), "conv2d_stem1")
+        if PROFILER is not None:
+            PROFILER.run("conv_stem1", tag, 2.0 * n * oh * ow * pc.cout * 9, _go_stem)
+        else:
+            _go_stem()
+        return out
     # algorithmic FLOPs of this launch (2*MAC, un-padded channel counts)
     taps = 9.0 / 4.0 if pc.transposed else float(k * k)
     flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps

@@ -96,6 +96,12 @@ int gpemsr_conv2d_direct(const float* x, int n, int h, int w, int ld, int cin,
                          const float* weight, const float* bias, int cout, int ksize, int stride,
                          int act, const float* residual, int res_ld, float* out, int out_ld, void* stream);
 
+/* 1-channel -> cout (multiple of 4) 3x3 stride-1 stem convolution; x is a dense 1-channel image [n][h][w]; weight in the
+ * packed [9][cout][8] layout.  HBM-write-bound.  replaces: vgg conv1_1 on the expanded 1-channel image (model/GPEMSR.py:386,390;
+ * weights summed over the 3 identical input channels), conv_first (:329), refmaskconv1 (:396), indexer input conv. */
+int gpemsr_conv2d_stem1(const float* x, int n, int h, int w, const float* weight, const float* bias, int cout,
+                        int act, float* out, int out_ld, void* stream);
+
 /* ---------------------------------------------------------------------------
  * GroupNorm(32, eps) statistics + fused apply (+ReLU, +residual)
  * replaces: model/blocks.py:5-6,13-28  (Normalize -> ReLU, and x + block(x))

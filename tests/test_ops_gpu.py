@@ -372,3 +372,19 @@ def test_conv_large_grids_are_bit_stable(case):
             _close(out.nchw(), want, tol=1e-5, what=f"large conv {case}")
         else:
             assert torch.equal(o, ref), f"non-deterministic result for {case}"
+
+
+def test_conv_stem_one_channel():
+    """1 -> 64 3x3 stem kernel (VGG conv1_1 on the expanded image, conv_first) vs torch."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_vgg_first
+    dev = _dev()
+    x = torch.rand(3, 1, 37, 52, generator=torch.Generator().manual_seed(301))
+    wt, b = _rand(64, 1, 3, 3, seed=302), _rand(64, seed=303)
+    out = ops.conv2d([_to_act(x, dev)], pack_conv(wt, b, dev), ops.ACT_LRELU)
+    torch.cuda.synchronize()
+    _close(out.nchw(), F.leaky_relu(F.conv2d(x, wt, b, 1, 1), 0.1), tol=1e-5, what="stem lrelu")
+    w3, b3 = _rand(64, 3, 3, 3, seed=304), _rand(64, seed=305)
+    out = ops.conv2d([_to_act(x, dev)], pack_vgg_first(w3, b3, dev), ops.ACT_RELU)
+    torch.cuda.synchronize()
+    _close(out.nchw(), F.relu(F.conv2d(x.expand(-1, 3, -1, -1), w3, b3, 1, 1)), tol=1e-5, what="vgg conv1_1")
