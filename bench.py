@@ -101,10 +101,22 @@ def main():
     conv = summ.get("conv_mfma", {"launches": 0, "ms": 0.0, "flops": 0.0})
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
     alg_gflop_tile = conv["flops"] / 1e9 / (args.steps * B) if args.steps * B else 0.0
+    # HBM bytes per launch of the same kernel family from the separate rocprofv3 --pmc passes committed under profiles/
+    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); PMC cannot be collected inside this process.
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_fp32_v3_pmc_summary.json")
+    if s == 8 and lr == 128 and B == 16 and os.path.exists(pmc_file):
+        try:
+            fam = json.load(open(pmc_file))["conv_mfma_family"]
+            traffic, traffic_src = round(fam["hbm_bytes_per_launch"]), "profiles/r01_fp32_v3_pmc_summary.json (separate --pmc passes, same command)"
+        except Exception:
+            pass
     roofline = {
         "bound": "mfma", "kernel": "conv_mfma_kernel (implicit-GEMM conv/GEMM family, v_mfma_f32_32x32x2_f32)",
         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+        "traffic_source": traffic_src,
+        "algorithmic_gflop_per_launch": round(conv["flops"] / 1e9 / max(conv["launches"], 1), 2),
         "launches_per_step": conv["launches"] // max(args.steps, 1),
         "avg_launch_us": round(1e3 * conv["ms"] / max(conv["launches"], 1), 2),
         "algorithmic_gflop_per_tile_in_kernel": round(alg_gflop_tile, 1),

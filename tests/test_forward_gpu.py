@@ -138,3 +138,40 @@ def test_full_size_properties():
     # global residual structure: out - bilinear(x_centre) is the learned detail, bounded
     base = torch.nn.functional.interpolate(x[:, 2].cpu(), scale_factor=8, mode="bilinear", align_corners=False)
     assert float((out.cpu() - base).abs().max()) < 5.0
+
+
+def test_x16_ragged_size_exercises_spynet_resize():
+    """x16 on a 20x24 tile: 4H = 80 is not a multiple of 32, so basicsr SpyNet resizes its input to 96x96, the pyramid
+    has odd levels (3x3 coarsest, replicate-padded flow upsampling) and the flow is rescaled per axis."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    from oracle import gpemsr_oracle as orc
+    model = _model(16)
+    x = synth_lr_tiles(1, 5, 20, 24, seed=78, kind="smooth")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    otr, tr = {}, {}
+    with torch.no_grad():
+        want, want_ref = orc.gpemsr_forward(sd, x, scale=16, trace=otr)
+    out, ref_img = model(x.cuda(), forced_code_idx=otr["code_idx"].cuda(), trace=tr)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 1, 320, 384)
+    for got, w, name in ((out, want, "out"), (ref_img, want_ref, "ref_img"), (torch.cat(tr["aligned"]), otr["aligned"], "aligned")):
+        err = float((got.cpu() - w).abs().max() / w.abs().max())
+        assert err <= REL_TOL, f"{name}: rel err {err:.3e}"
+
+
+def test_batch_crossing_chunk_boundaries():
+    """B = 5 windows = 25 slices: crosses frame_chunk (20) and tile_chunk (4); every window must equal its solo result."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    model = _model(8)
+    x = synth_lr_tiles(5, 5, 16, 16, seed=79, kind="uniform").cuda()
+    tr = {}
+    out, ref = model(x, trace=tr)
+    idx = torch.cat(tr["code_idx"]).view(5, -1)
+    for b in (0, 3, 4):
+        o1, r1 = model(x[b:b + 1], forced_code_idx=idx[b])
+        assert float((o1 - out[b:b + 1]).abs().max()) <= 1e-5 * float(out.abs().max()), b
+        assert float((r1 - ref[b:b + 1]).abs().max()) <= 1e-5 * float(ref.abs().max()), b
+    with pytest.raises(AssertionError):
+        model(torch.rand(1, 5, 1, 12, 16).cuda())          # x8 needs LR sizes that are multiples of 8
+    with pytest.raises(AssertionError):
+        model(torch.rand(1, 3, 1, 16, 16).cuda())          # N must equal nframes
