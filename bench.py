@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--tiles", type=int, default=16, help="tiles (5-slice windows) per GPU per step")
     ap.add_argument("--lr", type=int, default=128)
     ap.add_argument("--scale", type=int, default=8, choices=(8, 16))
+    ap.add_argument("--precision", type=str, default="fp32", choices=("fp32", "bf16x3", "bf16"),
+                    help="fp32 = exact fp32 MFMA (BASELINE configs[1], the default); bf16x3 = 3x3 convs on the bf16 matrix pipe with "
+                         "split hi+lo operands (fp32-grade, ~1e-5/op); bf16 = plain bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lr", type=int, default=128, help="LR size of the CPU-oracle sample tile")
     ap.add_argument("--layer-report", type=str, default="", help="write a per-layer conv timing table to this file")
@@ -66,7 +69,7 @@ def main():
     dev = torch.device("cuda", local)
 
     opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{args.scale}.yml"))
-    model = build_model(opt, load_prior_files=False).eval().to(dev)
+    model = build_model(opt, load_prior_files=False, precision=args.precision).eval().to(dev)
     B, s, lr = args.tiles, args.scale, args.lr
     x = synth_lr_tiles(B, 5, lr, lr, seed=1000 + rank, kind="uniform").to(dev)     # resident in HBM before timing
 
@@ -99,6 +102,7 @@ def main():
     value = mp_per_step * args.steps / dt
     summ = prof.summary()
     conv = summ.get("conv_mfma", {"launches": 0, "ms": 0.0, "flops": 0.0})
+    split = summ.get("conv_split")
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
     alg_gflop_tile = conv["flops"] / 1e9 / (args.steps * B) if args.steps * B else 0.0
     # HBM bytes per launch of the same kernel family from the separate rocprofv3 --pmc passes committed under profiles/
@@ -124,6 +128,13 @@ def main():
         "kernel_time_share_of_step": round(conv["ms"] * 1e-3 / dt, 3),
         "whole_path_tflops_essential": round(ESSENTIAL_GFLOP_PER_TILE[s] * B * args.steps / dt / 1e3, 2),
     }
+    if split is not None:
+        roofline["split_bf16_kernel"] = {
+            "kernel": "conv_split_kernel (3x3 convs, v_mfma_f32_32x32x16_bf16, %s)" % args.precision,
+            "achieved_algorithmic_tflops": round(split["flops"] / (split["ms"] * 1e-3) / 1e12, 2),
+            "peak_bf16_dense_tflops": 2500.0, "mfma_products_per_algorithmic_product": 3 if args.precision == "bf16x3" else 1,
+            "launches_per_step": split["launches"] // max(args.steps, 1),
+            "time_share_of_step": round(split["ms"] * 1e-3 / dt, 3)}
     if args.layer_report and rank == 0:
         rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
         with open(args.layer_report, "w") as f:
@@ -159,7 +170,9 @@ def main():
             "metric": "output megapixels/sec, 8x EMSR 128->1024 tiles" if s == 8 else "output megapixels/sec, 16x EMSR 64->1024 tiles",
             "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split hi+lo bf16 MFMA, fp32 accumulate) for 3x3 convs, f32 elsewhere",
+                      "bf16": "bf16 MFMA (fp32 accumulate) for 3x3 convs, f32 elsewhere"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{s}x EMSR stage-3 forward, batch={B} synthetic 5x1x{lr}x{lr} LR windows per GPU -> "
                                    f"{lr * s}x{lr * s} HR tiles, fp32 (BASELINE.json configs[1])",
                        "tiles_per_gpu": B, "global_tiles": B * world, "lr": lr, "scale": s,

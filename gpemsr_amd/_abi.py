@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_LRELU_SIGMOID = 0, 1, 2, 3, 4
 
 # every symbol include/gpemsr_hip.h declares (checked by tests/test_abi_cpu.py)
 SYMBOLS = [
-    "gpemsr_abi_version", "gpemsr_last_error", "gpemsr_device_info", "gpemsr_conv2d", "gpemsr_conv2d_direct", "gpemsr_conv2d_stem1",
+    "gpemsr_abi_version", "gpemsr_last_error", "gpemsr_device_info", "gpemsr_conv2d", "gpemsr_conv2d_split", "gpemsr_conv2d_direct", "gpemsr_conv2d_stem1",
     "gpemsr_groupnorm_stats", "gpemsr_groupnorm_apply", "gpemsr_softmax_rows", "gpemsr_argmax_rows",
     "gpemsr_gather_rows", "gpemsr_bilinear", "gpemsr_avgpool2", "gpemsr_pool3s2_maxavg", "gpemsr_spynet_prep",
     "gpemsr_dcn_columns", "gpemsr_patch_cosine", "gpemsr_temporal_gate", "gpemsr_frame_mix_lrelu",
@@ -66,6 +66,7 @@ def load():
         raise RuntimeError(f"gpemsr_amd: ABI version {v} != 1")
     p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     lib.gpemsr_conv2d.argtypes = [C.POINTER(ConvDesc), p]
+    lib.gpemsr_conv2d_split.argtypes = [C.POINTER(ConvDesc), p, i64, i32, p]
     lib.gpemsr_conv2d_direct.argtypes = [p, i32, i32, i32, i32, i32, p, p, i32, i32, i32, i32, p, i32, p, i32, p]
     lib.gpemsr_conv2d_stem1.argtypes = [p, i32, i32, i32, p, p, i32, i32, p, i32, p]
     lib.gpemsr_groupnorm_stats.argtypes = [p, i32, i32, i32, i32, i32, f32, p, i32, p, p]

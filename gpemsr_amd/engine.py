@@ -27,7 +27,7 @@ import torch
 
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
-from .packing import pack_conv, pack_convT, pack_dcn, pack_linear, pack_vgg_first
+from .packing import pack_conv, pack_conv_split, pack_convT, pack_dcn, pack_linear, pack_vgg_first
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -45,7 +45,8 @@ def _seq_len(sd, prefix: str) -> int:
 
 class Engine:
     def __init__(self, sd: Dict[str, torch.Tensor], device, scale: int, nframes: int = 5, groups: int = 8,
-                 nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 20, tile_chunk: int = 4):
+                 nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 20, tile_chunk: int = 4,
+                 precision: str = "fp32"):
         assert scale in (8, 16)
         assert nf == 64, "kernels are specialised for nf=64 (every shipped option file)"
         self.sd = sd
@@ -54,6 +55,11 @@ class Engine:
         self.center = nframes // 2
         self.dec_nrb = dec_num_res_blocks
         self.frame_chunk, self.tile_chunk = frame_chunk, tile_chunk
+        assert precision in ("fp32", "bf16x3", "bf16"), precision
+        # fp32: exact fp32 MFMA everywhere (default).  bf16x3 / bf16: 3x3 stride-1 convolutions whose sources are all
+        # multiples of 16 channels run on the bf16 matrix pipe (split hi+lo = fp32-grade, or plain bf16); every other
+        # op stays fp32 (incl. the indexer's logits GEMM + argmax).
+        self.precision = precision
         self.pc: Dict[str, ops.PackedConv] = {}
         self.par: Dict[str, torch.Tensor] = {}
         self._pack_all()
@@ -89,6 +95,8 @@ class Engine:
                 self.pc[name] = pack_conv(w, b, dev, scale=float(int(c) ** (-0.5)))   # fold C^-1/2 (blocks.py:76)
             elif w.dim() == 4:
                 self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
+                if self.precision != "fp32" and w.shape[2] == 3 and all(c % 16 == 0 for c in self.pc[name].splits):
+                    self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             elif w.dim() == 2 and name.endswith("indexer.embedding"):
                 self.pc[name] = pack_linear(w, b, dev)
             elif w.dim() == 2 and name.endswith("codebook.embedding"):
@@ -105,7 +113,7 @@ class Engine:
 
     # ------------------------------------------------------------------ helpers
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
-        return ops.conv2d(srcs, self.pc[name], act, tag=name, **kw)
+        return ops.conv2d(srcs, self.pc[name], act, tag=name, precision=self.precision, **kw)
 
     def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:
         """basicsr ResidualBlockNoBN chain; ``pixmul`` multiplies the output of the LAST block

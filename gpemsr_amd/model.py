@@ -40,12 +40,14 @@ class GPEMSR(nn.Module):
     reference call sites work unchanged:
       init_seed    seed of the deterministic synthetic initialisation used until a
                    checkpoint is loaded (the reference's files are Google-Drive only);
-      frame_chunk / tile_chunk   batching granularity of the two halves of the forward.
+      frame_chunk / tile_chunk   batching granularity of the two halves of the forward;
+      precision    "fp32" (default: exact fp32 MFMA), "bf16x3" (3x3 convs on the bf16 matrix pipe with split hi+lo
+                   operands, fp32-grade: ~1e-5 per op) or "bf16" (plain bf16 operands, fp32 accumulate).
     """
 
     def __init__(self, ref_path_G, ref_path_Indexer, argref, nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10,
                  w_ref=True, ref_fusion_feat_RBs=3, align_mode='POD', fusion_mode='ThreeDA', mode='16to1', scale=16,
-                 init_seed: int = 0, frame_chunk: int = 20, tile_chunk: int = 4):
+                 init_seed: int = 0, frame_chunk: int = 20, tile_chunk: int = 4, precision: str = "fp32"):
         super().__init__()
         if not (w_ref and align_mode == 'POD' and fusion_mode == 'ThreeDA'):
             raise NotImplementedError("gpemsr_amd implements the shipped configuration: w_ref=True, POD, ThreeDA")
@@ -56,6 +58,7 @@ class GPEMSR(nn.Module):
         self.w_ref, self.align_mode, self.fusion_mode, self.mode = w_ref, align_mode, fusion_mode, mode
         self._dec_nrb = int(argref["Decoder"]["num_resblock_per_scale"])
         self._chunks = (frame_chunk, tile_chunk)
+        self.precision = precision
         self._specs = param_specs(argref=argref, nf=nf, nframes=nframes, groups=groups, front_RBs=front_RBs,
                                   back_RBs=back_RBs, w_ref=w_ref, ref_fusion_feat_RBs=ref_fusion_feat_RBs,
                                   align_mode=align_mode, fusion_mode=fusion_mode, mode=mode, scale=scale)
@@ -93,7 +96,7 @@ class GPEMSR(nn.Module):
             _abi.load()                        # fail loudly if the HIP library is missing
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             self._engine = Engine(sd, device, self.scale, self.nframes, self.groups, self.nf, self._dec_nrb,
-                                  frame_chunk=self._chunks[0], tile_chunk=self._chunks[1])
+                                  frame_chunk=self._chunks[0], tile_chunk=self._chunks[1], precision=self.precision)
         return self._engine
 
     def forward(self, x, forced_code_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):

@@ -134,6 +134,7 @@ class PackedConv:
     ck: int
     transposed: bool = False
     pixel_shuffle: bool = False
+    w16: Optional[torch.Tensor] = None     # split-bf16 weights [2][tap][cout][cin] (packing.pack_conv_split), optional
 
     @property
     def cin(self) -> int:
@@ -142,7 +143,8 @@ class PackedConv:
 
 def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
            pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
-           src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "") -> Act:
+           src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
+           precision: str = "fp32") -> Act:
     lib = _abi.load()
     if isinstance(srcs, Act):
         srcs = [srcs]
@@ -210,6 +212,19 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
         d.pixmul = pixmul.ptr
     d.pixel_shuffle = int(pc.pixel_shuffle)
     d.out, d.out_ld = out.ptr, out.ld
+    use_split = (precision in ("bf16x3", "bf16") and pc.w16 is not None and k == 3 and stride == 1 and not pc.transposed
+                 and weight_image_stride == 0 and src_image_stride is None
+                 and all(s.c % 16 == 0 and s.ld % 4 == 0 and s.ptr % 16 == 0 for s in srcs))
+    if use_split:
+        nsplit = 2 if precision == "bf16x3" else 1
+        plane = pc.w16.shape[1] * pc.w16.shape[2] * pc.w16.shape[3]
+        def _go_split():
+            _abi.check(lib.gpemsr_conv2d_split(C.byref(d), pc.w16.data_ptr(), plane, nsplit, _stream()), "conv2d_split")
+        if PROFILER is not None:
+            PROFILER.run("conv_split", tag, flops, _go_split)
+        else:
+            _go_split()
+        return out
     if PROFILER is not None:
         PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"))
     else:

@@ -86,3 +86,19 @@ def pack_vgg_first(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
     """vgg conv1_1 applied to a 1-channel image expanded to 3 identical channels
     (model/GPEMSR.py:386,390) == a 1->64 conv with the weights summed over Cin."""
     return pack_conv(w.detach().to(torch.float32).sum(dim=1, keepdim=True), b, device)
+
+
+def pack_conv_split(pc: PackedConv, w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch.Tensor:
+    """Split-bf16 weights for gpemsr_conv2d_split: [plane (hi, lo)][tap][cout][cin] bf16 with hi = bf16(w) (round to nearest
+    even) and lo = bf16(w - hi).  Same tap / row order as the fp32 packing of ``pc`` (incl. the PixelShuffle row permutation);
+    no channel padding (every source must have c % 16 == 0)."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and all(c % 16 == 0 for c in pc.splits)
+    wt = w.detach().to(torch.float32).cpu().permute(2, 3, 0, 1).reshape(9, cout, cin)
+    if pixel_shuffle:
+        cq = cout // 4
+        perm = torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)
+        wt = wt[:, perm]
+    hi = wt.to(torch.bfloat16)
+    lo = (wt - hi.to(torch.float32)).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=0).contiguous().to(device)

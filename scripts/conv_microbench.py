@@ -8,7 +8,8 @@ from gpemsr_amd.packing import pack_conv, pack_convT
 
 dev = torch.device("cuda", 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+only = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None
+precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 SHAPES = [  # name, n, cin, cout, k, stride, h, w, kind, residual
     ("rb64_128", 80, 64, 64, 3, 1, 128, 128, "conv", True),
     ("rb64_512", 20, 64, 64, 3, 1, 512, 512, "conv", True),
@@ -38,9 +39,13 @@ for name, n, cin, cout, k, stride, h, w, kind, use_res in SHAPES:
         pc = ops.PackedConv(wt, None, 1, cout, (cin,), 32)
         flops = 2.0 * n * h * w * cin * cout
     else:
-        pc = pack_conv(torch.randn(cout, cin, k, k) * 0.05, torch.randn(cout), dev, pixel_shuffle=(kind == "ps"))
+        wfull = torch.randn(cout, cin, k, k) * 0.05
+        pc = pack_conv(wfull, torch.randn(cout), dev, pixel_shuffle=(kind == "ps"))
+        if precision != "fp32" and k == 3 and stride == 1 and cin % 16 == 0:
+            from gpemsr_amd.packing import pack_conv_split
+            pc.w16 = pack_conv_split(pc, wfull, dev, pixel_shuffle=(kind == "ps"))
         flops = 2.0 * n * (h // stride) * (w // stride) * cin * cout * k * k
-    kw = dict(stride=stride)
+    kw = dict(stride=stride, precision=precision)
     if kind == "bmm":
         kw["weight_image_stride"] = cout * cin
     out = ops.conv2d([x], pc, ops.ACT_LRELU, **kw)

@@ -388,3 +388,50 @@ def test_conv_stem_one_channel():
     out = ops.conv2d([_to_act(x, dev)], pack_vgg_first(w3, b3, dev), ops.ACT_RELU)
     torch.cuda.synchronize()
     _close(out.nchw(), F.relu(F.conv2d(x.expand(-1, 3, -1, -1), w3, b3, 1, 1)), tol=1e-5, what="vgg conv1_1")
+
+
+SPLIT_CASES = [(2, (64,), 64, 16, 16, 1, True, False, False), (1, (64, 128, 64), 64, 24, 40, 0, False, False, False),
+               (2, (256,), 256, 16, 32, 0, False, False, False), (1, (64,), 256, 12, 20, 2, False, False, True),
+               (1, (64, 64), 64, 33, 47, 0, True, True, False), (3, (128,), 32, 40, 36, 1, False, False, False),
+               (1, (512,), 512, 8, 8, 0, False, False, False), (2, (64,), 216, 16, 16, 0, False, False, False)]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_split_bf16x3(case):
+    """Split-bf16 (hi*hi + hi*lo + lo*hi) 3x3 convolution: fp32-grade result on the bf16 matrix pipe."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_conv_split
+    n, cins, cout, h, w, act, use_res, use_mul, ps = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _rand(n, cin, h, w, seed=401)
+    wt = _rand(cout, cin, 3, 3, seed=402, scale=1.0 / np.sqrt(cin * 9))
+    b = _rand(cout, seed=403, scale=0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    if act == 1:
+        want = F.relu(want)
+    elif act == 2:
+        want = F.leaky_relu(want, 0.1)
+    if ps:
+        want = F.pixel_shuffle(want, 2)
+    res = _rand(*want.shape, seed=404) if use_res else None
+    mul = torch.rand(want.shape[0], 1, want.shape[2], want.shape[3], generator=torch.Generator().manual_seed(405)) if use_mul else None
+    if res is not None:
+        want = want + res
+    if mul is not None:
+        want = want * mul
+    srcs, off = [], 0
+    for c in cins:
+        srcs.append(_to_act(x[:, off:off + c], dev)); off += c
+    pc = pack_conv(wt, b, dev, cins, pixel_shuffle=ps)
+    pc.w16 = pack_conv_split(pc, wt, dev, pixel_shuffle=ps)
+    kw = dict(residual=_to_act(res, dev) if use_res else None, pixmul=_to_act(mul, dev) if use_mul else None)
+    out3 = ops.conv2d(srcs, pc, act, precision="bf16x3", **kw)
+    torch.cuda.synchronize()
+    _close(out3.nchw(), want.float(), tol=3e-5, what=f"bf16x3 {case}")
+    out1 = ops.conv2d(srcs, pc, act, precision="bf16", **kw)
+    torch.cuda.synchronize()
+    _close(out1.nchw(), want.float(), tol=2e-2, what=f"bf16 {case}")
+    again = ops.conv2d(srcs, pc, act, precision="bf16x3", **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(again.torch(), out3.torch())
