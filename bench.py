@@ -54,6 +54,7 @@ def main():
                     help="fp32 = exact fp32 MFMA (BASELINE configs[1], the default); bf16x3 = 3x3 convs on the bf16 matrix pipe with "
                          "split hi+lo operands (fp32-grade, ~1e-5/op); bf16 = plain bf16 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-by-the-driver) bf16x3 measurement")
     ap.add_argument("--cpu-lr", type=int, default=128, help="LR size of the CPU-oracle sample tile")
     ap.add_argument("--layer-report", type=str, default="", help="write a per-layer conv timing table to this file")
     args = ap.parse_args()
@@ -143,6 +144,40 @@ def main():
                 tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0
                 f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{tf:.1f}\n")
 
+    # Extra, reported beside the official number (never replaces it): the same step with precision='bf16x3'
+    # (3x3/7x7 convs on the bf16 matrix pipe with split hi+lo operands; meets the same 1e-3 parity bar, see tests).
+    extras = None
+    if args.precision == "fp32" and not args.no_extras:
+        out_ref = out[:B].clone()
+        del model
+        torch.cuda.empty_cache()
+        m3 = build_model(opt, load_prior_files=False, precision="bf16x3").eval().to(dev)
+        def step3():
+            o, _ = gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True)
+            return o
+        step3()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            o3 = step3()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        d3 = time.perf_counter() - t3
+        if world > 1:
+            tt = torch.tensor([d3], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            d3 = float(tt.item())
+        rel = float((o3[:B] - out_ref).abs().max() / out_ref.abs().max())
+        extras = {"bf16x3": {"value": round(mp_per_step * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
+                             "dtype": "bf16x3: fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate "
+                                      "(3x3/7x7 convs); f32 elsewhere",
+                             "rel_err_vs_fp32_path_free_running": rel,
+                             "speedup_vs_fp32_path": round((dt / args.steps) / (d3 / args.steps), 3)}}
+        model = m3
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample of the same workload: ONE 5-slice window through the CPU oracle on the host cores
@@ -178,7 +213,7 @@ def main():
                        "tiles_per_gpu": B, "global_tiles": B * world, "lr": lr, "scale": s,
                        "weights": "deterministic synthetic init (reference checkpoints are not redistributable)",
                        "parallelism": f"tiles sharded over {world} GPU(s), RCCL all-gather of HR slabs" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

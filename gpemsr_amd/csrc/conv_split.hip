@@ -1,4 +1,4 @@
-// 3x3 stride-1 convolution on the bf16 matrix pipe with fp32-grade accuracy ("split-bf16"):
+// 3x3 / 7x7 stride-1 convolution on the bf16 matrix pipe with fp32-grade accuracy ("split-bf16"):
 // every fp32 operand x is represented as hi + lo with hi = bf16(x), lo = bf16(x - hi) and the product is
 // evaluated as hi*hi + hi*lo + lo*hi with three v_mfma_f32_32x32x16_bf16 into an fp32 accumulator (the dropped
 // lo*lo term is 2^-16 relative).  NSPLIT = 1 keeps only hi*hi (plain bf16 inputs, fp32 accumulate).
@@ -24,7 +24,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SW = 32;            // tile width (pixels)
 constexpr int SA_LOADS = 6;       // raw-A float4 slots per thread (10x34 halo x 4 / 256 -> 6)
-constexpr int SB_LOADS = 3;       // weight 16-B slots per thread per plane (3 taps x 128 couts x 2 / 256)
+constexpr int SB_LOADS = 3;       // weight 16-B slots per thread per plane (3 taps x 128 couts x 2 / 256; 7 taps x 32 x 2 / 256 -> 2)
 
 struct SplitParams {
   const float* src[GPEMSR_MAX_SRC];
@@ -43,7 +43,7 @@ struct SplitParams {
   float* out; int out_ld;
   int out_vec, res_vec;
   int tiles_x, tiles_y, tiles_n;
-  int halo_h, halo_w;
+  int halo_h, halo_w, pad;
   int na, nb;                          // DMA slots per thread: raw A image, one weight plane of one stage
   int raw_bytes, sp_plane_bytes, b_plane_bytes;
   int nblocks;
@@ -61,14 +61,14 @@ __device__ __forceinline__ unsigned bf16_rn(float x) {
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <int BN, int WM, int WN, int TH, int NSPLIT>
+template <int BN, int WM, int WN, int TH, int NSPLIT, int KW>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   constexpr int NPIX = TH * SW;
   constexpr int PM = NPIX / WM;
   constexpr int MT = PM / 32;
   constexpr int WNT = BN / WN;
   constexpr int NT = WNT / 32;
-  constexpr int KW = 3, G = 3;        // taps per stage (one filter row), stages per chunk
+  constexpr int G = KW;               // KW taps per stage (one filter row), G = KW stages per chunk
   constexpr int CK = 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   const int ty = t % P.tiles_y; t /= P.tiles_y;
   const int img = t;
   const int oy0 = ty * TH, ox0 = tx * SW, n0 = tn * BN;
-  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const int iy0 = oy0 - P.pad, ix0 = ox0 - P.pad;
   const int halo_px = P.halo_h * P.halo_w;
 
   // ---- per-thread staging slots ----
@@ -257,11 +257,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
         }
     };
     load_tap(0, 0);
-    load_tap(1, 1);
-    mma_tap(0);
-    load_tap(0, 2);
-    mma_tap(1);
-    mma_tap(0);
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) {          // software pipelined by two (static register sets)
+      if (kx + 1 < KW) load_tap((kx + 1) & 1, kx + 1);
+      mma_tap(kx & 1);
+    }
 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
     __builtin_amdgcn_s_barrier();                                                // ... and everybody's; all reads of this stage done
@@ -366,9 +366,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   }
 }
 
-template <int BN, int WM, int WN, int TH, int NSPLIT>
+template <int BN, int WM, int WN, int TH, int NSPLIT, int KW>
 static int launch_split(const SplitParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_split_kernel<BN, WM, WN, TH, NSPLIT>;
+  auto kfn = conv_split_kernel<BN, WM, WN, TH, NSPLIT, KW>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -388,7 +388,9 @@ using namespace gpemsr;
 extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight_bf16, int64_t plane_stride, int nsplit, void* stream) {
   GP_REQUIRE(d && weight_bf16 && d->out, "conv2d_split: null pointer");
   GP_REQUIRE(nsplit == 1 || nsplit == 2, "conv2d_split: nsplit=%d", nsplit);
-  GP_REQUIRE(d->ksize == 3 && d->stride == 1 && !d->transposed && d->weight_image_stride == 0, "conv2d_split: only 3x3 stride-1 convolutions");
+  GP_REQUIRE((d->ksize == 3 || d->ksize == 7) && d->stride == 1 && !d->transposed && d->weight_image_stride == 0,
+             "conv2d_split: only 3x3 / 7x7 stride-1 convolutions");
+  if (d->ksize == 7) GP_REQUIRE(!d->pixel_shuffle, "conv2d_split: 7x7 has no pixel_shuffle form");
   GP_REQUIRE(d->nsrc >= 1 && d->nsrc <= GPEMSR_MAX_SRC && d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "conv2d_split: bad geometry");
   if (d->pixel_shuffle) GP_REQUIRE(d->cout % 16 == 0, "conv2d_split: pixel_shuffle needs cout%%16==0");
   SplitParams P{};
@@ -402,7 +404,7 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
     cin_pad += d->src[s].c;
   }
   GP_REQUIRE((reinterpret_cast<uintptr_t>(weight_bf16) & 15) == 0 && plane_stride % 8 == 0, "conv2d_split: weight alignment");
-  GP_REQUIRE((long long)9 * d->cout * cin_pad * 2 < (1ll << 32), "conv2d_split: weight plane too large");
+  GP_REQUIRE((long long)d->ksize * d->ksize * d->cout * cin_pad * 2 < (1ll << 32), "conv2d_split: weight plane too large");
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.oh = d->h; P.ow = d->w;
   P.OH = d->pixel_shuffle ? 2 * d->h : d->h; P.OW = d->pixel_shuffle ? 2 * d->w : d->w;
   P.cin_pad = cin_pad; P.cout = d->cout;
@@ -412,16 +414,19 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   P.out = d->out; P.out_ld = d->out_ld;
   P.out_vec = (d->out_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
   P.res_vec = d->residual && (d->res_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->residual) & 15) == 0);
-  const int BN = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
-  const int TH = BN == 128 ? 4 : 8;
-  P.halo_h = TH + 2; P.halo_w = SW + 2;
+  const int KW = d->ksize;
+  // 7x7: 32-cout blocks of 4x32 pixels keep the (larger) halo + 7-tap weight images at two workgroups per CU
+  const int BN = KW == 7 ? 32 : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128));
+  const int TH = (BN == 128 || KW == 7) ? 4 : 8;
+  P.pad = KW / 2;
+  P.halo_h = TH + KW - 1; P.halo_w = SW + KW - 1;
   P.tiles_x = cdiv(P.ow, SW); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d_split: grid too large");
   P.nblocks = (int)nb;
   const int halo_px = P.halo_h * P.halo_w;
   P.na = cdiv((long long)halo_px * 4, 256);
-  P.nb = cdiv((long long)3 * BN * 2, 256);
+  P.nb = cdiv((long long)KW * BN * 2, 256);
   GP_REQUIRE(P.na <= SA_LOADS && P.nb <= SB_LOADS, "conv2d_split: tile too large");
   P.raw_bytes = P.na * 4096;
   P.sp_plane_bytes = (halo_px * 32 + 255) & ~255;
@@ -431,12 +436,13 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   if (epi > lds) lds = epi;
   GP_REQUIRE(lds <= 160 * 1024, "conv2d_split: LDS %zu too large", lds);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (KW == 7) return nsplit == 2 ? launch_split<32, 4, 1, 4, 2, 7>(P, lds, st) : launch_split<32, 4, 1, 4, 1, 7>(P, lds, st);
   if (nsplit == 2) {
-    if (BN == 32) return launch_split<32, 4, 1, 8, 2>(P, lds, st);
-    if (BN == 64) return launch_split<64, 4, 1, 8, 2>(P, lds, st);
-    return launch_split<128, 2, 2, 4, 2>(P, lds, st);
+    if (BN == 32) return launch_split<32, 4, 1, 8, 2, 3>(P, lds, st);
+    if (BN == 64) return launch_split<64, 4, 1, 8, 2, 3>(P, lds, st);
+    return launch_split<128, 2, 2, 4, 2, 3>(P, lds, st);
   }
-  if (BN == 32) return launch_split<32, 4, 1, 8, 1>(P, lds, st);
-  if (BN == 64) return launch_split<64, 4, 1, 8, 1>(P, lds, st);
-  return launch_split<128, 2, 2, 4, 1>(P, lds, st);
+  if (BN == 32) return launch_split<32, 4, 1, 8, 1, 3>(P, lds, st);
+  if (BN == 64) return launch_split<64, 4, 1, 8, 1, 3>(P, lds, st);
+  return launch_split<128, 2, 2, 4, 1, 3>(P, lds, st);
 }

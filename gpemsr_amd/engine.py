@@ -95,7 +95,7 @@ class Engine:
                 self.pc[name] = pack_conv(w, b, dev, scale=float(int(c) ** (-0.5)))   # fold C^-1/2 (blocks.py:76)
             elif w.dim() == 4:
                 self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
-                if self.precision != "fp32" and w.shape[2] == 3 and all(c % 16 == 0 for c in self.pc[name].splits):
+                if self.precision != "fp32" and w.shape[2] in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits):
                     self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             elif w.dim() == 2 and name.endswith("indexer.embedding"):
                 self.pc[name] = pack_linear(w, b, dev)

@@ -41,7 +41,7 @@ for name, n, cin, cout, k, stride, h, w, kind, use_res in SHAPES:
     else:
         wfull = torch.randn(cout, cin, k, k) * 0.05
         pc = pack_conv(wfull, torch.randn(cout), dev, pixel_shuffle=(kind == "ps"))
-        if precision != "fp32" and k == 3 and stride == 1 and cin % 16 == 0:
+        if precision != "fp32" and k in (3, 7) and stride == 1 and cin % 16 == 0:
             from gpemsr_amd.packing import pack_conv_split
             pc.w16 = pack_conv_split(pc, wfull, dev, pixel_shuffle=(kind == "ps"))
         flops = 2.0 * n * (h // stride) * (w // stride) * cin * cout * k * k

@@ -175,3 +175,59 @@ def test_batch_crossing_chunk_boundaries():
         model(torch.rand(1, 5, 1, 12, 16).cuda())          # x8 needs LR sizes that are multiples of 8
     with pytest.raises(AssertionError):
         model(torch.rand(1, 3, 1, 16, 16).cuda())          # N must equal nframes
+
+
+_PMODELS = {}
+
+
+def _pmodel(scale, precision):
+    key = (scale, precision)
+    if key not in _PMODELS:
+        from gpemsr_amd.config import build_model, load_options
+        opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{scale}.yml"))
+        _PMODELS[key] = build_model(opt, load_prior_files=False, precision=precision).eval().to(torch.device("cuda", 0))
+    return _PMODELS[key]
+
+
+@pytest.mark.parametrize("tag", ["x8_lr32_b1_smooth", "x16_lr16_b1_smooth"])
+def test_bf16x3_mode_meets_the_fp32_parity_bar(tag, golden_dir):
+    """precision='bf16x3' (split hi+lo bf16 MFMA for the 3x3/7x7 convs) against the REFERENCE golden vectors:
+    same 1e-3 bar as the exact-fp32 path, same code indices free-running, |dPSNR| < 0.01 dB."""
+    d = np.load(os.path.join(golden_dir, tag + ".npz"))
+    scale = int(d["scale"])
+    model = _pmodel(scale, "bf16x3")
+    x = torch.from_numpy(d["x"]).cuda()
+    tr = {}
+    out, ref_img = model(x, forced_code_idx=torch.from_numpy(d["code_idx"]).cuda(), trace=tr)
+    torch.cuda.synchronize()
+    for name, t in (("logits", torch.cat(tr["logits"])), ("ref_img", ref_img), ("L1_fused", tr["L1_fused"]),
+                    ("aligned", torch.cat(tr["aligned"])), ("fused", torch.cat(tr["fused"])), ("out", out)):
+        _cmp(t, d, name, tol=2e-4)          # observed <= 3e-5; the bar is 1e-3
+    tr2 = {}
+    out_free, _ = model(x, trace=tr2)
+    idx = torch.cat(tr2["code_idx"]).cpu().numpy()
+    safe = d["logit_margin"] > 1e-3
+    assert (idx[safe] == d["code_idx"][safe]).all()
+    from gpemsr_amd import ops
+    from gpemsr_amd.imgutil import calculate_psnr
+    u8 = ops.tensor2img_u8(out[0, 0]).cpu().numpy()
+    assert np.abs(u8.astype(np.int32) - d["out_u8"].astype(np.int32)).max() <= 1
+    base = torch.nn.functional.interpolate(torch.from_numpy(d["x"])[0:1, 2], scale_factor=scale, mode="bilinear", align_corners=False)
+    base_u8 = (base.squeeze().clamp(0, 1).numpy() * 255.0).round().astype(np.uint8)
+    assert abs(calculate_psnr(u8, base_u8) - float(d["psnr_vs_base"])) < 0.01
+
+
+def test_bf16_mode_is_within_its_looser_bar(golden_dir):
+    """precision='bf16' (plain bf16 operands): not parity-grade -- bounded at 2e-2 relative, |dPSNR| < 0.01 dB."""
+    d = np.load(os.path.join(golden_dir, "x8_lr32_b1_smooth.npz"))
+    model = _pmodel(8, "bf16")
+    out, ref_img = model(torch.from_numpy(d["x"]).cuda(), forced_code_idx=torch.from_numpy(d["code_idx"]).cuda())
+    torch.cuda.synchronize()
+    _cmp(out, d, "out", tol=2e-2)
+    _cmp(ref_img, d, "ref_img", tol=2e-2)
+    from gpemsr_amd import ops
+    from gpemsr_amd.imgutil import calculate_psnr
+    u8 = ops.tensor2img_u8(out[0, 0]).cpu().numpy()
+    base = torch.nn.functional.interpolate(torch.from_numpy(d["x"])[0:1, 2], scale_factor=8, mode="bilinear", align_corners=False)
+    base_u8 = (base.squeeze().clamp(0, 1).numpy() * 255.0).round().astype(np.uint8)
+    assert abs(calculate_psnr(u8, base_u8) - float(d["psnr_vs_base"])) < 0.01

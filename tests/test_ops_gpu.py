@@ -390,6 +390,25 @@ def test_conv_stem_one_channel():
     _close(out.nchw(), F.relu(F.conv2d(x.expand(-1, 3, -1, -1), w3, b3, 1, 1)), tol=1e-5, what="vgg conv1_1")
 
 
+SPLIT7_CASES = [(2, 32, 64, 20, 44), (1, 64, 32, 33, 32), (1, 32, 16, 16, 70), (3, 16, 40, 9, 9)]
+
+
+@pytest.mark.parametrize("case", SPLIT7_CASES)
+def test_conv_split_7x7(case):
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_conv_split
+    n, cin, cout, h, w = case
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=411)
+    wt, b = _rand(cout, cin, 7, 7, seed=412, scale=1.0 / np.sqrt(cin * 49)), _rand(cout, seed=413, scale=0.1)
+    want = F.relu(F.conv2d(x.double(), wt.double(), b.double(), 1, 3)).float()
+    pc = pack_conv(wt, b, dev)
+    pc.w16 = pack_conv_split(pc, wt, dev)
+    out = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_RELU, precision="bf16x3")
+    torch.cuda.synchronize()
+    _close(out.nchw(), want, tol=3e-5, what=f"bf16x3 7x7 {case}")
+
+
 SPLIT_CASES = [(2, (64,), 64, 16, 16, 1, True, False, False), (1, (64, 128, 64), 64, 24, 40, 0, False, False, False),
                (2, (256,), 256, 16, 32, 0, False, False, False), (1, (64,), 256, 12, 20, 2, False, False, True),
                (1, (64, 64), 64, 33, 47, 0, True, True, False), (3, (128,), 32, 40, 36, 1, False, False, False),
