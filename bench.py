@@ -149,6 +149,9 @@ def main():
     extras = None
     if args.precision == "fp32" and not args.no_extras:
         out_ref = out[:B].clone()
+        tr_ref = {}
+        o2_ref, _ = model(x[:2], trace=tr_ref)                  # two windows, for the teacher-forced comparison
+        idx_ref = torch.cat(tr_ref["code_idx"])
         del model
         torch.cuda.empty_cache()
         m3 = build_model(opt, load_prior_files=False, precision="bf16x3").eval().to(dev)
@@ -171,10 +174,17 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             d3 = float(tt.item())
         rel = float((o3[:B] - out_ref).abs().max() / out_ref.abs().max())
+        tr3 = {}
+        o2_tf, _ = m3(x[:2], forced_code_idx=idx_ref)
+        m3(x[:2], trace=tr3)
+        rel_tf = float((o2_tf - o2_ref).abs().max() / o2_ref.abs().max())
+        agree = float((torch.cat(tr3["code_idx"]) == idx_ref).float().mean())
         extras = {"bf16x3": {"value": round(mp_per_step * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
                              "dtype": "bf16x3: fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate "
                                       "(3x3/7x7 convs); f32 elsewhere",
-                             "rel_err_vs_fp32_path_free_running": rel,
+                             "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
+                             "code_index_agreement_free_running_2_windows": agree,
+                             "rel_err_vs_fp32_path_free_running_all_windows": rel,
                              "speedup_vs_fp32_path": round((dt / args.steps) / (d3 / args.steps), 3)}}
         model = m3
 
