@@ -55,10 +55,12 @@ __device__ __forceinline__ void sglds16(unsigned voff, const void* base, unsigne
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
 
-// round-to-nearest-even fp32 -> bf16 bits (finite inputs; NaN payloads are not preserved -- activations are finite)
-__device__ __forceinline__ unsigned bf16_rn(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+// two fp32 -> packed bf16 pair (lo half = a, hi half = b), round to nearest even: one v_cvt_pk_bf16_f32
+typedef unsigned bf16x2_t;
+__device__ __forceinline__ bf16x2_t cvt_pk_bf16(float a, float b) {
+  bf16x2_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 template <int BN, int WM, int WN, int TH, int NSPLIT, int KW>
@@ -182,16 +184,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
       if (a_slot[i]) {
         const int e = tid + i * 256;
         const float4 v = *reinterpret_cast<const float4*>(raw + e * 16);
-        const float xs[4] = {v.x, v.y, v.z, v.w};
-        unsigned hb[4], lb4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          hb[k] = bf16_rn(xs[k]);
-          lb4[k] = bf16_rn(xs[k] - __uint_as_float(hb[k] << 16));
-        }
+        // hi = bf16(x) (RNE, v_cvt_pk_bf16_f32), lo = bf16(x - hi)
+        const bf16x2_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
         const int off = (e >> 2) * 32 + (e & 3) * 8;
-        *reinterpret_cast<uint2*>(asp + off) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
-        if (NSPLIT == 2) *reinterpret_cast<uint2*>(asp + P.sp_plane_bytes + off) = make_uint2(lb4[0] | (lb4[1] << 16), lb4[2] | (lb4[3] << 16));
+        *reinterpret_cast<uint2*>(asp + off) = make_uint2(h01, h23);
+        if (NSPLIT == 2) {
+          const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xFFFF0000u);
+          const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xFFFF0000u);
+          *reinterpret_cast<uint2*>(asp + P.sp_plane_bytes + off) = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
+        }
       }
     }
   };
