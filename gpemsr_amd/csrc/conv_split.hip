@@ -63,7 +63,9 @@ __device__ __forceinline__ bf16x2_t cvt_pk_bf16(float a, float b) {
   return r;
 }
 
-template <int BN, int WM, int WN, int TH, int NSPLIT, int KW>
+// CONVT: ConvTranspose2d(k3,s2,p1,op1) in the phase-stacked 2x2-tap form of conv_mfma.hip (KW = 2, BN = 128 = 4 phases x 32
+// couts per wave, tap (dy,dx) feeds the phases with py >= dy, px >= dx; masked N tiles are neither read nor multiplied).
+template <int BN, int WM, int WN, int TH, int NSPLIT, int KW, bool CONVT>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   constexpr int NPIX = TH * SW;
   constexpr int PM = NPIX / WM;
@@ -233,7 +235,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
     const char* A = asp + (grp * P.halo_w) * 32;               // filter row `grp`
     const char* B = bring + (stage & 1) * b_slot_bytes + b_frag;
     bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    auto tap_mask = [&](int kx) -> unsigned {      // CONVT: N tiles (phases q = 2py+px) fed by tap (dy = grp, dx = kx)
+      if (!CONVT) return 0xFu;
+      return grp ? (kx ? 0x8u : 0xCu) : (kx ? 0xAu : 0xFu);
+    };
     auto load_tap = [&](int set, int kx) {
+      const unsigned mask = tap_mask(kx);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         ah[set][mt] = *reinterpret_cast<const bf16x8*>(A + a_frag[mt] + kx * 32);
@@ -241,15 +248,18 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        if (CONVT && !((mask >> nt) & 1u)) continue;
         bh[set][nt] = *reinterpret_cast<const bf16x8*>(B + (kx * BN + nt * 32) * 32);
         if (NSPLIT == 2) bl[set][nt] = *reinterpret_cast<const bf16x8*>(B + P.b_plane_bytes + (kx * BN + nt * 32) * 32);
       }
     };
-    auto mma_tap = [&](int set) {
+    auto mma_tap = [&](int set, int kx) {
+      const unsigned mask = tap_mask(kx);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+          if (CONVT && !((mask >> nt) & 1u)) continue;
           if (NSPLIT == 2) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[set][mt], bh[set][nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[set][mt], bl[set][nt], acc[mt][nt], 0, 0, 0);
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) {          // software pipelined by two (static register sets)
       if (kx + 1 < KW) load_tap((kx + 1) & 1, kx + 1);
-      mma_tap(kx & 1);
+      mma_tap(kx & 1, kx);
     }
 
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
@@ -297,8 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   for (int pass = 0; pass < NCP * NPP; ++pass) {
     const int cpass = pass % NCP, ppass = pass / NCP;
     const int nidx = n0 + cpass * EW + 4 * ej;
-    int ch = nidx, sy = 0, sx = 0;
+    int ch = nidx, bidx = nidx, sy = 0, sx = 0;
     if (P.store_mode == 1) { const int q = nidx / P.cq; ch = nidx - q * P.cq; sy = q >> 1; sx = q & 1; }
+    else if (P.store_mode == 2) { const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); bidx = ch; sy = q >> 1; sx = q & 1; }
     const int nvalid = (P.cout - nidx) < 4 ? (P.cout - nidx) : 4;
     const bool full = nvalid == 4;
     int opix[ITER];
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (P.bias) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (k < nvalid) bv[k] = P.bias[nidx + k];
+      for (int k = 0; k < 4; ++k) if (k < nvalid) bv[k] = P.bias[bidx + k];
     }
     if (pass > 0) __syncthreads();
 #pragma unroll
@@ -367,9 +378,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   }
 }
 
-template <int BN, int WM, int WN, int TH, int NSPLIT, int KW>
+template <int BN, int WM, int WN, int TH, int NSPLIT, int KW, bool CONVT = false>
 static int launch_split(const SplitParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_split_kernel<BN, WM, WN, TH, NSPLIT, KW>;
+  auto kfn = conv_split_kernel<BN, WM, WN, TH, NSPLIT, KW, CONVT>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -389,8 +400,10 @@ using namespace gpemsr;
 extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight_bf16, int64_t plane_stride, int nsplit, void* stream) {
   GP_REQUIRE(d && weight_bf16 && d->out, "conv2d_split: null pointer");
   GP_REQUIRE(nsplit == 1 || nsplit == 2, "conv2d_split: nsplit=%d", nsplit);
-  GP_REQUIRE((d->ksize == 3 || d->ksize == 7) && d->stride == 1 && !d->transposed && d->weight_image_stride == 0,
-             "conv2d_split: only 3x3 / 7x7 stride-1 convolutions");
+  const bool tr = d->transposed != 0;
+  GP_REQUIRE(d->weight_image_stride == 0, "conv2d_split: per-image weights unsupported");
+  if (tr) GP_REQUIRE(d->ksize == 3 && !d->pixel_shuffle && !d->pixmul && d->cout % 32 == 0, "conv2d_split: transposed needs k=3, cout%%32==0");
+  else GP_REQUIRE((d->ksize == 3 || d->ksize == 7) && d->stride == 1, "conv2d_split: only 3x3 / 7x7 stride-1 convolutions (or transposed 3x3)");
   if (d->ksize == 7) GP_REQUIRE(!d->pixel_shuffle, "conv2d_split: 7x7 has no pixel_shuffle form");
   GP_REQUIRE(d->nsrc >= 1 && d->nsrc <= GPEMSR_MAX_SRC && d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "conv2d_split: bad geometry");
   if (d->pixel_shuffle) GP_REQUIRE(d->cout % 16 == 0, "conv2d_split: pixel_shuffle needs cout%%16==0");
@@ -405,21 +418,21 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
     cin_pad += d->src[s].c;
   }
   GP_REQUIRE((reinterpret_cast<uintptr_t>(weight_bf16) & 15) == 0 && plane_stride % 8 == 0, "conv2d_split: weight alignment");
-  GP_REQUIRE((long long)d->ksize * d->ksize * d->cout * cin_pad * 2 < (1ll << 32), "conv2d_split: weight plane too large");
+  GP_REQUIRE((long long)d->ksize * d->ksize * d->cout * cin_pad * 2 * (tr ? 2 : 1) < (1ll << 32), "conv2d_split: weight plane too large");
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.oh = d->h; P.ow = d->w;
-  P.OH = d->pixel_shuffle ? 2 * d->h : d->h; P.OW = d->pixel_shuffle ? 2 * d->w : d->w;
-  P.cin_pad = cin_pad; P.cout = d->cout;
+  P.OH = (d->pixel_shuffle || tr) ? 2 * d->h : d->h; P.OW = (d->pixel_shuffle || tr) ? 2 * d->w : d->w;
+  P.cin_pad = cin_pad; P.cout = tr ? 4 * d->cout : d->cout;        // transposed: 4*Cout phase-stacked GEMM columns
   P.weight = reinterpret_cast<const unsigned short*>(weight_bf16); P.plane_stride = plane_stride;
   P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;
-  P.store_mode = d->pixel_shuffle ? 1 : 0; P.cq = d->cout / 4;
+  P.store_mode = tr ? 2 : (d->pixel_shuffle ? 1 : 0); P.cq = d->cout / 4;
   P.out = d->out; P.out_ld = d->out_ld;
   P.out_vec = (d->out_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
   P.res_vec = d->residual && (d->res_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->residual) & 15) == 0);
-  const int KW = d->ksize;
+  const int KW = tr ? 2 : d->ksize;
   // 7x7: 32-cout blocks of 4x32 pixels keep the (larger) halo + 7-tap weight images at two workgroups per CU
-  const int BN = KW == 7 ? 32 : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128));
+  const int BN = tr ? 128 : (KW == 7 ? 32 : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128)));
   const int TH = (BN == 128 || KW == 7) ? 4 : 8;
-  P.pad = KW / 2;
+  P.pad = tr ? 0 : KW / 2;
   P.halo_h = TH + KW - 1; P.halo_w = SW + KW - 1;
   P.tiles_x = cdiv(P.ow, SW); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
@@ -437,6 +450,7 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   if (epi > lds) lds = epi;
   GP_REQUIRE(lds <= 160 * 1024, "conv2d_split: LDS %zu too large", lds);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (tr) return nsplit == 2 ? launch_split<128, 4, 1, 4, 2, 2, true>(P, lds, st) : launch_split<128, 4, 1, 4, 1, 2, true>(P, lds, st);
   if (KW == 7) return nsplit == 2 ? launch_split<32, 4, 1, 4, 2, 7>(P, lds, st) : launch_split<32, 4, 1, 4, 1, 7>(P, lds, st);
   if (nsplit == 2) {
     if (BN == 32) return launch_split<32, 4, 1, 8, 2, 3>(P, lds, st);

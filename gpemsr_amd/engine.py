@@ -27,7 +27,7 @@ import torch
 
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
-from .packing import pack_conv, pack_conv_split, pack_convT, pack_dcn, pack_linear, pack_vgg_first
+from .packing import pack_conv, pack_conv_split, pack_convT, pack_convT_split, pack_dcn, pack_linear, pack_vgg_first
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -88,6 +88,8 @@ class Engine:
                 self.pc[name] = pack_dcn(w, b, dev)
             elif w.dim() == 4 and (name.startswith("reffea_L") or name.endswith(".upblock")):
                 self.pc[name] = pack_convT(w, b, dev)
+                if self.precision != "fp32" and w.shape[0] % 16 == 0:
+                    self.pc[name].w16 = pack_convT_split(self.pc[name], dev)
             elif name == "vgg.slice1.0":
                 self.pc[name] = pack_vgg_first(w, b, dev)
             elif w.dim() == 4 and name.endswith((".q",)) and ".feat_extract." in name:

@@ -212,8 +212,8 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
         d.pixmul = pixmul.ptr
     d.pixel_shuffle = int(pc.pixel_shuffle)
     d.out, d.out_ld = out.ptr, out.ld
-    use_split = (precision in ("bf16x3", "bf16") and pc.w16 is not None and k in (3, 7) and stride == 1 and not pc.transposed
-                 and weight_image_stride == 0 and src_image_stride is None
+    use_split = (precision in ("bf16x3", "bf16") and pc.w16 is not None and k in (3, 7) and (stride == 1 or pc.transposed)
+                 and not (pc.transposed and pixmul is not None) and weight_image_stride == 0 and src_image_stride is None
                  and all(s.c % 16 == 0 and s.ld % 4 == 0 and s.ptr % 16 == 0 for s in srcs))
     if use_split:
         nsplit = 2 if precision == "bf16x3" else 1

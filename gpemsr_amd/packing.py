@@ -102,3 +102,12 @@ def pack_conv_split(pc: PackedConv, w: torch.Tensor, device, pixel_shuffle: bool
     hi = wt.to(torch.bfloat16)
     lo = (wt - hi.to(torch.float32)).to(torch.bfloat16)
     return torch.stack([hi, lo], dim=0).contiguous().to(device)
+
+
+def pack_convT_split(pc: PackedConv, device) -> torch.Tensor:
+    """Split-bf16 planes of the phase-stacked transposed-conv weights already packed in ``pc.w`` ([4 taps][4*Cout][cin])."""
+    wt = pc.w.detach().to(torch.float32).cpu()
+    assert pc.transposed and wt.shape[2] % 16 == 0
+    hi = wt.to(torch.bfloat16)
+    lo = (wt - hi.to(torch.float32)).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=0).contiguous().to(device)

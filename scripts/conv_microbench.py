@@ -33,6 +33,9 @@ for name, n, cin, cout, k, stride, h, w, kind, use_res in SHAPES:
     x = ops.from_nhwc(torch.randn(n, h, w, cin, device=dev))
     if kind == "convT":
         pc = pack_convT(torch.randn(cin, cout, 3, 3) * 0.05, torch.randn(cout), dev)
+        if precision != "fp32":
+            from gpemsr_amd.packing import pack_convT_split
+            pc.w16 = pack_convT_split(pc, dev)
         flops = 2.0 * n * h * w * cin * cout * 9
     elif kind == "bmm":
         wt = torch.randn(n, cout, cin, device=dev)

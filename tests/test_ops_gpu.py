@@ -390,6 +390,23 @@ def test_conv_stem_one_channel():
     _close(out.nchw(), F.relu(F.conv2d(x.expand(-1, 3, -1, -1), w3, b3, 1, 1)), tol=1e-5, what="vgg conv1_1")
 
 
+def test_conv_split_transposed():
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_convT, pack_convT_split
+    dev = _dev()
+    for (n, cin, cout, h, w, act) in [(2, 64, 64, 16, 16, 2), (1, 512, 256, 8, 8, 0), (1, 64, 64, 9, 37, 0), (1, 128, 64, 40, 33, 0)]:
+        x = _rand(n, cin, h, w, seed=421)
+        wt, b = _rand(cin, cout, 3, 3, seed=422, scale=1.0 / np.sqrt(cin * 2.25)), _rand(cout, seed=423, scale=0.1)
+        want = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1, output_padding=1).float()
+        if act == 2:
+            want = F.leaky_relu(want, 0.1)
+        pc = pack_convT(wt, b, dev)
+        pc.w16 = pack_convT_split(pc, dev)
+        out = ops.conv2d([_to_act(x, dev)], pc, act, precision="bf16x3")
+        torch.cuda.synchronize()
+        _close(out.nchw(), want, tol=3e-5, what=f"bf16x3 convT {(n, cin, cout, h, w)}")
+
+
 SPLIT7_CASES = [(2, 32, 64, 20, 44), (1, 64, 32, 33, 32), (1, 32, 16, 16, 70), (3, 16, 40, 9, 9)]
 
 
