@@ -6,11 +6,14 @@
 //
 // Same tiling and data flow as conv_mfma.hip (activations stay fp32 NHWC in HBM):
 //   * the fp32 halo tile of a 16-channel chunk arrives by LDS-DMA (raw image), is split ONCE into hi/lo bf16
-//     images by a cooperative pass ([pixel][16 bf16] = 32 B rows, so a lane's MFMA fragment -- 8 consecutive k of one
-//     pixel -- is one ds_read_b128 and the 64 lanes of a wave read a contiguous 2 KiB: conflict-free) and is then
-//     reused by the 3 taps of each of the 3 filter-row stages;
-//   * weights are split on the host (gpemsr_amd/packing.py::pack_conv_split) into [plane][tap][cout][cin_pad16] bf16
-//     and arrive by LDS-DMA into a 2-deep ring;
+//     images by a cooperative pass and is then reused by the 3 taps of each of the 3 filter-row stages.  Image layout
+//     [k-half][pixel][8 bf16]: a lane's MFMA fragment (8 consecutive k of one pixel) is one ds_read_b128 and lanes
+//     0-31 (k-half 0) / 32-63 (k-half 1) each read 512 contiguous bytes.  ([pixel][16 bf16] rows put the 32 lanes of a
+//     half on a 32-B stride = 2-way bank conflict in every ds_read_b128 lane group: SQ_LDS_BANK_CONFLICT was 46 % of
+//     SQ_LDS_IDX_ACTIVE; the half-plane layout took the 256->256 layer from 308 to 336-351 TF algorithmic);
+//   * weights are split on the host (gpemsr_amd/packing.py::pack_conv_split) into [plane][cin/16][tap][k-half][cout][8]
+//     bf16 -- the order they are staged in, so every LDS-DMA instruction reads 1 KiB of consecutive global memory and
+//     lands as the conflict-free [tap][k-half][BN][8] image -- into a 2-deep ring;
 //   * wave tile 64 pixels x 64 (or 32) couts, MFMA operand maps of guide section 3 (A[row = lane&31][k = 8*(lane>>5)+j]);
 //   * epilogue identical to conv_mfma.hip (LDS-staged coalesced float4 rows, batched residual loads, PixelShuffle).
 // Parity: tests/test_ops_gpu.py::test_conv_split_* (<= 3e-5 relative vs fp32 torch for NSPLIT = 2).
@@ -34,7 +37,7 @@ struct SplitParams {
   int nsrc;
   int n, h, w, oh, ow, OH, OW;
   int cin_pad, cout;
-  const unsigned short* weight;        // [plane][tap][cout][cin_pad] bf16
+  const unsigned short* weight;        // [plane][cin/16][tap][k-half][cout][8] bf16
   long long plane_stride;              // elements between the hi and lo planes
   const float* bias; int act;
   const float* residual; int res_ld;
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
     const int e = tid + i * 256;
     b_goff[i] = -1;
     if (i < P.nb && e < KW * BN * 2) {
-      const int row = e >> 1, j = e & 1, tt = row / BN, nn = row % BN;
-      if (n0 + nn < P.cout) b_goff[i] = (tt * P.cout + n0 + nn) * P.cin_pad + 8 * j;
+      const int tt = e / (2 * BN), j = (e / BN) & 1, nn = e % BN;      // LDS image [tap][k-half][BN][8 bf16]
+      if (n0 + nn < P.cout) b_goff[i] = ((tt * 2 + j) * P.cout + n0 + nn) * 8;       // global [chunk][tap][k-half][cout][8]
     }
   }
   int na_w = 0, nb_w = 0;
@@ -150,7 +153,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   int nchunks = 0;
   for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / CK;
   const int nstages = nchunks * G;
-  const int grp_stride = KW * P.cout * P.cin_pad;          // bf16 elements between filter rows
   int an_src = 0, an_c0 = 0;                                // A cursor: chunk whose raw image is issued next
   int bn_c0 = 0, bn_cpad = 0, bn_src = 0, bn_grp = 0, bn_stage = 0;   // B cursor: next stage to issue
 
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
     if (an_c0 >= P.c[an_src] && an_src + 1 < P.nsrc) { an_c0 = 0; ++an_src; }
   };
   auto issue_b = [&]() {
-    const unsigned short* wp = P.weight + (long long)bn_grp * grp_stride + bn_cpad + bn_c0;
+    const unsigned short* wp = P.weight + ((long long)((bn_cpad + bn_c0) >> 4) * (G * KW) + bn_grp * KW) * (16 * P.cout);
     const unsigned lb = lds_b0 + (unsigned)((bn_stage & 1) * b_slot_bytes);
 #pragma unroll
     for (int pl = 0; pl < NSPLIT; ++pl) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
         const float4 v = *reinterpret_cast<const float4*>(raw + e * 16);
         // hi = bf16(x) (RNE, v_cvt_pk_bf16_f32), lo = bf16(x - hi)
         const bf16x2_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
-        const int off = (e >> 2) * 32 + (e & 3) * 8;
+        const int off = ((e >> 1) & 1) * (P.sp_plane_bytes >> 1) + (e >> 2) * 16 + (e & 1) * 8;   // [k-half][pixel][8 bf16]
         *reinterpret_cast<uint2*>(asp + off) = make_uint2(h01, h23);
         if (NSPLIT == 2) {
           const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xFFFF0000u);
@@ -204,9 +206,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    a_frag[mt] = ((p / SW) * P.halo_w + (p % SW)) * 32 + 16 * lh;
+    a_frag[mt] = ((p / SW) * P.halo_w + (p % SW)) * 16 + lh * (P.sp_plane_bytes >> 1);
   }
-  const int b_frag = (wn * WNT + li) * 32 + 16 * lh;
+  const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
     if (stage + 1 < nstages) issue_b();                        // next stage's weights -> other ring slot
     if (grp == 0 && chunk + 1 < nchunks) issue_a();            // next chunk's raw image (the raw buffer is free: split(chunk) is done)
 
-    const char* A = asp + (grp * P.halo_w) * 32;               // filter row `grp`
+    const char* A = asp + (grp * P.halo_w) * 16;               // filter row `grp`
     const char* B = bring + (stage & 1) * b_slot_bytes + b_frag;
     bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
     auto tap_mask = [&](int kx) -> unsigned {      // CONVT: N tiles (phases q = 2py+px) fed by tap (dy = grp, dx = kx)
@@ -243,14 +245,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
       const unsigned mask = tap_mask(kx);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        ah[set][mt] = *reinterpret_cast<const bf16x8*>(A + a_frag[mt] + kx * 32);
-        if (NSPLIT == 2) al[set][mt] = *reinterpret_cast<const bf16x8*>(A + P.sp_plane_bytes + a_frag[mt] + kx * 32);
+        ah[set][mt] = *reinterpret_cast<const bf16x8*>(A + a_frag[mt] + kx * 16);
+        if (NSPLIT == 2) al[set][mt] = *reinterpret_cast<const bf16x8*>(A + P.sp_plane_bytes + a_frag[mt] + kx * 16);
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if (CONVT && !((mask >> nt) & 1u)) continue;
-        bh[set][nt] = *reinterpret_cast<const bf16x8*>(B + (kx * BN + nt * 32) * 32);
-        if (NSPLIT == 2) bl[set][nt] = *reinterpret_cast<const bf16x8*>(B + P.b_plane_bytes + (kx * BN + nt * 32) * 32);
+        bh[set][nt] = *reinterpret_cast<const bf16x8*>(B + kx * BN * 32 + nt * 512);
+        if (NSPLIT == 2) bl[set][nt] = *reinterpret_cast<const bf16x8*>(B + P.b_plane_bytes + kx * BN * 32 + nt * 512);
       }
     };
     auto mma_tap = [&](int set, int kx) {

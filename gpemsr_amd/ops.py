@@ -217,7 +217,7 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
                  and all(s.c % 16 == 0 and s.ld % 4 == 0 and s.ptr % 16 == 0 for s in srcs))
     if use_split:
         nsplit = 2 if precision == "bf16x3" else 1
-        plane = pc.w16.shape[1] * pc.w16.shape[2] * pc.w16.shape[3]
+        plane = pc.w16[0].numel()
         def _go_split():
             _abi.check(lib.gpemsr_conv2d_split(C.byref(d), pc.w16.data_ptr(), plane, nsplit, _stream()), "conv2d_split")
         if PROFILER is not None:

@@ -89,9 +89,9 @@ def pack_vgg_first(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
 
 
 def pack_conv_split(pc: PackedConv, w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch.Tensor:
-    """Split-bf16 weights for gpemsr_conv2d_split: [plane (hi, lo)][tap][cout][cin] bf16 with hi = bf16(w) (round to nearest
-    even) and lo = bf16(w - hi).  Same tap / row order as the fp32 packing of ``pc`` (incl. the PixelShuffle row permutation);
-    no channel padding (every source must have c % 16 == 0)."""
+    """Split-bf16 weights for gpemsr_conv2d_split: [plane (hi, lo)][cin/16][tap][k-half][cout][8] bf16 (see _stage_order)
+    with hi = bf16(w) (round to nearest even) and lo = bf16(w - hi).  Same tap / row order as the fp32 packing of ``pc``
+    (incl. the PixelShuffle row permutation); no channel padding (every source must have c % 16 == 0)."""
     cout, cin, kh, kw = w.shape
     assert kh == kw and kh in (3, 7) and all(c % 16 == 0 for c in pc.splits)
     wt = w.detach().to(torch.float32).cpu().permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
@@ -99,15 +99,26 @@ def pack_conv_split(pc: PackedConv, w: torch.Tensor, device, pixel_shuffle: bool
         cq = cout // 4
         perm = torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)
         wt = wt[:, perm]
+    return _split_planes(wt, device)
+
+
+def _stage_order(w3: torch.Tensor) -> torch.Tensor:
+    """[tap][cout][cin] -> [cin/16][tap][k-half][cout][8]: the order in which the split kernel stages weights, so that one
+    LDS-DMA instruction (64 lanes x 16 B, lane-linear in LDS) reads 1 KB of consecutive global memory: for a 16-channel
+    chunk, a tap and a half of the chunk (8 channels = one MFMA operand register quad), the couts are contiguous."""
+    t, cout, cin = w3.shape
+    assert cin % 16 == 0
+    return w3.reshape(t, cout, cin // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
+
+
+def _split_planes(wt: torch.Tensor, device) -> torch.Tensor:
     hi = wt.to(torch.bfloat16)
     lo = (wt - hi.to(torch.float32)).to(torch.bfloat16)
-    return torch.stack([hi, lo], dim=0).contiguous().to(device)
+    return torch.stack([_stage_order(hi), _stage_order(lo)], dim=0).contiguous().to(device)
 
 
 def pack_convT_split(pc: PackedConv, device) -> torch.Tensor:
     """Split-bf16 planes of the phase-stacked transposed-conv weights already packed in ``pc.w`` ([4 taps][4*Cout][cin])."""
     wt = pc.w.detach().to(torch.float32).cpu()
     assert pc.transposed and wt.shape[2] % 16 == 0
-    hi = wt.to(torch.bfloat16)
-    lo = (wt - hi.to(torch.float32)).to(torch.bfloat16)
-    return torch.stack([hi, lo], dim=0).contiguous().to(device)
+    return _split_planes(wt, device)

@@ -92,7 +92,8 @@ int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream);
 /* The same 3x3 stride-1 convolution on the bf16 matrix pipe.  nsplit = 2: every fp32 operand is split into hi + lo bf16 and the
  * product evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation (relative error ~2^-16 per product: fp32-grade for the 1e-3
  * parity bar, 5.3x less matrix-pipe time); nsplit = 1: plain bf16 operands.  `d` is interpreted as for gpemsr_conv2d except that
- * d->weight is ignored: weight_bf16 = [plane (hi, lo)][tap][cout][cin_total] bf16 (gpemsr_amd/packing.py::pack_conv_split),
+ * d->weight is ignored: weight_bf16 = [plane (hi, lo)][cin_total/16][tap][k-half][cout][8] bf16 -- the kernel's staging order
+ * (gpemsr_amd/packing.py::pack_conv_split / _stage_order),
  * plane_stride in elements.  Every source needs c % 16 == 0 and 16-byte aligned rows.  Activations stay fp32 in HBM. */
 int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight_bf16, int64_t plane_stride, int nsplit, void* stream);
 
