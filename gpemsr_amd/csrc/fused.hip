@@ -130,6 +130,16 @@ __global__ __launch_bounds__(256) void copy_images_kernel(const float* src, floa
   }
 }
 
+// dst image j = src image idx[j] (volume mode: the 5 cached frames of every window, edge windows repeat a frame)
+__global__ __launch_bounds__(256) void gather_images_kernel(const float* src, const int* idx, float* dst, long long n_dst,
+                                                            long long elems4) {
+  const long long total = n_dst * elems4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long j = e / elems4, k = e % elems4;
+    reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[(long long)idx[j] * elems4 + k];
+  }
+}
+
 inline unsigned grid_for(long long total) {
   const long long b = (total + 255) / 256;
   return (unsigned)(b < 32768 ? (b < 1 ? 1 : b) : 32768);
@@ -196,4 +206,12 @@ extern "C" int gpemsr_copy_images(const float* src, float* dst, int64_t n_dst, i
   hipLaunchKernelGGL(copy_images_kernel, dim3(grid_for(n_dst * (elems_per_image / 4))), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), src, dst, (long long)n_dst, (long long)(elems_per_image / 4), div, mul, add);
   return check_launch("copy_images");
+}
+
+extern "C" int gpemsr_gather_images(const float* src, const int* idx, float* dst, int64_t n_dst, int64_t elems_per_image, void* stream) {
+  GP_REQUIRE(src && idx && dst && n_dst > 0 && elems_per_image > 0 && elems_per_image % 4 == 0, "gather_images: bad args");
+  GP_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, "gather_images: alignment");
+  hipLaunchKernelGGL(gather_images_kernel, dim3(grid_for(n_dst * (elems_per_image / 4))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, idx, dst, (long long)n_dst, (long long)(elems_per_image / 4));
+  return check_launch("gather_images");
 }

@@ -371,23 +371,19 @@ class Engine:
         return ops.threeda_combine(feat, attn, add, f2, f3)
 
     # ------------------------------------------------------------------ whole forward
-    def forward(self, x: torch.Tensor, forced_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):
-        if not x.is_cuda:
-            raise RuntimeError("gpemsr_amd: forward needs a device (cuda/HIP) tensor; there is no CPU path")
-        B, N, C, H, W = x.shape
-        assert N == self.N and C == 1, "expected [B, nframes, 1, H, W]"
-        s = self.scale
-        if s == 8:
+    def _check_lr(self, H: int, W: int):
+        if self.scale == 8:
             assert H % 8 == 0 and W % 8 == 0, "x8: LR height/width must be multiples of 8"
         else:
             assert H % 4 == 0 and W % 4 == 0, "x16: LR height/width must be multiples of 4"
-        x = x.to(torch.float32).contiguous()
-        xa = Act(x, B * N, H, W, 1, 1, 0)
-        nfr = B * N
+
+    def _front_all(self, xa: Act, forced_idx, trace):
+        """Per-frame half (everything up to the L1/L2/L3 pyramid, model/GPEMSR.py:325-426) for all frames of ``xa``."""
+        nfr, H, W, s = xa.n, xa.h, xa.w, self.scale
         L1 = ops.new_act(nfr, H, W, 64, device=self.dev)
         L2 = ops.new_act(nfr, H // 2, W // 2, 64, device=self.dev)
         L3 = ops.new_act(nfr, H // 4, W // 4, 64, device=self.dev)
-        ref_img = torch.empty(B, N, C, H * s, W * s, dtype=torch.float32, device=self.dev)
+        ref_img = torch.empty(nfr, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
         ref_act = Act(ref_img, nfr, H * s, W * s, 1, 1, 0)
         lat = (H // 2) * (W // 2) if s == 8 else H * W
         for f0 in range(0, nfr, self.frame_chunk):
@@ -399,15 +395,25 @@ class Engine:
             del r
         if trace is not None:
             trace["L1_fused"] = L1.nchw()
-        out = torch.empty(B, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
-        out_act = Act(out, B, H * s, W * s, 1, 1, 0)
-        for b0 in range(0, B, self.tile_chunk):
-            bm = min(self.tile_chunk, B - b0)
-            P = bm * N
-            nbr = [L1.images(b0 * N, P), L2.images(b0 * N, P), L3.images(b0 * N, P)]
-            ref = [ops.copy_images(t, P, N, N, b0 * N + self.center) for t in (L1, L2, L3)]
-            nbr_frame = xa.images(b0 * N, P)
-            ref_frame = ops.copy_images(xa, P, N, N, b0 * N + self.center)
+        return (L1, L2, L3), ref_img
+
+    def _back(self, xa: Act, pyr, windows: torch.Tensor, trace) -> torch.Tensor:
+        """Per-window half (POD alignment, ThreeDA, reconstruction, upsampler; model/GPEMSR.py:427-455).
+        ``windows`` [Wn, N] int32 (device): frame numbers of every window; the centre is column N // 2."""
+        N, s, H, W = self.N, self.scale, xa.h, xa.w
+        Wn = windows.shape[0]
+        out = torch.empty(Wn, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
+        out_act = Act(out, Wn, H * s, W * s, 1, 1, 0)
+        for b0 in range(0, Wn, self.tile_chunk):
+            bm = min(self.tile_chunk, Wn - b0)
+            win = windows[b0:b0 + bm]
+            nbr_idx = win.reshape(-1).contiguous()
+            cen_idx = win[:, self.center].contiguous()
+            ref_idx = cen_idx.repeat_interleave(N).contiguous()
+            nbr = [ops.gather_images(t, nbr_idx) for t in pyr]
+            ref = [ops.gather_images(t, ref_idx) for t in pyr]
+            nbr_frame = ops.gather_images(xa, nbr_idx)
+            ref_frame = ops.gather_images(xa, ref_idx)
             aligned = self.pod(nbr, ref, nbr_frame, ref_frame, trace)
             if trace is not None:
                 trace.setdefault("aligned", []).append(aligned.nchw().view(bm, N, 64, H, W))
@@ -429,7 +435,41 @@ class Engine:
             o = self.conv(o, "HRconv", ACT_LRELU)
             if trace is not None:
                 trace.setdefault("hr", []).append(o.nchw())
-            xc = ops.copy_images(xa, bm, 1, N, b0 * N + self.center)
-            base = ops.bilinear(xc, H * s, W * s)
+            base = ops.bilinear(ops.gather_images(xa, cen_idx), H * s, W * s)
             self.conv(o, "conv_last", ACT_NONE, residual=base, out=out_act.images(b0, bm))
+        return out
+
+    def forward(self, x: torch.Tensor, forced_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):
+        """GPEMSR.forward (model/GPEMSR.py:323-456): independent windows x[B, N, 1, H, W] -> (out, ref_img)."""
+        if not x.is_cuda:
+            raise RuntimeError("gpemsr_amd: forward needs a device (cuda/HIP) tensor; there is no CPU path")
+        B, N, C, H, W = x.shape
+        assert N == self.N and C == 1, "expected [B, nframes, 1, H, W]"
+        self._check_lr(H, W)
+        x = x.to(torch.float32).contiguous()
+        xa = Act(x, B * N, H, W, 1, 1, 0)
+        pyr, ref_img = self._front_all(xa, forced_idx, trace)
+        windows = torch.arange(B * N, dtype=torch.int32, device=self.dev).view(B, N)
+        out = self._back(xa, pyr, windows, trace)
+        return out, ref_img.view(B, N, C, H * self.scale, W * self.scale)
+
+    def forward_volume(self, frames: torch.Tensor, windows: torch.Tensor, forced_idx: Optional[torch.Tensor] = None):
+        """Volume mode: the sliding windows of output_GPEMSR.py:54-128 share 4 of their 5 slices,
+        and everything up to the L1/L2/L3 pyramid depends on one slice only, so the per-frame half runs ONCE per slice and
+        each window gathers its frames' cached features.  Results are bit-identical to ``forward`` on the stacked windows
+        (every kernel treats the images of a batch independently).
+        frames [T, 1, H, W]; windows [Wn, N] integer frame numbers (edge windows repeat frames) -> (out [Wn, 1, sH, sW],
+        ref_img [T, 1, sH, sW])."""
+        if not frames.is_cuda:
+            raise RuntimeError("gpemsr_amd: forward_volume needs a device (cuda/HIP) tensor; there is no CPU path")
+        T, C, H, W = frames.shape
+        assert C == 1, "expected [T, 1, H, W]"
+        self._check_lr(H, W)
+        windows = torch.as_tensor(windows)
+        assert windows.dim() == 2 and windows.shape[1] == self.N, "windows must be [Wn, nframes]"
+        assert int(windows.min()) >= 0 and int(windows.max()) < T, "window frame number out of range"
+        frames = frames.to(torch.float32).contiguous()
+        xa = Act(frames, T, H, W, 1, 1, 0)
+        pyr, ref_img = self._front_all(xa, forced_idx, None)
+        out = self._back(xa, pyr, windows.to(device=self.dev, dtype=torch.int32).contiguous(), None)
         return out, ref_img

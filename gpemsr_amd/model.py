@@ -106,6 +106,16 @@ class GPEMSR(nn.Module):
         with torch.no_grad():
             return self._get_engine(x.device).forward(x, forced_code_idx, trace)
 
+    def forward_volume(self, frames, windows, forced_code_idx: Optional[torch.Tensor] = None):
+        """Volume mode: ``frames`` [T,1,H,W] are the distinct LR slices, ``windows`` [Wn,nframes] the slice numbers of
+        every sliding window (edge windows repeat slices, output_GPEMSR.py:54-84,98-128).  The per-slice half of the
+        network (VQGAN prior, VGG mask, prior fusion, pyramid) runs once per slice instead of once per window; results
+        equal ``forward`` on the stacked windows bit for bit.  Returns (out [Wn,1,sH,sW], ref_img [T,1,sH,sW])."""
+        if not frames.is_cuda:
+            raise RuntimeError("gpemsr_amd.GPEMSR.forward_volume: input must live on a cuda/HIP device")
+        with torch.no_grad():
+            return self._get_engine(frames.device).forward_volume(frames, windows, forced_code_idx)
+
     @property
     def vgg_features(self):
         return _VGGFeatures(self)

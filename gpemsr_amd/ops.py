@@ -359,6 +359,17 @@ def copy_channels(src: Act, dst: Act):
                "copy_channels")
 
 
+def gather_images(src: Act, idx: torch.Tensor) -> Act:
+    """dst image j = src image idx[j] (idx: int32 device tensor; dense NHWC images, ld == c)."""
+    assert src.ld == src.c and src.off == 0
+    assert idx.dtype == torch.int32 and idx.is_cuda and idx.is_contiguous()
+    n_dst = idx.numel()
+    dst = new_act(n_dst, src.h, src.w, src.c, device=src.buf.device)
+    _abi.check(_abi.load().gpemsr_gather_images(src.ptr, idx.data_ptr(), dst.ptr, n_dst, src.h * src.w * src.c, _stream()),
+               "gather_images")
+    return dst
+
+
 def copy_images(src: Act, n_dst: int, div: int, mul: int, add: int) -> Act:
     """dst image j = src image (j // div) * mul + add (dense NHWC images, ld == c)."""
     assert src.ld == src.c and src.off == 0

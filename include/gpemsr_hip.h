@@ -175,6 +175,9 @@ int gpemsr_copy_channels(const float* src, int src_ld, float* dst, int dst_ld, i
  * replaces the x[:, i] / [:, center].clone() indexing of model/GPEMSR.py:325,427-437,175. */
 int gpemsr_copy_images(const float* src, float* dst, int64_t n_dst, int64_t elems_per_image, int div, int mul, int add,
                        void* stream);
+/* image gather: dst image j = src image idx[j] (idx: int32 on the device).  Volume mode: the sliding
+ * 5-slice windows of output_GPEMSR.py:54-128 pick their frames' cached per-frame features instead of recomputing them. */
+int gpemsr_gather_images(const float* src, const int* idx, float* dst, int64_t n_dst, int64_t elems_per_image, void* stream);
 
 #ifdef __cplusplus
 }

@@ -231,3 +231,59 @@ def test_bf16_mode_is_within_its_looser_bar(golden_dir):
     base = torch.nn.functional.interpolate(torch.from_numpy(d["x"])[0:1, 2], scale_factor=8, mode="bilinear", align_corners=False)
     base_u8 = (base.squeeze().clamp(0, 1).numpy() * 255.0).round().astype(np.uint8)
     assert abs(calculate_psnr(u8, base_u8) - float(d["psnr_vs_base"])) < 0.01
+
+
+def test_volume_mode_equals_independent_windows():
+    """SURVEY section 8(f)1: the per-slice half runs once per slice and sliding windows gather cached features;
+    the result must equal the plain forward on the stacked windows bit for bit (incl. replicated edge slices)."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    model = _model(8)
+    T = 7
+    frames = synth_lr_tiles(1, T, 16, 16, seed=5, kind="smooth")[0].cuda()          # [T,1,16,16]
+    rows = [[0, 0, 0, 1, 2], [0, 0, 1, 2, 3]] + [[i, i + 1, i + 2, i + 3, i + 4] for i in range(T - 4)] \
+        + [[T - 4, T - 3, T - 2, T - 1, T - 1], [T - 3, T - 2, T - 1, T - 1, T - 1]]
+    win = torch.tensor(rows, dtype=torch.int32)
+    out_v, ref_v = model.forward_volume(frames, win)
+    x = torch.stack([frames[torch.tensor(r)] for r in rows], dim=0)                   # [Wn,5,1,16,16]
+    out_w, ref_w = model(x)
+    assert out_v.shape == (T, 1, 128, 128) and ref_v.shape == (T, 1, 128, 128)
+    assert torch.equal(out_v, out_w)
+    for w, r in enumerate(rows):
+        assert torch.equal(ref_w[w, 2], ref_v[r[2]])
+    with pytest.raises(AssertionError):
+        model.forward_volume(frames, torch.tensor([[0, 1, 2, 3, T]]))                 # frame number out of range
+    with pytest.raises(RuntimeError):
+        model.forward_volume(frames.cpu(), win)
+
+
+def test_cli_volume_cache_writes_the_same_pngs(tmp_path):
+    """output_GPEMSR.py end to end on a synthetic 7-slice volume: volume mode (default) and one forward per window
+    (volume_cache: false) must write identical files 0..n-1.png."""
+    import subprocess, sys, yaml
+    from PIL import Image
+    from gpemsr_amd.synth import synth_lr_tiles
+    n = 7
+    lr = (synth_lr_tiles(1, n, 16, 16, seed=9, kind="smooth")[0, :, 0].numpy() * 255).round().astype(np.uint8)
+    for d, arr in (("LQ", lr), ("GT", np.zeros((n, 128, 128), np.uint8))):
+        os.makedirs(tmp_path / d)
+        for i in range(n):
+            Image.fromarray(arr[i]).save(tmp_path / d / f"{i}.png")
+    opt = yaml.safe_load(open(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml")))
+    opt["dataset"]["dataroot_GT"], opt["dataset"]["dataroot_LQ"] = str(tmp_path / "GT"), str(tmp_path / "LQ")
+    opt["pretrain_path"] = str(tmp_path / "missing.pth")
+    opt["synthetic_weights_if_missing"] = True
+    outs = {}
+    for mode, cache in (("vol", True), ("win", False)):
+        opt["save_path"] = str(tmp_path / mode)
+        opt["volume_cache"] = cache
+        opt["volume_block"] = 4                     # 7 windows -> two blocks: exercises the halo re-computation
+        yml = tmp_path / f"{mode}.yml"
+        yaml.safe_dump(opt, open(yml, "w"))
+        env = dict(os.environ); env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "output_GPEMSR.py"), "-opt", str(yml)], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = [np.array(Image.open(tmp_path / mode / f"{k}.png")) for k in range(n)]
+        assert outs[mode][0].shape == (128, 128) and outs[mode][0].dtype == np.uint8
+    for k in range(n):
+        assert np.array_equal(outs["vol"][k], outs["win"][k]), k

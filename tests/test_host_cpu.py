@@ -203,3 +203,28 @@ def test_cli_window_order_matches_reference_edges(tmp_path):
     assert ids[2] == [0, 1, 2, 3, 4] and ids[n - 3] == [n - 5, n - 4, n - 3, n - 2, n - 1]
     assert ids[n - 2] == [n - 4, n - 3, n - 2, n - 1, n - 1] and ids[n - 1] == [n - 3, n - 2, n - 1, n - 1, n - 1]
     assert len(wins) == n and wins[0].shape == (5, 1, 8, 8) and wins[0].dtype == torch.float32
+
+
+def test_cli_index_windows_dedupes_slices(tmp_path):
+    """Volume mode bookkeeping: distinct LQ files in first-use order + [Wn,5] frame numbers that reproduce the windows."""
+    from PIL import Image
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cli", os.path.join(ROOT, "output_GPEMSR.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    n = 8
+    for d in ("GT", "LQ"):
+        os.makedirs(tmp_path / d)
+        for i in range(n):
+            Image.fromarray(np.full((8, 8), i * 10, dtype=np.uint8)).save(tmp_path / d / f"{i}.png")
+    ds = cli.CREMIWindows({"N_frames": 5, "dataroot_GT": str(tmp_path / "GT"), "dataroot_LQ": str(tmp_path / "LQ")})
+    wp = cli.window_paths(ds)
+    assert len(wp) == n
+    files, win = cli.index_windows(wp)
+    assert len(files) == n and win.shape == (n, 5) and win.dtype == torch.int32
+    frames = cli.load_frames(files)
+    full = cli.build_windows(ds)
+    for w in range(n):
+        assert torch.equal(frames[win[w].long()], full[w])
+    # a block in the middle of the volume only needs its own slices (+ halo)
+    files2, win2 = cli.index_windows(wp[3:5])
+    assert len(files2) == 6 and int(win2.max()) == 5 and win2[0].tolist() == [0, 1, 2, 3, 4]
