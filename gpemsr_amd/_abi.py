@@ -23,7 +23,8 @@ SYMBOLS = [
     "gpemsr_gather_rows", "gpemsr_bilinear", "gpemsr_avgpool2", "gpemsr_pool3s2_maxavg", "gpemsr_spynet_prep",
     "gpemsr_dcn_columns", "gpemsr_patch_cosine", "gpemsr_temporal_gate", "gpemsr_frame_mix_lrelu",
     "gpemsr_threeda_combine", "gpemsr_tensor2img_u8", "gpemsr_copy_channels", "gpemsr_copy_images",
-    "gpemsr_gather_images",
+    "gpemsr_gather_images", "gpemsr_maxpool2", "gpemsr_normalize3", "gpemsr_cx_channel_mean", "gpemsr_cx_center_normalize",
+    "gpemsr_cx_rows", "gpemsr_cx_reduce",
 ]
 
 
@@ -88,6 +89,13 @@ def load():
     lib.gpemsr_copy_channels.argtypes = [p, i32, p, i32, i64, i32, p]
     lib.gpemsr_copy_images.argtypes = [p, p, i64, i64, i32, i32, i32, p]
     lib.gpemsr_gather_images.argtypes = [p, p, p, i64, i64, p]
+    lib.gpemsr_maxpool2.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
+    f3 = C.POINTER(C.c_float)
+    lib.gpemsr_normalize3.argtypes = [p, i64, i32, f3, f3, p, i32, p]
+    lib.gpemsr_cx_channel_mean.argtypes = [p, i64, i32, i32, p, i64, p, p]
+    lib.gpemsr_cx_center_normalize.argtypes = [p, p, i64, i32, i32, p, i32, p]
+    lib.gpemsr_cx_rows.argtypes = [p, i64, i32, C.c_float, p, p]
+    lib.gpemsr_cx_reduce.argtypes = [p, p, i32, i32, i32, C.c_float, p, i64, p, p, p, p, p]
     lib.gpemsr_device_info.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     _lib = lib
     return lib

@@ -50,6 +50,26 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const float* x, int n, in
   }
 }
 
+// nn.MaxPool2d(2, 2) (torchvision vgg19 features 4/9/18/27), floor mode, 4 channels per thread
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld) {
+  const int oh = h / 2, ow = w / 2, c4 = c / 4;
+  const long long total = (long long)n * oh * ow * c4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ch = 4 * (int)(e % c4);
+    long long p = e / c4;
+    const int ox = (int)(p % ow); p /= ow;
+    const int oy = (int)(p % oh);
+    const int img = (int)(p / oh);
+    const float* b = x + (((long long)img * h + 2 * oy) * w + 2 * ox) * ld + ch;
+    const float4 v00 = *reinterpret_cast<const float4*>(b), v01 = *reinterpret_cast<const float4*>(b + ld);
+    const float4 v10 = *reinterpret_cast<const float4*>(b + (long long)w * ld), v11 = *reinterpret_cast<const float4*>(b + (long long)(w + 1) * ld);
+    float4 r;
+    r.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)); r.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+    r.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)); r.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+    *reinterpret_cast<float4*>(out + (((long long)img * oh + oy) * ow + ox) * out_ld + ch) = r;
+  }
+}
+
 __global__ __launch_bounds__(256) void pool3s2_kernel(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld) {
   const int oh = (h + 2 - 3) / 2 + 1, ow = (w + 2 - 3) / 2 + 1;
   const long long total = (long long)n * oh * ow * c;
@@ -191,6 +211,14 @@ extern "C" int gpemsr_avgpool2(const float* x, int n, int h, int w, int c, int l
   hipLaunchKernelGGL(avgpool2_kernel, dim3(grid_for((long long)n * (h / 2) * (w / 2) * c)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, n, h, w, c, ld, out, out_ld);
   return check_launch("avgpool2");
+}
+
+extern "C" int gpemsr_maxpool2(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && out && h >= 2 && w >= 2 && c % 4 == 0 && ld % 4 == 0 && out_ld % 4 == 0, "maxpool2: bad args (c, ld multiples of 4)");
+  GP_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "maxpool2: alignment");
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for((long long)n * (h / 2) * (w / 2) * (c / 4))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, n, h, w, c, ld, out, out_ld);
+  return check_launch("maxpool2");
 }
 
 extern "C" int gpemsr_pool3s2_maxavg(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld, void* stream) {

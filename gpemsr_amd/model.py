@@ -12,6 +12,7 @@ without the built library raises.
 from __future__ import annotations
 
 import os
+import weakref
 from collections import namedtuple
 from typing import Optional
 
@@ -27,7 +28,8 @@ def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, trainable: boo
     mod = root
     for p in parts[:-1]:
         if p not in mod._modules:
-            mod.add_module(p, nn.Module())
+            # `model.vgg` is callable like the reference's VGG19 (train_stage3.py:353-355 hands it to ContextualLoss)
+            mod.add_module(p, _VGGFeatures(root) if (mod is root and p == "vgg") else nn.Module())
         mod = mod._modules[p]
     if is_buffer:
         mod.register_buffer(parts[-1], tensor)
@@ -62,6 +64,8 @@ class GPEMSR(nn.Module):
         self._specs = param_specs(argref=argref, nf=nf, nframes=nframes, groups=groups, front_RBs=front_RBs,
                                   back_RBs=back_RBs, w_ref=w_ref, ref_fusion_feat_RBs=ref_fusion_feat_RBs,
                                   align_mode=align_mode, fusion_mode=fusion_mode, mode=mode, scale=scale)
+        # (`model.vgg` is created as a callable _VGGFeatures module when its first parameter is registered, so the
+        # state-dict key order stays the reference's)
         for name, spec in self._specs.items():
             _register(self, name, synth_tensor(name, spec, init_seed), spec.trainable, spec.is_buffer)
         self._engine = None
@@ -85,6 +89,28 @@ class GPEMSR(nn.Module):
     def _apply(self, fn, *a, **k):
         self._engine = None
         return super()._apply(fn, *a, **k)
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
+        new._rebind()
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = None                  # packed device copies are rebuilt on first use
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._rebind()
+
+    def _rebind(self):
+        if "vgg" in self._modules:
+            object.__setattr__(self._modules["vgg"], "_owner_ref", weakref.ref(self))
 
     def train(self, mode: bool = True):      # train() == eval(): no BatchNorm/Dropout in the network
         return super().train(mode)
@@ -118,21 +144,84 @@ class GPEMSR(nn.Module):
 
     @property
     def vgg_features(self):
-        return _VGGFeatures(self)
+        return self.vgg
 
 
 VggOutputs = namedtuple("VggOutputs", ['relu1_2', 'relu2_2', 'relu3_4', 'relu4_4', 'relu5_4'])
 
+# torchvision vgg19 `features` (cfg E, no BN) as sliced by model/VGG.py:17-29: (slice, index, kind)
+_VGG_LAYERS = (
+    (1, 0, "conv"), (1, 2, "conv"),
+    (2, 4, "pool"), (2, 5, "conv"), (2, 7, "conv"),
+    (3, 9, "pool"), (3, 10, "conv"), (3, 12, "conv"), (3, 14, "conv"), (3, 16, "conv"),
+    (4, 18, "pool"), (4, 19, "conv"), (4, 21, "conv"), (4, 23, "conv"), (4, 25, "conv"),
+    (5, 27, "pool"), (5, 28, "conv"), (5, 30, "conv"), (5, 32, "conv"), (5, 34, "conv"),
+)
+_VGG_TAPS = {'relu1_2': 1, 'relu2_2': 2, 'relu3_4': 3, 'relu4_4': 4, 'relu5_4': 5}
 
-class _VGGFeatures:
-    """``model.vgg`` lookalike (model/VGG.py:34-52): relu1_2 through the HIP conv kernels.
-    Slices 2-5 are only needed by the stage-3 contextual loss (train_stage3.py:352-355), which is
-    listed as 'next' in DESIGN.md; they raise until that row is built."""
 
-    def __init__(self, owner: GPEMSR):
-        self.owner = owner
+class _VGGFeatures(nn.Module):
+    """``model.vgg`` lookalike (model/VGG.py:34-52): calling it with a 3-channel NCHW batch returns the namedtuple of
+    relu1_2 ... relu5_4, every conv (+ReLU) on the HIP conv kernels and the four 2x2 max-pools on gpemsr_maxpool2.
+    The weights of slices 2-5 (frozen, only needed by the stage-3 contextual loss, train_stage3.py:352-359) are packed on
+    first use."""
+
+    def __init__(self, owner: "GPEMSR"):
+        super().__init__()
+        object.__setattr__(self, "_owner_ref", weakref.ref(owner))     # not a submodule: the owner contains us
+
+    @property
+    def owner(self) -> "GPEMSR":
+        return self._owner_ref()
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_owner_ref", None)            # weak references do not pickle; GPEMSR.__setstate__ rebinds
+        return st
+
+    def _pc(self, eng, sl: int, idx: int):
+        from .packing import pack_conv
+        name = f"vgg.slice{sl}.{idx}@rgb" if (sl, idx) == (1, 0) else f"vgg.slice{sl}.{idx}"
+        if name not in eng.pc:           # slice1.0 is packed for 1-channel input in the SR forward; here it sees RGB
+            key = f"vgg.slice{sl}.{idx}"
+            eng.pc[name] = pack_conv(eng.sd[key + ".weight"], eng.sd[key + ".bias"], eng.dev)
+        return eng.pc[name]
+
+    def features_nhwc(self, a, upto: str = 'relu5_4'):
+        """NHWC Act in -> the requested tap as an NHWC Act (stops there)."""
+        from . import ops
+        eng = self.owner._get_engine(a.buf.device)
+        last = _VGG_TAPS[upto]
+        for sl, idx, kind in _VGG_LAYERS:
+            if sl > last:
+                break
+            if kind == "pool":
+                a = ops.maxpool2(a)
+            else:
+                a = ops.conv2d([a], self._pc(eng, sl, idx), ops.ACT_RELU, tag=f"vgg.slice{sl}.{idx}", precision=eng.precision)
+        return a
+
+    def forward(self, x: torch.Tensor) -> VggOutputs:
+        from . import ops
+        if not x.is_cuda:
+            raise RuntimeError("gpemsr_amd: model.vgg needs a cuda/HIP tensor (there is no CPU path)")
+        assert x.dim() == 4 and x.shape[1] == 3, "VGG model takes 3 channel images."
+        with torch.no_grad():
+            eng = self.owner._get_engine(x.device)
+            a = ops.from_nchw(x.to(torch.float32))
+            taps, cur = [], 1
+            for sl, idx, kind in _VGG_LAYERS:
+                if sl != cur:
+                    taps.append(a.nchw()); cur = sl
+                if kind == "pool":
+                    a = ops.maxpool2(a)
+                else:
+                    a = ops.conv2d([a], self._pc(eng, sl, idx), ops.ACT_RELU, tag=f"vgg.slice{sl}.{idx}", precision=eng.precision)
+            taps.append(a.nchw())
+            return VggOutputs(*taps)
 
     def relu1_2(self, x1: torch.Tensor) -> torch.Tensor:
+        """relu1_2 of a 1-channel image expanded to 3 identical channels (the SR forward's use, model/GPEMSR.py:386,390)."""
         from . import ops
         eng = self.owner._get_engine(x1.device)
         a = ops.from_nchw(x1.to(torch.float32))

@@ -359,6 +359,58 @@ def copy_channels(src: Act, dst: Act):
                "copy_channels")
 
 
+def maxpool2(x: Act) -> Act:
+    """nn.MaxPool2d(2, 2), floor mode."""
+    out = new_act(x.n, x.h // 2, x.w // 2, x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_maxpool2(x.ptr, x.n, x.h, x.w, x.c, x.ld, out.ptr, out.ld, _stream()), "maxpool2")
+    return out
+
+
+def normalize3(x: Act, mean3, std3) -> Act:
+    """(x - mean_c) / std_c on a 3-channel image (ContextualLoss.forward)."""
+    assert x.c == 3
+    out = new_act(x.n, x.h, x.w, 3, device=x.buf.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    sd = (C.c_float * 3)(*[float(v) for v in std3])
+    _abi.check(_abi.load().gpemsr_normalize3(x.ptr, x.pixels, x.ld, m, sd, out.ptr, out.ld, _stream()), "normalize3")
+    return out
+
+
+def cx_normalized_pair(x: Act, y: Act):
+    """compute_cosine_distance's operands: (x - mean_y) and (y - mean_y), L2-normalised over channels per pixel."""
+    assert x.c == y.c
+    dev = x.buf.device
+    nblk = (y.pixels + 1023) // 1024
+    ws = torch.empty(nblk * y.c, dtype=torch.float32, device=dev)
+    mu = torch.empty(y.c, dtype=torch.float32, device=dev)
+    lib = _abi.load()
+    _abi.check(lib.gpemsr_cx_channel_mean(y.ptr, y.pixels, y.c, y.ld, ws.data_ptr(), ws.numel(), mu.data_ptr(), _stream()),
+               "cx_channel_mean")
+    xn = new_act(x.n, x.h, x.w, x.c, device=dev)
+    yn = new_act(y.n, y.h, y.w, y.c, device=dev)
+    _abi.check(lib.gpemsr_cx_center_normalize(x.ptr, mu.data_ptr(), x.pixels, x.c, x.ld, xn.ptr, xn.ld, _stream()), "cx_center_normalize")
+    _abi.check(lib.gpemsr_cx_center_normalize(y.ptr, mu.data_ptr(), y.pixels, y.c, y.ld, yn.ptr, yn.ld, _stream()), "cx_center_normalize")
+    return xn, yn
+
+
+def cx_from_similarity(sim: torch.Tensor, band_width: float):
+    """sim [n, Px, Py] (cosine similarities) -> (loss [1], c [n, Py]) by model/contextual.py:41-52."""
+    n, rows, cols = sim.shape
+    dev = sim.device
+    lib = _abi.load()
+    cx = torch.empty_like(sim)
+    _abi.check(lib.gpemsr_cx_rows(sim.data_ptr(), n * rows, cols, float(band_width), cx.data_ptr(), _stream()), "cx_rows")
+    nslab = (rows + 127) // 128
+    ws = torch.empty(2 * n * nslab * cols, dtype=torch.float32, device=dev)
+    rmax = torch.empty(n, cols, dtype=torch.float32, device=dev)
+    cw = torch.empty(n, cols, dtype=torch.float32, device=dev)
+    cxn = torch.empty(n, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    _abi.check(lib.gpemsr_cx_reduce(cx.data_ptr(), sim.data_ptr(), n, rows, cols, float(band_width), ws.data_ptr(), ws.numel(),
+                                    rmax.data_ptr(), cw.data_ptr(), cxn.data_ptr(), loss.data_ptr(), _stream()), "cx_reduce")
+    return loss, cw, cxn
+
+
 def gather_images(src: Act, idx: torch.Tensor) -> Act:
     """dst image j = src image idx[j] (idx: int32 device tensor; dense NHWC images, ld == c)."""
     assert src.ld == src.c and src.off == 0

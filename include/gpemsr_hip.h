@@ -175,6 +175,30 @@ int gpemsr_copy_channels(const float* src, int src_ld, float* dst, int dst_ld, i
  * replaces the x[:, i] / [:, center].clone() indexing of model/GPEMSR.py:325,427-437,175. */
 int gpemsr_copy_images(const float* src, float* dst, int64_t n_dst, int64_t elems_per_image, int div, int mul, int add,
                        void* stream);
+/* ---- stage-3 training loss, forward (train_stage3.py:343-359) ------------------------------
+ * nn.MaxPool2d(2,2) of torchvision vgg19 (model/VGG.py:17-29: features 4, 9, 18, 27), NHWC, c % 4 == 0 */
+int gpemsr_maxpool2(const float* x, int n, int h, int w, int c, int ld, float* out, int out_ld, void* stream);
+/* ContextualLoss.forward input normalisation (model/contextual.py:222-224): (x - mean_c) / std_c, 3-channel NHWC;
+ * mean3 / std3 are host pointers */
+int gpemsr_normalize3(const float* x, int64_t pixels, int ld, const float* mean3, const float* std3, float* out, int out_ld,
+                      void* stream);
+/* compute_cosine_distance (model/contextual.py:115-127): per-channel mean of y over all pixels of all images
+ * (workspace >= ceil(pixels/1024)*c floats) ... */
+int gpemsr_cx_channel_mean(const float* y, int64_t pixels, int c, int ld, float* workspace, int64_t workspace_floats,
+                           float* mean, void* stream);
+/* ... and out = F.normalize(x - mean, p=2, dim=channel) per pixel.  The similarity GEMM S[n,i,j] = <x^_i, y^_j> is
+ * gpemsr_conv2d (1x1, per-image weights = y^). */
+int gpemsr_cx_center_normalize(const float* x, const float* mean, int64_t pixels, int c, int ld, float* out, int out_ld,
+                               void* stream);
+/* compute_relative_distance + compute_cx (model/contextual.py:103-112) on rows of S: dist = clamp(1-S,0);
+ * cx = exp((1 - dist/(min_j dist + 1e-5))/h) / (sum_j + 1e-5).  cols % 4 == 0, <= 16384. */
+int gpemsr_cx_rows(const float* sim, int64_t rows, int cols, float band_width, float* cx, void* stream);
+/* contextual_loss (model/contextual.py:44-52): rmax[n,j] = max_i cx[n,i,j]; cw[n,j] = exp((1 - dist[n,i*,j])/h);
+ * cx_image[n] = sum_j rmax*cw / sum_j cw; loss = mean_n -log(cx_image + 1e-5).
+ * workspace >= 2 * n * ceil(rows/128) * cols floats. */
+int gpemsr_cx_reduce(const float* cx, const float* sim, int n, int rows, int cols, float band_width, float* workspace,
+                     int64_t workspace_floats, float* rmax, float* cw, float* cx_image, float* loss, void* stream);
+
 /* image gather: dst image j = src image idx[j] (idx: int32 on the device).  Volume mode: the sliding
  * 5-slice windows of output_GPEMSR.py:54-128 pick their frames' cached per-frame features instead of recomputing them. */
 int gpemsr_gather_images(const float* src, const int* idx, float* dst, int64_t n_dst, int64_t elems_per_image, void* stream);

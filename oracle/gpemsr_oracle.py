@@ -199,6 +199,67 @@ def vgg_relu1_2(sd: SD, prefix: str, x3: Tensor) -> Tensor:
     return F.relu(_conv(sd, prefix + ".slice1.2", h))
 
 
+# torchvision vgg19 `features` (cfg "E", no BN) cut into the five slices of model/VGG.py:17-29; M = MaxPool2d(2, 2)
+_VGG19_SLICES = ((1, (0, 2)), (2, ("M", 5, 7)), (3, ("M", 10, 12, 14, 16)), (4, ("M", 19, 21, 23, 25)), (5, ("M", 28, 30, 32, 34)))
+VGG_TAP_NAMES = ("relu1_2", "relu2_2", "relu3_4", "relu4_4", "relu5_4")
+
+
+def vgg19_taps(sd: SD, prefix: str, x3: Tensor, upto: str = "relu5_4") -> Dict[str, Tensor]:
+    """VGG19.forward of model/VGG.py:34-52 (third-party layer list: parity unpinned, see the header)."""
+    taps: Dict[str, Tensor] = {}
+    h = x3
+    for (sl, layers), tap in zip(_VGG19_SLICES, VGG_TAP_NAMES):
+        for l in layers:
+            h = F.max_pool2d(h, 2, 2) if l == "M" else F.relu(_conv(sd, f"{prefix}.slice{sl}.{l}", h))
+        taps[tap] = h
+        if tap == upto:
+            break
+    return taps
+
+
+def contextual_loss(x: Tensor, y: Tensor, band_width: float = 0.5) -> Tuple[Tensor, Tensor]:
+    """contextual_loss(..., loss_type='cosine') of model/contextual.py:8-52 on NCHW features:
+    compute_cosine_distance (:115-138), compute_relative_distance (:109-112), compute_cx (:103-106)."""
+    n, c = x.shape[:2]
+    mu = y.mean(dim=(0, 2, 3), keepdim=True)
+    xn = F.normalize(x - mu, p=2, dim=1).reshape(n, c, -1)
+    yn = F.normalize(y - mu, p=2, dim=1).reshape(n, c, -1)
+    dist = (1.0 - torch.bmm(xn.transpose(1, 2), yn)).clamp(min=0)             # [n, Px, Py]
+    rel = dist / (dist.min(dim=2, keepdim=True)[0] + 1e-5)
+    w = torch.exp((1.0 - rel) / band_width)
+    cx = w / (w.sum(dim=2, keepdim=True) + 1e-5)
+    best, arg = cx.max(dim=1, keepdim=True)                                   # over x positions, per y position
+    cw = torch.gather(torch.exp((1.0 - dist) / band_width), 1, arg)
+    per_image = (best * cw).squeeze(1).sum(dim=1) / cw.squeeze(1).sum(dim=1)
+    loss = torch.mean(-torch.log(per_image + 1e-5))
+    return loss, cw.view(n, 1, y.shape[2], y.shape[3])
+
+
+VGG_MEAN = (0.485, 0.456, 0.406)
+VGG_STD = (0.229, 0.224, 0.225)
+
+
+def contextual_loss_vgg(sd: SD, prefix: str, x3: Tensor, y3: Tensor, layer: str = "relu3_4", band_width: float = 0.5):
+    """ContextualLoss.forward (model/contextual.py:218-233) with use_vgg=True."""
+    m = torch.tensor(VGG_MEAN).view(1, 3, 1, 1)
+    sdv = torch.tensor(VGG_STD).view(1, 3, 1, 1)
+    fx = vgg19_taps(sd, prefix, (x3 - m) / sdv, layer)[layer]
+    fy = vgg19_taps(sd, prefix, (y3 - m) / sdv, layer)[layer]
+    return contextual_loss(fx, fy, band_width) + (fx, fy)
+
+
+def stage3_losses(sd: SD, sr: Tensor, ref_img: Tensor, gt: Tensor, prefix: str = "vgg"):
+    """The two loss values of train_EMSR_onestep (train_stage3.py:349-359): L1(GT, SR) and CX(VGG(SR x t copies),
+    VGG(ref_img frames))."""
+    rec = (gt - sr).abs().mean()
+    b, _, h, w = sr.shape
+    t = ref_img.shape[1]
+    sr_b = sr[:, None].expand(-1, -1, 3, -1, -1).expand(-1, t, -1, -1, -1).reshape(b * t, 3, h, w)
+    ref_b = ref_img.expand(-1, -1, 3, -1, -1).reshape(b * t, 3, h, w)
+    ref_loss, c, _, _ = contextual_loss_vgg(sd, prefix, sr_b, ref_b)
+    return rec, ref_loss, c
+
+
 # --------------------------------------------------------------------------
 # VQGAN prior (first-party; pinned by the golden vectors)
 # --------------------------------------------------------------------------

@@ -114,3 +114,31 @@ def test_gen_report_is_clean(golden_dir):
         assert r["idx_agree"] == 1.0
         for k in ("out", "ref_img", "L1_fea", "logits", "mask_cos", "L1_fused", "aligned", "fused"):
             assert r[k] < 1e-5, (r["case"], k, r[k])
+
+
+def test_oracle_contextual_loss_matches_reference_golden(golden_dir):
+    """oracle.contextual_loss / vgg19_taps / stage3_losses vs the vectors emitted by the reference's own
+    model/contextual.py + model/VGG.py (oracle/gen_golden_cx.py)."""
+    import numpy as np
+    import torch
+    from oracle import gpemsr_oracle as orc
+    d = np.load(os.path.join(golden_dir, "cx_x8.npz"))
+    T = lambda k: torch.from_numpy(d[k])
+    loss, c = orc.contextual_loss(T("f_x"), T("f_y"), 0.5)
+    assert abs(float(loss) - float(d["f_loss"])) <= 1e-6 * abs(float(d["f_loss"]))
+    assert np.allclose(c.numpy(), d["f_c"], rtol=1e-6, atol=1e-7)
+    loss, c = orc.contextual_loss(T("f_x"), T("f_x").flip(0) * 0.5 + 0.2, 0.1)
+    assert abs(float(loss) - float(d["f_loss_bw01"])) <= 1e-6 and np.allclose(c.numpy(), d["f_c_bw01"], rtol=1e-5, atol=1e-7)
+    sd = {k: v for k, v in _weights(8).items() if k.startswith("vgg.")}
+    with torch.no_grad():
+        loss, c, fx, _ = orc.contextual_loss_vgg(sd, "vgg", T("i_x"), T("i_y"))
+        assert np.allclose(fx.numpy(), d["i_x_relu3_4"], rtol=1e-5, atol=1e-6)
+        assert abs(float(loss) - float(d["i_loss"])) <= 1e-5 and np.allclose(c.numpy(), d["i_c"], rtol=1e-4, atol=1e-6)
+        m = torch.tensor(orc.VGG_MEAN).view(1, 3, 1, 1); s = torch.tensor(orc.VGG_STD).view(1, 3, 1, 1)
+        taps = orc.vgg19_taps(sd, "vgg", (T("i_x") - m) / s)
+        for name in orc.VGG_TAP_NAMES:
+            ref = d["i_x_" + name]
+            assert np.abs(taps[name].numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30), name
+        rec, ref_loss, u = orc.stage3_losses(sd, T("t_sr"), T("t_ref_img"), T("t_gt"))
+        assert abs(float(rec) - float(d["t_rec_loss"])) <= 1e-7
+        assert abs(float(ref_loss) - float(d["t_ref_loss"])) <= 1e-5 and np.allclose(u.numpy(), d["t_u"], rtol=1e-4, atol=1e-6)
