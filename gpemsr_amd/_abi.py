@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_LRELU_SIGMOID = 0, 1, 2, 3, 4
 
 # every symbol include/gpemsr_hip.h declares (checked by tests/test_abi_cpu.py)
 SYMBOLS = [
-    "gpemsr_abi_version", "gpemsr_last_error", "gpemsr_device_info", "gpemsr_conv2d", "gpemsr_conv2d_split", "gpemsr_conv2d_direct", "gpemsr_conv2d_stem1",
+    "gpemsr_abi_version", "gpemsr_last_error", "gpemsr_device_info", "gpemsr_conv2d", "gpemsr_conv2d_split", "gpemsr_split_pack_rows", "gpemsr_conv2d_direct", "gpemsr_conv2d_stem1",
     "gpemsr_groupnorm_stats", "gpemsr_groupnorm_apply", "gpemsr_softmax_rows", "gpemsr_argmax_rows",
     "gpemsr_gather_rows", "gpemsr_bilinear", "gpemsr_avgpool2", "gpemsr_pool3s2_maxavg", "gpemsr_spynet_prep",
     "gpemsr_dcn_columns", "gpemsr_patch_cosine", "gpemsr_temporal_gate", "gpemsr_frame_mix_lrelu",
@@ -88,6 +88,7 @@ def load():
     lib.gpemsr_tensor2img_u8.argtypes = [p, i64, p, p]
     lib.gpemsr_copy_channels.argtypes = [p, i32, p, i32, i64, i32, p]
     lib.gpemsr_copy_images.argtypes = [p, p, i64, i64, i32, i32, i32, p]
+    lib.gpemsr_split_pack_rows.argtypes = [p, i32, i32, i32, i32, i64, p, p]
     lib.gpemsr_gather_images.argtypes = [p, p, p, i64, i64, p]
     lib.gpemsr_maxpool2.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
     f3 = C.POINTER(C.c_float)

@@ -26,7 +26,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SW = 32;            // tile width (pixels)
-constexpr int SA_LOADS = 6;       // raw-A float4 slots per thread (10x34 halo x 4 / 256 -> 6)
+constexpr int SA_LOADS = 6;       // raw-A float4 slots per thread (10x34 halo x 4 / 256 -> 6; GEMM: 128 px x 8 / 256 -> 4)
 constexpr int SB_LOADS = 3;       // weight 16-B slots per thread per plane (3 taps x 128 couts x 2 / 256; 7 taps x 32 x 2 / 256 -> 2)
 
 struct SplitParams {
@@ -39,6 +39,8 @@ struct SplitParams {
   int cin_pad, cout;
   const unsigned short* weight;        // [plane][cin/16][tap][k-half][cout][8] bf16
   long long plane_stride;              // elements between the hi and lo planes
+  long long w_img_stride;              // elements between the weights of consecutive images (0: shared; GEMM with per-image B)
+  int sub_plane_bytes;                 // GEMM: bytes of one 16-channel sub-chunk image (both k-halves)
   const float* bias; int act;
   const float* residual; int res_ld;
   const float* pixmul;
@@ -68,15 +70,21 @@ __device__ __forceinline__ bf16x2_t cvt_pk_bf16(float a, float b) {
 
 // CONVT: ConvTranspose2d(k3,s2,p1,op1) in the phase-stacked 2x2-tap form of conv_mfma.hip (KW = 2, BN = 128 = 4 phases x 32
 // couts per wave, tap (dy,dx) feeds the phases with py >= dy, px >= dx; masked N tiles are neither read nor multiplied).
-template <int BN, int WM, int WN, int TH, int NSPLIT, int KW, bool CONVT>
+// GEMM: 1x1 convolution / Linear / batched matrix product (per-image B through w_img_stride).  There is no halo and no
+// tap reuse, so a stage covers KW 16-channel sub-chunks instead of KW filter taps: the raw image is [pixel][16*KW fp32]
+// (one contiguous 64*KW-byte run per pixel), the split images are [sub-chunk][k-half][pixel][8 bf16], and "tap" kx of the
+// inner loop selects sub-chunk kx at the SAME pixel.  The staged weight image [sub-chunk][k-half][BN][8] is KW consecutive
+// chunks of the global [cin/16][1][k-half][cout][8] order.
+template <int BN, int WM, int WN, int TH, int NSPLIT, int KW, bool CONVT, bool GEMM = false>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   constexpr int NPIX = TH * SW;
   constexpr int PM = NPIX / WM;
   constexpr int MT = PM / 32;
   constexpr int WNT = BN / WN;
   constexpr int NT = WNT / 32;
-  constexpr int G = KW;               // KW taps per stage (one filter row), G = KW stages per chunk
-  constexpr int CK = 16;
+  constexpr int G = GEMM ? 1 : KW;    // conv: KW taps per stage (one filter row), G = KW stages per chunk
+  constexpr int CK = GEMM ? 16 * KW : 16;   // channels per chunk
+  constexpr int PCS = CK / 4;         // 16-byte pieces per pixel of a raw chunk image
 
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   char* const raw = smem_c;                                   // fp32 [halo_px][16]
@@ -109,9 +117,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   for (int i = 0; i < SA_LOADS; ++i) {
     const int e = tid + i * 256;
     a_pix[i] = -1; a_slot[i] = false;
-    if (i < P.na && e < halo_px * 4) {
+    if (i < P.na && e < halo_px * PCS) {
       a_slot[i] = true;
-      const int hp = e >> 2;
+      const int hp = e / PCS;
       const int iy = iy0 + hp / P.halo_w, ix = ix0 + hp % P.halo_w;
       if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) a_pix[i] = iy * P.w + ix;
     }
@@ -161,12 +169,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
     const unsigned pixb = (unsigned)P.ld[an_src] * 4u;
 #pragma unroll
     for (int i = 0; i < SA_LOADS; ++i)
-      if (a_pix[i] >= 0) sglds16((unsigned)a_pix[i] * pixb + 16u * (unsigned)((tid + i * 256) & 3), sp, lds0 + i * 4096u);
+      if (a_pix[i] >= 0) sglds16((unsigned)a_pix[i] * pixb + 16u * (unsigned)((tid + i * 256) % PCS), sp, lds0 + i * 4096u);
     an_c0 += CK;
     if (an_c0 >= P.c[an_src] && an_src + 1 < P.nsrc) { an_c0 = 0; ++an_src; }
   };
   auto issue_b = [&]() {
-    const unsigned short* wp = P.weight + ((long long)((bn_cpad + bn_c0) >> 4) * (G * KW) + bn_grp * KW) * (16 * P.cout);
+    const unsigned short* wp = P.weight + (long long)img * P.w_img_stride +
+                               (GEMM ? (long long)((bn_cpad + bn_c0) >> 4) : ((long long)((bn_cpad + bn_c0) >> 4) * (G * KW) + bn_grp * KW)) * (16 * P.cout);
     const unsigned lb = lds_b0 + (unsigned)((bn_stage & 1) * b_slot_bytes);
 #pragma unroll
     for (int pl = 0; pl < NSPLIT; ++pl) {
@@ -190,7 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
         const float4 v = *reinterpret_cast<const float4*>(raw + e * 16);
         // hi = bf16(x) (RNE, v_cvt_pk_bf16_f32), lo = bf16(x - hi)
         const bf16x2_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
-        const int off = ((e >> 1) & 1) * (P.sp_plane_bytes >> 1) + (e >> 2) * 16 + (e & 1) * 8;   // [k-half][pixel][8 bf16]
+        const int q = e % PCS, hp = e / PCS;                     // q: 4-channel piece of the pixel's chunk
+        const int off = GEMM ? (q >> 2) * P.sub_plane_bytes + ((q >> 1) & 1) * (P.sub_plane_bytes >> 1) + hp * 16 + (q & 1) * 8
+                             : (q >> 1) * (P.sp_plane_bytes >> 1) + hp * 16 + (q & 1) * 8;   // [k-half][pixel][8 bf16]
         *reinterpret_cast<uint2*>(asp + off) = make_uint2(h01, h23);
         if (NSPLIT == 2) {
           const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xFFFF0000u);
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    a_frag[mt] = ((p / SW) * P.halo_w + (p % SW)) * 16 + lh * (P.sp_plane_bytes >> 1);
+    a_frag[mt] = ((p / SW) * P.halo_w + (p % SW)) * 16 + lh * ((GEMM ? P.sub_plane_bytes : P.sp_plane_bytes) >> 1);
   }
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
 
@@ -245,8 +256,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
       const unsigned mask = tap_mask(kx);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        ah[set][mt] = *reinterpret_cast<const bf16x8*>(A + a_frag[mt] + kx * 16);
-        if (NSPLIT == 2) al[set][mt] = *reinterpret_cast<const bf16x8*>(A + P.sp_plane_bytes + a_frag[mt] + kx * 16);
+        ah[set][mt] = *reinterpret_cast<const bf16x8*>(A + a_frag[mt] + kx * (GEMM ? P.sub_plane_bytes : 16));
+        if (NSPLIT == 2) al[set][mt] = *reinterpret_cast<const bf16x8*>(A + P.sp_plane_bytes + a_frag[mt] + kx * (GEMM ? P.sub_plane_bytes : 16));
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -380,9 +391,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   }
 }
 
-template <int BN, int WM, int WN, int TH, int NSPLIT, int KW, bool CONVT = false>
+template <int BN, int WM, int WN, int TH, int NSPLIT, int KW, bool CONVT = false, bool GEMM = false>
 static int launch_split(const SplitParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_split_kernel<BN, WM, WN, TH, NSPLIT, KW, CONVT>;
+  auto kfn = conv_split_kernel<BN, WM, WN, TH, NSPLIT, KW, CONVT, GEMM>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -395,25 +406,65 @@ static int launch_split(const SplitParams& P, size_t lds, hipStream_t st) {
   return check_launch("conv_split_kernel");
 }
 
+
+// fp32 rows [n][rows][K] -> the split kernel's staged weight order [n][plane (hi, lo)][K/16][k-half][rows][8] bf16: the B
+// operand of a batched matrix product (attention: k for q.k^T, v^T for P.v) is produced at run time, so it is split and
+// re-ordered by this pass instead of on the host.  One thread = 8 consecutive k of one row.
+__global__ __launch_bounds__(256) void split_pack_rows_kernel(const float* src, int rows, int K, int ld, long long img_stride,
+                                                              unsigned short* dst, long long total) {
+  const int kb_n = K >> 3;
+  const long long plane = (long long)rows * K;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int r = (int)(idx % rows);
+    const long long t = idx / rows;
+    const int kb = (int)(t % kb_n);
+    const long long img = t / kb_n;
+    const float* sp = src + img * img_stride + (long long)r * ld + kb * 8;
+    const float4 a = *reinterpret_cast<const float4*>(sp), b = *reinterpret_cast<const float4*>(sp + 4);
+    const bf16x2_t h0 = cvt_pk_bf16(a.x, a.y), h1 = cvt_pk_bf16(a.z, a.w), h2 = cvt_pk_bf16(b.x, b.y), h3 = cvt_pk_bf16(b.z, b.w);
+    const bf16x2_t l0 = cvt_pk_bf16(a.x - __uint_as_float(h0 << 16), a.y - __uint_as_float(h0 & 0xFFFF0000u));
+    const bf16x2_t l1 = cvt_pk_bf16(a.z - __uint_as_float(h1 << 16), a.w - __uint_as_float(h1 & 0xFFFF0000u));
+    const bf16x2_t l2 = cvt_pk_bf16(b.x - __uint_as_float(h2 << 16), b.y - __uint_as_float(h2 & 0xFFFF0000u));
+    const bf16x2_t l3 = cvt_pk_bf16(b.z - __uint_as_float(h3 << 16), b.w - __uint_as_float(h3 & 0xFFFF0000u));
+    unsigned short* dp = dst + img * 2 * plane + ((long long)kb * rows + r) * 8;      // (kb>>1, kb&1) = (chunk, k-half)
+    *reinterpret_cast<uint4*>(dp) = make_uint4(h0, h1, h2, h3);
+    *reinterpret_cast<uint4*>(dp + plane) = make_uint4(l0, l1, l2, l3);
+  }
+}
+
 }  // namespace gpemsr
 
 using namespace gpemsr;
+
+extern "C" int gpemsr_split_pack_rows(const float* src, int n, int rows, int k, int ld, int64_t img_stride, void* dst_bf16, void* stream) {
+  GP_REQUIRE(src && dst_bf16 && n > 0 && rows > 0 && k > 0 && k % 16 == 0 && ld % 4 == 0 && img_stride % 4 == 0,
+             "split_pack_rows: bad args (k %% 16 == 0, ld %% 4 == 0)");
+  GP_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_bf16)) & 15) == 0, "split_pack_rows: alignment");
+  const long long total = (long long)n * rows * (k / 8);
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(split_pack_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src, rows, k, ld, (long long)img_stride,
+                     reinterpret_cast<unsigned short*>(dst_bf16), total);
+  return check_launch("split_pack_rows");
+}
 
 extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight_bf16, int64_t plane_stride, int nsplit, void* stream) {
   GP_REQUIRE(d && weight_bf16 && d->out, "conv2d_split: null pointer");
   GP_REQUIRE(nsplit == 1 || nsplit == 2, "conv2d_split: nsplit=%d", nsplit);
   const bool tr = d->transposed != 0;
-  GP_REQUIRE(d->weight_image_stride == 0, "conv2d_split: per-image weights unsupported");
+  const bool gemm = !tr && d->ksize == 1;
+  GP_REQUIRE(d->weight_image_stride == 0 || gemm, "conv2d_split: per-image weights only for 1x1 (GEMM)");
   if (tr) GP_REQUIRE(d->ksize == 3 && !d->pixel_shuffle && !d->pixmul && d->cout % 32 == 0, "conv2d_split: transposed needs k=3, cout%%32==0");
-  else GP_REQUIRE((d->ksize == 3 || d->ksize == 7) && d->stride == 1, "conv2d_split: only 3x3 / 7x7 stride-1 convolutions (or transposed 3x3)");
+  else GP_REQUIRE((d->ksize == 1 || d->ksize == 3 || d->ksize == 7) && d->stride == 1, "conv2d_split: only 1x1 / 3x3 / 7x7 stride-1 convolutions (or transposed 3x3)");
+  if (gemm) GP_REQUIRE(!d->pixel_shuffle, "conv2d_split: 1x1 has no pixel_shuffle form");
   if (d->ksize == 7) GP_REQUIRE(!d->pixel_shuffle, "conv2d_split: 7x7 has no pixel_shuffle form");
   GP_REQUIRE(d->nsrc >= 1 && d->nsrc <= GPEMSR_MAX_SRC && d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "conv2d_split: bad geometry");
   if (d->pixel_shuffle) GP_REQUIRE(d->cout % 16 == 0, "conv2d_split: pixel_shuffle needs cout%%16==0");
   SplitParams P{};
   int cin_pad = 0;
   for (int s = 0; s < d->nsrc; ++s) {
-    GP_REQUIRE(d->src[s].ptr && d->src[s].c > 0 && d->src[s].c % 16 == 0 && d->src[s].ld % 4 == 0 &&
-               ((reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) == 0), "conv2d_split: source %d must have c%%16==0 and 16-B aligned rows", s);
+    GP_REQUIRE(d->src[s].ptr && d->src[s].c > 0 && d->src[s].c % (gemm ? 32 : 16) == 0 && d->src[s].ld % 4 == 0 &&
+               ((reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) == 0), "conv2d_split: source %d must have c%%16==0 (1x1: c%%32==0) and 16-B aligned rows", s);
     P.src[s] = d->src[s].ptr; P.ld[s] = d->src[s].ld; P.c[s] = d->src[s].c;
     P.img_stride[s] = d->src_image_stride[s] < 0 ? (long long)d->h * d->w * d->src[s].ld : d->src_image_stride[s];
     GP_REQUIRE(P.img_stride[s] % 4 == 0 && (long long)d->h * d->w * P.ld[s] * 4 < (1ll << 32), "conv2d_split: source %d too large / misaligned", s);
@@ -425,27 +476,29 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   P.OH = (d->pixel_shuffle || tr) ? 2 * d->h : d->h; P.OW = (d->pixel_shuffle || tr) ? 2 * d->w : d->w;
   P.cin_pad = cin_pad; P.cout = tr ? 4 * d->cout : d->cout;        // transposed: 4*Cout phase-stacked GEMM columns
   P.weight = reinterpret_cast<const unsigned short*>(weight_bf16); P.plane_stride = plane_stride;
+  P.w_img_stride = d->weight_image_stride;      // bf16 elements (1x1 with per-image B only)
   P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;
   P.store_mode = tr ? 2 : (d->pixel_shuffle ? 1 : 0); P.cq = d->cout / 4;
   P.out = d->out; P.out_ld = d->out_ld;
   P.out_vec = (d->out_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->out) & 15) == 0);
   P.res_vec = d->residual && (d->res_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->residual) & 15) == 0);
-  const int KW = tr ? 2 : d->ksize;
+  const int KW = tr ? 2 : (gemm ? 2 : d->ksize);                  // GEMM: 2 sub-chunks of 16 channels per stage
   // 7x7: 32-cout blocks of 4x32 pixels keep the (larger) halo + 7-tap weight images at two workgroups per CU
-  const int BN = tr ? 128 : (KW == 7 ? 32 : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128)));
-  const int TH = (BN == 128 || KW == 7) ? 4 : 8;
-  P.pad = tr ? 0 : KW / 2;
-  P.halo_h = TH + KW - 1; P.halo_w = SW + KW - 1;
+  const int BN = tr ? 128 : (gemm ? (d->cout <= 64 ? 64 : 128) : (KW == 7 ? 32 : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128))));
+  const int TH = (BN == 128 || KW == 7 || gemm) ? 4 : 8;
+  P.pad = (tr || gemm) ? 0 : KW / 2;
+  P.halo_h = gemm ? TH : TH + KW - 1; P.halo_w = gemm ? SW : SW + KW - 1;
   P.tiles_x = cdiv(P.ow, SW); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d_split: grid too large");
   P.nblocks = (int)nb;
   const int halo_px = P.halo_h * P.halo_w;
-  P.na = cdiv((long long)halo_px * 4, 256);
+  P.na = cdiv((long long)halo_px * (gemm ? 4 * KW : 4), 256);
   P.nb = cdiv((long long)KW * BN * 2, 256);
   GP_REQUIRE(P.na <= SA_LOADS && P.nb <= SB_LOADS, "conv2d_split: tile too large");
   P.raw_bytes = P.na * 4096;
-  P.sp_plane_bytes = (halo_px * 32 + 255) & ~255;
+  P.sub_plane_bytes = (halo_px * 32 + 255) & ~255;
+  P.sp_plane_bytes = gemm ? KW * P.sub_plane_bytes : P.sub_plane_bytes;
   P.b_plane_bytes = P.nb * 4096;
   size_t lds = (size_t)P.raw_bytes + (size_t)nsplit * P.sp_plane_bytes + 2 * (size_t)nsplit * P.b_plane_bytes;
   const size_t epi = 128 * (size_t)((BN < 64 ? BN : 64) + 4) * 4;
@@ -453,6 +506,10 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   GP_REQUIRE(lds <= 160 * 1024, "conv2d_split: LDS %zu too large", lds);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (tr) return nsplit == 2 ? launch_split<128, 4, 1, 4, 2, 2, true>(P, lds, st) : launch_split<128, 4, 1, 4, 1, 2, true>(P, lds, st);
+  if (gemm) {
+    if (BN == 64) return nsplit == 2 ? launch_split<64, 2, 2, 4, 2, 2, false, true>(P, lds, st) : launch_split<64, 2, 2, 4, 1, 2, false, true>(P, lds, st);
+    return nsplit == 2 ? launch_split<128, 2, 2, 4, 2, 2, false, true>(P, lds, st) : launch_split<128, 2, 2, 4, 1, 2, false, true>(P, lds, st);
+  }
   if (KW == 7) return nsplit == 2 ? launch_split<32, 4, 1, 4, 2, 7>(P, lds, st) : launch_split<32, 4, 1, 4, 1, 7>(P, lds, st);
   if (nsplit == 2) {
     if (BN == 32) return launch_split<32, 4, 1, 8, 2, 3>(P, lds, st);

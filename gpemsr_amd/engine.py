@@ -94,10 +94,15 @@ class Engine:
                 self.pc[name] = pack_vgg_first(w, b, dev)
             elif w.dim() == 4 and name.endswith((".q",)) and ".feat_extract." in name:
                 c = w.shape[0]
-                self.pc[name] = pack_conv(w, b, dev, scale=float(int(c) ** (-0.5)))   # fold C^-1/2 (blocks.py:76)
+                sc = float(int(c) ** (-0.5))
+                self.pc[name] = pack_conv(w, b, dev, scale=sc)                        # fold C^-1/2 (blocks.py:76)
+                if self.precision != "fp32" and c % 32 == 0:
+                    self.pc[name].w16 = pack_conv_split(self.pc[name], w.detach().to(torch.float32) * sc, dev)
             elif w.dim() == 4:
                 self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
-                if self.precision != "fp32" and w.shape[2] in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits):
+                kk = w.shape[2]
+                if self.precision != "fp32" and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
+                                                 or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
                     self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             elif w.dim() == 2 and name.endswith("indexer.embedding"):
                 self.pc[name] = pack_linear(w, b, dev)
@@ -152,11 +157,18 @@ class Engine:
         for f0 in range(0, n, fc):
             m = min(fc, n - f0)
             qa = q.images(f0, m).reshape_hw(gh, gw)
-            S = ops.conv2d([qa], ops.PackedConv(k.images(f0, m).buf, None, 1, T, (c,), 32), ACT_NONE,
-                           weight_image_stride=T * c, tag=p + ".qk")
+            kf, vf = k.images(f0, m), vT.images(f0, m)
+            # bf16x3 / bf16: the B operands (k, v^T) are activations, so they are split + re-ordered on the device
+            k16 = ops.split_pack_rows(kf) if self.precision != "fp32" else None
+            S = ops.conv2d([qa], ops.PackedConv(kf.buf, None, 1, T, (c,), 32, w16=k16), ACT_NONE,
+                           weight_image_stride=T * c, tag=p + ".qk", precision=self.precision)
+            del k16
             ops.softmax_rows_(S.buf, m * T, T)
-            ops.conv2d([S], ops.PackedConv(vT.images(f0, m).buf, wv.b, 1, c, (T,), 32), ACT_NONE,
-                       weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw), tag=p + ".pv")
+            v16 = ops.split_pack_rows(vf) if self.precision != "fp32" else None
+            ops.conv2d([S], ops.PackedConv(vf.buf, wv.b, 1, c, (T,), 32, w16=v16), ACT_NONE,
+                       weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw), tag=p + ".pv",
+                       precision=self.precision)
+            del v16
         return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
 
     def _vt(self, wv_packed: torch.Tensor, hn: Act, n: int, c: int, T: int) -> Act:

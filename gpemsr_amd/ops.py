@@ -212,12 +212,18 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
         d.pixmul = pixmul.ptr
     d.pixel_shuffle = int(pc.pixel_shuffle)
     d.out, d.out_ld = out.ptr, out.ld
-    use_split = (precision in ("bf16x3", "bf16") and pc.w16 is not None and k in (3, 7) and (stride == 1 or pc.transposed)
-                 and not (pc.transposed and pixmul is not None) and weight_image_stride == 0 and src_image_stride is None
-                 and all(s.c % 16 == 0 and s.ld % 4 == 0 and s.ptr % 16 == 0 for s in srcs))
+    gemm16 = (k == 1 and stride == 1 and not pc.transposed and not pc.pixel_shuffle)
+    use_split = (precision in ("bf16x3", "bf16") and pc.w16 is not None and (k in (3, 7) or gemm16) and (stride == 1 or pc.transposed)
+                 and not (pc.transposed and pixmul is not None) and (weight_image_stride == 0 or gemm16) and src_image_stride is None
+                 and all(s.c % (32 if gemm16 else 16) == 0 and s.ld % 4 == 0 and s.ptr % 16 == 0 for s in srcs))
     if use_split:
         nsplit = 2 if precision == "bf16x3" else 1
-        plane = pc.w16[0].numel()
+        if weight_image_stride != 0:                 # per-image B from split_pack_rows: [n][plane][k/16][half][rows][8]
+            assert pc.w16.dim() == 6 and pc.w16.shape[1] == 2
+            plane = pc.w16[0, 0].numel()
+            d.weight_image_stride = 2 * plane          # bf16 elements
+        else:
+            plane = pc.w16[0].numel()
         def _go_split():
             _abi.check(lib.gpemsr_conv2d_split(C.byref(d), pc.w16.data_ptr(), plane, nsplit, _stream()), "conv2d_split")
         if PROFILER is not None:
@@ -409,6 +415,17 @@ def cx_from_similarity(sim: torch.Tensor, band_width: float):
     _abi.check(lib.gpemsr_cx_reduce(cx.data_ptr(), sim.data_ptr(), n, rows, cols, float(band_width), ws.data_ptr(), ws.numel(),
                                     rmax.data_ptr(), cw.data_ptr(), cxn.data_ptr(), loss.data_ptr(), _stream()), "cx_reduce")
     return loss, cw, cxn
+
+
+def split_pack_rows(a: Act) -> torch.Tensor:
+    """Rows of a dense NHWC act ([n][h*w rows][c = K]) -> the split kernel's per-image B operand
+    [n][plane (hi, lo)][K/16][k-half][rows][8] bf16 (attention: k for q.k^T, v^T for P.v)."""
+    assert a.ld == a.c and a.off == 0 and a.c % 16 == 0
+    rows = a.h * a.w
+    out = torch.empty(a.n, 2, a.c // 16, 2, rows, 8, dtype=torch.bfloat16, device=a.buf.device)
+    _abi.check(_abi.load().gpemsr_split_pack_rows(a.ptr, a.n, rows, a.c, a.ld, rows * a.ld, out.data_ptr(), _stream()),
+               "split_pack_rows")
+    return out
 
 
 def gather_images(src: Act, idx: torch.Tensor) -> Act:

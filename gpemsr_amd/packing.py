@@ -93,7 +93,7 @@ def pack_conv_split(pc: PackedConv, w: torch.Tensor, device, pixel_shuffle: bool
     with hi = bf16(w) (round to nearest even) and lo = bf16(w - hi).  Same tap / row order as the fp32 packing of ``pc``
     (incl. the PixelShuffle row permutation); no channel padding (every source must have c % 16 == 0)."""
     cout, cin, kh, kw = w.shape
-    assert kh == kw and kh in (3, 7) and all(c % 16 == 0 for c in pc.splits)
+    assert kh == kw and kh in (1, 3, 7) and all(c % (32 if kh == 1 else 16) == 0 for c in pc.splits)
     wt = w.detach().to(torch.float32).cpu().permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
     if pixel_shuffle:
         cq = cout // 4

@@ -96,6 +96,12 @@ int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream);
  * (gpemsr_amd/packing.py::pack_conv_split / _stage_order),
  * plane_stride in elements.  Every source needs c % 16 == 0 and 16-byte aligned rows.  Activations stay fp32 in HBM. */
 int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight_bf16, int64_t plane_stride, int nsplit, void* stream);
+/* 1x1 / Linear / batched-matmul form of gpemsr_conv2d_split: d->ksize == 1, stride 1, every source c % 32 == 0.  With
+ * d->weight_image_stride != 0 (in bf16 elements) image i uses the weights at weight_bf16 + i*stride -- the attention
+ * products of model/blocks.py:75,80, whose B operand is an activation.  gpemsr_split_pack_rows turns such fp32 rows
+ * [n][rows][k] into that layout ([n][plane (hi, lo)][k/16][k-half][rows][8] bf16; per-image stride 2*rows*k, plane
+ * stride rows*k). */
+int gpemsr_split_pack_rows(const float* src, int n, int rows, int k, int ld, int64_t img_stride, void* dst_bf16, void* stream);
 
 /* Direct (VALU) convolution for tiny channel counts: cout <= 16, any k<=7, stride 1/2/4.
  * replaces: POD.flowdsconv* (model/GPEMSR.py:70-75,101-106), SpyNet's last 16->2 conv,

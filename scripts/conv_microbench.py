@@ -40,11 +40,13 @@ for name, n, cin, cout, k, stride, h, w, kind, use_res in SHAPES:
     elif kind == "bmm":
         wt = torch.randn(n, cout, cin, device=dev)
         pc = ops.PackedConv(wt, None, 1, cout, (cin,), 32)
+        if precision != "fp32":
+            pc.w16 = ops.split_pack_rows(ops.Act(wt, n, cout // 32, 32, cin, cin, 0))
         flops = 2.0 * n * h * w * cin * cout
     else:
         wfull = torch.randn(cout, cin, k, k) * 0.05
         pc = pack_conv(wfull, torch.randn(cout), dev, pixel_shuffle=(kind == "ps"))
-        if precision != "fp32" and k in (3, 7) and stride == 1 and cin % 16 == 0:
+        if precision != "fp32" and (k in (3, 7) and cin % 16 == 0 or k == 1 and cin % 32 == 0) and stride == 1:
             from gpemsr_amd.packing import pack_conv_split
             pc.w16 = pack_conv_split(pc, wfull, dev, pixel_shuffle=(kind == "ps"))
         flops = 2.0 * n * (h // stride) * (w // stride) * cin * cout * k * k

@@ -471,3 +471,60 @@ def test_conv_split_bf16x3(case):
     again = ops.conv2d(srcs, pc, act, precision="bf16x3", **kw)
     torch.cuda.synchronize()
     assert torch.equal(again.torch(), out3.torch())
+
+
+SPLIT_GEMM_CASES = [(2, (64,), 64, 16, 32, 1, True), (1, (512,), 512, 8, 32, 0, True), (3, (256,), 96, 12, 32, 2, False),
+                    (1, (64, 32), 200, 5, 37, 0, False), (2, (32,), 1024, 4, 32, 0, False)]
+
+
+@pytest.mark.parametrize("case", SPLIT_GEMM_CASES)
+def test_conv_split_1x1(case):
+    """1x1 convolution / Linear on the split-bf16 kernel (GEMM form: a stage = two 16-channel sub-chunks)."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_conv_split
+    n, cins, cout, h, w, act, use_res = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _rand(n, cin, h, w, seed=431)
+    wt, b = _rand(cout, cin, 1, 1, seed=432, scale=1.0 / np.sqrt(cin)), _rand(cout, seed=433, scale=0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double())
+    want = F.relu(want) if act == 1 else (F.leaky_relu(want, 0.1) if act == 2 else want)
+    res = _rand(*want.shape, seed=434) if use_res else None
+    if res is not None:
+        want = want + res
+    srcs, off = [], 0
+    for c in cins:
+        srcs.append(_to_act(x[:, off:off + c], dev)); off += c
+    pc = pack_conv(wt, b, dev, cins)
+    pc.w16 = pack_conv_split(pc, wt, dev)
+    out = ops.conv2d(srcs, pc, act, precision="bf16x3", residual=_to_act(res, dev) if use_res else None)
+    torch.cuda.synchronize()
+    _close(out.nchw(), want.float(), tol=3e-5, what=f"bf16x3 1x1 {case}")
+    out1 = ops.conv2d(srcs, pc, act, precision="bf16", residual=_to_act(res, dev) if use_res else None)
+    torch.cuda.synchronize()
+    _close(out1.nchw(), want.float(), tol=2e-2, what=f"bf16 1x1 {case}")
+
+
+def test_split_batched_matmul_with_device_split_operand():
+    """Attention-shaped products: per-image B = an activation, split + re-ordered by gpemsr_split_pack_rows."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    n, T, c = 3, 256, 64
+    q = _rand(n, T, c, seed=441).to(dev)
+    k = _rand(n, T, c, seed=442).to(dev)
+    qa = ops.Act(q.contiguous(), n, T // 32, 32, c, c, 0)
+    ka = ops.Act(k.contiguous(), n, T // 32, 32, c, c, 0)
+    k16 = ops.split_pack_rows(ka)
+    assert k16.shape == (n, 2, c // 16, 2, T, 8) and k16.dtype == torch.bfloat16
+    # the packed planes reproduce k: hi + lo == k to 2^-16
+    rec = (k16[:, 0].float() + k16[:, 1].float()).permute(0, 3, 1, 2, 4).reshape(n, T, c)
+    assert float((rec - k).abs().max()) <= 2.0 ** -15 * float(k.abs().max())
+    S = ops.conv2d([qa], ops.PackedConv(ka.buf, None, 1, T, (c,), 32, w16=k16), ops.ACT_NONE, weight_image_stride=T * c,
+                   precision="bf16x3")
+    torch.cuda.synchronize()
+    want = torch.bmm(q.double(), k.double().transpose(1, 2)).float()
+    got = S.buf.view(n, T, T)
+    assert float((got - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    Sf = ops.conv2d([qa], ops.PackedConv(ka.buf, None, 1, T, (c,), 32), ops.ACT_NONE, weight_image_stride=T * c)
+    torch.cuda.synchronize()
+    assert float((Sf.buf.view(n, T, T) - want).abs().max()) <= 1e-5 * float(want.abs().max())
