@@ -167,46 +167,53 @@ def main():
                                   "speedup_vs_independent_windows": round(T * (lr * s) ** 2 / 1e6 / dv / value, 3)}}
         del ov, fr
     if args.precision == "fp32" and not args.no_extras:
+        # The same step on the bf16 matrix pipe, reported beside the official number (never replaces it):
+        #   bf16x3 = split hi+lo operands, fp32-grade (meets the same 1e-3 bar, see tests); bf16 = plain bf16 operands
+        #   (BASELINE configs[2] names "bf16 MFMA"), bounded at 2e-2 by its test.
         out_ref = out[:B].clone()
         tr_ref = {}
         o2_ref, _ = model(x[:2], trace=tr_ref)                  # two windows, for the teacher-forced comparison
         idx_ref = torch.cat(tr_ref["code_idx"])
         del model
-        torch.cuda.empty_cache()
-        m3 = build_model(opt, load_prior_files=False, precision="bf16x3").eval().to(dev)
-        def step3():
-            o, _ = gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True)
-            return o
-        step3()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            o3 = step3()
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        d3 = time.perf_counter() - t3
-        if world > 1:
-            tt = torch.tensor([d3], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            d3 = float(tt.item())
-        rel = float((o3[:B] - out_ref).abs().max() / out_ref.abs().max())
-        tr3 = {}
-        o2_tf, _ = m3(x[:2], forced_code_idx=idx_ref)
-        m3(x[:2], trace=tr3)
-        rel_tf = float((o2_tf - o2_ref).abs().max() / o2_ref.abs().max())
-        agree = float((torch.cat(tr3["code_idx"]) == idx_ref).float().mean())
         extras = dict(extras or {})
-        extras["bf16x3"] = {"value": round(mp_per_step * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
-                             "dtype": "bf16x3: fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate "
-                                      "(3x3/7x7 convs); f32 elsewhere",
-                             "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
-                             "code_index_agreement_free_running_2_windows": agree,
-                             "rel_err_vs_fp32_path_free_running_all_windows": rel,
-                             "speedup_vs_fp32_path": round((dt / args.steps) / (d3 / args.steps), 3)}
-        model = m3
+        dtypes = {"bf16x3": "bf16x3: fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate "
+                            "(1x1/3x3/7x7 convs, transposed convs, attention products); f32 elsewhere and in HBM",
+                  "bf16": "bf16 operands (rounded in the kernel), v_mfma_f32_32x32x16_bf16, fp32 accumulate (same layers); f32 elsewhere and in HBM"}
+        for mode in ("bf16x3", "bf16"):
+            torch.cuda.empty_cache()
+            m3 = build_model(opt, load_prior_files=False, precision=mode).eval().to(dev)
+            def step3():
+                o, _ = gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True)
+                return o
+            step3()
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                o3 = step3()
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            d3 = time.perf_counter() - t3
+            if world > 1:
+                tt = torch.tensor([d3], dtype=torch.float64, device=dev)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                d3 = float(tt.item())
+            rel = float((o3[:B] - out_ref).abs().max() / out_ref.abs().max())
+            tr3 = {}
+            o2_tf, _ = m3(x[:2], forced_code_idx=idx_ref)
+            m3(x[:2], trace=tr3)
+            rel_tf = float((o2_tf - o2_ref).abs().max() / o2_ref.abs().max())
+            agree = float((torch.cat(tr3["code_idx"]) == idx_ref).float().mean())
+            extras[mode] = {"value": round(mp_per_step * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
+                            "dtype": dtypes[mode],
+                            "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
+                            "code_index_agreement_free_running_2_windows": agree,
+                            "rel_err_vs_fp32_path_free_running_all_windows": rel,
+                            "speedup_vs_fp32_path": round((dt / args.steps) / (d3 / args.steps), 3)}
+            model = m3
+            del o3
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
