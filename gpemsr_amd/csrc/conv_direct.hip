@@ -77,6 +77,71 @@ __global__ __launch_bounds__(256) void conv_direct_vec_kernel(DirectParams P) {
   }
 }
 
+// 64 -> 1 channels, 3x3, stride 1 (decoder.output_layer and conv_last at 1024^2: pure read traffic, 256 B in per 4 B out).
+// 16 lanes own the 64 channels of a pixel (one float4 each); a lane group walks RUN consecutive output columns of one
+// row and loads every input pixel ONCE per filter row -- each loaded float4 feeds the three outputs it overlaps -- so a
+// pixel is fetched 3 x (RUN+2)/RUN times instead of 9 (the vec kernel above), all of it 256-B coalesced rows.
+template <int RUN>
+__global__ __launch_bounds__(256) void conv_c64_cout1_kernel(DirectParams P) {
+  __shared__ __attribute__((aligned(16))) float wsm[9 * 64];
+  for (int i = threadIdx.x; i < 9 * 64; i += 256) wsm[i] = P.weight[(i / 64) * P.cin_pad + (i % 64)];    // cout == 1
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  float4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(wsm + t * 64 + 4 * sub);
+  const int runs_x = (P.w + RUN - 1) / RUN;
+  const long long nrun = (long long)P.n * P.h * runs_x;
+  const float bias = P.bias ? P.bias[0] : 0.f;
+  for (long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); r < ((nrun + 15) / 16) * 16; r += (long long)gridDim.x * 16) {
+    const bool live = r < nrun;                       // every lane runs every iteration (shuffles below)
+    const long long rr = live ? r : 0;
+    const int x0 = (int)(rr % runs_x) * RUN;
+    const int oy = (int)((rr / runs_x) % P.h);
+    const int img = (int)(rr / ((long long)runs_x * P.h));
+    float acc[RUN];
+#pragma unroll
+    for (int j = 0; j < RUN; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy - 1 + ky;
+      if (iy < 0 || iy >= P.h) continue;
+      const float* rowp = P.x + (((long long)img * P.h + iy) * P.w) * P.ld + 4 * sub;
+#pragma unroll
+      for (int c = 0; c < RUN + 2; ++c) {             // input column x0 - 1 + c feeds outputs c-2, c-1, c (taps kx = 2, 1, 0)
+        const int ix = x0 - 1 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ix >= 0 && ix < P.w) v = *reinterpret_cast<const float4*>(rowp + (long long)ix * P.ld);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int j = c - kx;
+          if (j >= 0 && j < RUN) {
+            const float4 w4 = wv[ky * 3 + kx];
+            acc[j] = fmaf(v.x, w4.x, acc[j]); acc[j] = fmaf(v.y, w4.y, acc[j]);
+            acc[j] = fmaf(v.z, w4.z, acc[j]); acc[j] = fmaf(v.w, w4.w, acc[j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RUN; ++j)
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) acc[j] += __shfl_xor(acc[j], m);
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < RUN; ++j) {
+        const int ox = x0 + j;
+        if ((j & 15) == sub && ox < P.w) {
+          const long long pix = ((long long)img * P.h + oy) * P.w + ox;
+          float v = apply_act(acc[j] + bias, P.act);
+          if (P.residual) v += P.residual[pix * P.res_ld];
+          P.out[pix * P.out_ld] = v;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void conv_direct_scalar_kernel(DirectParams P) {
   const long long total = P.npix * P.cout;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -168,6 +233,13 @@ extern "C" int gpemsr_conv2d_direct(const float* x, int n, int h, int w, int ld,
   P.npix = (long long)n * P.oh * P.ow;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (cin == 16 || cin == 64);
+  if (vec_ok && cin == 64 && cout == 1 && ksize == 3 && stride == 1 && w >= 8) {
+    constexpr int RUN = 8;
+    const long long nrun = (long long)n * h * ((w + RUN - 1) / RUN);
+    const long long blocks = (nrun + 15) / 16;
+    hipLaunchKernelGGL(conv_c64_cout1_kernel<RUN>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, P);
+    return check_launch("conv_c64_cout1_kernel");
+  }
   const size_t lds = (size_t)ksize * ksize * cout * P.cin_pad * sizeof(float);
   if (vec_ok && lds <= 60 * 1024) {
     const int lpp = cin / 4;

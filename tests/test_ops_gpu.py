@@ -168,7 +168,7 @@ def test_batched_weight_gemm():
 
 
 DIRECT_CASES = [(2, 64, 1, 3, 1, 32, 32), (1, 16, 2, 7, 1, 16, 24), (1, 2, 16, 3, 4, 64, 64), (2, 16, 16, 3, 2, 16, 16),
-                (1, 64, 1, 3, 1, 7, 9)]
+                (1, 64, 1, 3, 1, 7, 9), (3, 64, 1, 3, 1, 20, 37)]
 
 
 @pytest.mark.parametrize("case", DIRECT_CASES)
