@@ -458,6 +458,10 @@ class Engine:
         B, N, C, H, W = x.shape
         assert N == self.N and C == 1, "expected [B, nframes, 1, H, W]"
         self._check_lr(H, W)
+        if B == 0:                                         # empty batch: nothing to launch
+            sc = self.scale
+            return (torch.empty(0, 1, H * sc, W * sc, dtype=torch.float32, device=self.dev),
+                    torch.empty(0, N, C, H * sc, W * sc, dtype=torch.float32, device=self.dev))
         x = x.to(torch.float32).contiguous()
         xa = Act(x, B * N, H, W, 1, 1, 0)
         pyr, ref_img = self._front_all(xa, forced_idx, trace)

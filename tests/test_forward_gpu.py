@@ -287,3 +287,30 @@ def test_cli_volume_cache_writes_the_same_pngs(tmp_path):
         assert outs[mode][0].shape == (128, 128) and outs[mode][0].dtype == np.uint8
     for k in range(n):
         assert np.array_equal(outs["vol"][k], outs["win"][k]), k
+
+
+def test_edge_shapes_empty_minimal_and_large_tile():
+    """Edge cases at the module boundary: an empty batch, the smallest legal tile, a non-square tile, and one LR 256x256
+    window (HR 2048x2048: 4x the pixels of the benchmark tile; exercises 32-bit offset limits and chunking)."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    model = _model(8)
+    out, ref = model(torch.zeros(0, 5, 1, 16, 16, device="cuda"))
+    assert out.shape == (0, 1, 128, 128) and ref.shape == (0, 5, 1, 128, 128)
+    x = synth_lr_tiles(1, 5, 8, 8, seed=3, kind="uniform").cuda()                 # smallest x8 tile: latent 4x4 = 16 tokens
+    with pytest.raises(RuntimeError):                                              # non-local block needs tokens % 32 == 0
+        model(x)
+    x = synth_lr_tiles(1, 5, 16, 32, seed=4, kind="smooth").cuda()                # non-square
+    out, ref = model(x)
+    assert out.shape == (1, 1, 128, 256) and ref.shape == (1, 5, 1, 128, 256) and torch.isfinite(out).all()
+    xt = synth_lr_tiles(1, 5, 32, 16, seed=4, kind="smooth").cuda()
+    out_t, _ = model(xt)
+    assert out_t.shape == (1, 1, 256, 128) and torch.isfinite(out_t).all()
+    x = synth_lr_tiles(1, 5, 256, 256, seed=6, kind="smooth").cuda()
+    out, ref = model(x)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 1, 2048, 2048) and ref.shape == (1, 5, 1, 2048, 2048)
+    assert torch.isfinite(out).all() and torch.isfinite(ref).all()
+    # the centre 1024^2 crop region must agree with... nothing to compare against at this size on the GPU box within
+    # seconds, so check a size-independent property instead: the output is the bilinear base plus a bounded residual
+    base = torch.nn.functional.interpolate(x[:, 2], scale_factor=8, mode="bilinear", align_corners=False)
+    assert float((out - base).abs().max()) < 10.0
