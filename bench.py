@@ -165,7 +165,7 @@ def main():
                                   "workload": f"{T} consecutive {lr}x{lr} LR slices -> {T} HR slices of {lr * s}^2 (sliding 5-slice windows, "
                                               "per-slice features cached; output_GPEMSR.py's loop)", "precision": args.precision,
                                   "speedup_vs_independent_windows": round(T * (lr * s) ** 2 / 1e6 / dv / value, 3)}}
-        del ov, fr
+        del ov
     if args.precision == "fp32" and not args.no_extras:
         # The same step on the bf16 matrix pipe, reported beside the official number (never replaces it):
         #   bf16x3 = split hi+lo operands, fp32-grade (meets the same 1e-3 bar, see tests); bf16 = plain bf16 operands
@@ -206,7 +206,17 @@ def main():
             m3(x[:2], trace=tr3)
             rel_tf = float((o2_tf - o2_ref).abs().max() / o2_ref.abs().max())
             agree = float((torch.cat(tr3["code_idx"]) == idx_ref).float().mean())
+            vol = None
+            if world == 1:
+                m3.forward_volume(fr, win)
+                torch.cuda.synchronize()
+                tv = time.perf_counter()
+                for _ in range(args.steps):
+                    m3.forward_volume(fr, win)
+                torch.cuda.synchronize()
+                vol = round(T * (lr * s) ** 2 / 1e6 / ((time.perf_counter() - tv) / args.steps), 3)
             extras[mode] = {"value": round(mp_per_step * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
+                            "volume_mode_value": vol,
                             "dtype": dtypes[mode],
                             "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
                             "code_index_agreement_free_running_2_windows": agree,
