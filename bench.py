@@ -245,7 +245,7 @@ def main():
                                   f"({cdt:.1f} s) of oracle/gpemsr_oracle.py (torch CPU fp32; SpyNet de-duplicated, VGG slice1 only)"}
         if args.cpu_lr == lr:
             err = float((out[:1].cpu() - o_cpu).abs().max() / o_cpu.abs().max())
-            cpu_baseline["gpu_vs_cpu_rel_err_free_running"] = round(err, 6)
+            cpu_baseline["gpu_vs_cpu_rel_err_free_running"] = float(f"{err:.3e}")
 
     if rank == 0:
         line = {
