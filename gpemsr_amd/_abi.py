@@ -79,7 +79,7 @@ def load():
     lib.gpemsr_bilinear.argtypes = [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, i32, p]
     lib.gpemsr_avgpool2.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
     lib.gpemsr_pool3s2_maxavg.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
-    lib.gpemsr_spynet_prep.argtypes = [p, p, p, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), p, p, p]
+    lib.gpemsr_spynet_prep.argtypes = [p, p, p, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), p, p, i32, p]
     lib.gpemsr_dcn_columns.argtypes = [p, i32, i32, i32, i32, i32, p, i32, i32, p, p]
     lib.gpemsr_patch_cosine.argtypes = [p, p, i32, i32, i32, i32, p, p]
     lib.gpemsr_temporal_gate.argtypes = [p, p, p, i32, i32, i32, i32, p, p]

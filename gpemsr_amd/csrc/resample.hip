@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void pool3s2_kernel(const float* x, int n, int
 // One SpyNet pyramid level: see gpemsr_hip.h
 __global__ __launch_bounds__(256) void spynet_prep_kernel(const float* ref, const float* supp, const float* fc, int n, int h, int w,
                                                           float m0, float m1, float m2, float s0, float s1, float s2,
-                                                          float* up, float* inp) {
+                                                          float* up, float* inp, int inp_ld) {
   const long long total = (long long)n * h * w;
   const int ch2 = h / 2, cw2 = w / 2;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -136,9 +136,13 @@ __global__ __launch_bounds__(256) void spynet_prep_kernel(const float* ref, cons
     if (y1 <= h - 1) wv += ly * (1.f - lx) * sp[(long long)y1 * w + x0];
     if (x1 <= w - 1 && y1 <= h - 1) wv += ly * lx * sp[(long long)y1 * w + x1];
     const float rv = ref[e];
-    float* o = inp + e * 8;
+    float* o = inp + e * inp_ld;
     *reinterpret_cast<float4*>(o) = make_float4((rv - m0) / s0, (rv - m1) / s1, (rv - m2) / s2, (wv - m0) / s0);
     *reinterpret_cast<float4*>(o + 4) = make_float4((wv - m1) / s1, (wv - m2) / s2, fx, fy);
+    if (inp_ld == 16) {            // zero channels 8..15: the 16-channel form feeds the split-bf16 7x7 kernel (cin % 16 == 0)
+      *reinterpret_cast<float4*>(o + 8) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(o + 12) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -230,13 +234,13 @@ extern "C" int gpemsr_pool3s2_maxavg(const float* x, int n, int h, int w, int c,
 }
 
 extern "C" int gpemsr_spynet_prep(const float* ref, const float* supp, const float* flow_coarse, int n, int h, int w,
-                                  const float* mean3, const float* std3, float* up_flow, float* inp8, void* stream) {
+                                  const float* mean3, const float* std3, float* up_flow, float* inp8, int inp_ld, void* stream) {
   GP_REQUIRE(ref && supp && up_flow && inp8 && mean3 && std3, "spynet_prep: null pointer");
   GP_REQUIRE(h >= 2 && w >= 2, "spynet_prep: level smaller than 2x2 (got %d x %d); basicsr SpyNet needs inputs >= 64 px", h, w);
-  GP_REQUIRE((reinterpret_cast<uintptr_t>(inp8) & 15) == 0, "spynet_prep: inp8 alignment");
+  GP_REQUIRE((reinterpret_cast<uintptr_t>(inp8) & 15) == 0 && (inp_ld == 8 || inp_ld == 16), "spynet_prep: inp8 alignment / inp_ld must be 8 or 16");
   // mean3/std3 are HOST pointers (3 floats each): constants of the basicsr SpyNet buffers
   hipLaunchKernelGGL(spynet_prep_kernel, dim3(grid_for((long long)n * h * w)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     ref, supp, flow_coarse, n, h, w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], up_flow, inp8);
+                     ref, supp, flow_coarse, n, h, w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], up_flow, inp8, inp_ld);
   return check_launch("spynet_prep");
 }
 

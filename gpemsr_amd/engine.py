@@ -71,8 +71,10 @@ class Engine:
             "reffusionconv1": (nf, 64), "reffusionconv2": (nf, 128, nf), "down_fea_conv2": (nf, nf),
             "reffusionconv3": (nf, 256, 2 * nf), "down_fea_conv3": (nf, 2 * nf), "reffusionconv4": (nf, 512, 3 * nf),
             "reduce_dim_conv": (nf, 3 * nf, nf) if self.scale == 16 else (nf, 2 * nf, nf),
-            "align_module.L3_offset_conv1": (nf, nf, 32, 2), "align_module.L2_offset_conv1": (nf, nf, 32, 2),
-            "align_module.L1_offset_conv1": (nf, nf, 32, 2), "align_module.L2_offset_conv2": (nf, nf),
+            # [nbr_fea, ref_fea, flow1|flow2|nbr_frame|ref_frame]: the 16+16 flow features and the 2 frames share ONE
+            # 48-channel buffer (14 zero channels, zero weight columns), so every source is a multiple of 16 channels
+            "align_module.L3_offset_conv1": (nf, nf, 48), "align_module.L2_offset_conv1": (nf, nf, 48),
+            "align_module.L1_offset_conv1": (nf, nf, 48), "align_module.L2_offset_conv2": (nf, nf),
             "align_module.L1_offset_conv2": (nf, nf), "align_module.L2_fea_conv": (nf, nf),
             "align_module.L1_fea_conv": (nf, nf), "align_module.cas_offset_conv1": (nf, nf),
         }
@@ -99,6 +101,11 @@ class Engine:
                 if self.precision != "fp32" and c % 32 == 0:
                     self.pc[name].w16 = pack_conv_split(self.pc[name], w.detach().to(torch.float32) * sc, dev)
             elif w.dim() == 4:
+                if name.endswith("_offset_conv1") and w.shape[1] == 2 * nf + 34:
+                    w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 14))       # 162 -> 176 input channels
+                if self.precision != "fp32" and w.shape[1] == 8 and w.shape[2] == 7 and ".spynet." in name:
+                    # SpyNet stems (8 -> 32, 7x7): zero-pad cin to 16 so they run on the split-bf16 kernel too
+                    w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 8))
                 self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
                 kk = w.shape[2]
                 if self.precision != "fp32" and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
@@ -292,7 +299,7 @@ class Engine:
         flow = None
         p = "align_module.spynet.basic_module"
         for lvl in range(6):
-            up, inp = ops.spynet_prep(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std)
+            up, inp = ops.spynet_prep(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std, pad16=self.precision != "fp32")
             t = self.conv(inp, f"{p}.{lvl}.basic_module.0", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.2", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.4", ACT_RELU)
@@ -317,25 +324,27 @@ class Engine:
         flow = self.spynet(ops.bilinear(nbr_frame, 4 * H, 4 * W), ops.bilinear(ref_frame, 4 * H, 4 * W))
         if trace is not None:
             trace.setdefault("flow", []).append(flow.nchw())
-        fl1 = ops.new_act(P, H, W, 32, device=self.dev)
+        def flow_frames(h, w):      # [flow1 16 | flow2 16 | nbr_frame | ref_frame | 14 zeros]
+            return Act(torch.zeros(P * h * w * 48, dtype=torch.float32, device=self.dev), P, h, w, 48, 48, 0)
+        fl1 = flow_frames(H, W)
         self.conv(flow, p + ".flowdsconv0_1", stride=4, out=fl1.slice(0, 16))
         self.conv(flow, p + ".flowdsconv0_2", stride=4, out=fl1.slice(16, 16))
-        fl2 = ops.new_act(P, H // 2, W // 2, 32, device=self.dev)
+        fl2 = flow_frames(H // 2, W // 2)
         self.conv(fl1.slice(0, 16), p + ".flowdsconv1_1", stride=2, out=fl2.slice(0, 16))
         self.conv(fl1.slice(16, 16), p + ".flowdsconv1_2", stride=2, out=fl2.slice(16, 16))
-        fl3 = ops.new_act(P, H // 4, W // 4, 32, device=self.dev)
+        fl3 = flow_frames(H // 4, W // 4)
         self.conv(fl2.slice(0, 16), p + ".flowdsconv2_1", stride=2, out=fl3.slice(0, 16))
         self.conv(fl2.slice(16, 16), p + ".flowdsconv2_2", stride=2, out=fl3.slice(16, 16))
-        fr1 = ops.new_act(P, H, W, 2, device=self.dev)
+        fr1 = fl1.slice(32, 2)
         ops.copy_channels(nbr_frame, fr1.slice(0, 1)); ops.copy_channels(ref_frame, fr1.slice(1, 1))
-        fr2 = ops.bilinear(fr1, H // 2, W // 2)
-        fr3 = ops.bilinear(fr2, H // 4, W // 4)
+        ops.bilinear(fr1, H // 2, W // 2, out=fl2.slice(32, 2))
+        ops.bilinear(fl2.slice(32, 2), H // 4, W // 4, out=fl3.slice(32, 2))
 
-        o3 = self.conv([nbr[2], ref[2], fl3, fr3], p + ".L3_offset_conv1", ACT_LRELU)
+        o3 = self.conv([nbr[2], ref[2], fl3], p + ".L3_offset_conv1", ACT_LRELU)
         o3 = self.conv(o3, p + ".L3_offset_conv2", ACT_LRELU)
         f3 = self.dcn(nbr[2], o3, p + ".L3_dcnpack", ACT_LRELU)
 
-        o2 = self.conv([nbr[1], ref[1], fl2, fr2], p + ".L2_offset_conv1", ACT_LRELU)
+        o2 = self.conv([nbr[1], ref[1], fl2], p + ".L2_offset_conv1", ACT_LRELU)
         o3u = ops.bilinear(o3, o3.h * 2, o3.w * 2, mul=2.0)
         o2 = self.conv([o2, o3u], p + ".L2_offset_conv2", ACT_LRELU)
         o2 = self.conv(o2, p + ".L2_offset_conv3", ACT_LRELU)
@@ -343,7 +352,7 @@ class Engine:
         f3u = ops.bilinear(f3, f3.h * 2, f3.w * 2)
         f2 = self.conv([f2, f3u], p + ".L2_fea_conv", ACT_LRELU)
 
-        o1 = self.conv([nbr[0], ref[0], fl1, fr1], p + ".L1_offset_conv1", ACT_LRELU)
+        o1 = self.conv([nbr[0], ref[0], fl1], p + ".L1_offset_conv1", ACT_LRELU)
         o2u = ops.bilinear(o2, o2.h * 2, o2.w * 2, mul=2.0)
         o1 = self.conv([o1, o2u], p + ".L1_offset_conv2", ACT_LRELU)
         o1 = self.conv(o1, p + ".L1_offset_conv3", ACT_LRELU)

@@ -298,16 +298,16 @@ def pool3s2_maxavg(x: Act) -> Act:
     return out
 
 
-def spynet_prep(ref: Act, supp: Act, flow_coarse: Optional[Act], mean3, std3):
+def spynet_prep(ref: Act, supp: Act, flow_coarse: Optional[Act], mean3, std3, pad16: bool = False):
     assert ref.c == 1 and ref.ld == 1 and supp.c == 1 and supp.ld == 1
     up = new_act(ref.n, ref.h, ref.w, 2, device=ref.buf.device)
-    inp = new_act(ref.n, ref.h, ref.w, 8, device=ref.buf.device)
+    inp = new_act(ref.n, ref.h, ref.w, 16 if pad16 else 8, device=ref.buf.device)   # pad16: channels 8..15 are zeros
     m = (C.c_float * 3)(*[float(v) for v in mean3])
     s = (C.c_float * 3)(*[float(v) for v in std3])
     if flow_coarse is not None:
         assert flow_coarse.ld == 2 and flow_coarse.h == ref.h // 2 and flow_coarse.w == ref.w // 2
     _abi.check(_abi.load().gpemsr_spynet_prep(ref.ptr, supp.ptr, flow_coarse.ptr if flow_coarse is not None else None,
-                                              ref.n, ref.h, ref.w, m, s, up.ptr, inp.ptr, _stream()), "spynet_prep")
+                                              ref.n, ref.h, ref.w, m, s, up.ptr, inp.ptr, inp.ld, _stream()), "spynet_prep")
     return up, inp
 
 

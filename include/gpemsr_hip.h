@@ -151,7 +151,7 @@ int gpemsr_pool3s2_maxavg(const float* x, int n, int h, int w, int c, int ld, fl
  * ref/supp are the 1-channel raw pyramids; mean3/std3 are HOST pointers to the three
  * ImageNet mean/std constants that basicsr broadcasts over the (1-channel) input. */
 int gpemsr_spynet_prep(const float* ref, const float* supp, const float* flow_coarse, int n, int h, int w,
-                       const float* mean3, const float* std3, float* up_flow, float* inp8, void* stream);
+                       const float* mean3, const float* std3, float* up_flow, float* inp8, int inp_ld, void* stream);
 /* Modulated deformable sampling (torchvision deform_conv2d, k3 p1): builds the column tensor
  * col[n][h][w][9*c] (tap-major) from x and the raw conv_offset output `om` ([.., 3*groups*9]:
  * chunk 0,1 -> offsets (basicsr DCNv2Pack cat(o1,o2)), chunk 2 -> mask logits). */
