@@ -106,7 +106,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA>
-__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvParams P) {
+__global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_kernel(ConvParams P) {
   constexpr int NPIX = TH * TILE_W;   // output pixels per workgroup (TH x 32)
   constexpr int PM = NPIX / WM;       // pixels per wave
   constexpr int MT = PM / 32;
@@ -391,6 +391,40 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvParams P) {
         }
       }
     };
+    if (MASKED && CK == 8) {
+      // transposed form: the stage is always the 4 taps (dy,dx) of the 2x2 stencil, so the tap loop is unrolled with
+      // COMPILE-TIME phase masks -- no branches between the MFMAs, fragments of masked N tiles are never read
+      float4 ta[2][MT], tb[2][NT];
+      auto tload = [&](int set, int t) {
+        const unsigned mk = (t == 0) ? 0xFu : (t == 1) ? 0xAu : (t == 2) ? 0xCu : 0x8u;
+        const int aoff = ((t >> 1) * P.halo_w + (t & 1)) * APIX;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ta[set][mt] = *reinterpret_cast<const float4*>(A + a_frag[mt] + aoff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if ((mk >> nt) & 1u) tb[set][nt] = *reinterpret_cast<const float4*>(B + (t * BN + nt * 32) * BPIX);
+      };
+      auto tmma = [&](int set, int t) {
+        const unsigned mk = (t == 0) ? 0xFu : (t == 1) ? 0xAu : (t == 2) ? 0xCu : 0x8u;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (!((mk >> nt) & 1u)) continue;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[set][mt].x, tb[set][nt].x, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[set][mt].y, tb[set][nt].y, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[set][mt].z, tb[set][nt].z, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[set][mt].w, tb[set][nt].w, acc[mt][nt], 0, 0, 0);
+          }
+        }
+      };
+      tload(0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t + 1 < 4) tload((t + 1) & 1, t + 1);
+        tmma(t & 1, t);
+      }
+    } else {
     unsigned m0 = 0xF, m1 = 0xF;
     load_step(fa0, fb0, m0);
     int st = 0;
@@ -401,6 +435,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvParams P) {
       mma_step(fa1, fb1, m1);
     }
     if (st < nsteps) mma_step(fa0, fb0, m0);
+    }
     if (DMA) {
       // everything issued BEFORE this stage has landed (this wave's part); the barrier makes all waves' parts visible
       // and guarantees every wave is done reading the buffers the next stage's DMA will overwrite.
@@ -578,7 +613,8 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
     else { P.tpg_h = 1; P.tpg_w = d->ksize; P.ngroups = d->ksize; }   // one filter row per stage (small LDS images -> more blocks per CU)
   }
   // 8x32-pixel blocks (every wave owns 64 pixels x all couts) for stride-1 k>=3 convs with cout <= 64; 4x32 otherwise
-  const int TH = (!tr && d->ksize == 3 && BN <= 64 && P.stride == 1) ? 8 : 4;   // (7x7: the LDS images would allow 1 block/CU)
+  // transposed: 8x32 input pixels (two A tiles per wave reuse every weight fragment; 72 MFMAs per stage and barrier)
+  const int TH = (tr || (d->ksize == 3 && BN <= 64 && P.stride == 1)) ? 8 : 4;   // (7x7: the LDS images would allow 1 block/CU)
   P.halo_h = (TH - 1) * P.stride + P.kh; P.halo_w = (TILE_W - 1) * P.stride + P.kw;
   P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
@@ -610,7 +646,7 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define GP_LAUNCH(CKv, BNv, WMv, WNv, THv, MK) \
   (dma ? launch<CKv, BNv, WMv, WNv, THv, MK, true>(P, lds, st) : launch<CKv, BNv, WMv, WNv, THv, MK, false>(P, lds, st))
-  if (tr) return GP_LAUNCH(8, 128, 4, 1, 4, true);
+  if (tr) return GP_LAUNCH(8, 128, 4, 1, 8, true);
   if (CK == 8) {
     if (BN == 32) return TH == 8 ? GP_LAUNCH(8, 32, 4, 1, 8, false) : GP_LAUNCH(8, 32, 4, 1, 4, false);
     if (BN == 64) return TH == 8 ? GP_LAUNCH(8, 64, 4, 1, 8, false) : GP_LAUNCH(8, 64, 2, 2, 4, false);
