@@ -41,6 +41,12 @@ namespace gpemsr {
 
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef GP_STAMP
+__device__ unsigned long long g_stamps[8 * 65536];
+#define GP_ST(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_stamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GP_ST(i)
+#endif
 
 constexpr int TILE_W = 32;                // a 32-pixel MFMA tile is one contiguous tile row: conflict-free A fragment reads
 constexpr int A_LOADS = 5;   // float4 per thread per A stage (17*33 halo px * 2 / 256 -> 5)
@@ -73,6 +79,7 @@ struct ConvParams {
   int na, nb;                     // DMA slots (float4 per thread) per A / B stage
   int ring;                       // DMA: weight images in a 3-deep ring, counted vmcnt (needs ngroups >= 2 or not; see kernel)
   int nblocks;
+  int epi_fast;                   // lean epilogue: float4 rows, cout % 4 == 0, 32-bit byte offsets, 16-B aligned bias
 };
 
 // One LDS-DMA piece: lane l's 16 bytes at (base + voff) land at LDS byte (lds_addr + 16*l); base and lds_addr are
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
   float* const As0 = smem;
   float* const Bs0 = smem + 2 * P.a_buf_floats;
 
+  GP_ST(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
     __syncthreads();
   }
 
+  GP_ST(1);
   int chunk = 0, grp = 0;
   for (int stage = 0; stage < nstages; ++stage) {
     int nchunk = chunk, ngrp = grp + 1;
@@ -449,6 +458,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
     chunk = nchunk; grp = ngrp;
   }
 
+  GP_ST(2);
   // ---- epilogue: accumulators -> LDS [pixel][EW+4] (64 output columns per pass) -> coalesced rows ----
   constexpr int EW = BN < 64 ? BN : 64;
   constexpr int EPIX = EW + 4;
@@ -465,6 +475,83 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
   const float* res_img = P.residual ? P.residual + img_pix0 * P.res_ld : nullptr;
   const float* mul_img = P.pixmul ? P.pixmul + img_pix0 : nullptr;
   float* out_img = P.out + img_pix0 * P.out_ld;
+  // The f32 MFMA executes on the vector ALUs, so every VALU instruction of this epilogue (and of the prologue) is paid in
+  // matrix-pipe time of the co-resident workgroups: in-kernel s_memtime stamps showed the general epilogue below taking
+  // 13 % (64->64 convs) to 59 % (transposed convs) of a workgroup's lifetime.  The fast path is the same data flow with
+  // the per-element work stripped to the bone: whole float4 columns only (cout % 4 == 0), 32-bit byte offsets from
+  // wave-uniform bases, one activation form per launch, no code for absent residual / multiplier operands.
+  if (P.epi_fast) {
+    const unsigned out_ldb = (unsigned)P.out_ld * 4u, res_ldb = (unsigned)P.res_ld * 4u;
+    const char* res_b = reinterpret_cast<const char*>(res_img);
+    char* out_b = reinterpret_cast<char*>(out_img);
+    const bool has_res = P.residual != nullptr, has_mul = P.pixmul != nullptr;
+    const int act = P.act;
+#pragma unroll 1
+    for (int pass = 0; pass < NCP * NPP; ++pass) {
+      const int cpass = pass % NCP, ppass = pass / NCP;
+      const int nidx = n0 + cpass * EW + 4 * ej;
+      int ch = nidx, bidx = nidx, sy = 0, sx = 0;
+      if (P.store_mode == STORE_PIXSHUF) {
+        const int q = nidx / P.cq; ch = nidx - q * P.cq; sy = q >> 1; sx = q & 1;
+      } else if (P.store_mode == STORE_CONVT) {
+        const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); bidx = ch; sy = q >> 1; sx = q & 1;
+      }
+      const bool colok = nidx < P.cout;
+      const bool up = P.store_mode != STORE_PLAIN;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias && colok) b4 = *reinterpret_cast<const float4*>(P.bias + bidx);
+      const unsigned chb = (unsigned)ch * 4u;
+      unsigned opx[ITER];                       // pixel index inside the image, ~0u = nothing to store
+      float4 rres[ITER];
+      float rmul[ITER];
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int p = ppass * 128 + ep0 + it * PSTEP;
+        const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+        const bool ok = colok && oy < P.oh && ox < P.ow;
+        const int Y = up ? 2 * oy + sy : oy, X = up ? 2 * ox + sx : ox;
+        opx[it] = ok ? (unsigned)(Y * P.OW + X) : 0xFFFFFFFFu;
+        if (has_res && ok) rres[it] = *reinterpret_cast<const float4*>(res_b + opx[it] * res_ldb + chb);
+        if (has_mul && ok) rmul[it] = mul_img[opx[it]];
+      }
+      if (pass > 0) __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col0 = wn * WNT + nt * 32;
+        if (col0 / EW != cpass) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int prow0 = wm * PM + mt * 32;
+          if (prow0 / 128 != ppass) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            E[(prow0 - ppass * 128 + row) * EPIX + (col0 - cpass * EW) + li] = acc[mt][nt][r];
+          }
+        }
+      }
+      __syncthreads();
+      const float* erow = E + ep0 * EPIX + 4 * ej;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        if (opx[it] == 0xFFFFFFFFu) continue;
+        float4 v = *reinterpret_cast<const float4*>(erow + it * PSTEP * EPIX);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (act == GPEMSR_ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (act == GPEMSR_ACT_LRELU) {          // max(v, 0.1 v) == (v > 0 ? v : 0.1 v)
+          v.x = fmaxf(v.x, 0.1f * v.x); v.y = fmaxf(v.y, 0.1f * v.y); v.z = fmaxf(v.z, 0.1f * v.z); v.w = fmaxf(v.w, 0.1f * v.w);
+        } else if (act != GPEMSR_ACT_NONE) {
+          v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+        }
+        if (has_res) { v.x += rres[it].x; v.y += rres[it].y; v.z += rres[it].z; v.w += rres[it].w; }
+        if (has_mul) { v.x *= rmul[it]; v.y *= rmul[it]; v.z *= rmul[it]; v.w *= rmul[it]; }
+        *reinterpret_cast<float4*>(out_b + opx[it] * out_ldb + chb) = v;
+      }
+    }
+    GP_ST(3);
+    return;
+  }
 #pragma unroll 1
   for (int pass = 0; pass < NCP * NPP; ++pass) {
     const int cpass = pass % NCP, ppass = pass / NCP;
@@ -507,6 +594,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
 #pragma unroll
       for (int k = 0; k < 4; ++k) if (k < nvalid) bv[k] = P.bias[bidx + k];
     }
+    if (pass == 0) GP_ST(4);
     // ---- (2) this pass's accumulator columns / pixel rows -> LDS ----
     if (pass > 0) __syncthreads();                       // previous pass fully read out
 #pragma unroll
@@ -525,6 +613,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
       }
     }
     __syncthreads();
+    if (pass == 0) GP_ST(5);
     // ---- (3) coalesced rows: bias, activation, residual, multiplier, store ----
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -543,7 +632,9 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
         for (int k = 0; k < 4; ++k) if (k < nvalid) op[k] = v[k];
       }
     }
+    if (pass == 0) GP_ST(6);
   }
+  GP_ST(3);
 }
 
 template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA>
@@ -620,6 +711,9 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d: grid too large");
   P.nblocks = (int)nb;
+  P.epi_fast = P.out_vec && (P.cout % 4 == 0) && (!d->residual || P.res_vec) && (!d->bias || (reinterpret_cast<uintptr_t>(d->bias) & 15) == 0) &&
+               ((long long)P.OH * P.OW * d->out_ld * 4 < (1ll << 32)) && (!d->residual || (long long)P.OH * P.OW * d->res_ld * 4 < (1ll << 32)) &&
+               (P.store_mode != STORE_PIXSHUF || P.cq % 4 == 0);
   GP_REQUIRE(P.halo_h * P.halo_w * (CK / 4) <= A_LOADS * 256, "conv2d: halo too large");
   // DMA staging needs: every source 16-B aligned rows with c % CK == 0 (no partial chunks), 32-bit byte offsets
   bool dma = true;
@@ -657,6 +751,12 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   return GP_LAUNCH(32, 128, 2, 2, 4, false);
 #undef GP_LAUNCH
 }
+
+#ifdef GP_STAMP
+extern "C" int gpemsr_debug_read_stamps(unsigned long long* host, int nblocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gpemsr::g_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks);
+}
+#endif
 
 // The Python binding (gpemsr_amd/_abi.py) mirrors this struct field by field.
 static_assert(sizeof(gpemsr_conv_desc) == 208, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");
