@@ -25,6 +25,12 @@ SYMBOLS = [
     "gpemsr_threeda_combine", "gpemsr_tensor2img_u8", "gpemsr_copy_channels", "gpemsr_copy_images",
     "gpemsr_gather_images", "gpemsr_maxpool2", "gpemsr_normalize3", "gpemsr_cx_channel_mean", "gpemsr_cx_center_normalize",
     "gpemsr_cx_rows", "gpemsr_cx_reduce",
+    # stage-3 training step: backward + optimizer
+    "gpemsr_conv2d_wgrad_workspace", "gpemsr_conv2d_wgrad", "gpemsr_act_bwd", "gpemsr_bias_grad", "gpemsr_axpy", "gpemsr_mul_pix",
+    "gpemsr_mul_pix_bwd", "gpemsr_bilinear_bwd", "gpemsr_dcn_columns_bwd", "gpemsr_temporal_gate_bwd", "gpemsr_frame_mix_lrelu_bwd",
+    "gpemsr_pool3s2_maxavg_bwd", "gpemsr_threeda_combine_bwd", "gpemsr_maxpool2_bwd", "gpemsr_scatter_add_images", "gpemsr_l1_loss",
+    "gpemsr_cx_backward", "gpemsr_cx_center_normalize_bwd", "gpemsr_gray_normalize3", "gpemsr_gray_normalize3_bwd",
+    "gpemsr_transpose_images", "gpemsr_adam_step",
 ]
 
 
@@ -97,6 +103,29 @@ def load():
     lib.gpemsr_cx_center_normalize.argtypes = [p, p, i64, i32, i32, p, i32, p]
     lib.gpemsr_cx_rows.argtypes = [p, i64, i32, C.c_float, p, p]
     lib.gpemsr_cx_reduce.argtypes = [p, p, i32, i32, i32, C.c_float, p, i64, p, p, p, p, p]
+    lib.gpemsr_conv2d_wgrad_workspace.argtypes = [i32, i32, i32, i32, i32, i32]
+    lib.gpemsr_conv2d_wgrad_workspace.restype = C.c_int64
+    lib.gpemsr_conv2d_wgrad.argtypes = [p, i32, i32, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, p, i64, p, i32, i32, p]
+    lib.gpemsr_act_bwd.argtypes = [p, i32, p, i32, i32, i32, i32, i32, i32, i32, p, i32, p]
+    lib.gpemsr_bias_grad.argtypes = [p, i64, i32, i32, p, i64, p, p]
+    lib.gpemsr_axpy.argtypes = [p, i32, p, i32, i64, i32, f32, p]
+    lib.gpemsr_mul_pix.argtypes = [p, i32, p, i64, i32, p, i32, p]
+    lib.gpemsr_mul_pix_bwd.argtypes = [p, i32, p, i32, p, i64, i32, p, i32, p, p]
+    lib.gpemsr_bilinear_bwd.argtypes = [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, i32, p]
+    lib.gpemsr_dcn_columns_bwd.argtypes = [p, i32, i32, i32, i32, i32, p, i32, i32, p, p, i32, p, i32, p]
+    lib.gpemsr_temporal_gate_bwd.argtypes = [p, p, p, p, i32, i32, i32, i32, p, p, p, p]
+    lib.gpemsr_frame_mix_lrelu_bwd.argtypes = [p, p, p, i64, i32, i32, p, p, p, p, p, i64, p]
+    lib.gpemsr_pool3s2_maxavg_bwd.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p, i32, p]
+    lib.gpemsr_threeda_combine_bwd.argtypes = [p, p, p, i64, p, p, p, p, p, p]
+    lib.gpemsr_maxpool2_bwd.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p, i32, p]
+    lib.gpemsr_scatter_add_images.argtypes = [p, p, p, i32, i32, i64, p]
+    lib.gpemsr_l1_loss.argtypes = [p, p, i64, f32, p, p, i64, p, p]
+    lib.gpemsr_cx_backward.argtypes = [p, p, p, p, p, i32, i32, i32, f32, f32, p, p, p, p]
+    lib.gpemsr_cx_center_normalize_bwd.argtypes = [p, p, p, i64, i32, i32, i32, p, i32, p]
+    lib.gpemsr_gray_normalize3.argtypes = [p, i64, f3, f3, p, p]
+    lib.gpemsr_gray_normalize3_bwd.argtypes = [p, i64, f3, p, p]
+    lib.gpemsr_transpose_images.argtypes = [p, p, i32, i32, i32, p]
+    lib.gpemsr_adam_step.argtypes = [p, p, p, p, i64, f32, f32, f32, f32, f32, i32, p]
     lib.gpemsr_device_info.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     _lib = lib
     return lib

@@ -1,0 +1,617 @@
+// Stage-3 training step, backward side (train_stage3.py:343-366 -> loss_total.backward(); optimizer_G.step()):
+// the elementwise / gather / reduction gradients of every op on the trainable part of the path.  The matrix work of
+// the backward reuses the forward machinery: data gradients of convolutions are convolutions (gpemsr_conv2d with
+// re-packed weights), weight gradients are in wgrad.hip.
+//
+// Convention: a gradient output marked "+=" is ACCUMULATED into a zero-initialised buffer (a tensor with several
+// consumers receives one contribution per consumer).  Everything here is deterministic (fixed summation order)
+// except gpemsr_dcn_columns_bwd's scatter into dx, which uses float atomics.
+#include "common.h"
+
+namespace gpemsr {
+
+inline unsigned bgrid(long long total) {
+  const long long b = (total + 255) / 256;
+  return (unsigned)(b < 32768 ? (b < 1 ? 1 : b) : 32768);
+}
+
+__device__ __forceinline__ float act_grad_from_output(float y, int act) {
+  switch (act) {
+    case GPEMSR_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case GPEMSR_ACT_LRELU: return y > 0.f ? 1.f : 0.1f;
+    case GPEMSR_ACT_SIGMOID: return y * (1.f - y);
+    case GPEMSR_ACT_LRELU_SIGMOID: return y * (1.f - y) * (y > 0.5f ? 1.f : 0.1f);
+    default: return 1.f;
+  }
+}
+
+// dz[n][h][w][c] = dy * act'(y); with pixel_shuffle dy / y are [n][2h][2w][c/4] and
+// dz[.., y, x, 4*cc + 2*i + j] = (dy * act')[.., 2y+i, 2x+j, cc]   (nn.PixelShuffle(2) backward).
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dy, int dy_ld, const float* y, int y_ld, int n, int h, int w,
+                                                      int c, int act, int ps, float* dz, int dz_ld) {
+  const long long total = (long long)n * h * w * c;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ch = (int)(e % c);
+    const long long p = e / c;
+    long long sp; int sc;
+    if (ps) {
+      const int xq = (int)(p % w), yq = (int)((p / w) % h);
+      const long long img = p / ((long long)w * h);
+      const int cc = ch >> 2, i = (ch >> 1) & 1, j = ch & 1;
+      sp = (img * (2 * h) + 2 * yq + i) * (2 * w) + 2 * xq + j;
+      sc = cc;
+    } else { sp = p; sc = ch; }
+    const float g = dy[sp * dy_ld + sc];
+    const float d = act == GPEMSR_ACT_NONE ? 1.f : act_grad_from_output(y[sp * y_ld + sc], act);
+    dz[p * dz_ld + ch] = g * d;
+  }
+}
+
+// column sums of dz[pixels][c] (bias gradient).  Stage 1: block b sums pixels b, b+G, ... for every channel.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* dz, long long pixels, int c, int ld, float* ws) {
+  // thread t owns channel t % cw of pixel lane t / cw (cw = min(c, 256)); lanes are folded in a fixed order through LDS
+  const int cw = c >= 256 ? 256 : c;
+  const int L = 256 / cw;
+  const int chl = threadIdx.x % cw, pl = threadIdx.x / cw;
+  __shared__ float red[256];
+  for (int c0 = 0; c0 < c; c0 += cw) {
+    const int ch = c0 + chl;
+    float s = 0.f;
+    if (pl < L && ch < c)
+      for (long long p = (long long)blockIdx.x * L + pl; p < pixels; p += (long long)gridDim.x * L) s += dz[p * ld + ch];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && ch < c) {
+      for (int l = 1; l < L; ++l) s += red[l * cw + chl];
+      ws[(long long)blockIdx.x * c + ch] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* ws, int blocks, int c, float* db) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += ws[(long long)b * c + ch];
+  db[ch] += s;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* src, int src_ld, float* dst, int dst_ld, long long pixels, int c, float alpha) {
+  const long long total = pixels * c;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long p = e / c; const int ch = (int)(e % c);
+    dst[p * dst_ld + ch] += alpha * src[p * src_ld + ch];
+  }
+}
+
+__global__ __launch_bounds__(256) void mul_pix_kernel(const float* x, int x_ld, const float* m, long long pixels, int c, float* out, int out_ld) {
+  const long long total = pixels * c;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long p = e / c; const int ch = (int)(e % c);
+    out[p * out_ld + ch] = x[p * x_ld + ch] * m[p];
+  }
+}
+
+// out = x * m[pixel]: dx += dy * m; dm[pixel] += sum_c dy * x.  One 16-lane group per pixel.
+__global__ __launch_bounds__(256) void mul_pix_bwd_kernel(const float* dy, int dy_ld, const float* x, int x_ld, const float* m,
+                                                          long long pixels, int c, float* dx, int dx_ld, float* dm) {
+  const int sub = threadIdx.x & 15;
+  const long long per_iter = (long long)gridDim.x * 16;
+  const long long niter = (pixels + per_iter - 1) / per_iter;
+  for (long long it = 0; it < niter; ++it) {
+    const long long p = it * per_iter + (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = p < pixels;
+    float s = 0.f;
+    if (valid) {
+      const float mv = m[p];
+      for (int ch = sub; ch < c; ch += 16) {
+        const float g = dy[p * dy_ld + ch];
+        s += g * x[p * x_ld + ch];
+        if (dx) dx[p * dx_ld + ch] += g * mv;
+      }
+    }
+#pragma unroll
+    for (int k = 8; k >= 1; k >>= 1) s += __shfl_xor(s, k);
+    if (valid && sub == 0 && dm) dm[p] += s;
+  }
+}
+
+__device__ __forceinline__ void bsrc_index(int dst, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
+  float s = align ? scale * dst : fmaxf(scale * (dst + 0.5f) - 0.5f, 0.f);
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - i0;
+}
+
+// F.interpolate(bilinear) backward in gather form: every input element sums the output pixels whose two source taps
+// include it, re-evaluating the forward's source-index formula (bit-identical weights, fixed order).
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* dy, int dy_ld, int n, int h, int w, int c, int oh, int ow,
+                                                           int align, float sh, float sw, float mul, float* dx, int dx_ld) {
+  const long long total = (long long)n * h * w * c;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ch = (int)(e % c);
+    long long p = e / c;
+    const int ix = (int)(p % w); p /= w;
+    const int iy = (int)(p % h);
+    const int img = (int)(p / h);
+    // conservative candidate ranges (exact membership is re-checked through bsrc_index)
+    int ylo, yhi, xlo, xhi;
+    if (align) {
+      ylo = sh > 0.f ? (int)floorf((iy - 1) / sh) - 1 : 0; yhi = sh > 0.f ? (int)ceilf((iy + 1) / sh) + 1 : oh - 1;
+      xlo = sw > 0.f ? (int)floorf((ix - 1) / sw) - 1 : 0; xhi = sw > 0.f ? (int)ceilf((ix + 1) / sw) + 1 : ow - 1;
+    } else {
+      ylo = (int)floorf((iy - 0.5f) / sh - 0.5f) - 1; yhi = (int)ceilf((iy + 1.5f) / sh - 0.5f) + 1;
+      xlo = (int)floorf((ix - 0.5f) / sw - 0.5f) - 1; xhi = (int)ceilf((ix + 1.5f) / sw - 0.5f) + 1;
+    }
+    if (iy == 0) ylo = 0;
+    if (ix == 0) xlo = 0;
+    if (iy == h - 1) yhi = oh - 1;
+    if (ix == w - 1) xhi = ow - 1;
+    ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, oh - 1); xhi = min(xhi, ow - 1);
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      int y0, y1; float ly;
+      bsrc_index(oy, sh, align, h, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        int x0, x1; float lx;
+        bsrc_index(ox, sw, align, w, x0, x1, lx);
+        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx != 0.f) row += wx * dy[(((long long)img * oh + oy) * ow + ox) * dy_ld + ch];
+      }
+      acc += wy * row;
+    }
+    dx[(((long long)img * h + iy) * w + ix) * dx_ld + ch] += acc * mul;
+  }
+}
+
+// Modulated deformable sampling backward (torchvision deform_conv2d backward for input / offset / mask, restated):
+// thread per (pixel, tap, group) as in the forward.  dom (+=) has one writer per element; dx (+=) is scattered with
+// float atomics (up to 4 corners x 8 channels per thread).
+__global__ __launch_bounds__(256) void dcn_columns_bwd_kernel(const float* x, int n, int h, int w, int c, int ld, const float* om,
+                                                              int om_ld, int groups, const float* dcol, float* dx, int dx_ld,
+                                                              float* dom, int dom_ld) {
+  const int cg = c / groups;            // 8
+  const int K = 9;
+  const long long total = (long long)n * h * w * groups * K;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int g = (int)(e % groups);
+    long long t = e / groups;
+    const int k = (int)(t % K); t /= K;
+    const long long pix = t;
+    const int xq = (int)(pix % w);
+    const int yq = (int)((pix / w) % h);
+    const int img = (int)(pix / ((long long)w * h));
+    const float* o = om + pix * om_ld;
+    const float dy = o[g * 2 * K + 2 * k], dxo = o[g * 2 * K + 2 * k + 1];
+    const float ml = o[2 * groups * K + g * K + k];
+    const float m = 1.f / (1.f + expf(-ml));
+    const float py = (float)(yq - 1 + k / 3) + dy, px = (float)(xq - 1 + k % 3) + dxo;
+    const float* dc = dcol + pix * (long long)(K * c) + k * c + g * cg;
+    const float4 d0 = *reinterpret_cast<const float4*>(dc), d1 = *reinterpret_cast<const float4*>(dc + 4);
+    const float dcv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    float g_m = 0.f, g_py = 0.f, g_px = 0.f;
+    if (py > -1.f && py < (float)h && px > -1.f && px < (float)w) {
+      const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+      const float ly = py - y0, lx = px - x0;
+      const float wts[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+      const float wdy[4] = {-(1.f - lx), -lx, (1.f - lx), lx};          // d wts / d py
+      const float wdx[4] = {-(1.f - ly), (1.f - ly), -ly, ly};          // d wts / d px
+      const int ys[4] = {y0, y0, y0 + 1, y0 + 1}, xs[4] = {x0, x0 + 1, x0, x0 + 1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (ys[q] >= 0 && ys[q] <= h - 1 && xs[q] >= 0 && xs[q] <= w - 1) {
+          const long long sp = ((long long)img * h + ys[q]) * w + xs[q];
+          const float* xp = x + sp * ld + g * cg;
+          const float4 a = *reinterpret_cast<const float4*>(xp), b = *reinterpret_cast<const float4*>(xp + 4);
+          const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          float dot = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) dot += dcv[r] * xv[r];
+          g_m += wts[q] * dot;
+          g_py += wdy[q] * dot;
+          g_px += wdx[q] * dot;
+          if (dx) {
+            float* dp = dx + sp * dx_ld + g * cg;
+            const float wm = wts[q] * m;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) atomicAdd(dp + r, wm * dcv[r]);
+          }
+        }
+      }
+    }
+    if (dom) {
+      float* dq = dom + pix * dom_ld;
+      dq[g * 2 * K + 2 * k] += g_py * m;
+      dq[g * 2 * K + 2 * k + 1] += g_px * m;
+      dq[2 * groups * K + g * K + k] += g_m * m * (1.f - m);
+    }
+  }
+}
+
+// ThreeDA temporal gate backward; one 16-lane group per (b, pixel), looping over the t frames so that the sum into
+// d_emb_ref has a fixed order.  c == 64.
+__global__ __launch_bounds__(256) void temporal_gate_bwd_kernel(const float* aligned, const float* emb, const float* emb_ref,
+                                                                const float* daf, int b, int t, int hw, int c,
+                                                                float* d_aligned, float* d_emb, float* d_emb_ref) {
+  const int sub = threadIdx.x & 15;
+  const long long items = (long long)b * hw;
+  const long long per_iter = (long long)gridDim.x * 16;
+  const long long niter = (items + per_iter - 1) / per_iter;
+  for (long long it = 0; it < niter; ++it) {
+    const long long item = it * per_iter + (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = item < items;
+    const long long ii = valid ? item : 0;
+    const int p = (int)(ii % hw);
+    const int bi = (int)(ii / hw);
+    const float4 e0 = *reinterpret_cast<const float4*>(emb_ref + ii * c + 4 * sub);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ti = 0; ti < t; ++ti) {
+      const long long fi = ((long long)bi * t + ti) * hw + p;
+      const float4 e1 = *reinterpret_cast<const float4*>(emb + fi * c + 4 * sub);
+      const float4 v = *reinterpret_cast<const float4*>(aligned + fi * c + 4 * sub);
+      const float4 dg = *reinterpret_cast<const float4*>(daf + ii * ((long long)t * c) + ti * c + 4 * sub);
+      float d = e1.x * e0.x + e1.y * e0.y + e1.z * e0.z + e1.w * e0.w;
+      float s = dg.x * v.x + dg.y * v.y + dg.z * v.z + dg.w * v.w;
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) { d += __shfl_xor(d, m); s += __shfl_xor(s, m); }
+      const float g = 1.f / (1.f + expf(-d));
+      const float dd = s * g * (1.f - g);
+      if (valid) {
+        float4* da = reinterpret_cast<float4*>(d_aligned + fi * c + 4 * sub);
+        float4 a = *da; a.x += dg.x * g; a.y += dg.y * g; a.z += dg.z * g; a.w += dg.w * g; *da = a;
+        float4* de = reinterpret_cast<float4*>(d_emb + fi * c + 4 * sub);
+        float4 q = *de; q.x += dd * e0.x; q.y += dd * e0.y; q.z += dd * e0.z; q.w += dd * e0.w; *de = q;
+        acc.x += dd * e1.x; acc.y += dd * e1.y; acc.z += dd * e1.z; acc.w += dd * e1.w;
+      }
+    }
+    if (valid) {
+      float4* dr = reinterpret_cast<float4*>(d_emb_ref + ii * c + 4 * sub);
+      float4 r = *dr; r.x += acc.x; r.y += acc.y; r.z += acc.z; r.w += acc.w; *dr = r;
+    }
+  }
+}
+
+// Conv3d(t,t,1)+LeakyReLU backward.  out = lrelu(bias_i + sum_k M[i][k] af[k]).  d_af += M^T dz; per-block partial sums of
+// dM (t*t) and dbias (t) go to ws[block][t*t + t]; frame_mix_bwd_final adds them up in block order.
+__global__ __launch_bounds__(256) void frame_mix_bwd_kernel(const float* af, const float* out, const float* dout, long long pixels,
+                                                            int t, int c, const float* m, float* d_af, float* ws) {
+  const int c4 = c >> 2;
+  const long long total = pixels * c4;
+  float pm[30];                          // t <= 5: 25 + 5
+  const int nred = t * t + t;
+  for (int i = 0; i < nred; ++i) pm[i] = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e % c4);
+    const long long p = e / c4;
+    const long long base = p * ((long long)t * c) + 4 * j;
+    float4 in[5], dz[5];
+    for (int k = 0; k < t; ++k) {
+      in[k] = *reinterpret_cast<const float4*>(af + base + k * c);
+      const float4 o = *reinterpret_cast<const float4*>(out + base + k * c);
+      float4 g = *reinterpret_cast<const float4*>(dout + base + k * c);
+      g.x *= o.x > 0.f ? 1.f : 0.1f; g.y *= o.y > 0.f ? 1.f : 0.1f; g.z *= o.z > 0.f ? 1.f : 0.1f; g.w *= o.w > 0.f ? 1.f : 0.1f;
+      dz[k] = g;
+    }
+    for (int k = 0; k < t; ++k) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < t; ++i) {
+        const float wv = m[i * t + k];
+        s.x = fmaf(wv, dz[i].x, s.x); s.y = fmaf(wv, dz[i].y, s.y); s.z = fmaf(wv, dz[i].z, s.z); s.w = fmaf(wv, dz[i].w, s.w);
+      }
+      float4* dp = reinterpret_cast<float4*>(d_af + base + k * c);
+      float4 q = *dp; q.x += s.x; q.y += s.y; q.z += s.z; q.w += s.w; *dp = q;
+    }
+    for (int i = 0; i < t; ++i) {
+      for (int k = 0; k < t; ++k)
+        pm[i * t + k] += dz[i].x * in[k].x + dz[i].y * in[k].y + dz[i].z * in[k].z + dz[i].w * in[k].w;
+      pm[t * t + i] += (dz[i].x + dz[i].y) + (dz[i].z + dz[i].w);
+    }
+  }
+  __shared__ float red[4][30];
+  for (int i = 0; i < nred; ++i) {
+    float v = pm[i];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nred) ws[(long long)blockIdx.x * nred + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void frame_mix_bwd_final_kernel(const float* ws, int blocks, int t, float* dm, float* dbias) {
+  const int i = threadIdx.x, nred = t * t + t;
+  if (i >= nred) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += ws[(long long)b * nred + i];
+  if (i < t * t) dm[i] += s; else dbias[i - t * t] += s;
+}
+
+// MaxPool2d(3,2,1) | AvgPool2d(3,2,1) backward (dy = [max grads | avg grads]); gather form: every input element visits
+// the <= 4 windows that contain it and re-derives each window's arg-max (first maximum in scan order, as ATen).
+__global__ __launch_bounds__(256) void pool3s2_bwd_kernel(const float* x, int n, int h, int w, int c, int ld, const float* dy, int dy_ld,
+                                                          float* dx, int dx_ld) {
+  const int oh = (h - 1) / 2 + 1, ow = (w - 1) / 2 + 1;
+  const long long total = (long long)n * h * w * c;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ch = (int)(e % c);
+    long long p = e / c;
+    const int ix = (int)(p % w); p /= w;
+    const int iy = (int)(p % h);
+    const int img = (int)(p / h);
+    float acc = 0.f;
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy >= oh) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox >= ow) continue;
+        // window rows 2oy-1..2oy+1 contains iy by construction
+        float mx = -INFINITY; int ay = -1, ax = -1;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int yy = 2 * oy - 1 + ky;
+          if (yy < 0 || yy >= h) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            const int xx = 2 * ox - 1 + kx;
+            if (xx < 0 || xx >= w) continue;
+            const float v = x[(((long long)img * h + yy) * w + xx) * ld + ch];
+            if (v > mx) { mx = v; ay = yy; ax = xx; }
+          }
+        }
+        const float* g = dy + (((long long)img * oh + oy) * ow + ox) * dy_ld;
+        if (ay == iy && ax == ix) acc += g[ch];
+        acc += g[c + ch] * (1.f / 9.f);
+      }
+    }
+    dx[(((long long)img * h + iy) * w + ix) * dx_ld + ch] += acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void threeda_combine_bwd_kernel(const float* feat, const float* attn, const float* dout, long long count,
+                                                                  float* dfeat, float* dattn, float* dadd, float* df2, float* df3) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) {
+    const float g = dout[e];
+    const float s = 1.f / (1.f + expf(-attn[e]));
+    dfeat[e] += g * 2.f * s;
+    dattn[e] += g * feat[e] * 2.f * s * (1.f - s);
+    dadd[e] += g; df2[e] += g; df3[e] += g;
+  }
+}
+
+// nn.MaxPool2d(2,2) backward: dx[first max of the window] += dy
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* x, int n, int h, int w, int c, int ld, const float* dy, int dy_ld,
+                                                           float* dx, int dx_ld) {
+  const int oh = h / 2, ow = w / 2;
+  const long long total = (long long)n * oh * ow * c;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ch = (int)(e % c);
+    long long p = e / c;
+    const int ox = (int)(p % ow); p /= ow;
+    const int oy = (int)(p % oh);
+    const int img = (int)(p / oh);
+    const long long b00 = (((long long)img * h + 2 * oy) * w + 2 * ox);
+    const long long pos[4] = {b00, b00 + 1, b00 + w, b00 + w + 1};
+    float mx = -INFINITY; int a = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float v = x[pos[q] * ld + ch]; if (v > mx) { mx = v; a = q; } }
+    dx[pos[a] * dx_ld + ch] += dy[(((long long)img * oh + oy) * ow + ox) * dy_ld + ch];
+  }
+}
+
+// dtarget image i += sum over j with idx[j] == i of dsrc image j  (backward of gather_images / copy_images)
+__global__ __launch_bounds__(256) void scatter_add_images_kernel(const float* dsrc, const int* idx, float* dtarget, int n_src, int n_dst,
+                                                                 long long elems4) {
+  const long long total = (long long)n_src * elems4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e / elems4); const long long k = e % elems4;
+    float4 acc = reinterpret_cast<float4*>(dtarget)[e];
+    for (int j = 0; j < n_dst; ++j) {
+      if (idx[j] != i) continue;
+      const float4 v = reinterpret_cast<const float4*>(dsrc)[(long long)j * elems4 + k];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(dtarget)[e] = acc;
+  }
+}
+
+// torch.nn.L1Loss()(gt, sr) (mean) and its gradient w.r.t. sr: sign(sr - gt) * gscale / count
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* sr, const float* gt, long long count, float gscale, float* dsr, float* ws) {
+  float s = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) {
+    const float d = sr[e] - gt[e];
+    s += fabsf(d);
+    if (dsr) dsr[e] += (d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f));
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sum_scale_kernel(const float* ws, int blocks, float scale, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int b = 0; b < blocks; ++b) s += (double)ws[b];
+    out[0] = (float)(s * scale);
+  }
+}
+
+// torch.optim.Adam step (no amsgrad): train_stage3.py:163,365
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long long count, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) {
+    float gr = g[e];
+    const float pv = p[e];
+    if (wd != 0.f) gr += wd * pv;
+    const float mm = b1 * m[e] + (1.f - b1) * gr;
+    const float vv = b2 * v[e] + (1.f - b2) * gr * gr;
+    m[e] = mm; v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[e] = pv - (lr / bc1) * (mm / denom);
+  }
+}
+
+// dst[n][cols][rows] = src[n][rows][cols]  (per-image transpose through a 32x33 LDS tile)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* src, float* dst, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const long long img = blockIdx.z;
+  const float* s = src + img * (long long)rows * cols;
+  float* d = dst + img * (long long)rows * cols;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = s[(long long)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) d[(long long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+}  // namespace gpemsr
+
+using namespace gpemsr;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int gpemsr_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, int n, int h, int w, int c, int act,
+                              int pixel_shuffle, float* dz, int dz_ld, void* stream) {
+  GP_REQUIRE(dy && dz && (y || act == GPEMSR_ACT_NONE) && n > 0 && h > 0 && w > 0 && c > 0, "act_bwd: bad args");
+  GP_REQUIRE(!pixel_shuffle || c % 4 == 0, "act_bwd: pixel_shuffle needs c %% 4 == 0");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(bgrid((long long)n * h * w * c)), dim3(256), 0, ST(stream), dy, dy_ld, y, y_ld, n, h, w, c,
+                     act, pixel_shuffle, dz, dz_ld);
+  return check_launch("act_bwd");
+}
+
+extern "C" int gpemsr_bias_grad(const float* dz, int64_t pixels, int c, int ld, float* ws, int64_t ws_floats, float* db, void* stream) {
+  GP_REQUIRE(dz && ws && db && pixels > 0 && c > 0, "bias_grad: bad args");
+  int blocks = (int)(pixels < 512 ? pixels : 512);
+  if ((int64_t)blocks * c > ws_floats) blocks = (int)(ws_floats / c);
+  GP_REQUIRE(blocks >= 1, "bias_grad: workspace too small");
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, ST(stream), dz, (long long)pixels, c, ld, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, ST(stream), ws, blocks, c, db);
+  return check_launch("bias_grad");
+}
+
+extern "C" int gpemsr_axpy(const float* src, int src_ld, float* dst, int dst_ld, int64_t pixels, int c, float alpha, void* stream) {
+  GP_REQUIRE(src && dst && pixels > 0 && c > 0, "axpy: bad args");
+  hipLaunchKernelGGL(axpy_kernel, dim3(bgrid(pixels * c)), dim3(256), 0, ST(stream), src, src_ld, dst, dst_ld, (long long)pixels, c, alpha);
+  return check_launch("axpy");
+}
+
+extern "C" int gpemsr_mul_pix(const float* x, int x_ld, const float* m, int64_t pixels, int c, float* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && m && out && pixels > 0 && c > 0, "mul_pix: bad args");
+  hipLaunchKernelGGL(mul_pix_kernel, dim3(bgrid(pixels * c)), dim3(256), 0, ST(stream), x, x_ld, m, (long long)pixels, c, out, out_ld);
+  return check_launch("mul_pix");
+}
+
+extern "C" int gpemsr_mul_pix_bwd(const float* dy, int dy_ld, const float* x, int x_ld, const float* m, int64_t pixels, int c,
+                                  float* dx, int dx_ld, float* dm, void* stream) {
+  GP_REQUIRE(dy && x && m && pixels > 0 && c > 0, "mul_pix_bwd: bad args");
+  const long long blocks = (pixels + 15) / 16;
+  hipLaunchKernelGGL(mul_pix_bwd_kernel, dim3((unsigned)(blocks < 32768 ? blocks : 32768)), dim3(256), 0, ST(stream), dy, dy_ld, x, x_ld,
+                     m, (long long)pixels, c, dx, dx_ld, dm);
+  return check_launch("mul_pix_bwd");
+}
+
+extern "C" int gpemsr_bilinear_bwd(const float* dy, int dy_ld, int n, int h, int w, int c, int oh, int ow, int align_corners, float mul,
+                                   float* dx, int dx_ld, void* stream) {
+  GP_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, "bilinear_bwd: bad args");
+  float sh, sw;
+  if (align_corners) { sh = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f; sw = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f; }
+  else { sh = (float)((double)h / (double)oh); sw = (float)((double)w / (double)ow); }
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(bgrid((long long)n * h * w * c)), dim3(256), 0, ST(stream), dy, dy_ld, n, h, w, c, oh, ow,
+                     align_corners, sh, sw, mul, dx, dx_ld);
+  return check_launch("bilinear_bwd");
+}
+
+extern "C" int gpemsr_dcn_columns_bwd(const float* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
+                                      const float* dcol, float* dx, int dx_ld, float* dom, int dom_ld, void* stream) {
+  GP_REQUIRE(x && om && dcol, "dcn_columns_bwd: null pointer");
+  GP_REQUIRE(groups > 0 && c % groups == 0 && c / groups == 8 && ld % 4 == 0, "dcn_columns_bwd: needs 8 channels per deformable group");
+  GP_REQUIRE(om_ld >= 3 * groups * 9 && (!dom || dom_ld >= 3 * groups * 9), "dcn_columns_bwd: om_ld too small");
+  hipLaunchKernelGGL(dcn_columns_bwd_kernel, dim3(bgrid((long long)n * h * w * groups * 9)), dim3(256), 0, ST(stream), x, n, h, w, c, ld,
+                     om, om_ld, groups, dcol, dx, dx_ld, dom, dom_ld);
+  return check_launch("dcn_columns_bwd");
+}
+
+extern "C" int gpemsr_temporal_gate_bwd(const float* aligned, const float* emb, const float* emb_ref, const float* daf, int b, int t,
+                                        int hw, int c, float* d_aligned, float* d_emb, float* d_emb_ref, void* stream) {
+  GP_REQUIRE(aligned && emb && emb_ref && daf && d_aligned && d_emb && d_emb_ref, "temporal_gate_bwd: null pointer");
+  GP_REQUIRE(c == 64, "temporal_gate_bwd: c must be 64");
+  const long long blocks = ((long long)b * hw + 15) / 16;
+  hipLaunchKernelGGL(temporal_gate_bwd_kernel, dim3((unsigned)(blocks < 32768 ? blocks : 32768)), dim3(256), 0, ST(stream), aligned, emb,
+                     emb_ref, daf, b, t, hw, c, d_aligned, d_emb, d_emb_ref);
+  return check_launch("temporal_gate_bwd");
+}
+
+extern "C" int gpemsr_frame_mix_lrelu_bwd(const float* af, const float* out, const float* dout, int64_t pixels, int t, int c,
+                                          const float* m, float* d_af, float* dm, float* dbias, float* ws, int64_t ws_floats,
+                                          void* stream) {
+  GP_REQUIRE(af && out && dout && m && d_af && dm && dbias && ws && t <= 5 && c % 4 == 0, "frame_mix_bwd: bad args (t <= 5)");
+  const int nred = t * t + t;
+  long long blocks = (pixels * (c / 4) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks * nred > ws_floats) blocks = ws_floats / nred;
+  GP_REQUIRE(blocks >= 1, "frame_mix_bwd: workspace too small");
+  hipLaunchKernelGGL(frame_mix_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), af, out, dout, (long long)pixels, t, c, m, d_af, ws);
+  hipLaunchKernelGGL(frame_mix_bwd_final_kernel, dim3(1), dim3(64), 0, ST(stream), ws, (int)blocks, t, dm, dbias);
+  return check_launch("frame_mix_bwd");
+}
+
+extern "C" int gpemsr_pool3s2_maxavg_bwd(const float* x, int n, int h, int w, int c, int ld, const float* dy, int dy_ld, float* dx,
+                                         int dx_ld, void* stream) {
+  GP_REQUIRE(x && dy && dx && dy_ld >= 2 * c, "pool3s2_bwd: bad args");
+  hipLaunchKernelGGL(pool3s2_bwd_kernel, dim3(bgrid((long long)n * h * w * c)), dim3(256), 0, ST(stream), x, n, h, w, c, ld, dy, dy_ld, dx, dx_ld);
+  return check_launch("pool3s2_bwd");
+}
+
+extern "C" int gpemsr_threeda_combine_bwd(const float* feat, const float* attn, const float* dout, int64_t count, float* dfeat,
+                                          float* dattn, float* dadd, float* df2, float* df3, void* stream) {
+  GP_REQUIRE(feat && attn && dout && dfeat && dattn && dadd && df2 && df3 && count > 0, "threeda_combine_bwd: bad args");
+  hipLaunchKernelGGL(threeda_combine_bwd_kernel, dim3(bgrid(count)), dim3(256), 0, ST(stream), feat, attn, dout, (long long)count, dfeat,
+                     dattn, dadd, df2, df3);
+  return check_launch("threeda_combine_bwd");
+}
+
+extern "C" int gpemsr_maxpool2_bwd(const float* x, int n, int h, int w, int c, int ld, const float* dy, int dy_ld, float* dx, int dx_ld,
+                                   void* stream) {
+  GP_REQUIRE(x && dy && dx && h >= 2 && w >= 2, "maxpool2_bwd: bad args");
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(bgrid((long long)n * (h / 2) * (w / 2) * c)), dim3(256), 0, ST(stream), x, n, h, w, c, ld,
+                     dy, dy_ld, dx, dx_ld);
+  return check_launch("maxpool2_bwd");
+}
+
+extern "C" int gpemsr_scatter_add_images(const float* dsrc, const int* idx, float* dtarget, int n_src, int n_dst,
+                                         int64_t elems_per_image, void* stream) {
+  GP_REQUIRE(dsrc && idx && dtarget && n_src > 0 && n_dst > 0 && elems_per_image % 4 == 0, "scatter_add_images: bad args");
+  GP_REQUIRE(((reinterpret_cast<uintptr_t>(dsrc) | reinterpret_cast<uintptr_t>(dtarget)) & 15) == 0, "scatter_add_images: alignment");
+  hipLaunchKernelGGL(scatter_add_images_kernel, dim3(bgrid((long long)n_src * (elems_per_image / 4))), dim3(256), 0, ST(stream), dsrc, idx,
+                     dtarget, n_src, n_dst, (long long)(elems_per_image / 4));
+  return check_launch("scatter_add_images");
+}
+
+extern "C" int gpemsr_l1_loss(const float* sr, const float* gt, int64_t count, float grad_scale, float* dsr, float* ws,
+                              int64_t ws_floats, float* loss, void* stream) {
+  GP_REQUIRE(sr && gt && ws && loss && count > 0 && ws_floats >= 1, "l1_loss: bad args");
+  long long blocks = (count + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks > ws_floats) blocks = ws_floats;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), sr, gt, (long long)count,
+                     grad_scale / (float)count, dsr, ws);
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(64), 0, ST(stream), ws, (int)blocks, 1.f / (float)count, loss);
+  return check_launch("l1_loss");
+}
+
+extern "C" int gpemsr_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int step, void* stream) {
+  GP_REQUIRE(p && g && m && v && count > 0 && step >= 1, "adam_step: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(bgrid(count)), dim3(256), 0, ST(stream), p, g, m, v, (long long)count, lr, beta1, beta2, eps,
+                     weight_decay, (float)bc1, (float)sqrt(bc2));
+  return check_launch("adam_step");
+}
+
+extern "C" int gpemsr_transpose_images(const float* src, float* dst, int n, int rows, int cols, void* stream) {
+  GP_REQUIRE(src && dst && n > 0 && rows > 0 && cols > 0 && n <= 65535, "transpose_images: bad args");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, n), dim3(256), 0, ST(stream), src, dst, rows, cols);
+  return check_launch("transpose_images");
+}

@@ -1,0 +1,206 @@
+// Weight gradient of the convolution family on the f32 matrix pipe (v_mfma_f32_32x32x2_f32):
+//   dW[co][ci][ky][kx] = sum_{n,oy,ox} dZ[n][oy][ox][co] * X[n][oy*s + ky - p][ox*s + kx - p][ci]
+// i.e. a GEMM whose K dimension is the pixel axis.  NHWC makes both operands "k-major": for one pixel the 32 couts
+// (A) and the 32 cins (B) of an MFMA operand are contiguous, so a lane's operand register is ONE float read at
+// [pixel(lane>>5)][channel(lane&31)] -- no transposes anywhere.
+//
+// One 256-thread workgroup owns a 64(co) x 64(ci) block of dW for ALL k*k taps (wave w: co half w&1, ci half w>>1;
+// k*k accumulators of 32x32) and walks a slab of output tiles (TH rows x 32 pixels).  Per tile it stages the dZ tile
+// and the X halo tile ((TH-1)s+k rows x 31s+k cols) in LDS once; every tap reads the halo at a shifted offset (k*k-fold
+// reuse, as in the forward kernel).  LDS rows are only as wide as the channel block really is (1..64 floats), a lane
+// that reads past its row picks up finite-or-not garbage that lands in rows/cols of D which are never written back
+// (D[i][j] depends on A row i and B col j only).  Slabs write partial dW images [slab][tap][co][ci]; a second kernel
+// adds them in slab order into the OIHW gradient (+=), so the result is deterministic.
+//
+// ConvTranspose2d(k3,s2,p1,op1) weights [Cin][Cout][3][3] use the same routine with the roles swapped
+// (x := dOut at 2h x 2w, dz := the layer input at h x w, stride 2): out(2iy-1+ky) <- in(iy) * W[ci][co][ky][kx].
+#include "common.h"
+
+namespace gpemsr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradParams {
+  const float* x; int x_ld; int cin;
+  const float* dz; int dz_ld; int cout;
+  int n, h, w, oh, ow, stride, pad, th;
+  int tiles_x, tiles_y, total_tiles, tiles_per_slab;
+  int cwx_max, cwz_max, hr, hc;
+  int x_vec, dz_vec;                 // float4 loads allowed (ld % 4 == 0, base 16-B aligned)
+  float* part;
+};
+
+__device__ __forceinline__ float4 wg_load4(const float* row, int ch, int cmax, int vec) {
+  if (vec && ch + 3 < cmax) return *reinterpret_cast<const float4*>(row + ch);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ch < cmax) v.x = row[ch];
+  if (ch + 1 < cmax) v.y = row[ch + 1];
+  if (ch + 2 < cmax) v.z = row[ch + 2];
+  if (ch + 3 < cmax) v.w = row[ch + 3];
+  return v;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams P) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int cob = (wv & 1) * 32, cib = (wv >> 1) * 32;
+  const int con = min(64, P.cout - co0), cin_b = min(64, P.cin - ci0);     // valid channels of this block
+  const int cwz = (con + 3) & ~3, cwx = (cin_b + 3) & ~3;                  // LDS row widths of this block
+  float* dzs = smem;
+  float* xs = smem + P.th * 32 * P.cwz_max + 64;
+  const bool active = cob < con && cib < cin_b;
+  constexpr int T = KS * KS;
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int slab = blockIdx.x;
+  const int t0 = slab * P.tiles_per_slab;
+  const int t1 = min(t0 + P.tiles_per_slab, P.total_tiles);
+  const int cz4 = cwz >> 2, cx4 = cwx >> 2;
+  const int npx = P.th * 32, nhp = P.hr * P.hc;
+  for (int t = t0; t < t1; ++t) {
+    const int tx = t % P.tiles_x, ty = (t / P.tiles_x) % P.tiles_y, img = t / (P.tiles_x * P.tiles_y);
+    const int oy0 = ty * P.th, ox0 = tx * 32;
+    __syncthreads();                       // the previous tile's reads are done
+    for (int e = tid; e < npx * cz4; e += 256) {
+      const int c4 = e % cz4, px = e / cz4;
+      const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (oy < P.oh && ox < P.ow)
+        v = wg_load4(P.dz + (((long long)img * P.oh + oy) * P.ow + ox) * P.dz_ld, co0 + 4 * c4, P.cout, P.dz_vec);
+      *reinterpret_cast<float4*>(dzs + px * cwz + 4 * c4) = v;
+    }
+    const int iy0 = oy0 * P.stride - P.pad, ix0 = ox0 * P.stride - P.pad;
+    for (int e = tid; e < nhp * cx4; e += 256) {
+      const int c4 = e % cx4, hp = e / cx4;
+      const int iy = iy0 + hp / P.hc, ix = ix0 + hp % P.hc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w)
+        v = wg_load4(P.x + (((long long)img * P.h + iy) * P.w + ix) * P.x_ld, ci0 + 4 * c4, P.cin, P.x_vec);
+      *reinterpret_cast<float4*>(xs + hp * cwx + 4 * c4) = v;
+    }
+    __syncthreads();
+    if (active) {
+      const float* ap = dzs + lh * cwz + cob + l31;
+      const float* bp = xs + lh * P.stride * cwx + cib + l31;
+      for (int r = 0; r < P.th; ++r) {
+        const float* ar = ap + r * 32 * cwz;
+        const float* br = bp + r * P.stride * P.hc * cwx;
+#pragma unroll 2
+        for (int cp = 0; cp < 16; ++cp) {
+          const float a = ar[2 * cp * cwz];
+          const float* bq = br + 2 * cp * P.stride * cwx;
+#pragma unroll
+          for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+              const float b = bq[(ky * P.hc + kx) * cwx];
+              acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * KS + kx], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+  if (active) {
+    const int ci = ci0 + cib + l31;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + cob + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < P.cout && ci < P.cin)
+          P.part[(((long long)slab * T + t) * P.cout + co) * P.cin + ci] = acc[t][r];
+      }
+  }
+}
+
+// dw[(co*cin_total + cin_off + ci)*taps + tap] += sum_slab part[slab][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int slabs, int taps, int cout, int cin, float* dw,
+                                                           int cin_total, int cin_off) {
+  const long long total = (long long)taps * cout * cin;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int ci = (int)(e % cin);
+    const int co = (int)((e / cin) % cout);
+    const int tap = (int)(e / ((long long)cin * cout));
+    float s = 0.f;
+    for (int sl = 0; sl < slabs; ++sl) s += part[(long long)sl * total + e];
+    dw[((long long)co * cin_total + cin_off + ci) * taps + tap] += s;
+  }
+}
+
+}  // namespace gpemsr
+
+using namespace gpemsr;
+
+extern "C" int64_t gpemsr_conv2d_wgrad_workspace(int cin, int cout, int ksize, int n, int oh, int ow) {
+  const int th = 2;
+  const long long tiles = (long long)n * ((oh + th - 1) / th) * ((ow + 31) / 32);
+  long long tps = (tiles + 511) / 512;
+  if (tps < 2) tps = 2;
+  const long long slabs = (tiles + tps - 1) / tps;
+  return slabs * ksize * ksize * cout * cin;
+}
+
+extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const float* dz, int dz_ld, int cout, int n, int h, int w,
+                                   int oh, int ow, int ksize, int stride, float* ws, int64_t ws_floats, float* dw, int cin_total,
+                                   int cin_off, void* stream) {
+  GP_REQUIRE(x && dz && ws && dw && n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_wgrad: bad args");
+  GP_REQUIRE(ksize == 1 || ksize == 3, "conv2d_wgrad: ksize %d unsupported (1 or 3: every trainable convolution of the stage-3 network)", ksize);
+  GP_REQUIRE(stride == 1 || stride == 2 || stride == 4, "conv2d_wgrad: stride %d unsupported", stride);
+  const int pad = ksize / 2;
+  GP_REQUIRE(oh == (h + 2 * pad - ksize) / stride + 1 && ow == (w + 2 * pad - ksize) / stride + 1,
+             "conv2d_wgrad: dz geometry %dx%d does not match x %dx%d (k%d s%d)", oh, ow, h, w, ksize, stride);
+  GP_REQUIRE(cin_off >= 0 && cin_off + cin <= cin_total && x_ld >= cin && dz_ld >= cout, "conv2d_wgrad: channel ranges");
+  WgradParams P;
+  P.x = x; P.x_ld = x_ld; P.cin = cin; P.dz = dz; P.dz_ld = dz_ld; P.cout = cout;
+  P.n = n; P.h = h; P.w = w; P.oh = oh; P.ow = ow; P.stride = stride; P.pad = pad;
+  P.cwx_max = cin >= 64 ? 64 : (cin + 3) & ~3;
+  P.cwz_max = cout >= 64 ? 64 : (cout + 3) & ~3;
+  P.th = 2;
+  P.hc = 31 * stride + ksize;
+  auto lds_bytes = [&](int th) { return (size_t)(th * 32 * P.cwz_max + 64 + ((th - 1) * stride + ksize) * P.hc * P.cwx_max + 64) * 4; };
+  if (lds_bytes(P.th) > 160 * 1024) P.th = 1;
+  GP_REQUIRE(lds_bytes(P.th) <= 160 * 1024, "conv2d_wgrad: tile does not fit LDS");
+  P.hr = (P.th - 1) * stride + ksize;
+  P.tiles_x = (ow + 31) / 32; P.tiles_y = (oh + P.th - 1) / P.th;
+  const long long tiles = (long long)n * P.tiles_x * P.tiles_y;
+  GP_REQUIRE(tiles < (1ll << 31), "conv2d_wgrad: too many tiles");
+  P.total_tiles = (int)tiles;
+  const long long per_slab = (long long)ksize * ksize * cout * cin;
+  long long tps = (tiles + 511) / 512;
+  if (tps < 2) tps = 2;
+  long long slabs = (tiles + tps - 1) / tps;
+  if (slabs * per_slab > ws_floats) {                        // fewer, longer slabs if the workspace is small
+    slabs = ws_floats / per_slab;
+    GP_REQUIRE(slabs >= 1, "conv2d_wgrad: workspace too small (need >= %lld floats)", per_slab);
+    tps = (tiles + slabs - 1) / slabs;
+    slabs = (tiles + tps - 1) / tps;
+  }
+  P.tiles_per_slab = (int)tps;
+  P.x_vec = (x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  P.dz_vec = (dz_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+  P.part = ws;
+  const size_t lds = lds_bytes(P.th);
+  const dim3 grid((unsigned)slabs, (unsigned)((cout + 63) / 64), (unsigned)((cin + 63) / 64));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ksize == 3) {
+    static bool attr3 = false;
+    if (!attr3) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
+    hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), lds, st, P);
+  } else {
+    static bool attr1 = false;
+    if (!attr1) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), lds, st, P);
+  }
+  const long long total = per_slab;
+  const long long rb = (total + 255) / 256;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(rb < 32768 ? rb : 32768)), dim3(256), 0, st, ws, (int)slabs, ksize * ksize, cout, cin,
+                     dw, cin_total, cin_off);
+  return check_launch("conv2d_wgrad");
+}

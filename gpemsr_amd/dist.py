@@ -73,3 +73,12 @@ def forward_sharded(model, x_all_or_local: torch.Tensor, rank: int, world: int, 
     if B % world == 0:
         return all_gather_slabs(out, world), ref
     return all_gather_ragged(out, B, rank, world), ref
+
+
+def average_gradients(flat_grad: torch.Tensor, world: int) -> torch.Tensor:
+    """What DistributedDataParallel does for train_stage3.py:141: one all-reduce (RCCL on GPUs, gloo in the CPU tests) of the
+    flat gradient buffer, then the mean over replicas.  In place; returns the buffer."""
+    if world > 1:
+        torch.distributed.all_reduce(flat_grad)
+        flat_grad.mul_(1.0 / world)
+    return flat_grad

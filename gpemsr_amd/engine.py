@@ -60,6 +60,8 @@ class Engine:
         # multiples of 16 channels run on the bf16 matrix pipe (split hi+lo = fp32-grade, or plain bf16); every other
         # op stays fp32 (incl. the indexer's logits GEMM + argmax).
         self.precision = precision
+        self._forced_flow = None
+        self.o = ops            # operator namespace; the training engine swaps in a recording proxy (gpemsr_amd/train.py)
         self.pc: Dict[str, ops.PackedConv] = {}
         self.par: Dict[str, torch.Tensor] = {}
         self._pack_all()
@@ -78,56 +80,63 @@ class Engine:
             "align_module.L1_offset_conv2": (nf, nf), "align_module.L2_fea_conv": (nf, nf),
             "align_module.L1_fea_conv": (nf, nf), "align_module.cas_offset_conv1": (nf, nf),
         }
-        ps = {"upconv1", "upconv2", "upconv3", "upconv4"}
+        self._splits = splits
         for k, w in sd.items():
-            if not k.endswith(".weight"):
-                continue
-            name = k[:-7]
-            if name.startswith("refmodel.encoder.") or name.startswith("vgg.slice") and not name.startswith("vgg.slice1."):
-                continue                                   # never evaluated in the stage-3 forward
-            b = sd.get(name + ".bias")
-            if w.dim() == 4 and name.endswith("dcnpack"):
-                self.pc[name] = pack_dcn(w, b, dev)
-            elif w.dim() == 4 and (name.startswith("reffea_L") or name.endswith(".upblock")):
-                self.pc[name] = pack_convT(w, b, dev)
-                if self.precision != "fp32" and w.shape[0] % 16 == 0:
-                    self.pc[name].w16 = pack_convT_split(self.pc[name], dev)
-            elif name == "vgg.slice1.0":
-                self.pc[name] = pack_vgg_first(w, b, dev)
-            elif w.dim() == 4 and name.endswith((".q",)) and ".feat_extract." in name:
-                c = w.shape[0]
-                sc = float(int(c) ** (-0.5))
-                self.pc[name] = pack_conv(w, b, dev, scale=sc)                        # fold C^-1/2 (blocks.py:76)
-                if self.precision != "fp32" and c % 32 == 0:
-                    self.pc[name].w16 = pack_conv_split(self.pc[name], w.detach().to(torch.float32) * sc, dev)
-            elif w.dim() == 4:
-                if name.endswith("_offset_conv1") and w.shape[1] == 2 * nf + 34:
-                    w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 14))       # 162 -> 176 input channels
-                if self.precision != "fp32" and w.shape[1] == 8 and w.shape[2] == 7 and ".spynet." in name:
-                    # SpyNet stems (8 -> 32, 7x7): zero-pad cin to 16 so they run on the split-bf16 kernel too
-                    w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 8))
-                self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
-                kk = w.shape[2]
-                if self.precision != "fp32" and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
-                                                 or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
-                    self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
-            elif w.dim() == 2 and name.endswith("indexer.embedding"):
-                self.pc[name] = pack_linear(w, b, dev)
-            elif w.dim() == 2 and name.endswith("codebook.embedding"):
-                self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
-            elif w.dim() == 5:                             # ThreeDA.conv3D_{1,2}: [t,t,1,1,1]
-                self.par[k] = w.detach().to(torch.float32).reshape(w.shape[0], w.shape[1]).contiguous().to(dev)
-                self.par[name + ".bias"] = b.detach().to(torch.float32).contiguous().to(dev)
-            elif w.dim() == 1:                             # GroupNorm affine
-                self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
-                self.par[name + ".bias"] = b.detach().to(torch.float32).contiguous().to(dev)
+            self._pack_one(k, w)
         m, s = sd.get("align_module.spynet.mean"), sd.get("align_module.spynet.std")
         self.spy_mean = tuple(float(v) for v in m.flatten()) if m is not None else _SPY_MEAN
         self.spy_std = tuple(float(v) for v in s.flatten()) if s is not None else _SPY_STD
 
+    def _pack_one(self, k: str, w: torch.Tensor):
+        """Repack one state-dict entry into its kernel-native form (called for all at load, and again for the trainable
+        convolutions after every optimizer step by gpemsr_amd/train.py)."""
+        sd, dev, nf, splits = self.sd, self.dev, self.nf, self._splits
+        ps = {"upconv1", "upconv2", "upconv3", "upconv4"}
+        if not k.endswith(".weight"):
+            return
+        name = k[:-7]
+        if name.startswith("refmodel.encoder.") or name.startswith("vgg.slice") and not name.startswith("vgg.slice1."):
+            return                                   # never evaluated in the stage-3 forward
+        b = sd.get(name + ".bias")
+        if w.dim() == 4 and name.endswith("dcnpack"):
+            self.pc[name] = pack_dcn(w, b, dev)
+        elif w.dim() == 4 and (name.startswith("reffea_L") or name.endswith(".upblock")):
+            self.pc[name] = pack_convT(w, b, dev)
+            if self.precision != "fp32" and w.shape[0] % 16 == 0:
+                self.pc[name].w16 = pack_convT_split(self.pc[name], dev)
+        elif name == "vgg.slice1.0":
+            self.pc[name] = pack_vgg_first(w, b, dev)
+        elif w.dim() == 4 and name.endswith((".q",)) and ".feat_extract." in name:
+            c = w.shape[0]
+            sc = float(int(c) ** (-0.5))
+            self.pc[name] = pack_conv(w, b, dev, scale=sc)                        # fold C^-1/2 (blocks.py:76)
+            if self.precision != "fp32" and c % 32 == 0:
+                self.pc[name].w16 = pack_conv_split(self.pc[name], w.detach().to(torch.float32) * sc, dev)
+        elif w.dim() == 4:
+            if name.endswith("_offset_conv1") and w.shape[1] == 2 * nf + 34:
+                w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 14))       # 162 -> 176 input channels
+            if self.precision != "fp32" and w.shape[1] == 8 and w.shape[2] == 7 and ".spynet." in name:
+                # SpyNet stems (8 -> 32, 7x7): zero-pad cin to 16 so they run on the split-bf16 kernel too
+                w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 8))
+            self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
+            kk = w.shape[2]
+            if self.precision != "fp32" and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
+                                             or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
+                self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
+        elif w.dim() == 2 and name.endswith("indexer.embedding"):
+            self.pc[name] = pack_linear(w, b, dev)
+        elif w.dim() == 2 and name.endswith("codebook.embedding"):
+            self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
+        elif w.dim() == 5:                             # ThreeDA.conv3D_{1,2}: [t,t,1,1,1]
+            self.par[k] = w.detach().to(torch.float32).reshape(w.shape[0], w.shape[1]).contiguous().to(dev)
+            self.par[name + ".bias"] = b.detach().to(torch.float32).contiguous().to(dev)
+        elif w.dim() == 1:                             # GroupNorm affine
+            self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
+            self.par[name + ".bias"] = b.detach().to(torch.float32).contiguous().to(dev)
+
     # ------------------------------------------------------------------ helpers
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
-        return ops.conv2d(srcs, self.pc[name], act, tag=name, precision=self.precision, **kw)
+        return self.o.conv2d(srcs, self.pc[name], act, tag=name, precision=self.precision, **kw)
 
     def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:
         """basicsr ResidualBlockNoBN chain; ``pixmul`` multiplies the output of the LAST block
@@ -141,10 +150,10 @@ class Engine:
     # ------------------------------------------------------------------ VQGAN prior
     def vq_resblock(self, x: Act, p: str) -> Act:
         t = self.conv(x, p + ".block.0")
-        ops.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
+        self.o.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
         u = self.conv(t, p + ".block.3")
         skip = self.conv(x, p + ".channel_up") if (p + ".channel_up") in self.pc else x
-        return ops.groupnorm_relu(u, self.par[p + ".block.4.weight"], self.par[p + ".block.4.bias"], True, residual=skip, out=u)
+        return self.o.groupnorm_relu(u, self.par[p + ".block.4.weight"], self.par[p + ".block.4.bias"], True, residual=skip, out=u)
 
     def nonlocal_block(self, x: Act, p: str) -> Act:
         """model/blocks.py:61-83 with the score matrix materialised per frame chunk."""
@@ -152,36 +161,36 @@ class Engine:
         T = h * w
         if T % 32 != 0 or c % 32 != 0:
             raise RuntimeError(f"gpemsr_amd: non-local block needs latent tokens ({T}) and channels ({c}) to be multiples of 32")
-        hn = ops.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
+        hn = self.o.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
         q = self.conv(hn, p + ".q")                       # already scaled by C^-1/2
         k = self.conv(hn, p + ".k")
         gh, gw = T // 32, 32                               # GEMM rows as 32-wide "images" (the conv tile is 4x32 pixels)
         # V^T[c][j] = sum_c' Wv[c][c'] hn[j][c']  (bias folded into the PV product: softmax rows sum to 1)
         wv = self.pc[p + ".v"]
         vT = self._vt(wv.w, hn, n, c, T)
-        out = ops.new_act(n, h, w, c, device=self.dev)
+        out = self.o.new_act(n, h, w, c, device=self.dev)
         fc = max(1, min(n, (1 << 30) // (T * T * 4)))      # frames per score-matrix chunk (<= 1 GiB)
         for f0 in range(0, n, fc):
             m = min(fc, n - f0)
             qa = q.images(f0, m).reshape_hw(gh, gw)
             kf, vf = k.images(f0, m), vT.images(f0, m)
             # bf16x3 / bf16: the B operands (k, v^T) are activations, so they are split + re-ordered on the device
-            k16 = ops.split_pack_rows(kf) if self.precision != "fp32" else None
-            S = ops.conv2d([qa], ops.PackedConv(kf.buf, None, 1, T, (c,), 32, w16=k16), ACT_NONE,
+            k16 = self.o.split_pack_rows(kf) if self.precision != "fp32" else None
+            S = self.o.conv2d([qa], self.o.PackedConv(kf.buf, None, 1, T, (c,), 32, w16=k16), ACT_NONE,
                            weight_image_stride=T * c, tag=p + ".qk", precision=self.precision)
             del k16
-            ops.softmax_rows_(S.buf, m * T, T)
-            v16 = ops.split_pack_rows(vf) if self.precision != "fp32" else None
-            ops.conv2d([S], ops.PackedConv(vf.buf, wv.b, 1, c, (T,), 32, w16=v16), ACT_NONE,
+            self.o.softmax_rows_(S.buf, m * T, T)
+            v16 = self.o.split_pack_rows(vf) if self.precision != "fp32" else None
+            self.o.conv2d([S], self.o.PackedConv(vf.buf, wv.b, 1, c, (T,), 32, w16=v16), ACT_NONE,
                        weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw), tag=p + ".pv",
                        precision=self.precision)
             del v16
         return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
 
     def _vt(self, wv_packed: torch.Tensor, hn: Act, n: int, c: int, T: int) -> Act:
-        vT = ops.new_act(n, c // 32, 32, T, device=self.dev)
+        vT = self.o.new_act(n, c // 32, 32, T, device=self.dev)
         a = Act(wv_packed, n, c // 32, 32, c, c, 0)        # n "images" that all alias the one [C][C] weight matrix
-        ops.conv2d([a], ops.PackedConv(hn.buf, None, 1, T, (c,), 32), ACT_NONE, weight_image_stride=T * c,
+        self.o.conv2d([a], self.o.PackedConv(hn.buf, None, 1, T, (c,), 32), ACT_NONE, weight_image_stride=T * c,
                    src_image_stride=[0], out=vT, tag="nonlocal.vT")
         return vT
 
@@ -209,11 +218,11 @@ class Engine:
 
     def ref_extract(self, xf: Act, forced_idx: Optional[torch.Tensor], trace: Optional[dict]) -> List[Act]:
         logits = self.indexer_logits(xf)
-        idx = ops.argmax_rows(logits) if forced_idx is None else forced_idx.to(torch.int32).contiguous()
+        idx = self.o.argmax_rows(logits) if forced_idx is None else forced_idx.to(torch.int32).contiguous()
         if trace is not None:
             trace.setdefault("logits", []).append(logits.torch().clone())
             trace.setdefault("code_idx", []).append(idx.clone())
-        x = ops.gather_rows(self.par["refmodel.codebook.embedding.weight"], idx, logits.n, logits.h, logits.w)
+        x = self.o.gather_rows(self.par["refmodel.codebook.embedding.weight"], idx, logits.n, logits.h, logits.w)
         del logits
         p = "refmodel.decoder"
         for i in range(_seq_len(self.sd, p + ".input_layer")):
@@ -233,14 +242,14 @@ class Engine:
     def vgg_mask(self, ref_img: Act, up_lr: Act) -> Act:
         """model/GPEMSR.py:386-395 for a chunk of frames -> cosine map [n,sH/16,sW/16,1]."""
         n = ref_img.n
-        out = ops.new_act(n, ref_img.h // 16, ref_img.w // 16, 1, device=self.dev)
+        out = self.o.new_act(n, ref_img.h // 16, ref_img.w // 16, 1, device=self.dev)
         per = max(1, (1 << 30) // (ref_img.h * ref_img.w * 64 * 4))
         for i0 in range(0, n, per):
             m = min(per, n - i0)
             fa = self.conv(self.conv(ref_img.images(i0, m), "vgg.slice1.0", ACT_RELU), "vgg.slice1.2", ACT_RELU)
             fb = self.conv(self.conv(up_lr.images(i0, m), "vgg.slice1.0", ACT_RELU), "vgg.slice1.2", ACT_RELU)
-            o = ops.patch_cosine(fa, fb)
-            ops.copy_channels(o, out.images(i0, m))
+            o = self.o.patch_cosine(fa, fb)
+            self.o.copy_channels(o, out.images(i0, m))
         return out
 
     # ------------------------------------------------------------------ per-frame front half
@@ -254,7 +263,7 @@ class Engine:
         Lr3 = self.conv(Lr2, "reffea_L3_conv1", ACT_LRELU)
         Lr4 = self.conv(Lr3, "reffea_L4_conv1", ACT_LRELU) if s == 16 else None
         ref_x16, ref_x8, ref_x4, ref_x2, ref_img = self.ref_extract(xf, forced_idx, trace)
-        up_lr = ops.bilinear(xf, s * H, s * W)
+        up_lr = self.o.bilinear(xf, s * H, s * W)
         mask = self.vgg_mask(ref_img, up_lr)
         del up_lr
         if trace is not None:
@@ -268,13 +277,13 @@ class Engine:
         else:
             fine, mid, coarse = Lr3, Lr2, L1
         r2 = self.conv([fine, ref_x2], "reffusionconv1")
-        r2 = self.resblocks_nobn(r2, "fusion_fea_block1", pixmul=ops.bilinear(mask, mh * 8, mw * 8))
+        r2 = self.resblocks_nobn(r2, "fusion_fea_block1", pixmul=self.o.bilinear(mask, mh * 8, mw * 8))
         r2 = self.conv(r2, "down_fea_conv1", stride=2)
         r4 = self.conv([mid, ref_x4, r2], "reffusionconv2")
-        r4 = self.resblocks_nobn(r4, "fusion_fea_block2", pixmul=ops.bilinear(mask, mh * 4, mw * 4))
+        r4 = self.resblocks_nobn(r4, "fusion_fea_block2", pixmul=self.o.bilinear(mask, mh * 4, mw * 4))
         r4 = self.conv([r4, r2], "down_fea_conv2", stride=2)
         r8 = self.conv([coarse, ref_x8, r4], "reffusionconv3")
-        r8 = self.resblocks_nobn(r8, "fusion_fea_block3", pixmul=ops.bilinear(mask, mh * 2, mw * 2))
+        r8 = self.resblocks_nobn(r8, "fusion_fea_block3", pixmul=self.o.bilinear(mask, mh * 2, mw * 2))
         if s == 16:
             r8 = self.conv([r8, r4], "down_fea_conv3", stride=2)
             r16 = self.conv([L1, ref_x16, r8], "reffusionconv4")
@@ -292,36 +301,40 @@ class Engine:
         h, w = ref.h, ref.w
         hf, wf = ((h + 31) // 32) * 32, ((w + 31) // 32) * 32
         if (hf, wf) != (h, w):
-            ref, supp = ops.bilinear(ref, hf, wf), ops.bilinear(supp, hf, wf)
+            ref, supp = self.o.bilinear(ref, hf, wf), self.o.bilinear(supp, hf, wf)
         rp, sp = [ref], [supp]
         for _ in range(5):
-            rp.insert(0, ops.avgpool2(rp[0])); sp.insert(0, ops.avgpool2(sp[0]))
+            rp.insert(0, self.o.avgpool2(rp[0])); sp.insert(0, self.o.avgpool2(sp[0]))
         flow = None
         p = "align_module.spynet.basic_module"
         for lvl in range(6):
-            up, inp = ops.spynet_prep(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std, pad16=self.precision != "fp32")
+            up, inp = self.o.spynet_prep(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std, pad16=self.precision != "fp32")
             t = self.conv(inp, f"{p}.{lvl}.basic_module.0", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.2", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.4", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.6", ACT_RELU)
             flow = self.conv(t, f"{p}.{lvl}.basic_module.8", ACT_NONE, residual=up)
         if (hf, wf) != (h, w):
-            out = ops.new_act(flow.n, h, w, 2, device=self.dev)
-            ops.bilinear(flow.slice(0, 1), h, w, mul=float(w) / float(wf), out=out.slice(0, 1))
-            ops.bilinear(flow.slice(1, 1), h, w, mul=float(h) / float(hf), out=out.slice(1, 1))
+            out = self.o.new_act(flow.n, h, w, 2, device=self.dev)
+            self.o.bilinear(flow.slice(0, 1), h, w, mul=float(w) / float(wf), out=out.slice(0, 1))
+            self.o.bilinear(flow.slice(1, 1), h, w, mul=float(h) / float(hf), out=out.slice(1, 1))
             flow = out
         return flow
 
     def dcn(self, x: Act, feat: Act, name: str, act: int) -> Act:
         om = self.conv(feat, name + ".conv_offset", force_mfma=True)
-        col = ops.dcn_columns(x, om, self.groups)
+        col = self.o.dcn_columns(x, om, self.groups)
         return self.conv(col, name, act)
 
     def pod(self, nbr: List[Act], ref: List[Act], nbr_frame: Act, ref_frame: Act, trace) -> Act:
         """POD.forward (model/GPEMSR.py:98-140) for P = 5*B' (neighbour, centre) pairs at once."""
         p = "align_module"
         P, H, W = nbr_frame.n, nbr_frame.h, nbr_frame.w
-        flow = self.spynet(ops.bilinear(nbr_frame, 4 * H, 4 * W), ops.bilinear(ref_frame, 4 * H, 4 * W))
+        if self._forced_flow is not None:      # teacher-forced SpyNet output [P,4H,4W,2] (gradient parity tests)
+            flow = self._forced_flow
+            assert (flow.n, flow.h, flow.w, flow.c) == (P, 4 * H, 4 * W, 2)
+        else:
+            flow = self.spynet(self.o.bilinear(nbr_frame, 4 * H, 4 * W), self.o.bilinear(ref_frame, 4 * H, 4 * W))
         if trace is not None:
             trace.setdefault("flow", []).append(flow.nchw())
         def flow_frames(h, w):      # [flow1 16 | flow2 16 | nbr_frame | ref_frame | 14 zeros]
@@ -336,28 +349,28 @@ class Engine:
         self.conv(fl2.slice(0, 16), p + ".flowdsconv2_1", stride=2, out=fl3.slice(0, 16))
         self.conv(fl2.slice(16, 16), p + ".flowdsconv2_2", stride=2, out=fl3.slice(16, 16))
         fr1 = fl1.slice(32, 2)
-        ops.copy_channels(nbr_frame, fr1.slice(0, 1)); ops.copy_channels(ref_frame, fr1.slice(1, 1))
-        ops.bilinear(fr1, H // 2, W // 2, out=fl2.slice(32, 2))
-        ops.bilinear(fl2.slice(32, 2), H // 4, W // 4, out=fl3.slice(32, 2))
+        self.o.copy_channels(nbr_frame, fr1.slice(0, 1)); self.o.copy_channels(ref_frame, fr1.slice(1, 1))
+        self.o.bilinear(fr1, H // 2, W // 2, out=fl2.slice(32, 2))
+        self.o.bilinear(fl2.slice(32, 2), H // 4, W // 4, out=fl3.slice(32, 2))
 
         o3 = self.conv([nbr[2], ref[2], fl3], p + ".L3_offset_conv1", ACT_LRELU)
         o3 = self.conv(o3, p + ".L3_offset_conv2", ACT_LRELU)
         f3 = self.dcn(nbr[2], o3, p + ".L3_dcnpack", ACT_LRELU)
 
         o2 = self.conv([nbr[1], ref[1], fl2], p + ".L2_offset_conv1", ACT_LRELU)
-        o3u = ops.bilinear(o3, o3.h * 2, o3.w * 2, mul=2.0)
+        o3u = self.o.bilinear(o3, o3.h * 2, o3.w * 2, mul=2.0)
         o2 = self.conv([o2, o3u], p + ".L2_offset_conv2", ACT_LRELU)
         o2 = self.conv(o2, p + ".L2_offset_conv3", ACT_LRELU)
         f2 = self.dcn(nbr[1], o2, p + ".L2_dcnpack", ACT_NONE)
-        f3u = ops.bilinear(f3, f3.h * 2, f3.w * 2)
+        f3u = self.o.bilinear(f3, f3.h * 2, f3.w * 2)
         f2 = self.conv([f2, f3u], p + ".L2_fea_conv", ACT_LRELU)
 
         o1 = self.conv([nbr[0], ref[0], fl1], p + ".L1_offset_conv1", ACT_LRELU)
-        o2u = ops.bilinear(o2, o2.h * 2, o2.w * 2, mul=2.0)
+        o2u = self.o.bilinear(o2, o2.h * 2, o2.w * 2, mul=2.0)
         o1 = self.conv([o1, o2u], p + ".L1_offset_conv2", ACT_LRELU)
         o1 = self.conv(o1, p + ".L1_offset_conv3", ACT_LRELU)
         f1 = self.dcn(nbr[0], o1, p + ".L1_dcnpack", ACT_NONE)
-        f2u = ops.bilinear(f2, f2.h * 2, f2.w * 2)
+        f2u = self.o.bilinear(f2, f2.h * 2, f2.w * 2)
         f1 = self.conv([f1, f2u], p + ".L1_fea_conv", ACT_NONE)
 
         off = self.conv([f1, ref[0]], p + ".cas_offset_conv1", ACT_LRELU)
@@ -368,28 +381,28 @@ class Engine:
     def three_da(self, aligned: Act, B: int) -> Act:
         """ThreeDA.forward (model/GPEMSR.py:172-222); aligned is [B*N,h,w,c], frame-major per tile."""
         p, N = "ThreeDA", self.N
-        centre = ops.copy_images(aligned, B, 1, N, self.center)
+        centre = self.o.copy_images(aligned, B, 1, N, self.center)
         emb_ref = self.conv(centre, p + ".temporal_attn1")
         emb = self.conv(aligned, p + ".temporal_attn2")
-        af = ops.temporal_gate(aligned, emb, emb_ref, B, N)
-        m1 = ops.frame_mix_lrelu(af, N, self.par[p + ".conv3D_1.weight"], self.par[p + ".conv3D_1.bias"])
+        af = self.o.temporal_gate(aligned, emb, emb_ref, B, N)
+        m1 = self.o.frame_mix_lrelu(af, N, self.par[p + ".conv3D_1.weight"], self.par[p + ".conv3D_1.bias"])
         f1 = self.conv(m1, p + ".conv3D_fusion_1", ACT_LRELU)
-        m2 = ops.frame_mix_lrelu(af, N, self.par[p + ".conv3D_2.weight"], self.par[p + ".conv3D_2.bias"])
+        m2 = self.o.frame_mix_lrelu(af, N, self.par[p + ".conv3D_2.weight"], self.par[p + ".conv3D_2.bias"])
         f2 = self.conv(m2, p + ".conv3D_fusion_2", ACT_LRELU)
         feat = self.conv(af, p + ".feat_fusion", ACT_LRELU, residual=f1)
         f3 = self.conv(feat, p + ".conv2D_fusion_3")
         attn = self.conv(af, p + ".spatial_attn1", ACT_LRELU)
-        attn = self.conv(ops.pool3s2_maxavg(attn), p + ".spatial_attn2", ACT_LRELU)
+        attn = self.conv(self.o.pool3s2_maxavg(attn), p + ".spatial_attn2", ACT_LRELU)
         lvl = self.conv(attn, p + ".spatial_attn_l1", ACT_LRELU)
-        lvl = self.conv(ops.pool3s2_maxavg(lvl), p + ".spatial_attn_l2", ACT_LRELU)
+        lvl = self.conv(self.o.pool3s2_maxavg(lvl), p + ".spatial_attn_l2", ACT_LRELU)
         lvl = self.conv(lvl, p + ".spatial_attn_l3", ACT_LRELU)
-        lvl = ops.bilinear(lvl, lvl.h * 2, lvl.w * 2)
+        lvl = self.o.bilinear(lvl, lvl.h * 2, lvl.w * 2)
         attn = self.conv(attn, p + ".spatial_attn3", ACT_LRELU, residual=lvl)
         attn = self.conv(attn, p + ".spatial_attn4", ACT_LRELU)
-        attn = ops.bilinear(attn, attn.h * 2, attn.w * 2)
+        attn = self.o.bilinear(attn, attn.h * 2, attn.w * 2)
         attn = self.conv(attn, p + ".spatial_attn5")
         add = self.conv(self.conv(attn, p + ".spatial_attn_add1", ACT_LRELU), p + ".spatial_attn_add2")
-        return ops.threeda_combine(feat, attn, add, f2, f3)
+        return self.o.threeda_combine(feat, attn, add, f2, f3)
 
     # ------------------------------------------------------------------ whole forward
     def _check_lr(self, H: int, W: int):
@@ -401,9 +414,9 @@ class Engine:
     def _front_all(self, xa: Act, forced_idx, trace):
         """Per-frame half (everything up to the L1/L2/L3 pyramid, model/GPEMSR.py:325-426) for all frames of ``xa``."""
         nfr, H, W, s = xa.n, xa.h, xa.w, self.scale
-        L1 = ops.new_act(nfr, H, W, 64, device=self.dev)
-        L2 = ops.new_act(nfr, H // 2, W // 2, 64, device=self.dev)
-        L3 = ops.new_act(nfr, H // 4, W // 4, 64, device=self.dev)
+        L1 = self.o.new_act(nfr, H, W, 64, device=self.dev)
+        L2 = self.o.new_act(nfr, H // 2, W // 2, 64, device=self.dev)
+        L3 = self.o.new_act(nfr, H // 4, W // 4, 64, device=self.dev)
         ref_img = torch.empty(nfr, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
         ref_act = Act(ref_img, nfr, H * s, W * s, 1, 1, 0)
         lat = (H // 2) * (W // 2) if s == 8 else H * W
@@ -411,8 +424,8 @@ class Engine:
             m = min(self.frame_chunk, nfr - f0)
             fi = None if forced_idx is None else forced_idx.reshape(-1)[f0 * lat:(f0 + m) * lat]
             r = self.front(xa.images(f0, m), fi, trace)
-            ops.copy_channels(r["L1"], L1.images(f0, m)); ops.copy_channels(r["L2"], L2.images(f0, m))
-            ops.copy_channels(r["L3"], L3.images(f0, m)); ops.copy_channels(r["ref_img"], ref_act.images(f0, m))
+            self.o.copy_channels(r["L1"], L1.images(f0, m)); self.o.copy_channels(r["L2"], L2.images(f0, m))
+            self.o.copy_channels(r["L3"], L3.images(f0, m)); self.o.copy_channels(r["ref_img"], ref_act.images(f0, m))
             del r
         if trace is not None:
             trace["L1_fused"] = L1.nchw()
@@ -425,16 +438,17 @@ class Engine:
         Wn = windows.shape[0]
         out = torch.empty(Wn, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
         out_act = Act(out, Wn, H * s, W * s, 1, 1, 0)
+        self._last_out_act = out_act
         for b0 in range(0, Wn, self.tile_chunk):
             bm = min(self.tile_chunk, Wn - b0)
             win = windows[b0:b0 + bm]
             nbr_idx = win.reshape(-1).contiguous()
             cen_idx = win[:, self.center].contiguous()
             ref_idx = cen_idx.repeat_interleave(N).contiguous()
-            nbr = [ops.gather_images(t, nbr_idx) for t in pyr]
-            ref = [ops.gather_images(t, ref_idx) for t in pyr]
-            nbr_frame = ops.gather_images(xa, nbr_idx)
-            ref_frame = ops.gather_images(xa, ref_idx)
+            nbr = [self.o.gather_images(t, nbr_idx) for t in pyr]
+            ref = [self.o.gather_images(t, ref_idx) for t in pyr]
+            nbr_frame = self.o.gather_images(xa, nbr_idx)
+            ref_frame = self.o.gather_images(xa, ref_idx)
             aligned = self.pod(nbr, ref, nbr_frame, ref_frame, trace)
             if trace is not None:
                 trace.setdefault("aligned", []).append(aligned.nchw().view(bm, N, 64, H, W))
@@ -456,7 +470,7 @@ class Engine:
             o = self.conv(o, "HRconv", ACT_LRELU)
             if trace is not None:
                 trace.setdefault("hr", []).append(o.nchw())
-            base = ops.bilinear(ops.gather_images(xa, cen_idx), H * s, W * s)
+            base = self.o.bilinear(self.o.gather_images(xa, cen_idx), H * s, W * s)
             self.conv(o, "conv_last", ACT_NONE, residual=base, out=out_act.images(b0, bm))
         return out
 

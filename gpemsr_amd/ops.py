@@ -19,11 +19,17 @@ from ._abi import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, ACT_SIGMOID 
 
 
 class Act:
-    """NHWC float32 activation view: channels [off, off+c) of ``buf`` [n,h,w,ld]."""
-    __slots__ = ("buf", "n", "h", "w", "c", "ld", "off")
+    """NHWC float32 activation view: channels [off, off+c) of ``buf`` [n,h,w,ld].
 
-    def __init__(self, buf: torch.Tensor, n: int, h: int, w: int, c: int, ld: int, off: int = 0):
+    Training (gpemsr_amd/train.py): every view remembers the ``root`` allocation it was cut from; the root owns one
+    zero-initialised gradient buffer of the same size (``gbuf``, created on first use) and a ``rg`` flag ("some
+    producer of this memory depends on a trainable parameter"), so ``a.grad()`` is the same view over the gradient."""
+    __slots__ = ("buf", "n", "h", "w", "c", "ld", "off", "root", "gbuf", "rg")
+
+    def __init__(self, buf: torch.Tensor, n: int, h: int, w: int, c: int, ld: int, off: int = 0, root: "Act" = None):
         self.buf, self.n, self.h, self.w, self.c, self.ld, self.off = buf, n, h, w, c, ld, off
+        self.root = root if root is not None else self
+        self.gbuf, self.rg = None, False
 
     @property
     def ptr(self) -> int:
@@ -33,25 +39,42 @@ class Act:
     def pixels(self) -> int:
         return self.n * self.h * self.w
 
+    @property
+    def requires_grad(self) -> bool:
+        return self.root.rg
+
+    def mark_grad(self):
+        self.root.rg = True
+        return self
+
+    def grad(self) -> "Act":
+        """The gradient of this view (same geometry) inside the root's zero-initialised gradient buffer."""
+        r = self.root
+        if r.gbuf is None:
+            r.gbuf = torch.zeros(r.buf.numel(), dtype=torch.float32, device=r.buf.device)
+        delta = (self.buf.data_ptr() - r.buf.data_ptr()) // 4
+        assert 0 <= delta and delta + self.buf.numel() <= r.gbuf.numel()
+        return Act(r.gbuf[delta:delta + self.buf.numel()], self.n, self.h, self.w, self.c, self.ld, self.off)
+
     def slice(self, c0: int, c: int) -> "Act":
         assert 0 <= c0 and c0 + c <= self.c
-        return Act(self.buf, self.n, self.h, self.w, c, self.ld, self.off + c0)
+        return Act(self.buf, self.n, self.h, self.w, c, self.ld, self.off + c0, self.root)
 
     def images(self, i0: int, cnt: int) -> "Act":
         """Sub-range of images [i0, i0+cnt) (shares memory)."""
         assert 0 <= i0 and i0 + cnt <= self.n
         flat = self.buf.view(-1)
         start = i0 * self.h * self.w * self.ld
-        return Act(flat[start:start + cnt * self.h * self.w * self.ld], cnt, self.h, self.w, self.c, self.ld, self.off)
+        return Act(flat[start:start + cnt * self.h * self.w * self.ld], cnt, self.h, self.w, self.c, self.ld, self.off, self.root)
 
     def reshape_hw(self, h: int, w: int) -> "Act":
         assert h * w == self.h * self.w
-        return Act(self.buf, self.n, h, w, self.c, self.ld, self.off)
+        return Act(self.buf, self.n, h, w, self.c, self.ld, self.off, self.root)
 
     def regroup(self, n: int) -> "Act":
         """View [n0,h,w,..] as n images of (n0/n)*h rows (pixel order unchanged)."""
         assert self.n % n == 0
-        return Act(self.buf, n, (self.n // n) * self.h, self.w, self.c, self.ld, self.off)
+        return Act(self.buf, n, (self.n // n) * self.h, self.w, self.c, self.ld, self.off, self.root)
 
     def torch(self) -> torch.Tensor:
         """[n,h,w,c] torch view (for tests / boundary)."""
@@ -446,3 +469,159 @@ def copy_images(src: Act, n_dst: int, div: int, mul: int, add: int) -> Act:
     _abi.check(_abi.load().gpemsr_copy_images(src.ptr, dst.ptr, n_dst, src.h * src.w * src.c, div, mul, add, _stream()),
                "copy_images")
     return dst
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Stage-3 training step: raw wrappers of the backward entry points (include/gpemsr_hip.h, "backward + optimizer").
+# Gradient arguments named d* are ACCUMULATED into (zero-initialised) buffers; gpemsr_amd/train.py drives them.
+# ----------------------------------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(floats: int, device) -> torch.Tensor:
+    """One growing scratch buffer per device (stream-ordered reuse: every consumer finishes before the next launch)."""
+    key = str(device)
+    t = _WS.get(key)
+    if t is None or t.numel() < floats:
+        t = torch.empty(max(int(floats), 1 << 20), dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
+def axpy(src: Act, dst: Act, alpha: float = 1.0):
+    assert src.pixels == dst.pixels and src.c == dst.c
+    _abi.check(_abi.load().gpemsr_axpy(src.ptr, src.ld, dst.ptr, dst.ld, src.pixels, src.c, float(alpha), _stream()), "axpy")
+
+
+def mul_pix(x: Act, m: Act, out: Optional[Act] = None) -> Act:
+    assert m.c == 1 and m.ld == 1 and m.pixels == x.pixels
+    if out is None:
+        out = new_act(x.n, x.h, x.w, x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_mul_pix(x.ptr, x.ld, m.ptr, x.pixels, x.c, out.ptr, out.ld, _stream()), "mul_pix")
+    return out
+
+
+def mul_pix_bwd(dy: Act, x: Act, m: Act, dx: Optional[Act], dm: Optional[Act]):
+    _abi.check(_abi.load().gpemsr_mul_pix_bwd(dy.ptr, dy.ld, x.ptr, x.ld, m.ptr, x.pixels, x.c, dx.ptr if dx is not None else None,
+                                              dx.ld if dx is not None else 0, dm.ptr if dm is not None else None, _stream()),
+               "mul_pix_bwd")
+
+
+def act_bwd(dy: Act, y: Act, n: int, h: int, w: int, c: int, act: int, pixel_shuffle: bool) -> Act:
+    dz = new_act(n, h, w, c, device=dy.buf.device)
+    _abi.check(_abi.load().gpemsr_act_bwd(dy.ptr, dy.ld, y.ptr, y.ld, n, h, w, c, act, int(pixel_shuffle), dz.ptr, dz.ld, _stream()),
+               "act_bwd")
+    return dz
+
+
+def bias_grad(dz: Act, db: torch.Tensor):
+    ws = _workspace(512 * dz.c, dz.buf.device)
+    _abi.check(_abi.load().gpemsr_bias_grad(dz.ptr, dz.pixels, dz.c, dz.ld, ws.data_ptr(), ws.numel(), db.data_ptr(), _stream()),
+               "bias_grad")
+
+
+def conv2d_wgrad(x: Act, dz: Act, ksize: int, stride: int, dw: torch.Tensor, cin_total: int, cin_off: int, tag: str = ""):
+    """dw (OIHW [cout][cin_total][k][k], contiguous) += wgrad of a conv whose input slice is ``x`` and output gradient ``dz``."""
+    lib = _abi.load()
+    assert x.n == dz.n and dw.is_contiguous()
+    need = lib.gpemsr_conv2d_wgrad_workspace(x.c, dz.c, ksize, dz.n, dz.h, dz.w)
+    ws = _workspace(min(need, 1 << 28), x.buf.device)
+    flops = 2.0 * dz.pixels * dz.c * x.c * ksize * ksize
+
+    def _go():
+        _abi.check(lib.gpemsr_conv2d_wgrad(x.ptr, x.ld, x.c, dz.ptr, dz.ld, dz.c, x.n, x.h, x.w, dz.h, dz.w, ksize, stride,
+                                           ws.data_ptr(), ws.numel(), dw.data_ptr(), cin_total, cin_off, _stream()), "conv2d_wgrad")
+    if PROFILER is not None:
+        PROFILER.run("conv_wgrad", tag, flops, _go)
+    else:
+        _go()
+
+
+def bilinear_bwd(dy: Act, dx: Act, align_corners: bool = False, mul: float = 1.0):
+    _abi.check(_abi.load().gpemsr_bilinear_bwd(dy.ptr, dy.ld, dx.n, dx.h, dx.w, dx.c, dy.h, dy.w, int(align_corners), float(mul),
+                                               dx.ptr, dx.ld, _stream()), "bilinear_bwd")
+
+
+def dcn_columns_bwd(x: Act, om: Act, groups: int, dcol: Act, dx: Optional[Act], dom: Optional[Act]):
+    assert dcol.ld == dcol.c == 9 * x.c
+    _abi.check(_abi.load().gpemsr_dcn_columns_bwd(x.ptr, x.n, x.h, x.w, x.c, x.ld, om.ptr, om.ld, groups, dcol.ptr,
+                                                  dx.ptr if dx is not None else None, dx.ld if dx is not None else 0,
+                                                  dom.ptr if dom is not None else None, dom.ld if dom is not None else 0, _stream()),
+               "dcn_columns_bwd")
+
+
+def temporal_gate_bwd(aligned: Act, emb: Act, emb_ref: Act, daf: Act, b: int, t: int, d_aligned: Act, d_emb: Act, d_emb_ref: Act):
+    for a in (aligned, emb, emb_ref, daf, d_aligned, d_emb, d_emb_ref):
+        assert a.ld == a.c
+    _abi.check(_abi.load().gpemsr_temporal_gate_bwd(aligned.ptr, emb.ptr, emb_ref.ptr, daf.ptr, b, t, aligned.h * aligned.w, aligned.c,
+                                                    d_aligned.ptr, d_emb.ptr, d_emb_ref.ptr, _stream()), "temporal_gate_bwd")
+
+
+def frame_mix_lrelu_bwd(af: Act, out: Act, dout: Act, t: int, m: torch.Tensor, d_af: Act, dm: torch.Tensor, dbias: torch.Tensor):
+    ws = _workspace(1024 * 32, af.buf.device)
+    _abi.check(_abi.load().gpemsr_frame_mix_lrelu_bwd(af.ptr, out.ptr, dout.ptr, af.pixels, t, af.c // t, m.data_ptr(), d_af.ptr,
+                                                      dm.data_ptr(), dbias.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "frame_mix_bwd")
+
+
+def pool3s2_maxavg_bwd(x: Act, dy: Act, dx: Act):
+    _abi.check(_abi.load().gpemsr_pool3s2_maxavg_bwd(x.ptr, x.n, x.h, x.w, x.c, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _stream()),
+               "pool3s2_bwd")
+
+
+def threeda_combine_bwd(feat: Act, attn: Act, dout: Act, dfeat: Act, dattn: Act, dadd: Act, df2: Act, df3: Act):
+    for a in (feat, attn, dout, dfeat, dattn, dadd, df2, df3):
+        assert a.ld == a.c
+    _abi.check(_abi.load().gpemsr_threeda_combine_bwd(feat.ptr, attn.ptr, dout.ptr, feat.pixels * feat.c, dfeat.ptr, dattn.ptr,
+                                                      dadd.ptr, df2.ptr, df3.ptr, _stream()), "threeda_combine_bwd")
+
+
+def maxpool2_bwd(x: Act, dy: Act, dx: Act):
+    _abi.check(_abi.load().gpemsr_maxpool2_bwd(x.ptr, x.n, x.h, x.w, x.c, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _stream()), "maxpool2_bwd")
+
+
+def scatter_add_images(dsrc: Act, idx: torch.Tensor, dtarget: Act):
+    assert dsrc.ld == dsrc.c and dtarget.ld == dtarget.c and dsrc.off == 0 and dtarget.off == 0
+    assert idx.dtype == torch.int32 and idx.numel() == dsrc.n
+    _abi.check(_abi.load().gpemsr_scatter_add_images(dsrc.ptr, idx.data_ptr(), dtarget.ptr, dtarget.n, dsrc.n,
+                                                     dsrc.h * dsrc.w * dsrc.c, _stream()), "scatter_add_images")
+
+
+def l1_loss(sr: torch.Tensor, gt: torch.Tensor, grad_scale: float, dsr: Optional[torch.Tensor]) -> torch.Tensor:
+    assert sr.numel() == gt.numel() and sr.is_contiguous() and gt.is_contiguous()
+    ws = _workspace(1024, sr.device)
+    loss = torch.empty(1, dtype=torch.float32, device=sr.device)
+    _abi.check(_abi.load().gpemsr_l1_loss(sr.data_ptr(), gt.data_ptr(), sr.numel(), float(grad_scale),
+                                          dsr.data_ptr() if dsr is not None else None, ws.data_ptr(), ws.numel(), loss.data_ptr(),
+                                          _stream()), "l1_loss")
+    return loss
+
+
+def gray_normalize3(x: Act, mean3, std3) -> Act:
+    assert x.c == 1 and x.ld == 1
+    out = new_act(x.n, x.h, x.w, 3, device=x.buf.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    sd = (C.c_float * 3)(*[float(v) for v in std3])
+    _abi.check(_abi.load().gpemsr_gray_normalize3(x.ptr, x.pixels, m, sd, out.ptr, _stream()), "gray_normalize3")
+    return out
+
+
+def gray_normalize3_bwd(g: Act, std3, dx: Act):
+    assert g.c == 3 and g.ld == 3 and dx.c == 1 and dx.ld == 1
+    sd = (C.c_float * 3)(*[float(v) for v in std3])
+    _abi.check(_abi.load().gpemsr_gray_normalize3_bwd(g.ptr, g.pixels, sd, dx.ptr, _stream()), "gray_normalize3_bwd")
+
+
+def transpose_images(a: Act) -> Act:
+    """[n][rows = h*w][cols = c] -> [n][c][h*w] as an Act with h*w channels."""
+    assert a.ld == a.c and a.off == 0
+    rows = a.h * a.w
+    out = new_act(a.n, 1, a.c, rows, device=a.buf.device)
+    _abi.check(_abi.load().gpemsr_transpose_images(a.ptr, out.ptr, a.n, rows, a.c, _stream()), "transpose_images")
+    return out
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+              weight_decay: float, step: int):
+    _abi.check(_abi.load().gpemsr_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
+                                            float(beta2), float(eps), float(weight_decay), int(step), _stream()), "adam_step")

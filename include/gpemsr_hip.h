@@ -209,6 +209,78 @@ int gpemsr_cx_reduce(const float* cx, const float* sim, int n, int rows, int col
  * 5-slice windows of output_GPEMSR.py:54-128 pick their frames' cached per-frame features instead of recomputing them. */
 int gpemsr_gather_images(const float* src, const int* idx, float* dst, int64_t n_dst, int64_t elems_per_image, void* stream);
 
+
+/* ===========================================================================================================
+ * Stage-3 training step, backward + optimizer (train_stage3.py:343-366: loss_total.backward(); optimizer_G.step()).
+ * The reference gets these from torch.autograd / torch.optim; each entry point names the ATen backward it stands for.
+ * Gradient outputs marked "+=" ACCUMULATE into caller-zeroed buffers (one contribution per consumer of a tensor).
+ * Data gradients of convolutions are convolutions: gpemsr_conv2d with re-packed weights (stride-2 convs <-> the
+ * transposed form), see gpemsr_amd/train.py.
+ * ========================================================================================================= */
+/* Weight gradient (aten::convolution_backward, grad_weight): dw[co][cin_off+ci][ky][kx] += sum_pixels dz * x.
+ * x: [n][h][w][x_ld] (channels [0,cin) used), dz: [n][oh][ow][dz_ld] (channels [0,cout)); ksize 1|3, pad k/2,
+ * stride 1|2|4; dw is the OIHW tensor [cout][cin_total][k][k].  ConvTranspose2d(k3,s2,p1,op1) weights [Cin][Cout][3][3]:
+ * call with x := dOut (2h x 2w, Cout channels), dz := the layer input (Cin channels), stride 2.
+ * ws: >= gpemsr_conv2d_wgrad_workspace(...) floats (fewer is legal: slabs get longer). f32 MFMA, deterministic. */
+int64_t gpemsr_conv2d_wgrad_workspace(int cin, int cout, int ksize, int n, int oh, int ow);
+int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const float* dz, int dz_ld, int cout, int n, int h, int w,
+                        int oh, int ow, int ksize, int stride, float* ws, int64_t ws_floats, float* dw, int cin_total,
+                        int cin_off, void* stream);
+/* dz = dy * act'(y) with act' taken from the saved OUTPUT y (relu/lrelu/sigmoid/lrelu_sigmoid backward); h,w,c are the
+ * conv-output geometry; pixel_shuffle = 1: dy/y are [n][2h][2w][c/4] and the nn.PixelShuffle(2) backward is applied. */
+int gpemsr_act_bwd(const float* dy, int dy_ld, const float* y, int y_ld, int n, int h, int w, int c, int act,
+                   int pixel_shuffle, float* dz, int dz_ld, void* stream);
+/* db[c] += sum_pixels dz (grad_bias); ws >= min(pixels,512)*c floats */
+int gpemsr_bias_grad(const float* dz, int64_t pixels, int c, int ld, float* ws, int64_t ws_floats, float* db, void* stream);
+/* dst += alpha * src on channel slices (gradient of a residual add / fan-out accumulation) */
+int gpemsr_axpy(const float* src, int src_ld, float* dst, int dst_ld, int64_t pixels, int c, float alpha, void* stream);
+/* out = x * m[pixel] (the MPF mask multiply, model/GPEMSR.py:403-411, un-fused in training) and its backward:
+ * dx += dy * m (dx may be NULL); dm[pixel] += sum_c dy * x */
+int gpemsr_mul_pix(const float* x, int x_ld, const float* m, int64_t pixels, int c, float* out, int out_ld, void* stream);
+int gpemsr_mul_pix_bwd(const float* dy, int dy_ld, const float* x, int x_ld, const float* m, int64_t pixels, int c,
+                       float* dx, int dx_ld, float* dm, void* stream);
+/* upsample_bilinear2d_backward: dx[n][h][w] += mul * sum of the (oh x ow) output gradients, gather form, same index rule
+ * as gpemsr_bilinear */
+int gpemsr_bilinear_bwd(const float* dy, int dy_ld, int n, int h, int w, int c, int oh, int ow, int align_corners, float mul,
+                        float* dx, int dx_ld, void* stream);
+/* torchvision deform_conv2d backward w.r.t. input (dx +=, float atomics; may be NULL), offsets and mask logits
+ * (dom += in the conv_offset channel layout); dcol is the gradient of gpemsr_dcn_columns' output */
+int gpemsr_dcn_columns_bwd(const float* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
+                           const float* dcol, float* dx, int dx_ld, float* dom, int dom_ld, void* stream);
+/* ThreeDA pieces (model/GPEMSR.py:179-221), all +=, dense c == 64 tensors */
+int gpemsr_temporal_gate_bwd(const float* aligned, const float* emb, const float* emb_ref, const float* daf, int b, int t,
+                             int hw, int c, float* d_aligned, float* d_emb, float* d_emb_ref, void* stream);
+int gpemsr_frame_mix_lrelu_bwd(const float* af, const float* out, const float* dout, int64_t pixels, int t, int c,
+                               const float* m, float* d_af, float* dm, float* dbias, float* ws, int64_t ws_floats, void* stream);
+int gpemsr_pool3s2_maxavg_bwd(const float* x, int n, int h, int w, int c, int ld, const float* dy, int dy_ld, float* dx,
+                              int dx_ld, void* stream);
+int gpemsr_threeda_combine_bwd(const float* feat, const float* attn, const float* dout, int64_t count, float* dfeat,
+                               float* dattn, float* dadd, float* df2, float* df3, void* stream);
+/* max_pool2d(2,2) backward (VGG, first maximum of a window wins as in ATen) */
+int gpemsr_maxpool2_bwd(const float* x, int n, int h, int w, int c, int ld, const float* dy, int dy_ld, float* dx, int dx_ld,
+                        void* stream);
+/* backward of gpemsr_gather_images / gpemsr_copy_images: dtarget[i] += sum_{j: idx[j]==i} dsrc[j] (fixed order) */
+int gpemsr_scatter_add_images(const float* dsrc, const int* idx, float* dtarget, int n_src, int n_dst, int64_t elems_per_image,
+                              void* stream);
+/* torch.nn.L1Loss()(GT, SR) (mean) -> loss[0]; dsr += grad_scale * sign(sr - gt) / count (dsr may be NULL); ws >= 1024 */
+int gpemsr_l1_loss(const float* sr, const float* gt, int64_t count, float grad_scale, float* dsr, float* ws, int64_t ws_floats,
+                   float* loss, void* stream);
+/* contextual_loss backward w.r.t. the similarity matrix (model/contextual.py:36-52 through autograd); scale = dL/d(cx_loss).
+ * idx_ws: n*cols int32, coef_ws: 2*n*cols floats; dsim [n][rows][cols] is written. */
+int gpemsr_cx_backward(const float* sim, const float* cx, const float* rmax, const float* cw, const float* cx_image, int n,
+                       int rows, int cols, float band_width, float scale, int32_t* idx_ws, float* coef_ws, float* dsim,
+                       void* stream);
+int gpemsr_cx_center_normalize_bwd(const float* x, const float* mean, const float* g, int64_t pixels, int c, int ld, int g_ld,
+                                   float* dx, int dx_ld, void* stream);
+/* 1-channel image -> the normalised 3-channel VGG input (train_stage3.py:356-358 + model/contextual.py:222-224) and back */
+int gpemsr_gray_normalize3(const float* x, int64_t pixels, const float* mean3, const float* std3, float* out, void* stream);
+int gpemsr_gray_normalize3_bwd(const float* g, int64_t pixels, const float* std3, float* dx, void* stream);
+/* per-image transpose dst[n][cols][rows] = src[n][rows][cols] (y^T for the dS . y^ product) */
+int gpemsr_transpose_images(const float* src, float* dst, int n, int rows, int cols, void* stream);
+/* torch.optim.Adam.step (train_stage3.py:163,365; no amsgrad), `step` counts from 1 */
+int gpemsr_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

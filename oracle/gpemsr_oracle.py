@@ -375,13 +375,16 @@ def patch_cosine(a: Tensor, b: Tensor) -> Tensor:
 
 
 def pod_align(sd: SD, p: str, nbr: List[Tensor], ref: List[Tensor], nbr_frame: Tensor, ref_frame: Tensor,
-              dedup_spynet: bool = True) -> Tensor:
+              dedup_spynet: bool = True, forced_flow: Optional[Tensor] = None) -> Tensor:
     """POD.forward, model/GPEMSR.py:98-140.  The reference evaluates SpyNet
     twice with identical arguments (:99-100); the results are identical, so the
     oracle evaluates it once unless ``dedup_spynet`` is False."""
     up_n, up_r = _bilinear(nbr_frame, 4), _bilinear(ref_frame, 4)
-    flow1 = spynet(sd, p + ".spynet", up_n, up_r)
-    flow2 = flow1 if dedup_spynet else spynet(sd, p + ".spynet", up_n, up_r)
+    if forced_flow is not None:        # teacher-forced SpyNet output (gradient parity tests: the flow is a constant input
+        flow1 = flow2 = forced_flow    # of the trainable part and SpyNet amplifies rounding differences to ~1e-3)
+    else:
+        flow1 = spynet(sd, p + ".spynet", up_n, up_r)
+        flow2 = flow1 if dedup_spynet else spynet(sd, p + ".spynet", up_n, up_r)
     L1_f1 = _conv(sd, p + ".flowdsconv0_1", flow1, 4, 1)
     L1_f2 = _conv(sd, p + ".flowdsconv0_2", flow2, 4, 1)
     L2_f1 = _conv(sd, p + ".flowdsconv1_1", L1_f1, 2, 1)
@@ -459,7 +462,7 @@ def three_da(sd: SD, p: str, aligned: Tensor, center: int) -> Tensor:
 
 
 def gpemsr_forward(sd: SD, x: Tensor, scale: int = 8, num_res_blocks_dec: int = 1,
-                   forced_idx: Optional[Tensor] = None, trace: Optional[dict] = None,
+                   forced_idx: Optional[Tensor] = None, trace: Optional[dict] = None, forced_flow: Optional[Tensor] = None,
                    as_written: bool = False) -> Tuple[Tensor, Tensor]:
     """GPEMSR.forward, model/GPEMSR.py:323-456.
 
@@ -534,7 +537,8 @@ def gpemsr_forward(sd: SD, x: Tensor, scale: int = 8, num_res_blocks_dec: int = 
     aligned = []
     for i in range(N):
         nbr_l = [L1v[:, i].clone(), L2v[:, i].clone(), L3v[:, i].clone()]
-        aligned.append(pod_align(sd, "align_module", nbr_l, ref_l, x[:, i], x_center, dedup_spynet=not as_written))
+        aligned.append(pod_align(sd, "align_module", nbr_l, ref_l, x[:, i], x_center, dedup_spynet=not as_written,
+                                 forced_flow=None if forced_flow is None else forced_flow[:, i]))
     aligned = torch.stack(aligned, dim=1)
     t["aligned"] = aligned
     fea = three_da(sd, "ThreeDA", aligned, center)

@@ -33,4 +33,4 @@ def deform_conv2d(input, offset, weight, bias=None, stride=1, padding=1, dilatio
     out = torch.einsum('bckhw,ock->bohw', cols, weight.reshape(Co, C, K))
     if bias is not None:
         out = out + bias.view(1, -1, 1, 1)
-    return out
+    return out.contiguous()          # torchvision returns a dense NCHW tensor (callers .view() it, model/GPEMSR.py:176)

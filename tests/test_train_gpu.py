@@ -1,0 +1,549 @@
+"""Stage-3 training step (train_stage3.py:343-366) on the HIP kernels, through the C ABI.
+
+Three layers of evidence:
+  1. known-answer tests of every backward entry point against torch CPU autograd of the matching functional op
+     (tight tolerance: these pin the kernels);
+  2. recorded-convolution tests: the data/weight/bias gradients of representative layers of the engine (stride 1 / 2,
+     transposed, PixelShuffle, multi-source with a padded source, 1-channel ends, un-fused residual and mask multiply)
+     against torch autograd with the same weights;
+  3. the end-to-end golden: losses, gradients of all 212 trainable tensors and the parameters after two Adam steps
+     against vectors emitted by the UNMODIFIED reference (oracle/gen_golden_train.py -> tests/golden/train_x8.npz).
+
+Tolerance of (3): the code indices and SpyNet flows of the frozen sub-networks are teacher-forced.  What remains is the
+conditioning of the gradient itself: LeakyReLU/ReLU kinks, max-pool arg-maxes and the floor() of the deformable sampling
+make it piecewise -- perturbing the weights by 1e-7 (relative) moves some POD-side gradient tensors by 2e-3 in the CPU
+oracle itself.  So tensors downstream of the alignment are held to 1e-3, the rest to 3e-2 with the
+median below 3e-3, and the kernels are pinned by (1) and (2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _to_act(x_nchw, dev, ld=None, off=0):
+    from gpemsr_amd import ops
+    n, c, h, w = x_nchw.shape
+    ld = c if ld is None else ld
+    buf = torch.full((n, h, w, ld), 7.0)
+    buf[..., off:off + c] = x_nchw.permute(0, 2, 3, 1)
+    return ops.Act(buf.to(dev).contiguous(), n, h, w, c, ld, off)
+
+
+def _zeros_like_act(a, ld=None, off=0):
+    from gpemsr_amd import ops
+    ld = a.c if ld is None else ld
+    return ops.Act(torch.zeros(a.n * a.h * a.w * ld, device=a.buf.device), a.n, a.h, a.w, a.c, ld, off)
+
+
+def _close(got, want, tol=2e-5, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    ref = max(want.abs().max().item(), 1e-6)
+    assert err <= tol * ref + 1e-7, f"{what}: max err {err:.3e} vs ref max {ref:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ (1) kernels
+WGRAD_CASES = [
+    # n, h, w, cin, cout, k, stride, x_ld, x_off, dz_ld
+    (2, 16, 16, 64, 64, 3, 1, None, 0, None),
+    (1, 20, 36, 34, 64, 3, 1, 48, 0, None),          # logical 34 channels of a 48-wide buffer (POD offset_conv1)
+    (2, 32, 32, 2, 16, 3, 4, None, 0, 48),           # flowdsconv0: stride 4, output is a slice of the 48-wide buffer
+    (2, 16, 16, 16, 16, 3, 2, 48, 16, 48),
+    (1, 16, 16, 64, 216, 3, 1, None, 0, None),
+    (2, 8, 8, 320, 64, 1, 1, None, 0, None),
+    (1, 64, 64, 64, 1, 3, 1, None, 0, None),         # conv_last
+    (1, 16, 16, 1, 64, 3, 1, None, 0, None),         # conv_first
+    (1, 18, 18, 128, 128, 3, 2, None, 0, None),
+    (3, 7, 45, 64, 64, 3, 1, None, 0, None),         # ragged tiles
+    (1, 16, 16, 576, 64, 1, 1, None, 0, None),       # DCN contraction
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv2d_wgrad(case):
+    from gpemsr_amd import ops
+    n, h, w, cin, cout, k, stride, x_ld, x_off, dz_ld = case
+    dev = _dev()
+    p = k // 2
+    oh, ow = (h + 2 * p - k) // stride + 1, (w + 2 * p - k) // stride + 1
+    x = _rand(n, cin, h, w, seed=1)
+    dz = _rand(n, cout, oh, ow, seed=2)
+    wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(x, wt, None, stride, p).backward(dz)
+    xa = _to_act(x, dev, x_ld, x_off)
+    dza = _to_act(dz, dev, dz_ld, 0)
+    cin_total, cin_off = cin + 5, 3
+    prior = _rand(cout, cin_total, k, k, seed=3)
+    dw = prior.clone().to(dev)
+    ops.conv2d_wgrad(xa, dza, k, stride, dw, cin_total, cin_off)
+    want = prior.clone()
+    want[:, cin_off:cin_off + cin] += wt.grad
+    _close(dw, want, 3e-5, "wgrad")                 # accumulates, leaves the other channels alone
+
+
+def test_conv2d_wgrad_transposed_roles():
+    """ConvTranspose2d(k3,s2,p1,op1) weight gradient = the stride-2 wgrad with x := dOut, dz := input."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    x = _rand(2, 64, 8, 12, seed=4)
+    wt = (_rand(64, 32, 3, 3, seed=5) * 0.1).requires_grad_(True)
+    go = _rand(2, 32, 16, 24, seed=6)
+    F.conv_transpose2d(x, wt, None, stride=2, padding=1, output_padding=1).backward(go)
+    dw = torch.zeros(64, 32, 3, 3, device=dev)
+    ops.conv2d_wgrad(_to_act(go, dev), _to_act(x, dev), 3, 2, dw, 32, 0)
+    _close(dw, wt.grad, 3e-5, "convT wgrad")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("ps", [False, True])
+def test_act_bwd(act, ps):
+    from gpemsr_amd import ops
+    dev = _dev()
+    z = _rand(2, 16, 6, 10, seed=7, scale=2.0).requires_grad_(True)
+    f = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.1), 3: torch.sigmoid,
+         4: lambda t: torch.sigmoid(F.leaky_relu(t, 0.1))}[act]
+    y = f(F.pixel_shuffle(z, 2) if ps else z)
+    gy = _rand(*y.shape, seed=8)
+    y.backward(gy)
+    dz = ops.act_bwd(_to_act(gy, dev), _to_act(y.detach(), dev), 2, 6, 10, 16, act, ps)
+    _close(dz.nchw(), z.grad, 1e-5, "act_bwd")
+
+
+def test_bias_grad_axpy_mulpix():
+    from gpemsr_amd import ops
+    dev = _dev()
+    dz = _rand(3, 216, 9, 11, seed=9)
+    db = torch.ones(216, device=dev)
+    ops.bias_grad(_to_act(dz, dev, 224, 4), db)
+    _close(db, 1.0 + dz.sum(dim=(0, 2, 3)), 2e-5, "bias_grad")
+    a, b = _rand(2, 20, 5, 7, seed=10), _rand(2, 20, 5, 7, seed=11)
+    bb = _to_act(b, dev, 24, 2)
+    ops.axpy(_to_act(a, dev), bb, 0.5)
+    _close(bb.nchw(), b + 0.5 * a, 1e-6, "axpy")
+    x = _rand(2, 64, 6, 8, seed=12).requires_grad_(True)
+    m = torch.rand(2, 1, 6, 8, generator=torch.Generator().manual_seed(13)).requires_grad_(True)
+    gy = _rand(2, 64, 6, 8, seed=14)
+    (x * m).backward(gy)
+    xa, ma = _to_act(x.detach(), dev), _to_act(m.detach(), dev)
+    _close(ops.mul_pix(xa, ma).nchw(), (x * m).detach(), 1e-6, "mul_pix")
+    dx, dm = _zeros_like_act(xa), _zeros_like_act(ma)
+    ops.mul_pix_bwd(_to_act(gy, dev), xa, ma, dx, dm)
+    _close(dx.nchw(), x.grad, 1e-6, "mul_pix dx")
+    _close(dm.nchw(), m.grad, 1e-5, "mul_pix dm")
+
+
+@pytest.mark.parametrize("cfg", [(8, 8, 16, 16, False), (6, 10, 24, 40, False), (8, 8, 64, 64, False), (16, 16, 8, 8, False),
+                                 (5, 7, 10, 14, True), (9, 6, 20, 17, False)])
+def test_bilinear_bwd(cfg):
+    from gpemsr_amd import ops
+    h, w, oh, ow, align = cfg
+    dev = _dev()
+    x = _rand(2, 3, h, w, seed=15).requires_grad_(True)
+    y = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=align) * 2.0
+    gy = _rand(*y.shape, seed=16)
+    y.backward(gy)
+    dx = _zeros_like_act(_to_act(x.detach(), dev), 4, 1)
+    ops.bilinear_bwd(_to_act(gy, dev), dx, align, 2.0)
+    _close(dx.nchw(), x.grad, 2e-5, "bilinear_bwd")
+
+
+def test_dcn_columns_bwd():
+    from gpemsr_amd import ops
+    from oracle import gpemsr_oracle as orc
+    dev = _dev()
+    B, C, H, W = 2, 64, 12, 10
+    x = _rand(B, C, H, W, seed=17).requires_grad_(True)
+    om = (_rand(B, 216, H, W, seed=18) * 2.5).requires_grad_(True)       # offsets reach outside the image
+    wt = (_rand(64, 64, 3, 3, seed=19) * 0.05)
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    y = orc.deform_conv2d_v2(x, torch.cat((o1, o2), 1), torch.sigmoid(m), wt, torch.zeros(64))
+    gy = _rand(*y.shape, seed=20)
+    y.backward(gy)
+    # HIP: col = dcn_columns(x, om); y = col . W1  ->  dcol = gy . W1^T (torch, plumbing of the test), then the kernel
+    w1 = wt.permute(0, 2, 3, 1).reshape(64, 9 * 64)                      # [cout][tap][cin]
+    dcol = torch.einsum("bohw,ok->bhwk", gy, w1).contiguous()
+    xa, oma = _to_act(x.detach(), dev), _to_act(om.detach(), dev)
+    col = ops.dcn_columns(xa, oma, 8)
+    ref_col_y = torch.einsum("bhwk,ok->bohw", col.torch().cpu(), w1)
+    _close(ref_col_y, y.detach(), 2e-5, "dcn forward through columns")
+    dx, dom = _zeros_like_act(xa), _zeros_like_act(oma)
+    ops.dcn_columns_bwd(xa, oma, 8, ops.from_nhwc(dcol.to(dev)), dx, dom)
+    _close(dx.nchw(), x.grad, 3e-5, "dcn dx")
+    _close(dom.nchw(), om.grad, 3e-5, "dcn d(offset, mask)")
+
+
+def test_threeda_pieces_bwd():
+    from gpemsr_amd import ops
+    dev = _dev()
+    b, t, c, h, w = 2, 5, 64, 6, 7
+    al = _rand(b * t, c, h, w, seed=21).requires_grad_(True)
+    emb = _rand(b * t, c, h, w, seed=22, scale=0.3).requires_grad_(True)
+    er = _rand(b, c, h, w, seed=23, scale=0.3).requires_grad_(True)
+    corr = torch.sigmoid((emb.view(b, t, c, h, w) * er[:, None]).sum(2, keepdim=True))
+    af = (al.view(b, t, c, h, w) * corr).reshape(b, t * c, h, w)
+    g = _rand(*af.shape, seed=24)
+    af.backward(g)
+    ala, ea, ra = _to_act(al.detach(), dev), _to_act(emb.detach(), dev), _to_act(er.detach(), dev)
+    afa = ops.temporal_gate(ala, ea, ra, b, t)
+    _close(afa.nchw(), af.detach(), 1e-5, "temporal_gate")
+    d1, d2, d3 = _zeros_like_act(ala), _zeros_like_act(ea), _zeros_like_act(ra)
+    ops.temporal_gate_bwd(ala, ea, ra, _to_act(g, dev), b, t, d1, d2, d3)
+    _close(d1.nchw(), al.grad, 1e-5, "d aligned"); _close(d2.nchw(), emb.grad, 2e-5, "d emb"); _close(d3.nchw(), er.grad, 2e-5, "d emb_ref")
+
+    # Conv3d(t,t,1) over the frame axis + LeakyReLU
+    x = _rand(b, t * c, h, w, seed=25).requires_grad_(True)
+    M = _rand(t, t, seed=26).requires_grad_(True)
+    bias = _rand(t, seed=27).requires_grad_(True)
+    y = F.leaky_relu(torch.einsum("ik,bkchw->bichw", M, x.view(b, t, c, h, w)) + bias.view(1, t, 1, 1, 1), 0.1).reshape(b, t * c, h, w)
+    gy = _rand(*y.shape, seed=28)
+    y.backward(gy)
+    xa = _to_act(x.detach(), dev)
+    Md, bd = M.detach().to(dev).contiguous(), bias.detach().to(dev).contiguous()
+    ya = ops.frame_mix_lrelu(xa, t, Md, bd)
+    _close(ya.nchw(), y.detach(), 1e-5, "frame_mix")
+    dxa, dM, dB = _zeros_like_act(xa), torch.zeros(t, t, device=dev), torch.zeros(t, device=dev)
+    ops.frame_mix_lrelu_bwd(xa, ya, _to_act(gy, dev), t, Md, dxa, dM, dB)
+    _close(dxa.nchw(), x.grad, 1e-5, "frame_mix dx"); _close(dM, M.grad, 3e-5, "frame_mix dM"); _close(dB, bias.grad, 3e-5, "frame_mix db")
+
+    # MaxPool2d(3,2,1) | AvgPool2d(3,2,1)
+    for hh, ww in ((8, 8), (7, 9)):
+        x = _rand(2, 16, hh, ww, seed=29).requires_grad_(True)
+        y = torch.cat([F.max_pool2d(x, 3, 2, 1), F.avg_pool2d(x, 3, 2, 1)], 1)
+        gy = _rand(*y.shape, seed=30)
+        y.backward(gy)
+        xa = _to_act(x.detach(), dev)
+        dxa = _zeros_like_act(xa)
+        ops.pool3s2_maxavg_bwd(xa, _to_act(gy, dev), dxa)
+        _close(dxa.nchw(), x.grad, 1e-5, "pool3s2 bwd")
+
+    # out = feat * sigmoid(attn) * 2 + add + f2 + f3
+    ts = [_rand(2, 64, 5, 6, seed=31 + i).requires_grad_(True) for i in range(5)]
+    out = ts[0] * torch.sigmoid(ts[1]) * 2 + ts[2] + ts[3] + ts[4]
+    go = _rand(*out.shape, seed=40)
+    out.backward(go)
+    acts = [_to_act(v.detach(), dev) for v in ts]
+    gs = [_zeros_like_act(a) for a in acts]
+    ops.threeda_combine_bwd(acts[0], acts[1], _to_act(go, dev), *gs)
+    for gi, v in zip(gs, ts):
+        _close(gi.nchw(), v.grad, 1e-5, "threeda_combine bwd")
+
+
+def test_maxpool2_scatter_l1_gray_bwd():
+    from gpemsr_amd import ops
+    dev = _dev()
+    x = F.relu(_rand(2, 8, 10, 12, seed=41)).requires_grad_(True)       # ties at 0 as after a ReLU
+    y = F.max_pool2d(x, 2, 2)
+    gy = _rand(*y.shape, seed=42)
+    y.backward(gy)
+    xa = _to_act(x.detach(), dev)
+    dxa = _zeros_like_act(xa)
+    ops.maxpool2_bwd(xa, _to_act(gy, dev), dxa)
+    keep = (x.detach() > 0)
+    _close(dxa.nchw().cpu() * keep, x.grad * keep, 1e-6, "maxpool2 bwd (positions a ReLU keeps)")
+    _close(dxa.nchw().cpu().sum(), x.grad.sum(), 1e-5, "maxpool2 bwd mass")
+
+    src = _rand(4, 8, 3, 4, seed=43)
+    idx = torch.tensor([2, 0, 2, 3, 2, 1, 0], dtype=torch.int32)
+    gd = _rand(7, 8, 3, 4, seed=44)
+    want = torch.zeros_like(src).index_add_(0, idx.long(), gd)
+    tgt = _zeros_like_act(_to_act(src, dev))
+    ops.scatter_add_images(_to_act(gd, dev), idx.to(dev), tgt)
+    _close(tgt.nchw(), want, 1e-6, "scatter_add_images")
+
+    sr = _rand(2, 1, 16, 16, seed=45).requires_grad_(True)
+    gt = _rand(2, 1, 16, 16, seed=46)
+    loss = torch.nn.L1Loss()(gt, sr) * 0.7
+    loss.backward()
+    dsr = torch.zeros(2, 1, 16, 16, device=dev)
+    got = ops.l1_loss(sr.detach().to(dev).contiguous(), gt.to(dev).contiguous(), 0.7, dsr)
+    _close(got[0] * 0.7, loss.detach(), 1e-6, "l1 value"); _close(dsr, sr.grad, 1e-6, "l1 grad")
+
+    from gpemsr_amd.train import VGG_MEAN, VGG_STD
+    x1 = torch.rand(2, 1, 6, 6, generator=torch.Generator().manual_seed(47)).requires_grad_(True)
+    m, s = torch.tensor(VGG_MEAN).view(1, 3, 1, 1), torch.tensor(VGG_STD).view(1, 3, 1, 1)
+    y3 = (x1.expand(-1, 3, -1, -1) - m) / s
+    g3 = _rand(2, 3, 6, 6, seed=48)
+    y3.backward(g3)
+    xa = _to_act(x1.detach(), dev)
+    _close(ops.gray_normalize3(xa, VGG_MEAN, VGG_STD).nchw(), y3.detach(), 1e-6, "gray_normalize3")
+    dxa = _zeros_like_act(xa)
+    ops.gray_normalize3_bwd(_to_act(g3, dev), VGG_STD, dxa)
+    _close(dxa.nchw(), x1.grad, 1e-6, "gray_normalize3 bwd")
+
+
+def test_adam_matches_torch():
+    from gpemsr_amd import ops
+    dev = _dev()
+    p0 = _rand(1000, seed=49)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=4e-4, betas=(0.9, 0.99))
+    p, m, v = p0.clone().to(dev), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for step in range(1, 4):
+        g = _rand(1000, seed=50 + step, scale=1e-3)
+        g[::7] = 0.0
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g.to(dev), m, v, 4e-4, 0.9, 0.99, 1e-8, 0.0, step)
+        _close(p, ref.detach(), 1e-6, f"adam step {step}")
+
+
+# ------------------------------------------------------------------------------------------------ trainer fixtures
+_TR = {}
+
+
+def _trainer():
+    if "t" not in _TR:
+        from gen_golden_train import TRAIN_OPT
+        from gpemsr_amd.config import build_model, load_options
+        from gpemsr_amd.train import Stage3Trainer
+        opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+        model = build_model(opt, load_prior_files=False).to(_dev())
+        _TR["t"] = Stage3Trainer(model, TRAIN_OPT, _dev())
+    return _TR["t"]
+
+
+def test_contextual_backward_matches_autograd():
+    """d CX / d features against torch autograd of the oracle's contextual_loss (x repeated t times)."""
+    from gpemsr_amd import ops
+    from oracle import gpemsr_oracle as orc
+    tr = _trainer()
+    dev = _dev()
+    b, t, c, h, w = 2, 3, 64, 8, 8
+    fx = F.relu(_rand(b, c, h, w, seed=60)).requires_grad_(True)
+    fy = F.relu(_rand(b * t, c, h, w, seed=61) + 0.2)
+    loss, _ = orc.contextual_loss(fx.repeat_interleave(t, dim=0), fy, 0.5)
+    (loss * 0.37).backward()
+    fxa = _to_act(fx.detach(), dev).mark_grad()
+    tr.eng.tape = []
+    got = tr.contextual_features(fxa, _to_act(fy, dev), t, 0.37)
+    for fn in reversed(tr.eng.tape):
+        fn()
+    tr.eng.tape = None
+    _close(got[0], loss.detach(), 1e-5, "cx loss")
+    _close(fxa.grad().nchw(), fx.grad, 2e-4, "d cx / d features")
+
+
+LAYER_CASES = [
+    # name, source channel widths (as the engine passes them), h, w, act, stride, with_residual, with_pixmul
+    ("recon_trunk.0.conv1", (64,), 16, 16, 1, 1, False, False),
+    ("recon_trunk.0.conv2", (64,), 12, 20, 0, 1, True, False),
+    ("fusion_fea_block1.0.conv2", (64,), 16, 16, 0, 1, True, True),
+    ("down_fea_conv1", (64,), 16, 16, 0, 2, False, False),
+    ("down_fea_conv2", (64, 64), 16, 32, 0, 2, False, False),
+    ("reffusionconv2", (64, 128, 64), 8, 8, 0, 1, False, False),
+    ("reffea_L2_conv1", (64,), 8, 12, 2, 1, False, False),
+    ("upconv1", (64,), 8, 8, 2, 1, False, False),
+    ("align_module.flowdsconv1_1", (16,), 16, 16, 0, 2, False, False),
+    ("align_module.L3_offset_conv1", (64, 64, 48), 8, 8, 2, 1, False, False),
+    ("align_module.L1_dcnpack.conv_offset", (64,), 8, 8, 0, 1, False, False),
+    ("refmaskconv3", (64,), 8, 8, 4, 1, False, False),
+    ("conv_last", (64,), 16, 32, 0, 1, True, False),
+    ("ThreeDA.feat_fusion", (320,), 8, 8, 2, 1, True, False),
+    ("reduce_dim_conv", (64, 128, 64), 8, 8, 0, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", LAYER_CASES)
+def test_recorded_convolution_backward(case):
+    """Engine.conv with the tape on: dX per source, dW, db (and d residual, d mask) against torch autograd."""
+    from gpemsr_amd import ops
+    name, widths, h, w, act, stride, with_res, with_mul = case
+    tr = _trainer()
+    eng, dev = tr.eng, _dev()
+    W = eng.sd[name + ".weight"].detach().cpu()
+    Bv = eng.sd[name + ".bias"].detach().cpu()
+    transposed = name.startswith("reffea_L")
+    ps = name.startswith("upconv")
+    cin_total = W.shape[0] if transposed else W.shape[1]
+    n = 2
+    xs, acts, c0 = [], [], 0
+    for i, cw in enumerate(widths):
+        ci = min(cw, cin_total - c0)
+        x = _rand(n, cw, h, w, seed=70 + i)
+        if ci < cw:
+            x[:, ci:] = 0.0                                             # padded channels of the 48-wide POD buffer
+        x.requires_grad_(True)
+        xs.append(x)
+        acts.append(_to_act(x.detach(), dev).mark_grad())
+        c0 += ci
+    xin = xs[0]
+    if len(xs) > 1:
+        pieces, c0 = [], 0
+        for x in xs:
+            ci = min(x.shape[1], cin_total - c0)
+            pieces.append(x[:, :ci]); c0 += ci
+        xin = torch.cat(pieces, 1)
+    Wt = W.clone().requires_grad_(True)
+    Bt = Bv.clone().requires_grad_(True)
+    if transposed:
+        z = F.conv_transpose2d(xin, Wt, Bt, stride=2, padding=1, output_padding=1)
+    else:
+        z = F.conv2d(xin, Wt, Bt, stride, W.shape[2] // 2)
+    if ps:
+        z = F.pixel_shuffle(z, 2)
+    y = {0: lambda v: v, 1: F.relu, 2: lambda v: F.leaky_relu(v, 0.1), 4: lambda v: torch.sigmoid(F.leaky_relu(v, 0.1))}[act](z)
+    res = mul = None
+    kw = {}
+    if with_res:
+        res = _rand(*y.shape, seed=80).requires_grad_(True)
+        y = y + res
+        kw["residual"] = _to_act(res.detach(), dev).mark_grad()
+    if with_mul:
+        mul = torch.rand(n, 1, y.shape[2], y.shape[3], generator=torch.Generator().manual_seed(81)).requires_grad_(True)
+        y = y * mul
+        kw["pixmul"] = _to_act(mul.detach(), dev).mark_grad()
+    gy = _rand(*y.shape, seed=82)
+    y.backward(gy)
+
+    base = name
+    tr.flat_g.zero_()
+    eng.tape = []
+    if stride != 1:
+        kw["stride"] = stride
+    out = eng.conv(acts if len(acts) > 1 else acts[0], name, act, **kw)
+    _close(out.nchw(), y.detach(), 2e-5, name + " forward")
+    ops.axpy(_to_act(gy, dev), out.grad())
+    for fn in reversed(eng.tape):
+        fn()
+    eng.tape = None
+    torch.cuda.synchronize()
+    _close(tr.gw[base], Wt.grad, 5e-5, name + " dW")
+    _close(tr.gb[base], Bt.grad, 5e-5, name + " db")
+    for x, a in zip(xs, acts):
+        ci = min(x.shape[1], cin_total)
+        _close(a.grad().nchw()[:, :ci], x.grad[:, :ci], 5e-5, name + " dX")
+    if with_res:
+        _close(kw["residual"].grad().nchw(), res.grad, 2e-5, name + " d residual")
+    if with_mul:
+        _close(kw["pixmul"].grad().nchw(), mul.grad, 5e-5, name + " d mask")
+    tr.flat_g.zero_()
+
+
+def test_dcn_layer_backward():
+    """Engine.dcn (conv_offset -> deformable columns -> contraction) against autograd of the oracle's DCNv2Pack."""
+    from gpemsr_amd import ops
+    from oracle import gpemsr_oracle as orc
+    tr = _trainer()
+    eng, dev = tr.eng, _dev()
+    p = "align_module.L1_dcnpack"
+    sd = {k: eng.sd[k].detach().cpu().clone().requires_grad_(True) for k in (p + ".weight", p + ".bias", p + ".conv_offset.weight", p + ".conv_offset.bias")}
+    x = _rand(2, 64, 10, 12, seed=90).requires_grad_(True)
+    feat = _rand(2, 64, 10, 12, seed=91, scale=3.0).requires_grad_(True)
+    y = orc.dcn_v2_pack(sd, p, x, feat)
+    gy = _rand(*y.shape, seed=92)
+    y.backward(gy)
+    xa, fa = _to_act(x.detach(), dev).mark_grad(), _to_act(feat.detach(), dev).mark_grad()
+    tr.flat_g.zero_()
+    eng.tape = []
+    out = eng.dcn(xa, fa, p, 0)
+    _close(out.nchw(), y.detach(), 3e-5, "dcn forward")
+    ops.axpy(_to_act(gy, dev), out.grad())
+    for fn in reversed(eng.tape):
+        fn()
+    eng.tape = None
+    _close(tr.gw[p], sd[p + ".weight"].grad, 5e-5, "dcn dW"); _close(tr.gb[p], sd[p + ".bias"].grad, 5e-5, "dcn db")
+    _close(tr.gw[p + ".conv_offset"], sd[p + ".conv_offset.weight"].grad, 1e-4, "conv_offset dW")
+    _close(xa.grad().nchw(), x.grad, 5e-5, "dcn dx"); _close(fa.grad().nchw(), feat.grad, 1e-4, "dcn dfeat")
+    tr.flat_g.zero_()
+
+
+# ------------------------------------------------------------------------------------------------ (3) the reference golden
+def test_two_training_steps_match_reference_golden(golden_dir):
+    from gen_golden_train import FULL, TRAIN_OPT, projection
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.train import Stage3Trainer
+    d = np.load(os.path.join(golden_dir, "train_x8.npz"))
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    model = build_model(opt, load_prior_files=False).to(dev)           # a fresh model: this test updates the weights
+    tr = Stage3Trainer(model, TRAIN_OPT, dev)
+    LR, GT = torch.from_numpy(d["LR"]).to(dev), torch.from_numpy(d["GT"]).to(dev)
+    idx, flow = torch.from_numpy(d["code_idx"]).to(dev), torch.from_numpy(d["flow"]).to(dev)
+    names = [str(n) for n in d["grad_names"]]
+    downstream = ("ThreeDA.", "recon_trunk.", "upconv", "HRconv", "conv_last")
+
+    # ---- step 1: losses, SR, every gradient tensor
+    rec, ref = tr.forward_backward(LR, GT, idx, flow)
+    torch.cuda.synchronize()
+    assert abs(rec.item() - float(d["rec_loss_1"])) <= 1e-5 * float(d["rec_loss_1"])
+    assert abs(ref.item() - float(d["ref_loss_1"])) <= 2e-5 * float(d["ref_loss_1"])
+    _close(tr.last_sr.view(d["SR"].shape), torch.from_numpy(d["SR"]), 1e-5, "SR")
+    errs = {}
+    for i, k in enumerate(names):
+        base, leaf = k.rsplit(".", 1)
+        g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().reshape(-1).double().cpu()
+        want = d["grad_stats"][i]
+        if want[0] == 0.0:                       # tensors the x8 graph never touches: no gradient in the reference
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        got = (g.norm().item(), (g * projection(k, g.numel())).sum().item())
+        errs[k] = max(abs(got[0] - want[0]), abs(got[1] - want[2])) / want[0]
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print("gradient parity, worst:", [(k, f"{e:.1e}") for k, e in worst], "median %.1e" % np.median(list(errs.values())))
+    for k, e in errs.items():
+        assert e <= (1e-3 if k.startswith(downstream) else 3e-2), f"{k}: gradient statistic off by {e:.2e}"
+    assert np.median(list(errs.values())) <= 3e-3
+    for k in FULL:
+        base, leaf = k.rsplit(".", 1)
+        g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().cpu().reshape(d["grad__" + k].shape)
+        _close(g, torch.from_numpy(d["grad__" + k]), 1e-3 if k.startswith(downstream) else 3e-2, "grad " + k)
+
+    # ---- Adam step 1 (+ scheduler), then step 2 from the updated weights
+    tr2 = Stage3Trainer(build_model(opt, load_prior_files=False).to(dev), TRAIN_OPT, dev)
+    o1 = tr2.step(LR, GT, idx, flow)
+    assert abs(o1["lr"] - float(d["lr_after_1"])) <= 1e-12
+    sdm = tr2.model.state_dict()
+    for k in FULL:                                # first Adam step moves every element by ~lr * sign(g): elements whose
+        want = torch.from_numpy(d["param1__" + k])          # gradient is within rounding of zero may go either way
+        got = sdm[k].detach().cpu().reshape(want.shape)
+        frac_bad = ((got - want).abs() > 1e-6 + 1e-4 * want.abs()).float().mean().item()
+        assert frac_bad <= 0.02, f"param after step 1 {k}: {frac_bad:.3f} of the elements differ"
+    o2 = tr2.step(LR, GT, idx, flow)
+    torch.cuda.synchronize()
+    assert abs(o2["rec_loss"].item() - float(d["rec_loss_2"])) <= 2e-3 * float(d["rec_loss_2"])
+    assert abs(o2["ref_loss"].item() - float(d["ref_loss_2"])) <= 2e-3 * float(d["ref_loss_2"])
+    assert abs(o2["lr"] - float(d["lr_after_2"])) <= 1e-12
+    print("step-2 losses", o2["rec_loss"].item(), float(d["rec_loss_2"]), o2["ref_loss"].item(), float(d["ref_loss_2"]))
+
+
+def test_training_reduces_the_loss_and_is_repeatable():
+    """Size-independent properties: a few steps on one batch lower the total loss; two trainers from the same state give
+    the same losses (only the deformable scatter uses float atomics: tolerance 1e-4, not bit equality)."""
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    topt = dict(lr_G=1e-4, beta1=0.9, beta2=0.99, T_period=[1000, 1000], restarts=[1000], restart_weights=[1], eta_min=1e-7,
+                rec_loss_factor=1, ref_loss_factor=0.001)
+    LR = synth_lr_tiles(1, 5, 32, 32, seed=5, kind="smooth").to(dev)           # the reference's training crop: 32 -> 256
+    GT = torch.rand(1, 1, 256, 256, generator=torch.Generator().manual_seed(6)).to(dev)
+    runs = []
+    for _ in range(2):
+        tr = Stage3Trainer(build_model(opt, load_prior_files=False).to(dev), topt, dev)
+        losses = []
+        for _ in range(4):
+            o = tr.step(LR, GT)
+            losses.append(o["rec_loss"].item() + 0.001 * o["ref_loss"].item())
+        runs.append(losses)
+    print("losses", runs[0])
+    assert all(np.isfinite(runs[0])) and runs[0][-1] < runs[0][0]
+    assert np.allclose(runs[0], runs[1], rtol=1e-4)
