@@ -1,0 +1,122 @@
+"""`bench.py --mode train`: BASELINE.json configs[4] -- the 8x EMSR stage-3 training step (forward + backward incl. the VGG
+contextual loss + Adam), batch 8 per GPU of the reference's training crops (LR 32x32 -> 256x256, option/train_stage3_x8.yml),
+one process per GPU, one RCCL all-reduce of the flat gradient buffer per step (weak scaling).  Same timing protocol as the
+forward bench: W warm-up steps, then exactly K steps between barrier + synchronize pairs, max over ranks."""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import torch
+
+PEAK_F32_MATRIX_TFLOPS = 157.3
+TRAIN_OPT = dict(lr_G=4e-4, beta1=0.9, beta2=0.99, lr_scheme="CosineAnnealingLR_Restart", T_period=[40000, 80000, 120000, 120000, 120000],
+                 restarts=[40000, 120000, 240000, 360000], restart_weights=[1, 1, 1, 1], eta_min=1e-7, rec_loss_factor=1,
+                 ref_loss_factor=0.001)                     # option/train_stage3_x8.yml:90-108
+
+
+def run(args, root: str, effective_cores):
+    from . import dist as gdist, ops
+    from .config import build_model, load_options
+    from .synth import synth_lr_tiles
+    from .train import Stage3Trainer
+
+    rank, world, local = gdist.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    s = args.scale
+    opt = load_options(os.path.join(root, "option", f"output_GPEMSR_x{s}.yml"))
+    model = build_model(opt, load_prior_files=False).to(dev)
+    trainer = Stage3Trainer(model, TRAIN_OPT, dev, world=world)
+    B = args.train_batch
+    lr = args.train_lr
+    LR = synth_lr_tiles(B, 5, lr, lr, seed=2000 + rank, kind="smooth").to(dev)
+    GT = torch.rand(B, 1, lr * s, lr * s, generator=torch.Generator().manual_seed(3000 + rank)).to(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(LR, GT)
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = None if args.no_profile else prof
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o = trainer.step(LR, GT)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * B * args.steps / dt
+    summ = prof.summary()
+    fam = {k: summ.get(k, {"launches": 0, "ms": 0.0, "flops": 0.0}) for k in ("conv_mfma", "conv_wgrad")}
+    flops = sum(v["flops"] for v in fam.values())
+    ms = sum(v["ms"] for v in fam.values())
+    launches = sum(v["launches"] for v in fam.values())
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    def tf(d):
+        return round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2) if d["ms"] > 0 else 0.0
+    roofline = {
+        "bound": "mfma", "kernel": "f32 MFMA convolution family of the step: conv_mfma_kernel (forward + data gradients) and wgrad_kernel "
+                                   "(weight gradients), v_mfma_f32_32x32x2_f32",
+        "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4),
+        "traffic": None,
+        "algorithmic_gflop_per_launch": round(flops / 1e9 / max(launches, 1), 3), "launches_per_step": launches // max(args.steps, 1),
+        "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
+        "forward_and_dgrad_tflops": tf(fam["conv_mfma"]), "wgrad_tflops": tf(fam["conv_wgrad"]),
+        "algorithmic_gflop_per_sample": round(flops / 1e9 / (B * args.steps), 1),
+        "kernel_time_share_of_step": round(ms * 1e-3 / dt, 3),
+    }
+    if args.layer_report and rank == 0:
+        rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
+        with open(args.layer_report, "w") as f:
+            f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\n")
+            for (kern, tag), d in rows:
+                f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{tf(d)}\n")
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded sample: ONE training sample (forward + both losses + backward) through the CPU oracle under torch autograd
+        from oracle import gpemsr_oracle as orc
+        cores = effective_cores()
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        for k, p in model.named_parameters():
+            if p.requires_grad:
+                sd[k].requires_grad_(True)
+        xc, gc = LR[:1].cpu(), GT[:1].cpu()
+        t1 = time.perf_counter()
+        out, ref = orc.gpemsr_forward(sd, xc, scale=s)
+        rec, refl, _ = orc.stage3_losses(sd, out, ref.detach(), gc)
+        (rec * TRAIN_OPT["rec_loss_factor"] + TRAIN_OPT["ref_loss_factor"] * refl).backward()
+        cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(1.0 / cdt, 5), "unit": "training samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": f"1 sample [1,5,1,{lr},{lr}] -> {lr * s}^2: forward + L1 + contextual loss + backward ({cdt:.1f} s) of "
+                                  "oracle/gpemsr_oracle.py under torch CPU autograd (no optimizer step)"}
+    if rank == 0:
+        line = {
+            "metric": f"stage-3 training samples/sec, {s}x EMSR (LR {lr}x{lr} -> {lr * s}x{lr * s} crops), batch {B}/GPU",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{s}x EMSR stage-3 training step (train_stage3.py:343-366): forward, L1 + 0.001 x contextual(VGG relu3_4) loss, "
+                                   f"backward, Adam; batch {B}/GPU of 5x1x{lr}x{lr} LR crops (BASELINE.json configs[4]; the reference's step has "
+                                   "no discriminator)", "batch_per_gpu": B, "global_batch": B * world, "lr": lr, "scale": s,
+                       "trainable_parameters": trainer.n_params,
+                       "weights": "deterministic synthetic init", "parallelism": f"data parallel over {world} GPU(s), one RCCL all-reduce of the "
+                       f"flat gradient buffer ({trainer.flat_g.numel() * 4 / 1e6:.1f} MB) per step" if world > 1 else "single GPU"},
+            "losses_last_step": {"rec": float(o["rec_loss"].item()), "ref": float(o["ref_loss"].item())},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()

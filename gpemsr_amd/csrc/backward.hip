@@ -68,12 +68,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* dz, lo
     __syncthreads();
   }
 }
+// one wave per channel: lane l sums blocks l, l+64, ..., then a fixed shuffle tree
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* ws, int blocks, int c, float* db) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ch >= c) return;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += ws[(long long)b * c + ch];
-  db[ch] += s;
+  for (int b = lane; b < blocks; b += 64) s += ws[(long long)b * c + ch];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) db[ch] += s;
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(const float* src, int src_ld, float* dst, int dst_ld, long long pixels, int c, float alpha) {
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void dcn_columns_bwd_kernel(const float* x, in
             float* dp = dx + sp * dx_ld + g * cg;
             const float wm = wts[q] * m;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) atomicAdd(dp + r, wm * dcv[r]);
+            for (int r = 0; r < 8; ++r) unsafeAtomicAdd(dp + r, wm * dcv[r]);      // hardware global_atomic_add_f32 (no CAS loop)
           }
         }
       }
@@ -483,11 +486,11 @@ extern "C" int gpemsr_act_bwd(const float* dy, int dy_ld, const float* y, int y_
 
 extern "C" int gpemsr_bias_grad(const float* dz, int64_t pixels, int c, int ld, float* ws, int64_t ws_floats, float* db, void* stream) {
   GP_REQUIRE(dz && ws && db && pixels > 0 && c > 0, "bias_grad: bad args");
-  int blocks = (int)(pixels < 512 ? pixels : 512);
+  int blocks = (int)(pixels < 256 ? pixels : 256);
   if ((int64_t)blocks * c > ws_floats) blocks = (int)(ws_floats / c);
   GP_REQUIRE(blocks >= 1, "bias_grad: workspace too small");
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, ST(stream), dz, (long long)pixels, c, ld, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 255) / 256), dim3(256), 0, ST(stream), ws, blocks, c, db);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((c + 3) / 4), dim3(256), 0, ST(stream), ws, blocks, c, db);
   return check_launch("bias_grad");
 }
 

@@ -4,10 +4,11 @@
 // (A) and the 32 cins (B) of an MFMA operand are contiguous, so a lane's operand register is ONE float read at
 // [pixel(lane>>5)][channel(lane&31)] -- no transposes anywhere.
 //
-// One 256-thread workgroup owns a 64(co) x 64(ci) block of dW for ALL k*k taps (wave w: co half w&1, ci half w>>1;
-// k*k accumulators of 32x32) and walks a slab of output tiles (TH rows x 32 pixels).  Per tile it stages the dZ tile
-// and the X halo tile ((TH-1)s+k rows x 31s+k cols) in LDS once; every tap reads the halo at a shifted offset (k*k-fold
-// reuse, as in the forward kernel).  LDS rows are only as wide as the channel block really is (1..64 floats), a lane
+// One 256-thread workgroup owns a 64(co) x 64(ci) block of dW for ONE FILTER ROW (k taps; wave w: co half w&1, ci half
+// w>>1; k accumulators of 32x32 = 48 VGPRs, so 4 workgroups share a CU) and walks a slab of output tiles (TH rows x 32
+// pixels).  Per tile it stages the dZ tile and the X rows that filter row touches (TH rows x 31s+k cols) in LDS once; the
+// k taps read them at shifted offsets.  Splitting the filter rows over workgroups instead of the pixel axis multiplies the
+// parallelism of the small training-crop layers by k without multiplying the partial-sum traffic.  LDS rows are only as wide as the channel block really is (1..64 floats), a lane
 // that reads past its row picks up finite-or-not garbage that lands in rows/cols of D which are never written back
 // (D[i][j] depends on A row i and B col j only).  Slabs write partial dW images [slab][tap][co][ci]; a second kernel
 // adds them in slab order into the OIHW gradient (+=), so the result is deterministic.
@@ -41,7 +42,7 @@ __device__ __forceinline__ float4 wg_load4(const float* row, int ch, int cmax, i
 }
 
 template <int KS>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams P) {
+__global__ __launch_bounds__(256, 4) void wgrad_kernel(WgradParams P) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -52,18 +53,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams P) {
   float* dzs = smem;
   float* xs = smem + P.th * 32 * P.cwz_max + 64;
   const bool active = cob < con && cib < cin_b;
-  constexpr int T = KS * KS;
-  f32x16 acc[T];
+  f32x16 acc[KS];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < KS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int slab = blockIdx.x;
+  const int slab = blockIdx.x / KS, ky = blockIdx.x % KS;                  // this workgroup's filter row
   const int t0 = slab * P.tiles_per_slab;
   const int t1 = min(t0 + P.tiles_per_slab, P.total_tiles);
   const int cz4 = cwz >> 2, cx4 = cwx >> 2;
-  const int npx = P.th * 32, nhp = P.hr * P.hc;
+  const int npx = P.th * 32, nhp = P.th * P.hc;
   for (int t = t0; t < t1; ++t) {
     const int tx = t % P.tiles_x, ty = (t / P.tiles_x) % P.tiles_y, img = t / (P.tiles_x * P.tiles_y);
     const int oy0 = ty * P.th, ox0 = tx * 32;
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams P) {
         v = wg_load4(P.dz + (((long long)img * P.oh + oy) * P.ow + ox) * P.dz_ld, co0 + 4 * c4, P.cout, P.dz_vec);
       *reinterpret_cast<float4*>(dzs + px * cwz + 4 * c4) = v;
     }
-    const int iy0 = oy0 * P.stride - P.pad, ix0 = ox0 * P.stride - P.pad;
+    const int ix0 = ox0 * P.stride - P.pad;
     for (int e = tid; e < nhp * cx4; e += 256) {
       const int c4 = e % cx4, hp = e / cx4;
-      const int iy = iy0 + hp / P.hc, ix = ix0 + hp % P.hc;
+      const int iy = (oy0 + hp / P.hc) * P.stride - P.pad + ky, ix = ix0 + hp % P.hc;      // LDS row r <-> output row oy0 + r
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w)
         v = wg_load4(P.x + (((long long)img * P.h + iy) * P.w + ix) * P.x_ld, ci0 + 4 * c4, P.cin, P.x_vec);
@@ -91,18 +91,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams P) {
       const float* bp = xs + lh * P.stride * cwx + cib + l31;
       for (int r = 0; r < P.th; ++r) {
         const float* ar = ap + r * 32 * cwz;
-        const float* br = bp + r * P.stride * P.hc * cwx;
-#pragma unroll 2
+        const float* br = bp + r * P.hc * cwx;
+#pragma unroll 4
         for (int cp = 0; cp < 16; ++cp) {
           const float a = ar[2 * cp * cwz];
           const float* bq = br + 2 * cp * P.stride * cwx;
 #pragma unroll
-          for (int ky = 0; ky < KS; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-              const float b = bq[(ky * P.hc + kx) * cwx];
-              acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ky * KS + kx], 0, 0, 0);
-            }
+          for (int kx = 0; kx < KS; ++kx)
+            acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[kx * cwx], acc[kx], 0, 0, 0);
         }
       }
     }
@@ -110,27 +106,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams P) {
   if (active) {
     const int ci = ci0 + cib + l31;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + cob + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (co < P.cout && ci < P.cin)
-          P.part[(((long long)slab * T + t) * P.cout + co) * P.cin + ci] = acc[t][r];
+          P.part[(((long long)slab * KS * KS + ky * KS + kx) * P.cout + co) * P.cin + ci] = acc[kx][r];
       }
   }
 }
 
-// dw[(co*cin_total + cin_off + ci)*taps + tap] += sum_slab part[slab][tap][co][ci]
+// dw[(co*cin_total + cin_off + ci)*taps + tap] += sum_slab part[slab][tap][co][ci].  64 consecutive elements per block, four
+// slab lanes each (lane q sums slabs q, q+4, ...), folded in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int slabs, int taps, int cout, int cin, float* dw,
                                                            int cin_total, int cin_off) {
   const long long total = (long long)taps * cout * cin;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int ci = (int)(e % cin);
-    const int co = (int)((e / cin) % cout);
-    const int tap = (int)(e / ((long long)cin * cout));
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  for (long long e0 = (long long)blockIdx.x * 64; e0 < total; e0 += (long long)gridDim.x * 64) {
+    const long long e = e0 + el;
     float s = 0.f;
-    for (int sl = 0; sl < slabs; ++sl) s += part[(long long)sl * total + e];
-    dw[((long long)co * cin_total + cin_off + ci) * taps + tap] += s;
+    if (e < total)
+      for (int sl = q; sl < slabs; sl += 4) s += part[(long long)sl * total + e];
+    red[q][el] = s;
+    __syncthreads();
+    if (q == 0 && e < total) {
+      const int ci = (int)(e % cin);
+      const int co = (int)((e / cin) % cout);
+      const int tap = (int)(e / ((long long)cin * cout));
+      dw[((long long)co * cin_total + cin_off + ci) * taps + tap] += (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    }
+    __syncthreads();
   }
 }
 
@@ -138,13 +144,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
 
 using namespace gpemsr;
 
+// slabs of the pixel axis: enough workgroups (slabs x filter rows x channel blocks) for ~4 per CU, at least 2 tiles each
+static long long wgrad_slabs(long long tiles, int cin, int cout, int ksize, long long* tps_out) {
+  const long long blocks = (long long)((cout + 63) / 64) * ((cin + 63) / 64) * ksize;
+  long long want = 1024 / blocks;
+  if (want < 1) want = 1;
+  long long tps = (tiles + want - 1) / want;
+  if (tps < 2) tps = 2;
+  *tps_out = tps;
+  return (tiles + tps - 1) / tps;
+}
+
 extern "C" int64_t gpemsr_conv2d_wgrad_workspace(int cin, int cout, int ksize, int n, int oh, int ow) {
   const int th = 2;
   const long long tiles = (long long)n * ((oh + th - 1) / th) * ((ow + 31) / 32);
-  long long tps = (tiles + 511) / 512;
-  if (tps < 2) tps = 2;
-  const long long slabs = (tiles + tps - 1) / tps;
-  return slabs * ksize * ksize * cout * cin;
+  long long tps;
+  return wgrad_slabs(tiles, cin, cout, ksize, &tps) * ksize * ksize * cout * cin;
 }
 
 extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const float* dz, int dz_ld, int cout, int n, int h, int w,
@@ -164,18 +179,17 @@ extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const floa
   P.cwz_max = cout >= 64 ? 64 : (cout + 3) & ~3;
   P.th = 2;
   P.hc = 31 * stride + ksize;
-  auto lds_bytes = [&](int th) { return (size_t)(th * 32 * P.cwz_max + 64 + ((th - 1) * stride + ksize) * P.hc * P.cwx_max + 64) * 4; };
+  auto lds_bytes = [&](int th) { return (size_t)(th * 32 * P.cwz_max + 64 + th * P.hc * P.cwx_max + 64) * 4; };
   if (lds_bytes(P.th) > 160 * 1024) P.th = 1;
   GP_REQUIRE(lds_bytes(P.th) <= 160 * 1024, "conv2d_wgrad: tile does not fit LDS");
-  P.hr = (P.th - 1) * stride + ksize;
+  P.hr = P.th;
   P.tiles_x = (ow + 31) / 32; P.tiles_y = (oh + P.th - 1) / P.th;
   const long long tiles = (long long)n * P.tiles_x * P.tiles_y;
   GP_REQUIRE(tiles < (1ll << 31), "conv2d_wgrad: too many tiles");
   P.total_tiles = (int)tiles;
   const long long per_slab = (long long)ksize * ksize * cout * cin;
-  long long tps = (tiles + 511) / 512;
-  if (tps < 2) tps = 2;
-  long long slabs = (tiles + tps - 1) / tps;
+  long long tps;
+  long long slabs = wgrad_slabs(tiles, cin, cout, ksize, &tps);
   if (slabs * per_slab > ws_floats) {                        // fewer, longer slabs if the workspace is small
     slabs = ws_floats / per_slab;
     GP_REQUIRE(slabs >= 1, "conv2d_wgrad: workspace too small (need >= %lld floats)", per_slab);
@@ -187,7 +201,7 @@ extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const floa
   P.dz_vec = (dz_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
   P.part = ws;
   const size_t lds = lds_bytes(P.th);
-  const dim3 grid((unsigned)slabs, (unsigned)((cout + 63) / 64), (unsigned)((cin + 63) / 64));
+  const dim3 grid((unsigned)(slabs * ksize), (unsigned)((cout + 63) / 64), (unsigned)((cin + 63) / 64));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (ksize == 3) {
     static bool attr3 = false;
@@ -199,7 +213,7 @@ extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const floa
     hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), lds, st, P);
   }
   const long long total = per_slab;
-  const long long rb = (total + 255) / 256;
+  const long long rb = (total + 63) / 64;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(rb < 32768 ? rb : 32768)), dim3(256), 0, st, ws, (int)slabs, ksize * ksize, cout, cin,
                      dw, cin_total, cin_off);
   return check_launch("conv2d_wgrad");
