@@ -29,7 +29,7 @@ def run(args, root: str, effective_cores):
     dev = torch.device("cuda", local)
     s = args.scale
     opt = load_options(os.path.join(root, "option", f"output_GPEMSR_x{s}.yml"))
-    model = build_model(opt, load_prior_files=False).to(dev)
+    model = build_model(opt, load_prior_files=False, precision=args.precision).to(dev)
     trainer = Stage3Trainer(model, TRAIN_OPT, dev, world=world)
     B = args.train_batch
     lr = args.train_lr
@@ -56,8 +56,10 @@ def run(args, root: str, effective_cores):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     value = world * B * args.steps / dt
+    n_params = trainer.n_params
     summ = prof.summary()
     fam = {k: summ.get(k, {"launches": 0, "ms": 0.0, "flops": 0.0}) for k in ("conv_mfma", "conv_wgrad")}
+    split = summ.get("conv_split")
     flops = sum(v["flops"] for v in fam.values())
     ms = sum(v["ms"] for v in fam.values())
     launches = sum(v["launches"] for v in fam.values())
@@ -76,6 +78,9 @@ def run(args, root: str, effective_cores):
         "algorithmic_gflop_per_sample": round(flops / 1e9 / (B * args.steps), 1),
         "kernel_time_share_of_step": round(ms * 1e-3 / dt, 3),
     }
+    if split is not None:
+        roofline["split_bf16_kernel"] = {"achieved_algorithmic_tflops": tf(split), "launches_per_step": split["launches"] // max(args.steps, 1),
+                                         "time_share_of_step": round(split["ms"] * 1e-3 / dt, 3)}
     if args.layer_report and rank == 0:
         rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
         with open(args.layer_report, "w") as f:
@@ -84,6 +89,7 @@ def run(args, root: str, effective_cores):
                 f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{tf(d)}\n")
 
     cpu_baseline = None
+    losses_fp32 = {"rec": float(o["rec_loss"].item()), "ref": float(o["ref_loss"].item())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded sample: ONE training sample (forward + both losses + backward) through the CPU oracle under torch autograd
         from oracle import gpemsr_oracle as orc
@@ -102,20 +108,44 @@ def run(args, root: str, effective_cores):
         cpu_baseline = {"value": round(1.0 / cdt, 5), "unit": "training samples/s", "cores": torch.get_num_threads(), "kind": "port",
                         "sample": f"1 sample [1,5,1,{lr},{lr}] -> {lr * s}^2: forward + L1 + contextual loss + backward ({cdt:.1f} s) of "
                                   "oracle/gpemsr_oracle.py under torch CPU autograd (no optimizer step)"}
+    extras = None
+    if world == 1 and args.precision == "fp32" and not args.no_extras:
+        # the same step with the FORWARD convolutions of the frozen sub-networks (VQGAN prior, VGG, SpyNet: about two thirds of
+        # the step's FLOPs, constants of the backward) on the split-bf16 kernel; trainable layers and all gradients stay f32
+        del trainer, model
+        torch.cuda.empty_cache()
+        m3 = build_model(opt, load_prior_files=False, precision="bf16x3").to(dev)
+        t3 = Stage3Trainer(m3, TRAIN_OPT, dev, world=world)
+        for _ in range(max(args.warmup, 1)):
+            t3.step(LR, GT)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            o3 = t3.step(LR, GT)
+        torch.cuda.synchronize()
+        d3 = time.perf_counter() - ta
+        extras = {"bf16x3_frozen_forward": {
+            "value": round(B * args.steps / d3, 3), "unit": "samples/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
+            "dtype": "frozen sub-networks' forward convolutions: fp32 operands split hi+lo bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate "
+                     "(fp32-grade, DESIGN 3.3); trainable layers, data and weight gradients: f32 MFMA",
+            "losses_last_step": {"rec": float(o3["rec_loss"].item()), "ref": float(o3["ref_loss"].item())},
+            "speedup_vs_fp32_step": round((dt / args.steps) / (d3 / args.steps), 3)}}
+        model = m3
     if rank == 0:
         line = {
             "metric": f"stage-3 training samples/sec, {s}x EMSR (LR {lr}x{lr} -> {lr * s}x{lr * s} crops), batch {B}/GPU",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "forward convolutions bf16x3 (split hi+lo bf16 MFMA, fp32 accumulate, fp32-grade); gradients f32",
+            "data": "synthetic",
             "config": {"workload": f"{s}x EMSR stage-3 training step (train_stage3.py:343-366): forward, L1 + 0.001 x contextual(VGG relu3_4) loss, "
                                    f"backward, Adam; batch {B}/GPU of 5x1x{lr}x{lr} LR crops (BASELINE.json configs[4]; the reference's step has "
                                    "no discriminator)", "batch_per_gpu": B, "global_batch": B * world, "lr": lr, "scale": s,
-                       "trainable_parameters": trainer.n_params,
+                       "trainable_parameters": n_params,
                        "weights": "deterministic synthetic init", "parallelism": f"data parallel over {world} GPU(s), one RCCL all-reduce of the "
-                       f"flat gradient buffer ({trainer.flat_g.numel() * 4 / 1e6:.1f} MB) per step" if world > 1 else "single GPU"},
-            "losses_last_step": {"rec": float(o["rec_loss"].item()), "ref": float(o["ref_loss"].item())},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+                       f"flat gradient buffer ({n_params * 4 / 1e6:.1f} MB) per step" if world > 1 else "single GPU"},
+            "losses_last_step": losses_fp32,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

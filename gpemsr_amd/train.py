@@ -33,7 +33,7 @@ from . import ops
 from .dist import average_gradients
 from .engine import Engine
 from .ops import ACT_NONE, ACT_RELU, Act
-from .packing import _pad_split, pack_conv
+from .packing import _pad_split, pack_conv, pack_conv_split
 
 VGG_MEAN = (0.485, 0.456, 0.406)
 VGG_STD = (0.229, 0.224, 0.225)
@@ -205,8 +205,8 @@ class TrainEngine(Engine):
 
     def __init__(self, sd, device, scale, nframes, groups, nf, dec_nrb, trainable, gw: Dict[str, torch.Tensor],
                  gb: Dict[str, torch.Tensor], precision: str = "fp32"):
+        self.trainable = set(trainable)                        # before the base constructor packs the weights
         super().__init__(sd, device, scale, nframes, groups, nf, dec_nrb, frame_chunk=1 << 20, tile_chunk=1 << 20, precision=precision)
-        self.trainable = set(trainable)
         self.gw, self.gb = gw, gb
         self.tape: Optional[list] = None
         self.o = TapeOps(self)
@@ -215,6 +215,8 @@ class TrainEngine(Engine):
             if kind == "conv":
                 key = f"vgg.slice{sl}.{idx}"
                 self.pc[key + "@rgb"] = pack_conv(sd[key + ".weight"], sd[key + ".bias"], device)
+                if precision != "fp32" and sd[key + ".weight"].shape[1] % 16 == 0:
+                    self.pc[key + "@rgb"].w16 = pack_conv_split(self.pc[key + "@rgb"], sd[key + ".weight"], device)
 
     def par_name(self, t: torch.Tensor) -> str:
         for k, v in self.par.items():
@@ -228,6 +230,13 @@ class TrainEngine(Engine):
             pc = _pack_convT_dev(w, self.dev)                  # per-step repack stays on the device
             pc.b = self.sd[name + ".bias"].detach().to(torch.float32).clone()
             self.pc[name] = pc
+            return
+        if name in getattr(self, "trainable", ()):             # trainable layers stay on the exact f32 kernel (their packed copy is
+            prec, self.precision = self.precision, "fp32"      # rebuilt every step; the split-bf16 packing is a host-side routine)
+            try:
+                super()._pack_one(k, w)
+            finally:
+                self.precision = prec
             return
         super()._pack_one(k, w)
 
@@ -396,7 +405,9 @@ class Stage3Trainer:
         _abi.load()
         self.model, self.dev, self.world = model, device, world
         assert all(p.is_cuda for p in model.parameters()), "move the model to the device first (model.to(device))"
-        assert model.precision == "fp32", "the training step is built for the exact-fp32 configuration"
+        # model.precision "fp32" (default, exact) or "bf16x3": the FORWARD convolutions (incl. the frozen prior / VGG, about two
+        # thirds of the step) run on the split-bf16 kernel (fp32-grade); data / weight gradients stay on the f32 pipe
+        assert model.precision in ("fp32", "bf16x3"), "training supports precision fp32 or bf16x3"
         self.opt = dict(opt_train)
         self.band_width = band_width
         # one flat buffer for the trainable parameters (and their gradient / Adam moments): the model's Parameters

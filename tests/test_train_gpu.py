@@ -547,3 +547,32 @@ def test_training_reduces_the_loss_and_is_repeatable():
     print("losses", runs[0])
     assert all(np.isfinite(runs[0])) and runs[0][-1] < runs[0][0]
     assert np.allclose(runs[0], runs[1], rtol=1e-4)
+
+
+def test_bf16x3_frozen_forward_meets_the_same_bar(golden_dir):
+    """precision='bf16x3' in training: the frozen sub-networks' forward convolutions on the split-bf16 kernel (fp32-grade);
+    losses and the gradients downstream of the alignment must stay within the fp32 path's tolerances of the reference."""
+    from gen_golden_train import TRAIN_OPT, projection
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.train import Stage3Trainer
+    d = np.load(os.path.join(golden_dir, "train_x8.npz"))
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    tr = Stage3Trainer(build_model(opt, load_prior_files=False, precision="bf16x3").to(dev), TRAIN_OPT, dev)
+    LR, GT = torch.from_numpy(d["LR"]).to(dev), torch.from_numpy(d["GT"]).to(dev)
+    rec, ref = tr.forward_backward(LR, GT, torch.from_numpy(d["code_idx"]).to(dev), torch.from_numpy(d["flow"]).to(dev))
+    torch.cuda.synchronize()
+    assert abs(rec.item() - float(d["rec_loss_1"])) <= 1e-4 * float(d["rec_loss_1"])
+    assert abs(ref.item() - float(d["ref_loss_1"])) <= 1e-3 * float(d["ref_loss_1"])
+    _close(tr.last_sr.view(d["SR"].shape), torch.from_numpy(d["SR"]), 1e-3, "SR")
+    names = [str(n) for n in d["grad_names"]]
+    errs = {}
+    for i, k in enumerate(names):
+        want = d["grad_stats"][i]
+        if want[0] == 0.0:
+            continue
+        base, leaf = k.rsplit(".", 1)
+        g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().reshape(-1).double().cpu()
+        errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
+    print("bf16x3 training: worst", sorted(errs.items(), key=lambda kv: -kv[1])[:3], "median %.1e" % np.median(list(errs.values())))
+    assert max(errs.values()) <= 5e-2 and np.median(list(errs.values())) <= 5e-3
