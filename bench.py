@@ -57,15 +57,19 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-by-the-driver) bf16x3 measurement")
     ap.add_argument("--cpu-lr", type=int, default=128, help="LR size of the CPU-oracle sample tile")
     ap.add_argument("--layer-report", type=str, default="", help="write a per-layer conv timing table to this file")
-    ap.add_argument("--mode", type=str, default="forward", choices=("forward", "train"),
-                    help="forward = BASELINE configs[1]/[2]/[3] (the headline metric, default); train = configs[4], the stage-3 training step")
+    ap.add_argument("--mode", type=str, default="forward", choices=("forward", "train", "train2"),
+                    help="forward = BASELINE configs[1]/[2]/[3] (the headline metric, default); train = configs[4], the stage-3 training step; train2 = the stage-2 (indexer) training step")
     ap.add_argument("--no-profile", action="store_true", help="--mode train: no per-launch HIP events (roofline fields become 0)")
     ap.add_argument("--train-batch", type=int, default=8, help="--mode train: samples per GPU per step")
+    ap.add_argument("--stage2-lr", type=int, default=128, help="--mode train2: LR size (GT is scale x larger; train_stage2_x8.yml: 1024 / 8)")
     ap.add_argument("--train-lr", type=int, default=32, help="--mode train: LR crop size (option/train_stage3_x8.yml LQ_size)")
     args = ap.parse_args()
     if args.mode == "train":
         from gpemsr_amd import bench_train
         return bench_train.run(args, ROOT, effective_cores)
+    if args.mode == "train2":
+        from gpemsr_amd import bench_train
+        return bench_train.run_stage2(args, ROOT, effective_cores)
 
     from gpemsr_amd import dist as gdist, ops
     from gpemsr_amd.config import build_model, load_options

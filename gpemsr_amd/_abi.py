@@ -31,6 +31,8 @@ SYMBOLS = [
     "gpemsr_pool3s2_maxavg_bwd", "gpemsr_threeda_combine_bwd", "gpemsr_maxpool2_bwd", "gpemsr_scatter_add_images", "gpemsr_l1_loss",
     "gpemsr_cx_backward", "gpemsr_cx_center_normalize_bwd", "gpemsr_gray_normalize3", "gpemsr_gray_normalize3_bwd",
     "gpemsr_transpose_images", "gpemsr_adam_step",
+    # stage-2 (indexer) training step
+    "gpemsr_groupnorm_bwd", "gpemsr_softmax_bwd_rows", "gpemsr_cross_entropy",
 ]
 
 
@@ -126,6 +128,9 @@ def load():
     lib.gpemsr_gray_normalize3_bwd.argtypes = [p, i64, f3, p, p]
     lib.gpemsr_transpose_images.argtypes = [p, p, i32, i32, i32, p]
     lib.gpemsr_adam_step.argtypes = [p, p, p, p, i64, f32, f32, f32, f32, f32, i32, p]
+    lib.gpemsr_groupnorm_bwd.argtypes = [p, i32, p, i32, i32, i32, i32, i32, p, p, p, i32, p, i64, p, i32, p, p, p]
+    lib.gpemsr_softmax_bwd_rows.argtypes = [p, p, i64, i32, p]
+    lib.gpemsr_cross_entropy.argtypes = [p, p, i64, i32, f32, p, p, p, p]
     lib.gpemsr_device_info.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     _lib = lib
     return lib

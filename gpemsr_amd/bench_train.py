@@ -150,3 +150,93 @@ def run(args, root: str, effective_cores):
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def run_stage2(args, root: str, effective_cores):
+    """`bench.py --mode train2`: the stage-2 (indexer) training step, train_stage2.py:351-366, at the reference's geometry
+    (option/train_stage2_x8.yml: batch 8, GT 1024x1024 -> LR 128x128), same timing protocol."""
+    from . import dist as gdist, ops
+    from .config import build_model, load_options
+    from .synth import synth_lr_tiles
+    from .train_stage2 import Stage2Trainer
+
+    rank, world, local = gdist.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    s = args.scale
+    opt = load_options(os.path.join(root, "option", f"output_GPEMSR_x{s}.yml"))
+    model = build_model(opt, load_prior_files=False).to(dev)
+    topt = dict(TRAIN_OPT, restarts=[40000, 80000, 240000, 360000])          # option/train_stage2_x8.yml:78-86
+    trainer = Stage2Trainer(model, topt, dev, world=world)
+    B, lr = args.train_batch, args.stage2_lr
+    LR = synth_lr_tiles(B, 1, lr, lr, seed=4000 + rank, kind="smooth")[:, 0].contiguous().to(dev)
+    GT = synth_lr_tiles(B, 1, lr * s, lr * s, seed=5000 + rank, kind="smooth")[:, 0].contiguous().to(dev)
+    for _ in range(args.warmup):
+        trainer.step(LR, GT)
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = None if args.no_profile else prof
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        o = trainer.step(LR, GT)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    summ = prof.summary()
+    fam = {k: summ.get(k, {"launches": 0, "ms": 0.0, "flops": 0.0}) for k in ("conv_mfma", "conv_wgrad")}
+    flops, ms = sum(v["flops"] for v in fam.values()), sum(v["ms"] for v in fam.values())
+    launches = sum(v["launches"] for v in fam.values())
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    def tf(d):
+        return round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2) if d["ms"] > 0 else 0.0
+    if args.layer_report and rank == 0:
+        rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
+        with open(args.layer_report, "w") as f:
+            f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\n")
+            for (kern, tag), d in rows:
+                f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{tf(d)}\n")
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import gpemsr_oracle as orc
+        torch.set_num_threads(effective_cores())
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        for k in list(sd):
+            if k.startswith("refmodel.indexer."):
+                sd[k].requires_grad_(True)
+        t1 = time.perf_counter()
+        loss, _, _ = orc.stage2_loss(sd, LR[:1].cpu(), GT[:1].cpu())
+        loss.backward()
+        cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(1.0 / cdt, 5), "unit": "training samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": f"1 sample (LR {lr}^2, GT {lr * s}^2): encoder + nearest code + indexer + cross-entropy + backward ({cdt:.1f} s) of "
+                                  "oracle/gpemsr_oracle.py under torch CPU autograd"}
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"stage-2 (indexer) training samples/sec, {s}x (GT {lr * s}x{lr * s} -> LR {lr}x{lr}), batch {B}/GPU",
+            "value": round(world * B * args.steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"stage-2 training step (train_stage2.py:351-366): frozen Encoder(GT) + nearest codebook vector -> targets; "
+                                   f"Indexer{s}(LR) -> logits; cross-entropy, backward, Adam; batch {B}/GPU (option/train_stage2_x{s}.yml geometry)",
+                       "batch_per_gpu": B, "lr": lr, "scale": s, "trainable_parameters": trainer.n_params,
+                       "parallelism": f"data parallel over {world} GPU(s), one RCCL all-reduce of the flat gradient buffer" if world > 1 else "single GPU"},
+            "loss_last_step": float(o["loss"].item()),
+            "roofline": {"bound": "mfma", "kernel": "f32 MFMA convolution family (forward incl. attention GEMMs, data gradients, wgrad_kernel)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None, "launches_per_step": launches // max(args.steps, 1),
+                         "forward_and_dgrad_tflops": tf(fam["conv_mfma"]), "wgrad_tflops": tf(fam["conv_wgrad"]),
+                         "kernel_time_share_of_step": round(ms * 1e-3 / dt, 3)},
+            "cpu_baseline": cpu_baseline}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()

@@ -95,8 +95,9 @@ class Engine:
         if not k.endswith(".weight"):
             return
         name = k[:-7]
-        if name.startswith("refmodel.encoder.") or name.startswith("vgg.slice") and not name.startswith("vgg.slice1."):
-            return                                   # never evaluated in the stage-3 forward
+        if (name.startswith("refmodel.encoder.") and not getattr(self, "pack_encoder", False)) or \
+                name.startswith("vgg.slice") and not name.startswith("vgg.slice1."):
+            return                                   # never evaluated in the stage-3 forward (stage 2 packs the encoder)
         b = sd.get(name + ".bias")
         if w.dim() == 4 and name.endswith("dcnpack"):
             self.pc[name] = pack_dcn(w, b, dev)

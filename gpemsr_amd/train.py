@@ -211,6 +211,7 @@ class TrainEngine(Engine):
         self.tape: Optional[list] = None
         self.o = TapeOps(self)
         self._dpc: Dict[tuple, ops.PackedConv] = {}
+        self.wscale: Dict[str, float] = {}                     # layers whose packed forward weights carry a folded scale
         for sl, idx, kind in _VGG_TO_RELU3_4:                  # the loss network sees RGB: pack slices 1-3 as they are
             if kind == "conv":
                 key = f"vgg.slice{sl}.{idx}"
@@ -292,6 +293,10 @@ class TrainEngine(Engine):
         if pc is not None:
             return pc
         w = self.sd[name.split("@")[0] + ".weight"].detach().to(torch.float32)
+        if w.dim() == 2:                                       # nn.Linear on NHWC == 1x1 conv
+            w = w[:, :, None, None]
+        if name in self.wscale:                                # weights packed with a folded scale (attention q)
+            w = w * self.wscale[name]
         if kind == "s1":          # stride-1 conv: rotate the taps, swap in/out channels
             pc = pack_conv(w[:, c0:c1].permute(1, 0, 2, 3).flip(2, 3), None, self.dev)
         elif kind == "s2":        # stride-2 conv k3 p1: its data gradient is ConvTranspose2d(k3,s2,p1,op1) with the same tensor
@@ -314,6 +319,8 @@ class TrainEngine(Engine):
         pc = self.pc[name]
         wkey = name.split("@")[0]
         w = self.sd[wkey + ".weight"]
+        if w.dim() == 2:
+            w = w[:, :, None, None]
         dY = y.grad()
         ps = pc.pixel_shuffle
         is_dcn = name.endswith("dcnpack")
@@ -329,10 +336,16 @@ class TrainEngine(Engine):
             dZ = dY
         if residual is not None and residual.requires_grad:
             ops.axpy(dY, residual.grad())
+        sc = self.wscale.get(name)
         if trainable:
             gb = self.gb.get(wkey)
             if gb is not None:
-                ops.bias_grad(dZ, gb)
+                if sc is None:
+                    ops.bias_grad(dZ, gb)
+                else:                                          # y = (sc*W) x + sc*b: d/db = sc * sum dZ
+                    tmp = torch.zeros_like(gb)
+                    ops.bias_grad(dZ, tmp)
+                    gb.add_(tmp, alpha=sc)
         if is_dcn:                                            # srcs = [col]; weight [cout][cin][3][3] <-> 1x1 over [9*cin]
             col = srcs[0]
             if trainable:
@@ -358,7 +371,12 @@ class TrainEngine(Engine):
             ci = min(s.c, cin_total - c0)                     # logical channels of this source (a padded buffer may be wider)
             xs = s if ci == s.c else s.slice(0, ci)
             if trainable:
-                ops.conv2d_wgrad(xs, dZ, k, stride, self.gw[wkey], cin_total, c0, tag=name)
+                if sc is None:
+                    ops.conv2d_wgrad(xs, dZ, k, stride, self.gw[wkey], cin_total, c0, tag=name)
+                else:
+                    tmpw = torch.zeros_like(self.gw[wkey])
+                    ops.conv2d_wgrad(xs, dZ, k, stride, tmpw, cin_total, c0, tag=name)
+                    self.gw[wkey].add_(tmpw, alpha=sc)
             if s.requires_grad:
                 g = xs.grad()
                 if stride == 1:
@@ -395,6 +413,32 @@ class TrainEngine(Engine):
         return self._last_out_act, ref_img
 
 
+def flatten_parameters(named, device):
+    """One flat fp32 buffer for the given (name, Parameter) list plus same-sized gradient / Adam-moment buffers; the
+    Parameters become views of the first (state_dict() / checkpoints always show the current weights).  Returns
+    (flat_p, flat_g, flat_m, flat_v, gw, gb, names): gw / gb map a layer name to the gradient view of its weight / bias."""
+    sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]
+    total = sum(sizes)
+    flat_p = torch.zeros(total, dtype=torch.float32, device=device)
+    flat_g = torch.zeros(total, dtype=torch.float32, device=device)
+    flat_m = torch.zeros(total, dtype=torch.float32, device=device)
+    flat_v = torch.zeros(total, dtype=torch.float32, device=device)
+    gw, gb, off, names = {}, {}, 0, set()
+    for (k, p), sz in zip(named, sizes):
+        view = flat_p[off:off + p.numel()].view(p.shape)
+        view.copy_(p.detach().to(device=device, dtype=torch.float32))
+        p.data = view
+        g = flat_g[off:off + p.numel()].view(p.shape)
+        base, leaf = k.rsplit(".", 1)
+        names.add(base)
+        if leaf == "weight":
+            gw[base] = g.view(g.shape[0], g.shape[1]) if g.dim() == 5 else g          # Conv3d [t,t,1,1,1] -> [t,t]
+        else:
+            gb[base] = g
+        off += sz
+    return flat_p, flat_g, flat_m, flat_v, gw, gb, names
+
+
 class Stage3Trainer:
     """``train_EMSR_onestep`` (train_stage3.py:343-366).  ``opt_train`` is the ``train:`` block of
     option/train_stage3_x{8,16}.yml (lr_G, beta1, beta2, lr_scheme, T_period, restarts, restart_weights, eta_min,
@@ -413,27 +457,8 @@ class Stage3Trainer:
         # one flat buffer for the trainable parameters (and their gradient / Adam moments): the model's Parameters
         # become views of it, so state_dict() / checkpoints always show the current weights
         named = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
-        sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]
-        total = sum(sizes)
-        self.flat_p = torch.zeros(total, dtype=torch.float32, device=device)
-        self.flat_g = torch.zeros(total, dtype=torch.float32, device=device)
-        self.flat_m = torch.zeros(total, dtype=torch.float32, device=device)
-        self.flat_v = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_p, self.flat_g, self.flat_m, self.flat_v, gw, gb, names = flatten_parameters(named, device)
         self.n_params = sum(p.numel() for _, p in named)
-        gw, gb, off = {}, {}, 0
-        names = set()
-        for (k, p), sz in zip(named, sizes):
-            view = self.flat_p[off:off + p.numel()].view(p.shape)
-            view.copy_(p.detach().to(device=device, dtype=torch.float32))
-            p.data = view
-            g = self.flat_g[off:off + p.numel()].view(p.shape)
-            base, leaf = k.rsplit(".", 1)
-            names.add(base)
-            if leaf == "weight":
-                gw[base] = g.view(g.shape[0], g.shape[1]) if g.dim() == 5 else g          # Conv3d [t,t,1,1,1] -> [t,t]
-            else:
-                gb[base] = g
-            off += sz
         model._engine = None
         sd = {k: v.detach() for k, v in model.state_dict().items()}
         self.eng = TrainEngine(sd, device, model.scale, model.nframes, model.groups, model.nf, model._dec_nrb, names, gw, gb,

@@ -281,6 +281,19 @@ int gpemsr_transpose_images(const float* src, float* dst, int n, int rows, int c
 int gpemsr_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, void* stream);
 
+/* ---- stage-2 (indexer) training step, train_stage2.py:351-366: what the VQGAN-style blocks add to the stage-3 set ----
+ * GroupNorm(groups, eps)(+ReLU) backward (native_group_norm_backward + threshold_backward): x is the layer input, mean_rstd
+ * the forward statistics [n][groups][2]; dx += ; dgamma/dbeta += (may both be NULL).  ws >= n*parts*c*2 + n*c*2 + n*groups*2
+ * floats with parts = clamp(hw/64, 1, 64). */
+int gpemsr_groupnorm_bwd(const float* x, int ld, const float* dy, int dy_ld, int n, int hw, int c, int groups,
+                         const float* mean_rstd, const float* gamma, const float* beta, int relu, float* ws, int64_t ws_floats,
+                         float* dx, int dx_ld, float* dgamma, float* dbeta, void* stream);
+/* F.softmax(dim=-1) backward on rows, in place over dp: ds = p * (dp - sum_j dp*p)   (model/blocks.py:77) */
+int gpemsr_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int cols, void* stream);
+/* torch.nn.CrossEntropyLoss() (mean): loss[0]; row_loss[rows] scratch; dlogits (may be NULL) = grad_scale * (softmax - onehot) / rows */
+int gpemsr_cross_entropy(const float* logits, const int32_t* target, int64_t rows, int cols, float grad_scale, float* row_loss,
+                         float* loss, float* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -318,6 +318,34 @@ def indexer_logits(sd: SD, p: str, x: Tensor) -> Tensor:
     return F.linear(h.permute(0, 2, 3, 1), sd[p + ".embedding.weight"].to(x.dtype), sd[p + ".embedding.bias"].to(x.dtype))
 
 
+def encoder_latent(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Encoder.forward, model/encoder.py:36-39 (same Sequential structure as the indexer, no classification head)."""
+    h = F.relu(_conv(sd, p + ".input_layer.0", x))
+    for i in range(_count_seq(sd, p + ".feat_extract")):
+        h = _vq_layer(sd, f"{p}.feat_extract.{i}", h)
+    for i in range(_count_seq(sd, p + ".output_layer")):
+        h = _vq_layer(sd, f"{p}.output_layer.{i}", h)
+    return h
+
+
+def codebook_nearest(sd: SD, p: str, z: Tensor) -> Tensor:
+    """Codebook.forward's indices, model/codebook.py:15-23: argmin_k |z|^2 + |e_k|^2 - 2 z.e_k over NHWC-flattened z."""
+    zf = z.permute(0, 2, 3, 1).reshape(-1, z.shape[1])
+    E = sd[p + ".embedding.weight"].to(z.dtype)
+    d = (zf ** 2).sum(dim=1, keepdim=True) + (E ** 2).sum(dim=1) - 2 * zf @ E.t()
+    return torch.argmin(d, dim=1)
+
+
+def stage2_loss(sd: SD, lr: Tensor, gt: Tensor, forced_target: Optional[Tensor] = None, p: str = "refmodel"):
+    """lrGenerator8/16.forward + CrossEntropyLoss (model/vqgan_indexer.py:77-84, train_stage2.py:357-359)
+    -> (loss, logits [B*h*w, 1024], target [B*h*w])."""
+    logits = indexer_logits(sd, p + ".indexer", lr)
+    logits = logits.reshape(-1, logits.shape[-1])
+    with torch.no_grad():
+        target = codebook_nearest(sd, p + ".codebook", encoder_latent(sd, p + ".encoder", gt)) if forced_target is None else forced_target
+    return F.cross_entropy(logits, target), logits, target
+
+
 def codebook_lookup(sd: SD, p: str, logits: Tensor, forced_idx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """model/codebook.py:34-43: softmax -> topk(1) == argmax of the logits."""
     B, H, W, C = logits.shape

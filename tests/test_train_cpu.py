@@ -91,3 +91,31 @@ def test_gradient_averaging_gloo_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_oracle_stage2_step_matches_reference_golden(golden_dir):
+    """Indexer training step (train_stage2.py:351-366): the oracle's encoder / nearest-code / indexer / cross-entropy under
+    autograd against the reference golden (oracle/gen_golden_stage2.py)."""
+    import yaml
+    from gen_golden_train import projection
+    from gpemsr_amd.arch import param_specs
+    from gpemsr_amd.synth import synth_state_dict
+    from oracle import gpemsr_oracle as orc
+    d = np.load(os.path.join(golden_dir, "stage2_x8.npz"))
+    opt = yaml.safe_load(open(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml")))
+    kw = {k: v for k, v in opt["network"].items() if k not in ("ref_path_G", "ref_path_Indexer")}
+    sd = synth_state_dict(param_specs(scale=8, **kw), seed=0)
+    names = [str(n) for n in d["grad_names"]]
+    for k in names:
+        sd["refmodel." + k] = sd["refmodel." + k].clone().requires_grad_(True)
+    loss, logits, target = orc.stage2_loss(sd, torch.from_numpy(d["LR"]), torch.from_numpy(d["GT"]))
+    assert torch.equal(target.to(torch.int32), torch.from_numpy(d["target_idx"]))          # free-running arg-min agrees
+    assert abs(loss.item() - float(d["loss_1"])) <= 1e-5 * float(d["loss_1"])
+    assert np.abs(logits.detach().numpy()[::4] - d["logits_1_every4"]).max() <= 1e-4 * np.abs(d["logits_1_every4"]).max()
+    loss.backward()
+    errs = []
+    for i, k in enumerate(names):
+        g = sd["refmodel." + k].grad.reshape(-1).double()
+        want = d["grad_stats"][i]
+        errs.append(max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0])
+    assert max(errs) <= 2e-2 and np.median(errs) <= 1e-3, (max(errs), np.median(errs))
