@@ -9,7 +9,7 @@ cannot be imported because train_stage3.py imports cv2/tensorboard at module lev
 against the reference objects).  Two consecutive steps are run so that the optimizer state, the scheduler and the
 re-packing of updated weights are all pinned.
 
-Writes tests/golden/train_x8.npz: inputs (LR, GT), the code indices of the frozen prior (teacher forcing) and its SpyNet flows (same purpose: a constant input that is ill-conditioned in fp32), both loss
+Writes tests/golden/train_x8.npz (and train_x16.npz with --scale16): inputs (LR, GT), the code indices of the frozen prior (teacher forcing) and its SpyNet flows (same purpose: a constant input that is ill-conditioned in fp32), both loss
 values per step, per-parameter gradient statistics of step 1 (L2 norm, sum, and a seeded random projection) for every
 trainable tensor, the full gradients of a few small tensors, and parameter values after each step for the same few.
     python oracle/gen_golden_train.py
@@ -47,9 +47,8 @@ def hash_name(name: str) -> int:
     return h
 
 
-def main():
+def main(scale: int = 8, B: int = 2, lr_size: int = 16):
     torch.set_num_threads(8)
-    scale = 8
     import yaml
     with open(os.path.join(gg.REF_ROOT, f"option/output_GPEMSR_x{scale}.yml"), encoding="utf-8") as f:
         opt = yaml.safe_load(f)
@@ -60,8 +59,7 @@ def main():
     from model.contextual import ContextualLoss                          # the reference, unmodified
     import model.lr_scheduler as lr_scheduler                             # the reference, unmodified
 
-    B, lr_size = 2, 16
-    LR = synth_lr_tiles(B, 5, lr_size, lr_size, seed=77, kind="smooth")
+    LR = synth_lr_tiles(B, 5, lr_size, lr_size, seed=77 + scale, kind="smooth")
     g = torch.Generator().manual_seed(78)
     GT = torch.rand(B, 1, lr_size * scale, lr_size * scale, generator=g)
 
@@ -132,7 +130,7 @@ def main():
     for _ in range(16):
         o.step(); sc.step(); seq.append(o.param_groups[0]["lr"])
     arrs["sched_multistep"] = np.array(seq, dtype=np.float64)
-    path = os.path.join(gg.GOLD, "train_x8.npz")
+    path = os.path.join(gg.GOLD, f"train_x{scale}.npz")
     np.savez_compressed(path, **arrs)
     print("wrote", path, os.path.getsize(path), "bytes; min logit margin", arrs["min_logit_margin"])
     gn = arrs["grad_stats"][:, 0]
@@ -140,4 +138,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--scale16" in sys.argv:
+        main(16, 1, 16)          # x16: one window of 5 x 16x16 -> 256x256 (every x16-only layer gets a gradient)
+    else:
+        main()

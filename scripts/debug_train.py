@@ -15,7 +15,8 @@ model = build_model(opt, load_prior_files=False).to(dev)
 tr = Stage3Trainer(model, TRAIN_OPT, dev)
 LR, GT = torch.from_numpy(d["LR"]).to(dev), torch.from_numpy(d["GT"]).to(dev)
 idx = torch.from_numpy(d["code_idx"]).to(dev)
-rec, ref = tr.forward_backward(LR, GT, idx)
+flow = torch.from_numpy(d['flow']).to(dev)
+rec, ref = tr.forward_backward(LR, GT, idx, flow)
 torch.cuda.synchronize()
 print("rec", rec.item(), d["rec_loss_1"], "ref", ref.item(), d["ref_loss_1"])
 sr = tr.last_sr.cpu().numpy()
@@ -47,7 +48,7 @@ kw = {k: v for k, v in o["network"].items() if k not in ("ref_path_G", "ref_path
 sd = synth_state_dict(param_specs(scale=8, **kw), seed=0)
 for k in names:
     sd[k] = sd[k].clone().requires_grad_(True)
-out, refi = orc.gpemsr_forward(sd, LR.cpu(), scale=8, forced_idx=idx.cpu().long())
+out, refi = orc.gpemsr_forward(sd, LR.cpu(), scale=8, forced_idx=idx.cpu().long(), forced_flow=flow.cpu())
 rec_o, ref_o, _ = orc.stage3_losses(sd, out, refi.detach(), GT.cpu())
 (rec_o * TRAIN_OPT["rec_loss_factor"] + TRAIN_OPT["ref_loss_factor"] * ref_o).backward()
 errs = []
@@ -61,3 +62,10 @@ for k in names:
 errs.sort(reverse=True)
 print("HIP vs oracle autograd, ||dg|| / ||g||, worst:", [(f"{e:.1e}", k) for e, k in errs[:10]])
 print("median", np.median([e for e, _ in errs]), "count > 1e-3:", sum(e > 1e-3 for e, _ in errs))
+
+for k in ["ThreeDA.spatial_attn3.weight", "ThreeDA.spatial_attn2.bias", "ThreeDA.spatial_attn_l2.bias", "ThreeDA.spatial_attn5.bias", "ThreeDA.spatial_attn_add2.bias", "ThreeDA.conv2D_fusion_3.bias"]:
+    base, leaf = k.rsplit(".", 1)
+    g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().reshape(-1).double().cpu()
+    w = sd[k].grad.reshape(-1).double()
+    dd = (g - w).abs()
+    print(k, "rel", (dd.norm() / w.norm()).item(), "max|d|", dd.max().item(), "max|w|", w.abs().max().item(), "n>10%max", int((dd > 0.1 * dd.max()).sum()), "of", dd.numel())
