@@ -235,6 +235,94 @@ __global__ __launch_bounds__(256) void dcn_columns_bwd_kernel(const float* x, in
   }
 }
 
+
+// Tiled flavour of the same backward: one workgroup owns an 8x8-pixel tile (all taps and groups) and accumulates the
+// input-gradient scatter in an LDS window of the tile +- DCN_M pixels with LDS float atomics (ds_add_f32); only what
+// falls outside the window, and one flush of the window's non-zero entries, go to global atomics -- about an order of
+// magnitude fewer L2 atomics than one per (corner, channel).  dom as above.
+#define DCN_T 8
+#define DCN_M 4
+#define DCN_WW (DCN_T + 2 * DCN_M)
+__global__ __launch_bounds__(256) void dcn_columns_bwd_tiled_kernel(const float* x, int n, int h, int w, int c, int ld, const float* om,
+                                                                    int om_ld, int groups, const float* dcol, float* dx, int dx_ld,
+                                                                    float* dom, int dom_ld, int tiles_x, int tiles_y) {
+  extern __shared__ float win[];                           // [DCN_WW][DCN_WW][c]
+  const int cg = c / groups, K = 9;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, img = blockIdx.x / (tiles_x * tiles_y);
+  const int y0t = ty * DCN_T, x0t = tx * DCN_T;
+  const int wy0 = y0t - DCN_M, wx0 = x0t - DCN_M;
+  for (int e = threadIdx.x; e < DCN_WW * DCN_WW * c; e += 256) win[e] = 0.f;
+  __syncthreads();
+  const int items = DCN_T * DCN_T * K * groups;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int g = it % groups;
+    const int k = (it / groups) % K;
+    const int lp = it / (groups * K);
+    const int yq = y0t + lp / DCN_T, xq = x0t + lp % DCN_T;
+    if (yq >= h || xq >= w) continue;
+    const long long pix = ((long long)img * h + yq) * w + xq;
+    const float* o = om + pix * om_ld;
+    const float dy = o[g * 2 * K + 2 * k], dxo = o[g * 2 * K + 2 * k + 1];
+    const float ml = o[2 * groups * K + g * K + k];
+    const float m = 1.f / (1.f + expf(-ml));
+    const float py = (float)(yq - 1 + k / 3) + dy, px = (float)(xq - 1 + k % 3) + dxo;
+    const float* dc = dcol + pix * (long long)(K * c) + k * c + g * cg;
+    const float4 d0 = *reinterpret_cast<const float4*>(dc), d1 = *reinterpret_cast<const float4*>(dc + 4);
+    const float dcv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    float g_m = 0.f, g_py = 0.f, g_px = 0.f;
+    if (py > -1.f && py < (float)h && px > -1.f && px < (float)w) {
+      const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+      const float ly = py - y0, lx = px - x0;
+      const float wts[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+      const float wdy[4] = {-(1.f - lx), -lx, (1.f - lx), lx};
+      const float wdx[4] = {-(1.f - ly), (1.f - ly), -ly, ly};
+      const int ys[4] = {y0, y0, y0 + 1, y0 + 1}, xs[4] = {x0, x0 + 1, x0, x0 + 1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (ys[q] >= 0 && ys[q] <= h - 1 && xs[q] >= 0 && xs[q] <= w - 1) {
+          const long long sp = ((long long)img * h + ys[q]) * w + xs[q];
+          const float* xp = x + sp * ld + g * cg;
+          const float4 a = *reinterpret_cast<const float4*>(xp), b = *reinterpret_cast<const float4*>(xp + 4);
+          const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          float dot = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) dot += dcv[r] * xv[r];
+          g_m += wts[q] * dot; g_py += wdy[q] * dot; g_px += wdx[q] * dot;
+          if (dx) {
+            const float wm = wts[q] * m;
+            const int wy = ys[q] - wy0, wx = xs[q] - wx0;
+            if (wy >= 0 && wy < DCN_WW && wx >= 0 && wx < DCN_WW) {
+              float* lp2 = win + (wy * DCN_WW + wx) * c + g * cg;
+#pragma unroll
+              for (int r = 0; r < 8; ++r) unsafeAtomicAdd(lp2 + r, wm * dcv[r]);
+            } else {
+              float* dp = dx + sp * dx_ld + g * cg;
+#pragma unroll
+              for (int r = 0; r < 8; ++r) unsafeAtomicAdd(dp + r, wm * dcv[r]);
+            }
+          }
+        }
+      }
+    }
+    if (dom) {
+      float* dq = dom + pix * dom_ld;
+      dq[g * 2 * K + 2 * k] += g_py * m;
+      dq[g * 2 * K + 2 * k + 1] += g_px * m;
+      dq[2 * groups * K + g * K + k] += g_m * m * (1.f - m);
+    }
+  }
+  if (!dx) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < DCN_WW * DCN_WW * c; e += 256) {
+    const float v = win[e];
+    if (v == 0.f) continue;
+    const int ch = e % c, wp = e / c;
+    const int yy = wy0 + wp / DCN_WW, xx = wx0 + wp % DCN_WW;
+    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+    unsafeAtomicAdd(dx + (((long long)img * h + yy) * w + xx) * dx_ld + ch, v);
+  }
+}
+
 // ThreeDA temporal gate backward; one 16-lane group per (b, pixel), looping over the t frames so that the sum into
 // d_emb_ref has a fixed order.  c == 64.
 __global__ __launch_bounds__(256) void temporal_gate_bwd_kernel(const float* aligned, const float* emb, const float* emb_ref,
@@ -531,6 +619,13 @@ extern "C" int gpemsr_dcn_columns_bwd(const float* x, int n, int h, int w, int c
   GP_REQUIRE(x && om && dcol, "dcn_columns_bwd: null pointer");
   GP_REQUIRE(groups > 0 && c % groups == 0 && c / groups == 8 && ld % 4 == 0, "dcn_columns_bwd: needs 8 channels per deformable group");
   GP_REQUIRE(om_ld >= 3 * groups * 9 && (!dom || dom_ld >= 3 * groups * 9), "dcn_columns_bwd: om_ld too small");
+  const size_t lds = (size_t)DCN_WW * DCN_WW * c * sizeof(float);
+  const long long tiles = (long long)n * ((h + DCN_T - 1) / DCN_T) * ((w + DCN_T - 1) / DCN_T);
+  if (dx && lds <= 64 * 1024 && tiles < (1ll << 31)) {
+    hipLaunchKernelGGL(dcn_columns_bwd_tiled_kernel, dim3((unsigned)tiles), dim3(256), lds, ST(stream), x, n, h, w, c, ld, om, om_ld, groups, dcol,
+                       dx, dx_ld, dom, dom_ld, (w + DCN_T - 1) / DCN_T, (h + DCN_T - 1) / DCN_T);
+    return check_launch("dcn_columns_bwd");
+  }
   hipLaunchKernelGGL(dcn_columns_bwd_kernel, dim3(bgrid((long long)n * h * w * groups * 9)), dim3(256), 0, ST(stream), x, n, h, w, c, ld,
                      om, om_ld, groups, dcol, dx, dx_ld, dom, dom_ld);
   return check_launch("dcn_columns_bwd");

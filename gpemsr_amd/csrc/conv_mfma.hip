@@ -705,7 +705,9 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   }
   // 8x32-pixel blocks (every wave owns 64 pixels x all couts) for stride-1 k>=3 convs with cout <= 64; 4x32 otherwise
   // transposed: 8x32 input pixels (two A tiles per wave reuse every weight fragment; 72 MFMAs per stage and barrier)
-  const int TH = (tr || (d->ksize == 3 && BN <= 64 && P.stride == 1)) ? 8 : 4;   // (7x7: the LDS images would allow 1 block/CU)
+  int TH = (tr || (d->ksize == 3 && BN <= 64 && P.stride == 1)) ? 8 : 4;   // (7x7: the LDS images would allow 1 block/CU)
+  // small launches (training crops): 8-row blocks would leave CUs idle, the 4x32 flavour doubles the block count
+  if (!tr && TH == 8 && (long long)d->n * cdiv(P.oh, 8) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 1024) TH = 4;
   P.halo_h = (TH - 1) * P.stride + P.kh; P.halo_w = (TILE_W - 1) * P.stride + P.kw;
   P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
