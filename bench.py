@@ -121,11 +121,11 @@ def main():
     # HBM bytes per launch of the same kernel family from the separate rocprofv3 --pmc passes committed under profiles/
     # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); PMC cannot be collected inside this process.
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_fp32_v3_pmc_summary.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01c_fp32_pmc_summary.json")
     if s == 8 and lr == 128 and B == 16 and os.path.exists(pmc_file):
         try:
             fam = json.load(open(pmc_file))["conv_mfma_family"]
-            traffic, traffic_src = round(fam["hbm_bytes_per_launch"]), "profiles/r01_fp32_v3_pmc_summary.json (separate --pmc passes, same command)"
+            traffic, traffic_src = round(fam["hbm_bytes_per_launch"]), "profiles/r01c_fp32_pmc_summary.json (separate --pmc passes of the same command, scripts/pmc_round.sh)"
         except Exception:
             pass
     roofline = {
