@@ -34,16 +34,16 @@ FULL = ("indexer.input_layer.0.weight", "indexer.feat_extract.0.block.1.weight",
         "indexer.feat_extract.3.channel_up.bias", "indexer.embedding.bias", "indexer.output_layer.3.bias")
 
 
-def main():
+def main(scale: int = 8):
     torch.set_num_threads(8)
     sys.path.insert(0, REF_ROOT)
-    from model.vqgan_indexer import lrGenerator8                          # the reference, unmodified
+    from model.vqgan_indexer import lrGenerator8, lrGenerator16          # the reference, unmodified
     import model.lr_scheduler as lr_scheduler
-    with open(os.path.join(REF_ROOT, "option/output_GPEMSR_x8.yml"), encoding="utf-8") as f:
+    with open(os.path.join(REF_ROOT, f"option/output_GPEMSR_x{scale}.yml"), encoding="utf-8") as f:
         opt = yaml.safe_load(f)
     kw = {k: v for k, v in opt["network"].items() if k not in ("ref_path_G", "ref_path_Indexer")}
     sd = synth_state_dict(param_specs(scale=opt["scale"], **kw), seed=0)
-    gen = lrGenerator8(opt["network"]["argref"])
+    gen = (lrGenerator8 if scale == 8 else lrGenerator16)(opt["network"]["argref"])
     gen.load_state_dict({k[len("refmodel."):]: v for k, v in sd.items() if k.startswith("refmodel.")}, strict=True)
     # train_stage2.py:152-179
     for part in (gen.encoder, gen.codebook, gen.decoder):
@@ -55,9 +55,9 @@ def main():
     optimizer = torch.optim.Adam(params, lr=TRAIN_OPT["lr_G"], betas=(TRAIN_OPT["beta1"], TRAIN_OPT["beta2"]), weight_decay=0)
     scheduler = lr_scheduler.CosineAnnealingLR_Restart(optimizer, TRAIN_OPT["T_period"], eta_min=TRAIN_OPT["eta_min"],
                                                        restarts=TRAIN_OPT["restarts"], weights=TRAIN_OPT["restart_weights"])
-    B, lr_size = 2, 32
-    LR = synth_lr_tiles(B, 1, lr_size, lr_size, seed=91, kind="smooth")[:, 0]          # [B,1,32,32]
-    GT = synth_lr_tiles(B, 1, lr_size * 8, lr_size * 8, seed=92, kind="smooth")[:, 0]  # [B,1,256,256]
+    B, lr_size = (2, 32) if scale == 8 else (2, 16)
+    LR = synth_lr_tiles(B, 1, lr_size, lr_size, seed=91, kind="smooth")[:, 0]                  # [B,1,32,32] / [B,1,16,16]
+    GT = synth_lr_tiles(B, 1, lr_size * scale, lr_size * scale, seed=92, kind="smooth")[:, 0]  # [B,1,256,256]
     arrs = {"LR": LR.numpy(), "GT": GT.numpy()}
     for step in (1, 2):
         gen.train()
@@ -81,15 +81,17 @@ def main():
             arrs["grad_names"] = np.array(names)
             arrs["grad_stats"] = stats
             for k in FULL:
-                arrs["grad__" + k] = dict(zip(names, params))[k].grad.detach().numpy().copy()
+                if k in names:
+                    arrs["grad__" + k] = dict(zip(names, params))[k].grad.detach().numpy().copy()
         arrs[f"loss_{step}"] = np.float64(loss.item())
         optimizer.step()
         scheduler.step()
         arrs[f"lr_after_{step}"] = np.float64(optimizer.param_groups[0]["lr"])
         for k in FULL:
-            arrs[f"param{step}__" + k] = dict(zip(names, params))[k].detach().numpy().copy()
+            if k in names:
+                arrs[f"param{step}__" + k] = dict(zip(names, params))[k].detach().numpy().copy()
         print(f"step {step}: loss {loss.item():.6f}")
-    path = os.path.join(REPO, "tests", "golden", "stage2_x8.npz")
+    path = os.path.join(REPO, "tests", "golden", f"stage2_x{scale}.npz")
     np.savez_compressed(path, **arrs)
     gn = arrs["grad_stats"][:, 0]
     print("wrote", path, os.path.getsize(path), "bytes;", len(names), "trainable tensors; grad norms min %.2e max %.2e; margin %.3e" %
@@ -97,4 +99,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(16 if "--scale16" in sys.argv else 8)

@@ -168,3 +168,32 @@ def test_two_stage2_steps_match_reference_golden(golden_dir):
     torch.cuda.synchronize()
     print("step-2 loss", o2["loss"].item(), float(d["loss_2"]))
     assert abs(o2["loss"].item() - float(d["loss_2"])) <= 5e-3 * float(d["loss_2"])
+
+
+def test_x16_stage2_step_matches_reference_golden(golden_dir):
+    """Indexer16 (no down-sampling stage, model/indexer.py:6-55) through lrGenerator16: targets, loss and the gradients of all
+    110 trainable tensors against the reference's step."""
+    from gen_golden_stage2 import TRAIN_OPT
+    from gen_golden_train import projection
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.train_stage2 import Stage2Trainer
+    d = np.load(os.path.join(golden_dir, "stage2_x16.npz"))
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x16.yml"))
+    tr = Stage2Trainer(build_model(opt, load_prior_files=False).to(dev), TRAIN_OPT, dev)
+    LR, GT = torch.from_numpy(d["LR"]).to(dev), torch.from_numpy(d["GT"]).to(dev)
+    loss, _ = tr.forward_backward(LR, GT)
+    torch.cuda.synchronize()
+    assert float((tr.last_target == torch.from_numpy(d["target_idx"]).to(dev)).float().mean()) == 1.0
+    assert abs(loss.item() - float(d["loss_1"])) <= 1e-5 * float(d["loss_1"])
+    errs = {}
+    for i, k in enumerate([str(n) for n in d["grad_names"]]):
+        base, leaf = ("refmodel." + k).rsplit(".", 1)
+        g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().reshape(-1).double().cpu()
+        want = d["grad_stats"][i]
+        if k.endswith(".k.bias"):
+            assert g.norm().item() <= 1e-5 and want[0] <= 1e-5
+            continue
+        errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
+    print("x16 stage-2 gradient parity, worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3], "median %.1e" % np.median(list(errs.values())))
+    assert max(errs.values()) <= 2e-2 and np.median(list(errs.values())) <= 1e-3
