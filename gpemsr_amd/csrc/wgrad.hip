@@ -16,6 +16,7 @@
 // ConvTranspose2d(k3,s2,p1,op1) weights [Cin][Cout][3][3] use the same routine with the roles swapped
 // (x := dOut at 2h x 2w, dz := the layer input at h x w, stride 2): out(2iy-1+ky) <- in(iy) * W[ci][co][ky][kx].
 #include "common.h"
+#include <stdlib.h>
 
 namespace gpemsr {
 
@@ -116,6 +117,127 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(WgradParams P) {
   }
 }
 
+
+// ---- LDS-DMA flavour for full 64x64 channel blocks (the large layers) ---------------------------------------------------
+// Same tiling, but the two images of a tile go global -> LDS directly (global_load_lds_dwordx4: 64 lanes x 16 B = 4 pixel
+// rows of 256 B per wave-instruction, no VGPR round trip, no ds_write) into a double buffer: tile t+1 is in flight while
+// tile t is multiplied; one s_waitcnt vmcnt(0) + barrier per tile.  Out-of-image slots are zero-filled with ds_write by
+// the lane that would have fetched them.  The asm form is needed because hipcc drains a builtin LDS-DMA before the next
+// ds_read (same finding as conv_mfma.hip).
+__device__ __forceinline__ void wg_glds16(unsigned voff, const void* base, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned wg_lds_addr(const float* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradParams P) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform (SGPR): LDS piece addresses are scalar operands
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int cob = (wv & 1) * 32, cib = (wv >> 1) * 32;
+  const int nzp = P.th * 32;                              // dz pixels per tile
+  const int nxv = P.th * P.hc;                            // x pixels per tile ...
+  const int nxp = (nxv + 3) & ~3;                         // ... padded to whole 1-KiB pieces
+  const int buf_floats = (nzp + nxp) * 64 + 64;
+  f32x16 acc[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int slab = blockIdx.x / KS, ky = blockIdx.x % KS;
+  const int t0 = slab * P.tiles_per_slab;
+  const int t1 = min(t0 + P.tiles_per_slab, P.total_tiles);
+  const int sub = lane >> 4, c4 = lane & 15;              // pixel within a 4-pixel piece, float4 column
+  // Per-lane piece geometry is tile-invariant: precompute it once (f32 MFMA shares the vector ALUs, so per-tile address
+  // arithmetic costs matrix-pipe time).  This wave owns pieces wv, wv+4, ... of both images: <= 4 of dZ, <= 5 of X.
+  constexpr int MZ = 4, MX = 5;
+  const int nzpc = nzp / 4, nxpc = nxp / 4;
+  int z_dy[MZ], z_dx[MZ], x_r[MX], x_c[MX];
+  unsigned z_lds[MZ], x_lds[MX];                          // byte offsets of the piece inside a buffer (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < MZ; ++i) {
+    const int px = (wv + 4 * i) * 4 + sub;
+    z_dy[i] = px >> 5; z_dx[i] = px & 31;
+    z_lds[i] = (unsigned)(wv + 4 * i) * 1024u;
+  }
+#pragma unroll
+  for (int i = 0; i < MX; ++i) {
+    const int hp = (wv + 4 * i) * 4 + sub;
+    x_r[i] = hp < nxv ? hp / P.hc : -(1 << 20);           // padded tail of the last piece: never inside the image
+    x_c[i] = hp % P.hc;
+    x_lds[i] = (unsigned)(nzp * 256) + (unsigned)(wv + 4 * i) * 1024u;
+  }
+  const unsigned zcol = (unsigned)(co0 + 4 * c4) * 4u, xcol = (unsigned)(ci0 + 4 * c4) * 4u;
+
+  auto issue = [&](int t, float* buf) {
+    const int tx = t % P.tiles_x, ty = (t / P.tiles_x) % P.tiles_y, img = t / (P.tiles_x * P.tiles_y);
+    const int oy0 = ty * P.th, ox0 = tx * 32;
+    const float* zbase = P.dz + (long long)img * P.oh * P.ow * P.dz_ld;
+    const float* xbase = P.x + (long long)img * P.h * P.w * P.x_ld;
+    const unsigned lbase = wg_lds_addr(buf);
+#pragma unroll
+    for (int i = 0; i < MZ; ++i) {
+      if (wv + 4 * i < nzpc) {
+        const int oy = oy0 + z_dy[i], ox = ox0 + z_dx[i];
+        if (oy < P.oh && ox < P.ow)
+          wg_glds16((unsigned)((oy * P.ow + ox) * P.dz_ld) * 4u + zcol, zbase, __builtin_amdgcn_readfirstlane(lbase + z_lds[i]));
+        else
+          *reinterpret_cast<float4*>(buf + (z_lds[i] >> 2) + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const int iyb = oy0 * P.stride - P.pad + ky, ix0 = ox0 * P.stride - P.pad;
+#pragma unroll
+    for (int i = 0; i < MX; ++i) {
+      if (wv + 4 * i < nxpc) {
+        const int iy = iyb + x_r[i] * P.stride, ix = ix0 + x_c[i];
+        if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w)
+          wg_glds16((unsigned)((iy * P.w + ix) * P.x_ld) * 4u + xcol, xbase, __builtin_amdgcn_readfirstlane(lbase + x_lds[i]));
+        else
+          *reinterpret_cast<float4*>(buf + (x_lds[i] >> 2) + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  if (t0 < t1) issue(t0, smem);
+  for (int t = t0; t < t1; ++t) {
+    float* cur = smem + ((t - t0) & 1) * buf_floats;
+    float* nxt = smem + (((t - t0) & 1) ^ 1) * buf_floats;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // ... and its zero-fill ds_writes
+    __builtin_amdgcn_s_barrier();                         // everybody's pieces are visible; everybody left the other buffer
+    asm volatile("" ::: "memory");
+    if (t + 1 < t1) issue(t + 1, nxt);                    // in flight while tile t is multiplied
+    const float* ap = cur + lh * 64 + cob + l31;
+    const float* bp = cur + nzp * 64 + lh * P.stride * 64 + cib + l31;
+    for (int r = 0; r < P.th; ++r) {
+      const float* ar = ap + r * 32 * 64;
+      const float* br = bp + r * P.hc * 64;
+#pragma unroll 4
+      for (int cp = 0; cp < 16; ++cp) {
+        const float a = ar[2 * cp * 64];
+        const float* bq = br + 2 * cp * P.stride * 64;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+          acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[kx * 64], acc[kx], 0, 0, 0);
+      }
+    }
+  }
+  const int ci = ci0 + cib + l31;
+#pragma unroll
+  for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + cob + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      P.part[(((long long)slab * KS * KS + ky * KS + kx) * P.cout + co) * P.cin + ci] = acc[kx][r];
+    }
+}
+
 // dw[(co*cin_total + cin_off + ci)*taps + tap] += sum_slab part[slab][tap][co][ci].  64 consecutive elements per block, four
 // slab lanes each (lane q sums slabs q, q+4, ...), folded in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int slabs, int taps, int cout, int cin, float* dw,
@@ -144,10 +266,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
 
 using namespace gpemsr;
 
-// slabs of the pixel axis: enough workgroups (slabs x filter rows x channel blocks) for ~4 per CU, at least 2 tiles each
-static long long wgrad_slabs(long long tiles, int cin, int cout, int ksize, long long* tps_out) {
+// Slabs of the pixel axis.  `slots` = workgroups the chip holds at once (CUs x workgroups per CU).  A launch of slots+16
+// workgroups takes two rounds (measured: 74 vs 107 TFLOP/s on 256->256 @128^2), so the workgroup count (slabs x filter rows
+// x channel blocks) is fitted to one or two FULL rounds, whichever wastes less; more slabs only multiply the partial sums.
+static long long wgrad_slabs(long long tiles, int cin, int cout, int ksize, long long* tps_out, long long slots = 1024) {
+  static const long long forced = getenv("GPEMSR_WGRAD_WGS") ? atoll(getenv("GPEMSR_WGRAD_WGS")) : 0;
+  if (forced > 0) slots = forced;
   const long long blocks = (long long)((cout + 63) / 64) * ((cin + 63) / 64) * ksize;
-  long long want = 1024 / blocks;
+  long long want = slots / blocks;                              // one round
+  const long long want2 = 2 * slots / blocks;                   // two rounds
+  if (want < 1 || (want2 >= 1 && want2 * blocks * 1.0 / (2 * slots) > want * blocks * 1.0 / slots + 0.05)) want = want2;
   if (want < 1) want = 1;
   long long tps = (tiles + want - 1) / want;
   if (tps < 2) tps = 2;
@@ -200,9 +328,36 @@ extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const floa
   P.x_vec = (x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   P.dz_vec = (dz_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
   P.part = ws;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // LDS-DMA flavour: full 64x64 channel blocks, 16-B aligned rows, 32-bit byte offsets inside one image
+  const bool dma = (cout % 64 == 0) && (cin % 64 == 0) && P.x_vec && P.dz_vec && stride <= 2 &&
+                   ((long long)h * w * x_ld * 4 < (1ll << 32)) && ((long long)oh * ow * dz_ld * 4 < (1ll << 32)) &&
+                   ((((stride == 1 ? 2 : 1) * (31 * stride + ksize) + 3) / 4 + 3) / 4 <= 5) &&   // <= 5 X pieces per wave
+                   getenv("GPEMSR_WGRAD_NO_DMA") == nullptr;
+  if (dma) {
+    P.th = stride == 1 ? 2 : 1;
+    P.hr = P.th;
+    P.tiles_y = (oh + P.th - 1) / P.th;
+    const long long tl = (long long)n * P.tiles_x * P.tiles_y;
+    GP_REQUIRE(tl < (1ll << 31), "conv2d_wgrad: too many tiles");
+    P.total_tiles = (int)tl;
+    slabs = wgrad_slabs(tl, cin, cout, ksize, &tps, 512);          // 67.6 KB of LDS per workgroup: 2 per CU
+    if (slabs * per_slab > ws_floats) { slabs = ws_floats / per_slab; tps = (tl + slabs - 1) / slabs; slabs = (tl + tps - 1) / tps; }
+    P.tiles_per_slab = (int)tps;
+    const size_t ldsd = 2 * (size_t)((P.th * 32 + ((P.th * P.hc + 3) & ~3)) * 64 + 64) * 4;
+    const dim3 gridd((unsigned)(slabs * ksize), (unsigned)(cout / 64), (unsigned)(cin / 64));
+    if (ksize == 3) {
+      static bool a3 = false;
+      if (!a3) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a3 = true; }
+      hipLaunchKernelGGL(wgrad_dma_kernel<3>, gridd, dim3(256), ldsd, st, P);
+    } else {
+      static bool a1 = false;
+      if (!a1) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+      hipLaunchKernelGGL(wgrad_dma_kernel<1>, gridd, dim3(256), ldsd, st, P);
+    }
+  } else {
   const size_t lds = lds_bytes(P.th);
   const dim3 grid((unsigned)(slabs * ksize), (unsigned)((cout + 63) / 64), (unsigned)((cin + 63) / 64));
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (ksize == 3) {
     static bool attr3 = false;
     if (!attr3) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
@@ -211,6 +366,7 @@ extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const floa
     static bool attr1 = false;
     if (!attr1) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
     hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), lds, st, P);
+  }
   }
   const long long total = per_slab;
   const long long rb = (total + 63) / 64;
