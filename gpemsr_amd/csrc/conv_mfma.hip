@@ -36,6 +36,7 @@
 //
 // Replaces the ATen conv / conv_transpose / bmm / linear calls under model/GPEMSR.py:323-456.
 #include "common.h"
+#include <stdlib.h>
 
 namespace gpemsr {
 
@@ -708,6 +709,9 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   int TH = (tr || (d->ksize == 3 && BN <= 64 && P.stride == 1)) ? 8 : 4;   // (7x7: the LDS images would allow 1 block/CU)
   // small launches (training crops): 8-row blocks would leave CUs idle, the 4x32 flavour doubles the block count
   if (!tr && TH == 8 && (long long)d->n * cdiv(P.oh, 8) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 1024) TH = 4;
+  // still fewer blocks than the chip has slots (3 per CU): split 64 output channels over two 32-wide blocks
+  if (!tr && BN == 64 && getenv("GPEMSR_CONV_NO_BN32") == nullptr &&
+      (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 32;
   P.halo_h = (TH - 1) * P.stride + P.kh; P.halo_w = (TILE_W - 1) * P.stride + P.kw;
   P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
