@@ -609,3 +609,37 @@ def test_x16_training_step_matches_reference_golden(golden_dir):
     for k, e in errs.items():
         assert e <= (1e-3 if k.startswith(downstream) else 6e-2), f"{k}: gradient statistic off by {e:.2e}"
     assert np.median(list(errs.values())) <= 3e-3 and np.percentile(list(errs.values()), 90) <= 1.5e-2
+
+
+def test_training_step_non_square_ragged_crop_matches_oracle():
+    """LR 24x32 (SR 192x256; the latent token count must stay a multiple of 32): non-square maps whose rows/cols are ragged
+    against the 32-pixel conv / wgrad tiles and the 8x8 DCN tiles, 48x64 contextual-loss positions.  Losses and
+    upsampler-side gradients against the CPU oracle under torch autograd (code indices teacher-forced)."""
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
+    from oracle import gpemsr_oracle as orc
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    model = build_model(opt, load_prior_files=False).to(dev)
+    topt = dict(lr_G=1e-4, beta1=0.9, beta2=0.99, T_period=[1000, 1000], restarts=[1000], restart_weights=[1], eta_min=1e-7,
+                rec_loss_factor=1, ref_loss_factor=0.001)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = Stage3Trainer(model, topt, dev)
+    LR = synth_lr_tiles(1, 5, 24, 32, seed=21, kind="smooth")
+    GT = torch.rand(1, 1, 192, 256, generator=torch.Generator().manual_seed(22))
+    probe = ("conv_last.weight", "HRconv.bias", "upconv1.weight", "recon_trunk.0.conv1.weight")
+    for k in probe:
+        sd[k].requires_grad_(True)
+    tro = {}
+    out, ref = orc.gpemsr_forward(sd, LR, scale=8, trace=tro)
+    rec_o, ref_o, _ = orc.stage3_losses(sd, out, ref.detach(), GT)
+    (rec_o + 0.001 * ref_o).backward()
+    rec, refl = tr.forward_backward(LR.to(dev), GT.to(dev), tro["code_idx"].to(dev))
+    torch.cuda.synchronize()
+    assert abs(rec.item() - rec_o.item()) <= 1e-5 * rec_o.item()
+    assert abs(refl.item() - ref_o.item()) <= 1e-4 * ref_o.item()
+    for k in probe:
+        base, leaf = k.rsplit(".", 1)
+        g = (tr.gw if leaf == "weight" else tr.gb)[base]
+        _close(g, sd[k].grad, 1e-3, "grad " + k)
