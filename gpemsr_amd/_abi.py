@@ -19,7 +19,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_LRELU_SIGMOID = 0, 1, 2, 3, 4
 # every symbol include/gpemsr_hip.h declares (checked by tests/test_abi_cpu.py)
 SYMBOLS = [
     "gpemsr_abi_version", "gpemsr_last_error", "gpemsr_device_info", "gpemsr_conv2d", "gpemsr_conv2d_split", "gpemsr_split_pack_rows", "gpemsr_conv2d_direct", "gpemsr_conv2d_stem1",
-    "gpemsr_groupnorm_stats", "gpemsr_groupnorm_apply", "gpemsr_softmax_rows", "gpemsr_argmax_rows",
+    "gpemsr_groupnorm_stats", "gpemsr_groupnorm_apply", "gpemsr_softmax_rows", "gpemsr_softmax_rows_ld", "gpemsr_argmax_rows",
     "gpemsr_gather_rows", "gpemsr_bilinear", "gpemsr_avgpool2", "gpemsr_pool3s2_maxavg", "gpemsr_spynet_prep",
     "gpemsr_dcn_columns", "gpemsr_patch_cosine", "gpemsr_temporal_gate", "gpemsr_frame_mix_lrelu",
     "gpemsr_threeda_combine", "gpemsr_tensor2img_u8", "gpemsr_copy_channels", "gpemsr_copy_images",
@@ -82,6 +82,7 @@ def load():
     lib.gpemsr_groupnorm_stats.argtypes = [p, i32, i32, i32, i32, i32, f32, p, i32, p, p]
     lib.gpemsr_groupnorm_apply.argtypes = [p, i32, i32, i32, i32, i32, p, p, p, i32, p, i32, p, i32, p]
     lib.gpemsr_softmax_rows.argtypes = [p, i64, i32, p]
+    lib.gpemsr_softmax_rows_ld.argtypes = [p, i64, i32, i32, p]
     lib.gpemsr_argmax_rows.argtypes = [p, i64, i32, p, p]
     lib.gpemsr_gather_rows.argtypes = [p, i32, p, i64, p, i32, p]
     lib.gpemsr_bilinear.argtypes = [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, i32, p]

@@ -106,8 +106,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // one workgroup per row; cols <= 256*MAXV*4
 template <int MAXV>
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, int cols) {
-  float* row = x + (long long)blockIdx.x * cols;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, int cols, int ld) {
+  float* row = x + (long long)blockIdx.x * ld;
   const int c4 = cols >> 2;
   float4 v[MAXV];
   float m = -INFINITY;
@@ -211,9 +211,18 @@ extern "C" int gpemsr_softmax_rows(float* x, int64_t rows, int cols, void* strea
   GP_REQUIRE(x && rows > 0 && rows < (1ll << 31), "softmax_rows: bad rows");
   GP_REQUIRE(cols % 4 == 0 && cols <= 256 * 4 * 16, "softmax_rows: cols=%d unsupported", cols);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (cols <= 256 * 4 * 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, st, x, cols);
-  else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, x, cols);
+  if (cols <= 256 * 4 * 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, st, x, cols, cols);
+  else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, x, cols, cols);
   return check_launch("softmax_rows");
+}
+
+extern "C" int gpemsr_softmax_rows_ld(float* x, int64_t rows, int cols, int ld, void* stream) {
+  GP_REQUIRE(x && rows > 0 && rows < (1ll << 31) && ld >= cols && ld % 4 == 0, "softmax_rows_ld: bad rows / ld");
+  GP_REQUIRE(cols % 4 == 0 && cols <= 256 * 4 * 16, "softmax_rows_ld: cols=%d unsupported", cols);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (cols <= 256 * 4 * 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, st, x, cols, ld);
+  else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, st, x, cols, ld);
+  return check_launch("softmax_rows_ld");
 }
 
 extern "C" int gpemsr_argmax_rows(const float* x, int64_t rows, int cols, int32_t* idx, void* stream) {

@@ -160,8 +160,10 @@ class Engine:
         """model/blocks.py:61-83 with the score matrix materialised per frame chunk."""
         n, h, w, c = x.n, x.h, x.w, x.c
         T = h * w
-        if T % 32 != 0 or c % 32 != 0:
-            raise RuntimeError(f"gpemsr_amd: non-local block needs latent tokens ({T}) and channels ({c}) to be multiples of 32")
+        if c % 32 != 0 or T % 4 != 0:
+            raise RuntimeError(f"gpemsr_amd: non-local block needs channels ({c}) % 32 == 0 and latent tokens ({T}) % 4 == 0")
+        if T % 32 != 0:
+            return self._nonlocal_ragged(x, p)
         hn = self.o.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
         q = self.conv(hn, p + ".q")                       # already scaled by C^-1/2
         k = self.conv(hn, p + ".k")
@@ -186,6 +188,34 @@ class Engine:
                        weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw), tag=p + ".pv",
                        precision=self.precision)
             del v16
+        return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
+
+    def _nonlocal_ragged(self, x: Act, p: str) -> Act:
+        """The same block when the token count is not a multiple of 32 (e.g. 24x40 LR tiles -> 12x20 latents): the score rows
+        and v^T rows are padded with zeros to the GEMM's 32-column granule (row stride Tp), the row softmax runs over the T
+        real columns; the products stay on the exact f32 kernel in every precision mode."""
+        n, h, w, c = x.n, x.h, x.w, x.c
+        T = h * w
+        Tp = (T + 31) // 32 * 32
+        hn = self.o.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
+        q = self.conv(hn, p + ".q")
+        k = self.conv(hn, p + ".k")
+        wv = self.pc[p + ".v"]
+        vT = Act(torch.zeros(n * c * Tp, dtype=torch.float32, device=self.dev), n, c // 32, 32, T, Tp, 0)
+        a = Act(wv.w, n, c // 32, 32, c, c, 0)
+        self.o.conv2d([a], self.o.PackedConv(hn.buf, None, 1, T, (c,), 32), ACT_NONE, weight_image_stride=T * c,
+                      src_image_stride=[0], out=vT, tag="nonlocal.vT")
+        out = self.o.new_act(n, h, w, c, device=self.dev)
+        fc = max(1, min(n, (1 << 30) // (T * Tp * 4)))
+        for f0 in range(0, n, fc):
+            m = min(fc, n - f0)
+            S = Act(torch.zeros(m * T * Tp, dtype=torch.float32, device=self.dev), m, h, w, T, Tp, 0)
+            self.o.conv2d([q.images(f0, m)], self.o.PackedConv(k.images(f0, m).buf, None, 1, T, (c,), 32), ACT_NONE,
+                          weight_image_stride=T * c, out=S, tag=p + ".qk")
+            self.o.softmax_rows_(S.buf, m * T, T, Tp)
+            Sp = Act(S.buf, m, h, w, Tp, Tp, 0)               # padded columns are zeros and meet zero rows of v^T
+            self.o.conv2d([Sp], self.o.PackedConv(vT.images(f0, m).buf, wv.b, 1, c, (Tp,), 32), ACT_NONE,
+                          weight_image_stride=c * Tp, out=out.images(f0, m), tag=p + ".pv")
         return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
 
     def _vt(self, wv_packed: torch.Tensor, hn: Act, n: int, c: int, T: int) -> Act:

@@ -280,8 +280,11 @@ def groupnorm_relu(x: Act, gamma: torch.Tensor, beta: torch.Tensor, relu: bool =
     return out
 
 
-def softmax_rows_(x: torch.Tensor, rows: int, cols: int):
-    _abi.check(_abi.load().gpemsr_softmax_rows(x.data_ptr(), rows, cols, _stream()), "softmax_rows")
+def softmax_rows_(x: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None):
+    if ld is None or ld == cols:
+        _abi.check(_abi.load().gpemsr_softmax_rows(x.data_ptr(), rows, cols, _stream()), "softmax_rows")
+    else:
+        _abi.check(_abi.load().gpemsr_softmax_rows_ld(x.data_ptr(), rows, cols, ld, _stream()), "softmax_rows_ld")
 
 
 def argmax_rows(x: Act) -> torch.Tensor:

@@ -130,6 +130,8 @@ int gpemsr_groupnorm_apply(const float* x, int n, int hw, int c, int ld, int gro
 /* row softmax in place: x[rows][cols] (blocks.py:77), row argmax -> int32 (codebook.py:38-40,
  * ties -> lowest index) and row gather out[r] = table[idx[r]] (codebook.py:41). */
 int gpemsr_softmax_rows(float* x, int64_t rows, int cols, void* stream);
+/* the same on rows that sit ld >= cols floats apart (score matrices padded to the GEMM's 32-column granule) */
+int gpemsr_softmax_rows_ld(float* x, int64_t rows, int cols, int ld, void* stream);
 int gpemsr_argmax_rows(const float* x, int64_t rows, int cols, int32_t* idx, void* stream);
 int gpemsr_gather_rows(const float* table, int dim, const int32_t* idx, int64_t rows, float* out, int out_ld,
                        void* stream);

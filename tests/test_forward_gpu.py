@@ -159,6 +159,26 @@ def test_x16_ragged_size_exercises_spynet_resize():
         assert err <= REL_TOL, f"{name}: rel err {err:.3e}"
 
 
+@pytest.mark.parametrize("scale,h,w", [(8, 24, 40), (16, 20, 20)])
+def test_latent_token_count_not_multiple_of_32(scale, h, w):
+    """x8 24x40 -> 12x20 = 240 latent tokens, x16 20x20 -> 400: the attention products run on score rows padded to the
+    GEMM's 32-column granule (engine._nonlocal_ragged); results must match the CPU oracle like any other size."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    from oracle import gpemsr_oracle as orc
+    model = _model(scale)
+    x = synth_lr_tiles(1, 5, h, w, seed=80 + scale, kind="smooth")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    otr, tr = {}, {}
+    with torch.no_grad():
+        want, want_ref = orc.gpemsr_forward(sd, x, scale=scale, trace=otr)
+    out, ref_img = model(x.cuda(), forced_code_idx=otr["code_idx"].cuda(), trace=tr)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 1, h * scale, w * scale)
+    for got, wnt, name in ((out, want, "out"), (ref_img, want_ref, "ref_img"), (torch.cat(tr["logits"]), otr["logits"], "logits")):
+        err = float((got.cpu().reshape(wnt.shape) - wnt).abs().max() / wnt.abs().max())
+        assert err <= REL_TOL, f"{name}: rel err {err:.3e}"
+
+
 def test_batch_crossing_chunk_boundaries():
     """B = 5 windows = 25 slices: crosses frame_chunk (20) and tile_chunk (4); every window must equal its solo result."""
     from gpemsr_amd.synth import synth_lr_tiles
