@@ -4,7 +4,8 @@ Mirror of the reference's ``model/contextual.py``: ``ContextualLoss(vgg, band_wi
 is_CoBi=False, use_vgg=True, vgg_layer='relu3_4')`` with ``forward(x, y) -> (cx_loss, c)`` (model/contextual.py:175-233),
 and the functional ``contextual_loss(x, y, band_width, loss_type)`` (:8-52).  Only what the training step uses is built:
 the cosine distance (compute_cosine_distance :115-138); 'L1'/'L2' distances and the bilateral variant (is_CoBi) raise.
-This is the loss VALUE (validation / logging); its backward is listed as 'next' in DESIGN.md.
+Under ``torch.no_grad()`` (validation / logging) it returns the value only; with autograd on and ``x.requires_grad`` it is
+differentiable w.r.t. ``x`` through gpemsr_amd/autograd.py (what train_stage3.py:359-364 needs).
 """
 from __future__ import annotations
 
@@ -64,6 +65,19 @@ class ContextualLoss(torch.nn.Module):
             self.register_buffer('vgg_std', torch.tensor([[[0.229]], [[0.224]], [[0.225]]], requires_grad=False))
 
     def forward(self, x, y):
+        if torch.is_grad_enabled() and x.requires_grad:
+            # training (train_stage3.py:359, loss_total.backward()): same arithmetic behind torch.autograd Functions
+            from .autograd import CXForward, Normalize3
+            if hasattr(self, 'vgg_model'):
+                assert x.shape[1] == 3 and y.shape[1] == 3, 'VGG model takes 3 channel images.'
+                mean = [float(v) for v in self.vgg_mean.flatten()]
+                std = [float(v) for v in self.vgg_std.flatten()]
+                fx = getattr(self.vgg_model(Normalize3.apply(x, mean, std)), self.vgg_layer)
+                with torch.no_grad():
+                    fy = self.vgg_model.features_nhwc(ops.normalize3(_features_nhwc(y), mean, std), self.vgg_layer).nchw()
+            else:
+                fx, fy = x, y.detach()
+            return CXForward.apply(fx, fy, self.band_width)
         with torch.no_grad():
             if hasattr(self, 'vgg_model'):
                 assert x.shape[1] == 3 and y.shape[1] == 3, 'VGG model takes 3 channel images.'

@@ -69,6 +69,7 @@ class GPEMSR(nn.Module):
         for name, spec in self._specs.items():
             _register(self, name, synth_tensor(name, spec, init_seed), spec.trainable, spec.is_buffer)
         self._engine = None
+        self._train_state = None
         # the reference loads the frozen prior at construction (model/GPEMSR.py:275-276, 283-284)
         if ref_path_G is not None and os.path.exists(str(ref_path_G)):
             self.refmodel.load_state_dict(torch.load(ref_path_G, map_location="cpu"), strict=False)
@@ -84,10 +85,12 @@ class GPEMSR(nn.Module):
                     sd[k] = self.state_dict()[k]
         r = super().load_state_dict(sd, strict=strict, **kw)
         self._engine = None
+        self._train_state = None
         return r
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self._train_state = None
         return super()._apply(fn, *a, **k)
 
     def __deepcopy__(self, memo):
@@ -95,13 +98,14 @@ class GPEMSR(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k == "_engine" else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_engine", "_train_state") else copy.deepcopy(v, memo)
         new._rebind()
         return new
 
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engine"] = None                  # packed device copies are rebuilt on first use
+        st["_train_state"] = None
         return st
 
     def __setstate__(self, st):
@@ -125,10 +129,25 @@ class GPEMSR(nn.Module):
                                   frame_chunk=self._chunks[0], tile_chunk=self._chunks[1], precision=self.precision)
         return self._engine
 
+    def _get_train_state(self, device):
+        """State of the torch.autograd path (gpemsr_amd/autograd.py): built on the first differentiable forward."""
+        if getattr(self, "_train_state", None) is None or self._train_state.eng.dev != device:
+            from . import _abi
+            from .autograd import TrainState
+            _abi.load()
+            self._train_state = TrainState(self, device)
+        return self._train_state
+
     def forward(self, x, forced_code_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):
         if not x.is_cuda:
             raise RuntimeError("gpemsr_amd.GPEMSR.forward: input must live on a cuda/HIP device "
                                "(the MI355X kernel path is the only path)")
+        if self.training and torch.is_grad_enabled() and forced_code_idx is None and trace is None:
+            # train_stage3.py:343-349: model.train(); SR, ref_img = model(LR) with autograd on -> differentiable outputs whose
+            # backward is the recorded HIP tape (parameter gradients reach p.grad / DistributedDataParallel as usual)
+            from .autograd import SRForward
+            st = self._get_train_state(x.device)
+            return SRForward.apply(st, x, *st.params())
         with torch.no_grad():
             return self._get_engine(x.device).forward(x, forced_code_idx, trace)
 
@@ -206,6 +225,10 @@ class _VGGFeatures(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("gpemsr_amd: model.vgg needs a cuda/HIP tensor (there is no CPU path)")
         assert x.dim() == 4 and x.shape[1] == 3, "VGG model takes 3 channel images."
+        if torch.is_grad_enabled() and x.requires_grad:
+            # the training script hands model.vgg to ContextualLoss (train_stage3.py:352-355): differentiable w.r.t. x
+            from .autograd import VGGForward
+            return VggOutputs(*VGGForward.apply(self.owner._get_train_state(x.device), x))
         with torch.no_grad():
             eng = self.owner._get_engine(x.device)
             a = ops.from_nchw(x.to(torch.float32))

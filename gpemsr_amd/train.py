@@ -439,6 +439,59 @@ def flatten_parameters(named, device):
     return flat_p, flat_g, flat_m, flat_v, gw, gb, names
 
 
+def contextual_loss_taped(fx: Act, fy: Act, t: int, scale_ref: list, band_width: float, tape: list, dev):
+    """contextual_loss(x, y) (model/contextual.py:8-52) for x = every image of ``fx`` repeated t times, y = ``fy`` ([b*t] images).
+    Appends to ``tape`` the closure that adds d loss / d fx times ``scale_ref[0]`` (read at backward time) into ``fx.grad()``.
+    Returns (loss [1], c [n, Py])."""
+    b, n, c = fx.n, fy.n, fx.c
+    px, py = fx.h * fx.w, fy.h * fy.w
+    if px % 32 or py % 32 or c % 32:
+        raise RuntimeError(f"gpemsr_amd.train: contextual loss needs Hx*Wx, Hy*Wy and C to be multiples of 32 (got {px}, {py}, {c})")
+    lib = ops._abi.load()
+    nblk = (fy.pixels + 1023) // 1024
+    ws = torch.empty(nblk * c, dtype=torch.float32, device=dev)
+    mu = torch.empty(c, dtype=torch.float32, device=dev)
+    ops._abi.check(lib.gpemsr_cx_channel_mean(fy.ptr, fy.pixels, c, fy.ld, ws.data_ptr(), ws.numel(), mu.data_ptr(), ops._stream()), "cx_channel_mean")
+    xn = ops.new_act(b, fx.h, fx.w, c, device=dev)
+    yn = ops.new_act(n, fy.h, fy.w, c, device=dev)
+    ops._abi.check(lib.gpemsr_cx_center_normalize(fx.ptr, mu.data_ptr(), fx.pixels, c, fx.ld, xn.ptr, xn.ld, ops._stream()), "cx_center_normalize")
+    ops._abi.check(lib.gpemsr_cx_center_normalize(fy.ptr, mu.data_ptr(), fy.pixels, c, fy.ld, yn.ptr, yn.ld, ops._stream()), "cx_center_normalize")
+    xr = ops.copy_images(xn, n, t, 1, 0)                            # SR features repeated for the t reference frames
+    sim = ops.conv2d([xr.reshape_hw(px // 32, 32)], ops.PackedConv(yn.buf, None, 1, py, (c,), 32), ACT_NONE,
+                     weight_image_stride=py * c, tag="cx.sim")
+    simt = sim.buf.view(n, px, py)
+    cx = torch.empty_like(simt)
+    ops._abi.check(lib.gpemsr_cx_rows(simt.data_ptr(), n * px, py, float(band_width), cx.data_ptr(), ops._stream()), "cx_rows")
+    nslab = (px + 127) // 128
+    ws2 = torch.empty(2 * n * nslab * py, dtype=torch.float32, device=dev)
+    rmax = torch.empty(n, py, dtype=torch.float32, device=dev)
+    cw = torch.empty(n, py, dtype=torch.float32, device=dev)
+    cxn = torch.empty(n, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ops._abi.check(lib.gpemsr_cx_reduce(cx.data_ptr(), simt.data_ptr(), n, px, py, float(band_width), ws2.data_ptr(), ws2.numel(),
+                                        rmax.data_ptr(), cw.data_ptr(), cxn.data_ptr(), loss.data_ptr(), ops._stream()), "cx_reduce")
+    del ws2
+
+    def _cx_bwd():
+        idx = torch.empty(n * py, dtype=torch.int32, device=dev)
+        coef = torch.empty(2 * n * py, dtype=torch.float32, device=dev)
+        dsim = ops.new_act(n, px // 32, 32, py, device=dev)
+        ops._abi.check(lib.gpemsr_cx_backward(simt.data_ptr(), cx.data_ptr(), rmax.data_ptr(), cw.data_ptr(), cxn.data_ptr(), n, px, py,
+                                              float(band_width), float(scale_ref[0]), idx.data_ptr(), coef.data_ptr(), dsim.ptr,
+                                              ops._stream()), "cx_backward")
+        ynT = ops.transpose_images(yn)                              # [n][C][Py]: dX^ = dS . Y^ as a 1x1 with per-image weights
+        dxr = ops.conv2d([dsim], ops.PackedConv(ynT.buf, None, 1, c, (py,), 32), ACT_NONE, weight_image_stride=c * py, tag="cx.dgrad")
+        dxn = ops.new_act(b, fx.h, fx.w, c, device=dev)
+        dxn.buf.zero_()
+        rep = (torch.arange(n, device=dev) // t).to(torch.int32)
+        ops.scatter_add_images(dxr.reshape_hw(fx.h, fx.w), rep, dxn)
+        g = fx.grad()
+        ops._abi.check(lib.gpemsr_cx_center_normalize_bwd(fx.ptr, mu.data_ptr(), dxn.ptr, fx.pixels, c, fx.ld, dxn.ld, g.ptr, g.ld,
+                                                          ops._stream()), "cx_center_normalize_bwd")
+    tape.append(_cx_bwd)
+    return loss, cw
+
+
 class Stage3Trainer:
     """``train_EMSR_onestep`` (train_stage3.py:343-366).  ``opt_train`` is the ``train:`` block of
     option/train_stage3_x{8,16}.yml (lr_G, beta1, beta2, lr_scheme, T_period, restarts, restart_weights, eta_min,
@@ -460,6 +513,7 @@ class Stage3Trainer:
         self.flat_p, self.flat_g, self.flat_m, self.flat_v, gw, gb, names = flatten_parameters(named, device)
         self.n_params = sum(p.numel() for _, p in named)
         model._engine = None
+        model._train_state = None
         sd = {k: v.detach() for k, v in model.state_dict().items()}
         self.eng = TrainEngine(sd, device, model.scale, model.nframes, model.groups, model.nf, model._dec_nrb, names, gw, gb,
                                precision=model.precision)
@@ -503,54 +557,7 @@ class Stage3Trainer:
     def contextual_features(self, fx: Act, fy: Act, t: int, scale: float):
         """contextual_loss(x, y) (model/contextual.py:8-52) for x = every image of ``fx`` repeated t times, y = ``fy``
         ([b*t] images); appends the gradient w.r.t. ``fx`` (times ``scale``) to the tape."""
-        eng = self.eng
-        b, n, c = fx.n, fy.n, fx.c
-        px, py = fx.h * fx.w, fy.h * fy.w
-        if px % 32 or py % 32 or c % 32:
-            raise RuntimeError(f"gpemsr_amd.train: contextual loss needs Hx*Wx, Hy*Wy and C to be multiples of 32 (got {px}, {py}, {c})")
-        lib = ops._abi.load()
-        nblk = (fy.pixels + 1023) // 1024
-        ws = torch.empty(nblk * c, dtype=torch.float32, device=self.dev)
-        mu = torch.empty(c, dtype=torch.float32, device=self.dev)
-        ops._abi.check(lib.gpemsr_cx_channel_mean(fy.ptr, fy.pixels, c, fy.ld, ws.data_ptr(), ws.numel(), mu.data_ptr(), ops._stream()), "cx_channel_mean")
-        xn = ops.new_act(b, fx.h, fx.w, c, device=self.dev)
-        yn = ops.new_act(n, fy.h, fy.w, c, device=self.dev)
-        ops._abi.check(lib.gpemsr_cx_center_normalize(fx.ptr, mu.data_ptr(), fx.pixels, c, fx.ld, xn.ptr, xn.ld, ops._stream()), "cx_center_normalize")
-        ops._abi.check(lib.gpemsr_cx_center_normalize(fy.ptr, mu.data_ptr(), fy.pixels, c, fy.ld, yn.ptr, yn.ld, ops._stream()), "cx_center_normalize")
-        xr = ops.copy_images(xn, n, t, 1, 0)                            # SR features repeated for the t reference frames
-        sim = ops.conv2d([xr.reshape_hw(px // 32, 32)], ops.PackedConv(yn.buf, None, 1, py, (c,), 32), ACT_NONE,
-                         weight_image_stride=py * c, tag="cx.sim")
-        simt = sim.buf.view(n, px, py)
-        cx = torch.empty_like(simt)
-        ops._abi.check(lib.gpemsr_cx_rows(simt.data_ptr(), n * px, py, float(self.band_width), cx.data_ptr(), ops._stream()), "cx_rows")
-        nslab = (px + 127) // 128
-        ws2 = torch.empty(2 * n * nslab * py, dtype=torch.float32, device=self.dev)
-        rmax = torch.empty(n, py, dtype=torch.float32, device=self.dev)
-        cw = torch.empty(n, py, dtype=torch.float32, device=self.dev)
-        cxn = torch.empty(n, dtype=torch.float32, device=self.dev)
-        loss = torch.empty(1, dtype=torch.float32, device=self.dev)
-        ops._abi.check(lib.gpemsr_cx_reduce(cx.data_ptr(), simt.data_ptr(), n, px, py, float(self.band_width), ws2.data_ptr(), ws2.numel(),
-                                            rmax.data_ptr(), cw.data_ptr(), cxn.data_ptr(), loss.data_ptr(), ops._stream()), "cx_reduce")
-        del ws2
-
-        def _cx_bwd():
-            idx = torch.empty(n * py, dtype=torch.int32, device=self.dev)
-            coef = torch.empty(2 * n * py, dtype=torch.float32, device=self.dev)
-            dsim = ops.new_act(n, px // 32, 32, py, device=self.dev)
-            ops._abi.check(lib.gpemsr_cx_backward(simt.data_ptr(), cx.data_ptr(), rmax.data_ptr(), cw.data_ptr(), cxn.data_ptr(), n, px, py,
-                                                  float(self.band_width), float(scale), idx.data_ptr(), coef.data_ptr(), dsim.ptr,
-                                                  ops._stream()), "cx_backward")
-            ynT = ops.transpose_images(yn)                              # [n][C][Py]: dX^ = dS . Y^ as a 1x1 with per-image weights
-            dxr = ops.conv2d([dsim], ops.PackedConv(ynT.buf, None, 1, c, (py,), 32), ACT_NONE, weight_image_stride=c * py, tag="cx.dgrad")
-            dxn = ops.new_act(b, fx.h, fx.w, c, device=self.dev)
-            dxn.buf.zero_()
-            rep = (torch.arange(n, device=self.dev) // t).to(torch.int32)
-            ops.scatter_add_images(dxr.reshape_hw(fx.h, fx.w), rep, dxn)
-            g = fx.grad()
-            ops._abi.check(lib.gpemsr_cx_center_normalize_bwd(fx.ptr, mu.data_ptr(), dxn.ptr, fx.pixels, c, fx.ld, dxn.ld, g.ptr, g.ld,
-                                                              ops._stream()), "cx_center_normalize_bwd")
-        eng.tape.append(_cx_bwd)
-        return loss
+        return contextual_loss_taped(fx, fy, t, [float(scale)], self.band_width, self.eng.tape, self.dev)[0]
 
     # -- one optimisation step -----------------------------------------------------------------------------------------
     def forward_backward(self, LR: torch.Tensor, GT: torch.Tensor, forced_code_idx: Optional[torch.Tensor] = None,

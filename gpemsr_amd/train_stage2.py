@@ -184,6 +184,7 @@ class Stage2Trainer:
         self.flat_p, self.flat_g, self.flat_m, self.flat_v, gw, gb, names = flatten_parameters(named, device)
         self.n_params = sum(p.numel() for _, p in named)
         model._engine = None
+        model._train_state = None
         sd = {k: v.detach() for k, v in model.state_dict().items()}
         self.eng = Stage2Engine(sd, device, model.scale, model.nframes, model.groups, model.nf, model._dec_nrb, names, gw, gb)
         self.gw, self.gb = gw, gb

@@ -1,0 +1,79 @@
+"""The reference's training statements, verbatim, on the drop-in module (gpemsr_amd/autograd.py): ``model.train()``,
+``SR, ref_img = model(LR)``, ``ContextualLoss(model.vgg)``, ``loss_total.backward()``, ``torch.optim.Adam.step()`` --
+train_stage3.py:343-366 -- with torch.autograd driving the HIP tape.  Gradients in ``p.grad`` and the losses of two steps
+against the vectors of the UNMODIFIED reference (tests/golden/train_x8.npz; code indices are free-running here, as in the
+script: the golden's minimum logit margin is 2e-3, far above fp32 noise)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def test_reference_training_statements_run_unchanged(golden_dir):
+    from gen_golden_train import TRAIN_OPT, projection
+    from gpemsr_amd import GPEMSR                                     # the one changed import
+    from gpemsr_amd.config import load_options
+    from gpemsr_amd.contextual import ContextualLoss                  # reference: from model.contextual import ContextualLoss
+    d = np.load(os.path.join(golden_dir, "train_x8.npz"))
+    device = torch.device("cuda", 0)
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    net = opt["network"]
+    model = GPEMSR(ref_path_G=None, ref_path_Indexer=None, argref=net["argref"], nf=net["nf"], nframes=net["nframes"], groups=net["groups"],
+                   front_RBs=net["front_RBs"], back_RBs=net["back_RBs"], w_ref=net["w_ref"], ref_fusion_feat_RBs=net["ref_fusion_feat_RBs"],
+                   align_mode=net["align_mode"], fusion_mode=net["fusion_mode"], mode=net["mode"], scale=opt["scale"]).to(device)
+    # train_stage3.py:153-163
+    optim_params_G = [v for k, v in model.named_parameters() if v.requires_grad]
+    names = [k for k, v in model.named_parameters() if v.requires_grad]
+    assert names == [str(n) for n in d["grad_names"]]
+    optimizer_G = torch.optim.Adam(optim_params_G, lr=TRAIN_OPT["lr_G"], betas=(TRAIN_OPT["beta1"], TRAIN_OPT["beta2"]), weight_decay=0)
+    LR, GT = torch.from_numpy(d["LR"]), torch.from_numpy(d["GT"])
+    losses = []
+    for step in (1, 2):
+        # ---- train_EMSR_onestep, train_stage3.py:343-366, statement for statement ----
+        model.train()
+        GT = GT.to(device)
+        LR = LR.to(device)
+        optimizer_G.zero_grad()
+        SR, ref_img = model(LR)
+        L1_loss = torch.nn.L1Loss().to(device)
+        rec_loss = L1_loss(GT, SR)
+        CLoss = ContextualLoss(model.vgg).to(device)
+        b, c, h, w = SR.size()
+        b_ref, t, _, _, _ = ref_img.size()
+        sr_frame_batch = SR[:, None].expand(-1, -1, 3, -1, -1).expand(-1, t, -1, -1, -1).reshape(b * t, 3, h, w)
+        ref_frame_batch = ref_img.expand(-1, -1, 3, -1, -1).reshape(b_ref * t, 3, h, w)
+        ref_loss, u = CLoss(sr_frame_batch, ref_frame_batch)
+        loss_total = rec_loss * TRAIN_OPT['rec_loss_factor'] + TRAIN_OPT['ref_loss_factor'] * ref_loss
+        loss_total.backward()
+        if step == 1:
+            assert abs(rec_loss.item() - float(d["rec_loss_1"])) <= 1e-5 * float(d["rec_loss_1"])
+            assert abs(ref_loss.item() - float(d["ref_loss_1"])) <= 2e-5 * float(d["ref_loss_1"])
+            errs = {}
+            for i, (k, p) in enumerate(zip(names, optim_params_G)):
+                want = d["grad_stats"][i]
+                if want[0] == 0.0:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                    continue
+                g = p.grad.detach().reshape(-1).double().cpu()
+                errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
+            print("autograd path, gradient parity worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3], "median %.1e" % np.median(list(errs.values())))
+            trunk = ("recon_trunk.", "upconv", "HRconv", "conv_last")
+            for k, e in errs.items():
+                assert e <= (1e-3 if k.startswith(trunk) else 6e-2), f"{k}: {e:.2e}"
+            assert np.median(list(errs.values())) <= 3e-3
+        optimizer_G.step()
+        losses.append((rec_loss.item(), ref_loss.item()))
+    print("losses", losses, "reference", (float(d["rec_loss_2"]), float(d["ref_loss_2"])))
+    assert abs(losses[1][0] - float(d["rec_loss_2"])) <= 2e-3 * float(d["rec_loss_2"])
+    assert abs(losses[1][1] - float(d["ref_loss_2"])) <= 2e-3 * float(d["ref_loss_2"])
+    # validation afterwards (train_stage3.py: model.eval() + torch.no_grad()) takes the inference path
+    model.eval()
+    with torch.no_grad():
+        out, _ = model(LR)
+    assert out.shape == SR.shape and not out.requires_grad
