@@ -215,6 +215,8 @@ class TrainEngine(Engine):
         for sl, idx, kind in _VGG_TO_RELU3_4:                  # the loss network sees RGB: pack slices 1-3 as they are
             if kind == "conv":
                 key = f"vgg.slice{sl}.{idx}"
+                if (key + ".weight") not in sd:              # stage-2 generator objects carry no VGG
+                    continue
                 self.pc[key + "@rgb"] = pack_conv(sd[key + ".weight"], sd[key + ".bias"], device)
                 if precision != "fp32" and sd[key + ".weight"].shape[1] % 16 == 0:
                     self.pc[key + "@rgb"].w16 = pack_conv_split(self.pc[key + "@rgb"], sd[key + ".weight"], device)

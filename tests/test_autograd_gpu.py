@@ -77,3 +77,67 @@ def test_reference_training_statements_run_unchanged(golden_dir):
     with torch.no_grad():
         out, _ = model(LR)
     assert out.shape == SR.shape and not out.requires_grad
+
+
+def test_reference_stage2_statements_run_unchanged(golden_dir):
+    """train_stage2.py:120-179 + train_vqgan_onestep (:351-366) verbatim on gpemsr_amd.vqgan_indexer.lrGenerator8: torch's
+    CrossEntropyLoss and Adam, autograd through the HIP tape; losses of two steps and gradients vs tests/golden/stage2_x8.npz."""
+    from gen_golden_stage2 import TRAIN_OPT
+    from gen_golden_train import projection
+    from gpemsr_amd.arch import param_specs
+    from gpemsr_amd.config import load_options
+    from gpemsr_amd.synth import synth_state_dict
+    from gpemsr_amd.vqgan_indexer import lrGenerator8             # reference: from model.vqgan_indexer import VQGAN_Indexer8 / lrGenerator8
+    d = np.load(os.path.join(golden_dir, "stage2_x8.npz"))
+    device = torch.device("cuda", 0)
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    lrgenerator = lrGenerator8(opt["network"]["argref"])
+    kw = {k: v for k, v in opt["network"].items() if k not in ("ref_path_G", "ref_path_Indexer")}
+    sd = synth_state_dict(param_specs(scale=opt["scale"], **kw), seed=0)
+    lrgenerator.load_state_dict({k[len("refmodel."):]: v for k, v in sd.items() if k.startswith("refmodel.")}, strict=True)
+    lrgenerator = lrgenerator.to(device)
+    # train_stage2.py:152-179
+    for part in (lrgenerator.encoder, lrgenerator.codebook, lrgenerator.decoder):
+        for k, v in part.named_parameters():
+            v.requires_grad = False
+    optim_params_G = [v for k, v in lrgenerator.named_parameters() if v.requires_grad]
+    names = [k for k, v in lrgenerator.named_parameters() if v.requires_grad]
+    assert sorted(names) == sorted(str(n) for n in d["grad_names"])
+    optimizer_G = torch.optim.Adam(optim_params_G, lr=TRAIN_OPT["lr_G"], betas=(TRAIN_OPT["beta1"], TRAIN_OPT["beta2"]), weight_decay=0)
+    img_LR, img_GT = torch.from_numpy(d["LR"]), torch.from_numpy(d["GT"])
+    want_stats = {str(n): d["grad_stats"][i] for i, n in enumerate(d["grad_names"])}
+    losses = []
+    for step in (1, 2):
+        # ---- train_vqgan_onestep, train_stage2.py:351-362 ----
+        lrgenerator.train()
+        img_GT = img_GT.to(device)
+        img_LR = img_LR.to(device)
+        optimizer_G.zero_grad()
+        logits, gtcodebook_indices = lrgenerator(img_LR, img_GT)
+        CELoss = torch.nn.CrossEntropyLoss().to(device)
+        loss_total = CELoss(logits, gtcodebook_indices)
+        loss_total.backward()
+        if step == 1:
+            assert torch.equal(gtcodebook_indices.cpu().to(torch.int32), torch.from_numpy(d["target_idx"]))
+            errs = {}
+            for k, p in zip(names, optim_params_G):
+                want = want_stats[k]
+                g = p.grad.detach().reshape(-1).double().cpu()
+                if k.endswith(".k.bias"):
+                    assert g.norm().item() <= 1e-5
+                    continue
+                errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
+            print("stage-2 autograd path, worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3], "median %.1e" % np.median(list(errs.values())))
+            assert max(errs.values()) <= 2e-2 and np.median(list(errs.values())) <= 1e-3
+        optimizer_G.step()
+        losses.append(loss_total.item())
+    print("losses", losses, "reference", float(d["loss_1"]), float(d["loss_2"]))
+    assert abs(losses[0] - float(d["loss_1"])) <= 1e-5 * float(d["loss_1"])
+    assert abs(losses[1] - float(d["loss_2"])) <= 5e-3 * float(d["loss_2"])
+    # inference-side methods of the generator object (no autograd)
+    lrgenerator.eval()
+    with torch.no_grad():
+        feats = lrgenerator.ref_extract(img_LR)
+        logits2, idx2 = lrgenerator(img_LR, img_GT)
+    assert [tuple(f.shape[1:]) for f in feats] == [(512, 16, 16), (256, 32, 32), (128, 64, 64), (64, 128, 128), (1, 256, 256)]
+    assert logits2.shape == logits.shape and torch.equal(idx2, gtcodebook_indices)
