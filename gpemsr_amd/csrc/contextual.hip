@@ -180,9 +180,11 @@ __global__ __launch_bounds__(256) void normalize3_kernel(const float* x, long lo
 //     d dist_ij += dt_ij / (dmin_i + 1e-5);   d dmin_i = -sum_j dt_ij dist_ij / (dmin_i + 1e-5)^2 -> first arg-min j
 //   dS_ij = -(d dist_ij) where 1 - S_ij >= 0 (clamp(min=0) passes the gradient at equality), else 0.
 // Rows with empty J_i get an all-zero gradient.
-__global__ __launch_bounds__(256) void cx_bwd_cols_kernel(const float* cx, const float* rmax, const float* cw, const float* cxn,
-                                                          int n_img, int rows, int cols, float inv_h, float scale, int* idx, float* gr, float* gd) {
-  // per image: B = sum_j c_j (fixed order), then per column the arg-max row and the two coefficients
+__global__ __launch_bounds__(256) void cx_bwd_cols_kernel(const float* pmax, const int* pidx, int nslab, const float* rmax, const float* cw,
+                                                          const float* cxn, int n_img, int cols, float inv_h, float scale, int* idx, float* gr,
+                                                          float* gd) {
+  // per image: B = sum_j c_j (fixed order); per column: merge the row-slab arg-maxes of cx_colmax_partial_kernel (first
+  // maximum wins, slabs in order) and derive the two coefficients
   const int n = blockIdx.y;
   const float* c = cw + (long long)n * cols;
   __shared__ float red[4];
@@ -196,11 +198,10 @@ __global__ __launch_bounds__(256) void cx_bwd_cols_kernel(const float* cx, const
   const float g = -scale / ((float)n_img * (cxi + 1e-5f));
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= cols) return;
-  const float* base = cx + (long long)n * rows * cols + j;
   float best = -INFINITY; int bi = 0;
-  for (int i = 0; i < rows; ++i) {
-    const float v = base[(long long)i * cols];
-    if (v > best) { best = v; bi = i; }
+  for (int sb = 0; sb < nslab; ++sb) {
+    const long long o = ((long long)n * nslab + sb) * cols + j;
+    if (pmax[o] > best) { best = pmax[o]; bi = pidx[o]; }
   }
   const long long o = (long long)n * cols + j;
   idx[o] = bi;
@@ -426,10 +427,18 @@ extern "C" int gpemsr_cx_backward(const float* sim, const float* cx, const float
   GP_REQUIRE(sim && cx && rmax && cw && cx_image && idx_ws && coef_ws && dsim && n > 0 && rows > 0 && band_width > 0.f, "cx_backward: bad args");
   GP_REQUIRE(cols % 4 == 0 && cols <= 256 * 4 * 16 && n <= 65535, "cx_backward: cols=%d unsupported (multiple of 4, <= 16384)", cols);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // coef_ws: [gr | gd | slab maxima | slab arg-maxes], 2*n*cols + 2*n*nslab*cols floats with nslab = ceil(rows/128)
+  const int slab = 128;
+  const int nslab = (rows + slab - 1) / slab;
+  GP_REQUIRE(nslab <= 65535, "cx_backward: grid too large");
   float* gr = coef_ws;
   float* gd = coef_ws + (long long)n * cols;
-  hipLaunchKernelGGL(cx_bwd_cols_kernel, dim3((unsigned)((cols + 255) / 256), n), dim3(256), 0, st, cx, rmax, cw, cx_image, n, rows, cols,
-                     1.f / band_width, scale, idx_ws, gr, gd);
+  float* pmax = gd + (long long)n * cols;
+  int* pidx = reinterpret_cast<int*>(pmax + (long long)n * nslab * cols);
+  const unsigned gx = (unsigned)((cols + 255) / 256);
+  hipLaunchKernelGGL(cx_colmax_partial_kernel, dim3(gx, nslab, n), dim3(256), 0, st, cx, rows, cols, slab, pmax, pidx);
+  hipLaunchKernelGGL(cx_bwd_cols_kernel, dim3(gx, n), dim3(256), 0, st, pmax, pidx, nslab, rmax, cw, cx_image, n, cols, 1.f / band_width, scale,
+                     idx_ws, gr, gd);
   const unsigned nrows = (unsigned)((long long)n * rows);
   if (cols <= 256 * 4 * 4) hipLaunchKernelGGL(cx_bwd_rows_kernel<4>, dim3(nrows), dim3(256), 0, st, sim, idx_ws, gr, gd, rows, cols, 1.f / band_width, dsim);
   else hipLaunchKernelGGL(cx_bwd_rows_kernel<16>, dim3(nrows), dim3(256), 0, st, sim, idx_ws, gr, gd, rows, cols, 1.f / band_width, dsim);

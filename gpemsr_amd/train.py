@@ -476,7 +476,7 @@ def contextual_loss_taped(fx: Act, fy: Act, t: int, scale_ref: list, band_width:
 
     def _cx_bwd():
         idx = torch.empty(n * py, dtype=torch.int32, device=dev)
-        coef = torch.empty(2 * n * py, dtype=torch.float32, device=dev)
+        coef = torch.empty(2 * n * py * (1 + (px + 127) // 128), dtype=torch.float32, device=dev)
         dsim = ops.new_act(n, px // 32, 32, py, device=dev)
         ops._abi.check(lib.gpemsr_cx_backward(simt.data_ptr(), cx.data_ptr(), rmax.data_ptr(), cw.data_ptr(), cxn.data_ptr(), n, px, py,
                                               float(band_width), float(scale_ref[0]), idx.data_ptr(), coef.data_ptr(), dsim.ptr,

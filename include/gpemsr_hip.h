@@ -268,7 +268,7 @@ int gpemsr_scatter_add_images(const float* dsrc, const int* idx, float* dtarget,
 int gpemsr_l1_loss(const float* sr, const float* gt, int64_t count, float grad_scale, float* dsr, float* ws, int64_t ws_floats,
                    float* loss, void* stream);
 /* contextual_loss backward w.r.t. the similarity matrix (model/contextual.py:36-52 through autograd); scale = dL/d(cx_loss).
- * idx_ws: n*cols int32, coef_ws: 2*n*cols floats; dsim [n][rows][cols] is written. */
+ * idx_ws: n*cols int32, coef_ws: 2*n*cols*(1 + ceil(rows/128)) floats; dsim [n][rows][cols] is written. */
 int gpemsr_cx_backward(const float* sim, const float* cx, const float* rmax, const float* cw, const float* cx_image, int n,
                        int rows, int cols, float band_width, float scale, int32_t* idx_ws, float* coef_ws, float* dsim,
                        void* stream);
