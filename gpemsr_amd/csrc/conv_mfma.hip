@@ -80,6 +80,7 @@ struct ConvParams {
   int na, nb;                     // DMA slots (float4 per thread) per A / B stage
   int ring;                       // DMA: weight images in a 3-deep ring, counted vmcnt (needs ngroups >= 2 or not; see kernel)
   int nblocks;
+  int tw_lg;                      // log2 of the tile width in pixels: 5 (TH x 32 tiles) or 4 (2*TH x 16 tiles, for maps <= 16 wide)
   int epi_fast;                   // lean epilogue: float4 rows, cout % 4 == 0, 32-bit byte offsets, 16-B aligned bias
 };
 
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
   const int tx = t % P.tiles_x; t /= P.tiles_x;
   const int ty = t % P.tiles_y; t /= P.tiles_y;
   const int img = t;
-  const int oy0 = ty * TH, ox0 = tx * TILE_W, n0 = tn * BN;
+  const int tw_lg = P.tw_lg, tw_mask = (1 << tw_lg) - 1;
+  const int oy0 = ty * (NPIX >> tw_lg), ox0 = tx << tw_lg, n0 = tn * BN;
   const int S = P.stride;
   const int iy0 = oy0 * S - P.pad, ix0 = ox0 * S - P.pad;
   const int halo_px = P.halo_h * P.halo_w;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    a_frag[mt] = (((p / TILE_W) * S) * P.halo_w + (p % TILE_W) * S) * APIX + (SWZ ? 0 : 4 * lh);
+    a_frag[mt] = (((p >> tw_lg) * S) * P.halo_w + (p & tw_mask) * S) * APIX + (SWZ ? 0 : 4 * lh);
   }
   const int b_frag = (wn * WNT + li) * BPIX + (SWZ ? 0 : 4 * lh);
   const int swz_x = li & 7;            // SWZ: row & 7 of this lane's A and B rows (tile bases are multiples of 8)
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int p = ppass * 128 + ep0 + it * PSTEP;
-        const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+        const int oy = oy0 + (p >> tw_lg), ox = ox0 + (p & tw_mask);
         const bool ok = colok && oy < P.oh && ox < P.ow;
         const int Y = up ? 2 * oy + sy : oy, X = up ? 2 * ox + sx : ox;
         opx[it] = ok ? (unsigned)(Y * P.OW + X) : 0xFFFFFFFFu;
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int p = ppass * 128 + ep0 + it * PSTEP;
-      const int oy = oy0 + p / TILE_W, ox = ox0 + p % TILE_W;
+      const int oy = oy0 + (p >> tw_lg), ox = ox0 + (p & tw_mask);
       opix[it] = -1; rres[it] = make_float4(0.f, 0.f, 0.f, 0.f); rmul[it] = 1.f;
       if (oy < P.oh && ox < P.ow && nvalid > 0) {
         const int Y = P.store_mode == STORE_PLAIN ? oy : 2 * oy + sy, X = P.store_mode == STORE_PLAIN ? ox : 2 * ox + sx;
@@ -712,8 +714,13 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   // still fewer blocks than the chip has slots (3 per CU): split 64 output channels over two 32-wide blocks
   if (!tr && BN == 64 && getenv("GPEMSR_CONV_NO_BN32") == nullptr &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 32;
-  P.halo_h = (TH - 1) * P.stride + P.kh; P.halo_w = (TILE_W - 1) * P.stride + P.kw;
-  P.tiles_x = cdiv(P.ow, TILE_W); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
+  // narrow maps (training crops: 16x16 latents): 2*TH x 16-pixel tiles waste no columns; a 32-pixel MFMA tile is then two rows
+  const int pad32 = cdiv(P.ow, 32) * 32, pad16 = cdiv(P.ow, 16) * 16;
+  const int TW = (!tr && (pad32 - pad16) * 4 >= pad32 && getenv("GPEMSR_CONV_NO_TW16") == nullptr) ? 16 : TILE_W;   // >= 25 % fewer dead columns
+  P.tw_lg = TW == 16 ? 4 : 5;
+  const int TROWS = TH * TILE_W / TW;
+  P.halo_h = (TROWS - 1) * P.stride + P.kh; P.halo_w = (TW - 1) * P.stride + P.kw;
+  P.tiles_x = cdiv(P.ow, TW); P.tiles_y = cdiv(P.oh, TROWS); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d: grid too large");
   P.nblocks = (int)nb;
