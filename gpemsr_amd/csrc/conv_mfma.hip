@@ -711,7 +711,9 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   int TH = (tr || (d->ksize == 3 && BN <= 64 && P.stride == 1)) ? 8 : 4;   // (7x7: the LDS images would allow 1 block/CU)
   // small launches (training crops): 8-row blocks would leave CUs idle, the 4x32 flavour doubles the block count
   if (!tr && TH == 8 && (long long)d->n * cdiv(P.oh, 8) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 1024) TH = 4;
-  // still fewer blocks than the chip has slots (3 per CU): split 64 output channels over two 32-wide blocks
+  // still fewer blocks than the chip has slots (3 per CU): split the output channels over narrower blocks (128 -> 64 -> 32)
+  if (!tr && BN == 128 && d->ksize != 7 && getenv("GPEMSR_CONV_NO_BNSPLIT") == nullptr &&
+      (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 64;
   if (!tr && BN == 64 && getenv("GPEMSR_CONV_NO_BN32") == nullptr &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 32;
   // narrow maps (training crops: 16x16 latents): 2*TH x 16-pixel tiles waste no columns; a 32-pixel MFMA tile is then two rows
