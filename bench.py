@@ -65,10 +65,10 @@ def main():
     ap.add_argument("--train-lr", type=int, default=32, help="--mode train: LR crop size (option/train_stage3_x8.yml LQ_size)")
     args = ap.parse_args()
     if args.mode == "train":
-        from gpemsr_amd import bench_train
+        import bench_train
         return bench_train.run(args, ROOT, effective_cores)
     if args.mode == "train2":
-        from gpemsr_amd import bench_train
+        import bench_train
         return bench_train.run_stage2(args, ROOT, effective_cores)
 
     from gpemsr_amd import dist as gdist, ops

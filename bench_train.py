@@ -1,4 +1,5 @@
-"""`bench.py --mode train`: BASELINE.json configs[4] -- the 8x EMSR stage-3 training step (forward + backward incl. the VGG
+"""The training legs of bench.py (kept beside it, outside the package: the CPU-baseline leg below is the only code outside
+tests/ and smoke() that touches oracle/).  `bench.py --mode train`: BASELINE.json configs[4] -- the 8x EMSR stage-3 training step (forward + backward incl. the VGG
 contextual loss + Adam), batch 8 per GPU of the reference's training crops (LR 32x32 -> 256x256, option/train_stage3_x8.yml),
 one process per GPU, one RCCL all-reduce of the flat gradient buffer per step (weak scaling).  Same timing protocol as the
 forward bench: W warm-up steps, then exactly K steps between barrier + synchronize pairs, max over ranks."""
@@ -17,10 +18,10 @@ TRAIN_OPT = dict(lr_G=4e-4, beta1=0.9, beta2=0.99, lr_scheme="CosineAnnealingLR_
 
 
 def run(args, root: str, effective_cores):
-    from . import dist as gdist, ops
-    from .config import build_model, load_options
-    from .synth import synth_lr_tiles
-    from .train import Stage3Trainer
+    from gpemsr_amd import dist as gdist, ops
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
 
     rank, world, local = gdist.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -155,10 +156,10 @@ def run(args, root: str, effective_cores):
 def run_stage2(args, root: str, effective_cores):
     """`bench.py --mode train2`: the stage-2 (indexer) training step, train_stage2.py:351-366, at the reference's geometry
     (option/train_stage2_x8.yml: batch 8, GT 1024x1024 -> LR 128x128), same timing protocol."""
-    from . import dist as gdist, ops
-    from .config import build_model, load_options
-    from .synth import synth_lr_tiles
-    from .train_stage2 import Stage2Trainer
+    from gpemsr_amd import dist as gdist, ops
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train_stage2 import Stage2Trainer
 
     rank, world, local = gdist.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1

@@ -4,7 +4,7 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gpemsr_amd.bench_train import TRAIN_OPT
+from bench_train import TRAIN_OPT
 from gpemsr_amd.config import build_model, load_options
 from gpemsr_amd.contextual import ContextualLoss
 from gpemsr_amd.synth import synth_lr_tiles
