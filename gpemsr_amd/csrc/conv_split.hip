@@ -49,6 +49,7 @@ struct SplitParams {
   int out_vec, res_vec;
   int tiles_x, tiles_y, tiles_n;
   int halo_h, halo_w, pad;
+  int tw_lg;                           // log2 of the tile width: 5 (TH x 32 pixels) or 4 (2*TH x 16, maps <= 16 wide), as conv_mfma.hip
   int na, nb;                          // DMA slots per thread: raw A image, one weight plane of one stage
   int raw_bytes, sp_plane_bytes, b_plane_bytes;
   int nblocks;
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
   const int tx = t % P.tiles_x; t /= P.tiles_x;
   const int ty = t % P.tiles_y; t /= P.tiles_y;
   const int img = t;
-  const int oy0 = ty * TH, ox0 = tx * SW, n0 = tn * BN;
+  const int tw_lg = P.tw_lg, tw_mask = (1 << tw_lg) - 1;
+  const int oy0 = ty * (NPIX >> tw_lg), ox0 = tx << tw_lg, n0 = tn * BN;
   const int iy0 = oy0 - P.pad, ix0 = ox0 - P.pad;
   const int halo_px = P.halo_h * P.halo_w;
 
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    a_frag[mt] = ((p / SW) * P.halo_w + (p % SW)) * 16 + lh * ((GEMM ? P.sub_plane_bytes : P.sp_plane_bytes) >> 1);
+    a_frag[mt] = ((p >> tw_lg) * P.halo_w + (p & tw_mask)) * 16 + lh * ((GEMM ? P.sub_plane_bytes : P.sp_plane_bytes) >> 1);
   }
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
 
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitParams P) {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int p = ppass * 128 + ep0 + it * PSTEP;
-      const int oy = oy0 + p / SW, ox = ox0 + p % SW;
+      const int oy = oy0 + (p >> tw_lg), ox = ox0 + (p & tw_mask);
       opix[it] = -1; rres[it] = make_float4(0.f, 0.f, 0.f, 0.f); rmul[it] = 1.f;
       if (oy < P.oh && ox < P.ow && nvalid > 0) {
         const int Y = P.store_mode == 0 ? oy : 2 * oy + sy, X = P.store_mode == 0 ? ox : 2 * ox + sx;
@@ -487,8 +489,13 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   const int BN = tr ? 128 : (gemm ? (d->cout <= 64 ? 64 : 128) : (KW == 7 ? 32 : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128))));
   const int TH = (BN == 128 || KW == 7 || gemm) ? 4 : 8;
   P.pad = (tr || gemm) ? 0 : KW / 2;
-  P.halo_h = gemm ? TH : TH + KW - 1; P.halo_w = gemm ? SW : SW + KW - 1;
-  P.tiles_x = cdiv(P.ow, SW); P.tiles_y = cdiv(P.oh, TH); P.tiles_n = cdiv(P.cout, BN);
+  // narrow maps (16x16 latents of training crops): 2*TH x 16-pixel tiles instead of half-empty 32-wide ones
+  const int pad32 = cdiv(P.ow, 32) * 32, pad16 = cdiv(P.ow, 16) * 16;
+  const int TW = (!tr && !gemm && (pad32 - pad16) * 4 >= pad32) ? 16 : SW;
+  P.tw_lg = TW == 16 ? 4 : 5;
+  const int TROWS = TH * SW / TW;
+  P.halo_h = gemm ? TH : TROWS + KW - 1; P.halo_w = gemm ? SW : TW + KW - 1;
+  P.tiles_x = cdiv(P.ow, TW); P.tiles_y = cdiv(P.oh, TROWS); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d_split: grid too large");
   P.nblocks = (int)nb;
