@@ -5,13 +5,19 @@
 // [pixel(lane>>5)][channel(lane&31)] -- no transposes anywhere.
 //
 // One 256-thread workgroup owns a 64(co) x 64(ci) block of dW for ONE FILTER ROW (k taps; wave w: co half w&1, ci half
-// w>>1; k accumulators of 32x32 = 48 VGPRs, so 4 workgroups share a CU) and walks a slab of output tiles (TH rows x 32
-// pixels).  Per tile it stages the dZ tile and the X rows that filter row touches (TH rows x 31s+k cols) in LDS once; the
-// k taps read them at shifted offsets.  Splitting the filter rows over workgroups instead of the pixel axis multiplies the
-// parallelism of the small training-crop layers by k without multiplying the partial-sum traffic.  LDS rows are only as wide as the channel block really is (1..64 floats), a lane
-// that reads past its row picks up finite-or-not garbage that lands in rows/cols of D which are never written back
-// (D[i][j] depends on A row i and B col j only).  Slabs write partial dW images [slab][tap][co][ci]; a second kernel
-// adds them in slab order into the OIHW gradient (+=), so the result is deterministic.
+// w>>1; k accumulators of 32x32 = 48 VGPRs) and walks a slab of output tiles (TH rows x 32 pixels).  Per tile it stages
+// the dZ tile and the X rows that filter row touches (TH rows x 31s+k cols) in LDS once; the k taps read them at shifted
+// offsets.  Splitting the filter rows over workgroups instead of the pixel axis multiplies the parallelism of the small
+// training-crop layers by k without multiplying the partial-sum traffic.  Slabs write partial dW images
+// [slab][tap][co][ci]; a second kernel adds them in slab order into the OIHW gradient (+=): deterministic.
+//
+// Two flavours of the tile loop:
+//   wgrad_dma_kernel  full 64x64 channel blocks with 16-B aligned rows (the large layers): LDS-DMA into a double buffer,
+//                     tile t+1 in flight while tile t is multiplied (see its comment);
+//   wgrad_kernel      everything else (1-, 2-, 16-, 34-channel ends, unaligned slices): register-staged; LDS rows are only
+//                     as wide as the channel block really is (1..64 floats), a lane that reads past its row picks up
+//                     finite-or-not garbage that lands in rows/cols of D which are never written back (D[i][j] depends
+//                     on A row i and B col j only).
 //
 // ConvTranspose2d(k3,s2,p1,op1) weights [Cin][Cout][3][3] use the same routine with the roles swapped
 // (x := dOut at 2h x 2w, dz := the layer input at h x w, stride 2): out(2iy-1+ky) <- in(iy) * W[ci][co][ky][kx].
@@ -27,7 +33,7 @@ struct WgradParams {
   const float* dz; int dz_ld; int cout;
   int n, h, w, oh, ow, stride, pad, th;
   int tiles_x, tiles_y, total_tiles, tiles_per_slab;
-  int cwx_max, cwz_max, hr, hc;
+  int cwx_max, cwz_max, hr, hc;     // LDS row widths (register flavour); rows / columns of the staged X image
   int x_vec, dz_vec;                 // float4 loads allowed (ld % 4 == 0, base 16-B aligned)
   float* part;
 };
