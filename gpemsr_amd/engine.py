@@ -45,7 +45,7 @@ def _seq_len(sd, prefix: str) -> int:
 
 class Engine:
     def __init__(self, sd: Dict[str, torch.Tensor], device, scale: int, nframes: int = 5, groups: int = 8,
-                 nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 20, tile_chunk: int = 4,
+                 nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 80, tile_chunk: int = 16,
                  precision: str = "fp32"):
         assert scale in (8, 16)
         assert nf == 64, "kernels are specialised for nf=64 (every shipped option file)"

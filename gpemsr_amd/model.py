@@ -49,7 +49,7 @@ class GPEMSR(nn.Module):
 
     def __init__(self, ref_path_G, ref_path_Indexer, argref, nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10,
                  w_ref=True, ref_fusion_feat_RBs=3, align_mode='POD', fusion_mode='ThreeDA', mode='16to1', scale=16,
-                 init_seed: int = 0, frame_chunk: int = 20, tile_chunk: int = 4, precision: str = "fp32"):
+                 init_seed: int = 0, frame_chunk: int = 80, tile_chunk: int = 16, precision: str = "fp32"):
         super().__init__()
         if not (w_ref and align_mode == 'POD' and fusion_mode == 'ThreeDA'):
             raise NotImplementedError("gpemsr_amd implements the shipped configuration: w_ref=True, POD, ThreeDA")

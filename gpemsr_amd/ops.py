@@ -24,12 +24,16 @@ class Act:
     Training (gpemsr_amd/train.py): every view remembers the ``root`` allocation it was cut from; the root owns one
     zero-initialised gradient buffer of the same size (``gbuf``, created on first use) and a ``rg`` flag ("some
     producer of this memory depends on a trainable parameter"), so ``a.grad()`` is the same view over the gradient."""
-    __slots__ = ("buf", "n", "h", "w", "c", "ld", "off", "root", "gbuf", "rg")
+    __slots__ = ("buf", "n", "h", "w", "c", "ld", "off", "_root", "gbuf", "rg")
 
     def __init__(self, buf: torch.Tensor, n: int, h: int, w: int, c: int, ld: int, off: int = 0, root: "Act" = None):
         self.buf, self.n, self.h, self.w, self.c, self.ld, self.off = buf, n, h, w, c, ld, off
-        self.root = root if root is not None else self
+        self._root = root            # None for a root allocation (no self reference: buffers must die by ref-count, not by gc)
         self.gbuf, self.rg = None, False
+
+    @property
+    def root(self) -> "Act":
+        return self if self._root is None else self._root
 
     @property
     def ptr(self) -> int:

@@ -180,12 +180,18 @@ def test_latent_token_count_not_multiple_of_32(scale, h, w):
 
 
 def test_batch_crossing_chunk_boundaries():
-    """B = 5 windows = 25 slices: crosses frame_chunk (20) and tile_chunk (4); every window must equal its solo result."""
+    """B = 5 windows = 25 slices with frame_chunk = 20 and tile_chunk = 4 (the defaults are one chunk at this size): both
+    chunk boundaries are crossed; every window must equal its solo result."""
     from gpemsr_amd.synth import synth_lr_tiles
     model = _model(8)
     x = synth_lr_tiles(5, 5, 16, 16, seed=79, kind="uniform").cuda()
     tr = {}
-    out, ref = model(x, trace=tr)
+    old = model._chunks
+    model._chunks, model._engine = (20, 4), None
+    try:
+        out, ref = model(x, trace=tr)
+    finally:
+        model._chunks, model._engine = old, None
     idx = torch.cat(tr["code_idx"]).view(5, -1)
     for b in (0, 3, 4):
         o1, r1 = model(x[b:b + 1], forced_code_idx=idx[b])
