@@ -178,28 +178,48 @@ __global__ __launch_bounds__(256) void conv_stem1_kernel(const float* x, int n, 
   for (int i = threadIdx.x; i < 9 * cout; i += 256) wsm[i] = weight[((long long)(i / cout) * cout + (i % cout)) * cin_pad];
   for (int i = threadIdx.x; i < cout; i += 256) wsm[9 * cout + i] = bias ? bias[i] : 0.f;
   __syncthreads();
+  // a thread owns 4 output channels of SRUN consecutive pixels of one row: the 9 weight float4s stay in registers and the
+  // 3 x (SRUN+2) input window is read once -- the kernel is then bound by its 256-B-per-pixel output stream
+  constexpr int SRUN = 4;
   const int c4 = cout >> 2;
-  const long long total = (long long)n * h * w * c4;
+  const int runs = (w + SRUN - 1) / SRUN;
+  const long long total = (long long)n * h * runs * c4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int j = (int)(e % c4);
-    const long long pix = e / c4;
-    const int ox = (int)(pix % w), oy = (int)((pix / w) % h);
-    const long long img = pix / ((long long)w * h);
+    const long long rp = e / c4;
+    const int ox0 = (int)(rp % runs) * SRUN, oy = (int)((rp / runs) % h);
+    const long long img = rp / ((long long)runs * h);
     const float* xp = x + img * h * w;
-    float4 acc = *reinterpret_cast<const float4*>(wsm + 9 * cout + 4 * j);
+    float4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(wsm + t * cout + 4 * j);
+    const float4 bv = *reinterpret_cast<const float4*>(wsm + 9 * cout + 4 * j);
+    float win[3][SRUN + 2];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = oy - 1 + ky;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox - 1 + kx;
-        const float v = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? xp[(long long)iy * w + ix] : 0.f;
-        const float4 wv = *reinterpret_cast<const float4*>(wsm + (ky * 3 + kx) * cout + 4 * j);
-        acc.x = fmaf(v, wv.x, acc.x); acc.y = fmaf(v, wv.y, acc.y); acc.z = fmaf(v, wv.z, acc.z); acc.w = fmaf(v, wv.w, acc.w);
+      for (int q = 0; q < SRUN + 2; ++q) {
+        const int ix = ox0 - 1 + q;
+        win[ky][q] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? xp[(long long)iy * w + ix] : 0.f;
       }
     }
-    acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
-    *reinterpret_cast<float4*>(out + pix * out_ld + 4 * j) = acc;
+#pragma unroll
+    for (int r = 0; r < SRUN; ++r) {
+      if (ox0 + r >= w) break;
+      float4 acc = bv;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float v = win[ky][r + kx];
+          const float4 ww = wv[ky * 3 + kx];
+          acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y); acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
+        }
+      acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
+      const long long pix = (img * h + oy) * w + ox0 + r;
+      *reinterpret_cast<float4*>(out + pix * out_ld + 4 * j) = acc;
+    }
   }
 }
 
@@ -211,7 +231,7 @@ extern "C" int gpemsr_conv2d_stem1(const float* x, int n, int h, int w, const fl
                                    int act, float* out, int out_ld, void* stream) {
   GP_REQUIRE(x && weight && out && n > 0 && h > 0 && w > 0, "conv2d_stem1: bad args");
   GP_REQUIRE(cout % 4 == 0 && cout <= 512 && out_ld % 4 == 0 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0), "conv2d_stem1: cout/out alignment");
-  const long long total = (long long)n * h * w * (cout / 4);
+  const long long total = (long long)n * h * ((w + 3) / 4) * (cout / 4);
   const long long blocks = (total + 255) / 256;
   hipLaunchKernelGGL(conv_stem1_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), (size_t)10 * cout * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), x, n, h, w, weight, bias, cout, 8, act, out, out_ld);
