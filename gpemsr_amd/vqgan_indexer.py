@@ -17,7 +17,6 @@ from typing import Dict, List
 import torch
 import torch.nn as nn
 
-from . import ops
 from .arch import param_specs
 from .ops import Act
 from .synth import synth_tensor
