@@ -494,7 +494,28 @@ def contextual_loss_taped(fx: Act, fy: Act, t: int, scale_ref: list, band_width:
     return loss, cw
 
 
-class Stage3Trainer:
+class _TrainerState:
+    """Resume support shared by the trainers: what the reference keeps in its ``training_state`` files
+    (train_stage3.py:183-184: optimizer and scheduler state dicts) -- Adam moments, step counter, scheduler position.
+    The weights themselves travel in ``model.state_dict()`` as usual."""
+
+    def state_dict(self) -> dict:
+        names = [k for k, p in self.model.named_parameters() if p.data_ptr() >= self.flat_p.data_ptr()
+                 and p.data_ptr() < self.flat_p.data_ptr() + 4 * self.flat_p.numel()]
+        return {"step_count": self.step_count, "lr": self.lr, "scheduler": dict(vars(self.sched)),
+                "exp_avg": self.flat_m.detach().clone(), "exp_avg_sq": self.flat_v.detach().clone(), "param_names": names}
+
+    def load_state_dict(self, st: dict):
+        assert st["exp_avg"].numel() == self.flat_m.numel(), "optimizer state belongs to a different parameter set"
+        self.step_count, self.lr = int(st["step_count"]), float(st["lr"])
+        for k, v in st["scheduler"].items():
+            setattr(self.sched, k, v)
+        self.flat_m.copy_(st["exp_avg"].to(self.flat_m.device))
+        self.flat_v.copy_(st["exp_avg_sq"].to(self.flat_v.device))
+        self.eng.refresh_weights()
+
+
+class Stage3Trainer(_TrainerState):
     """``train_EMSR_onestep`` (train_stage3.py:343-366).  ``opt_train`` is the ``train:`` block of
     option/train_stage3_x{8,16}.yml (lr_G, beta1, beta2, lr_scheme, T_period, restarts, restart_weights, eta_min,
     rec_loss_factor, ref_loss_factor, weight_decay_G)."""

@@ -23,7 +23,7 @@ from . import ops
 from .dist import average_gradients
 from .engine import _seq_len
 from .ops import ACT_NONE, ACT_RELU, Act
-from .train import CosineAnnealingLRRestart, MultiStepLRRestart, TrainEngine, flatten_parameters
+from .train import CosineAnnealingLRRestart, MultiStepLRRestart, TrainEngine, _TrainerState, flatten_parameters
 
 
 class Stage2Engine(TrainEngine):
@@ -168,7 +168,7 @@ class Stage2Engine(TrainEngine):
             self.tape = tape
 
 
-class Stage2Trainer:
+class Stage2Trainer(_TrainerState):
     """``train_vqgan_onestep`` (train_stage2.py:351-366).  ``opt_train``: the ``train:`` block of
     option/train_stage2_x{8,16}.yml (lr_G, beta1, beta2, lr_scheme, T_period, restarts, restart_weights, eta_min,
     weight_decay_G)."""

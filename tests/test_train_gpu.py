@@ -643,3 +643,33 @@ def test_training_step_non_square_ragged_crop_matches_oracle():
         base, leaf = k.rsplit(".", 1)
         g = (tr.gw if leaf == "weight" else tr.gb)[base]
         _close(g, sd[k].grad, 1e-3, "grad " + k)
+
+
+def test_trainer_resume_continues_bit_for_bit_on_the_optimizer_side():
+    """Save after one step (model.state_dict() + trainer.state_dict()), rebuild, load, take the second step: parameters equal
+    those of the uninterrupted run (the forward has one float-atomic scatter, so 'equal' is 1e-6, not bitwise)."""
+    import io
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    topt = dict(lr_G=2e-4, beta1=0.9, beta2=0.99, T_period=[4, 6], restarts=[4], restart_weights=[0.5], eta_min=1e-7,
+                rec_loss_factor=1, ref_loss_factor=0.001)
+    LR = synth_lr_tiles(1, 5, 16, 16, seed=31, kind="smooth").to(dev)
+    GT = torch.rand(1, 1, 128, 128, generator=torch.Generator().manual_seed(32)).to(dev)
+    a = Stage3Trainer(build_model(opt, load_prior_files=False).to(dev), topt, dev)
+    a.step(LR, GT)
+    buf = io.BytesIO()
+    torch.save({"model": a.model.state_dict(), "trainer": a.state_dict()}, buf)
+    a.step(LR, GT)
+    ck = torch.load(io.BytesIO(buf.getvalue()), map_location="cpu", weights_only=False)
+    m2 = build_model(opt, load_prior_files=False)
+    m2.load_state_dict(ck["model"], strict=True)
+    b = Stage3Trainer(m2.to(dev), topt, dev)
+    b.load_state_dict(ck["trainer"])
+    assert b.step_count == 1 and b.lr == ck["trainer"]["lr"]
+    b.step(LR, GT)
+    assert a.lr == b.lr and a.step_count == b.step_count == 2
+    _close(b.flat_p, a.flat_p, 1e-6, "parameters after resume")
+    _close(b.flat_m, a.flat_m, 1e-4, "exp_avg after resume")
