@@ -18,6 +18,7 @@
 //   * epilogue identical to conv_mfma.hip (LDS-staged coalesced float4 rows, batched residual loads, PixelShuffle).
 // Parity: tests/test_ops_gpu.py::test_conv_split_* (<= 3e-5 relative vs fp32 torch for NSPLIT = 2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace gpemsr {
 
@@ -27,7 +28,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SW = 32;            // tile width (pixels)
 constexpr int SA_LOADS = 6;       // raw-A float4 slots per thread (10x34 halo x 4 / 256 -> 6; GEMM: 128 px x 8 / 256 -> 4)
-constexpr int SB_LOADS = 3;       // weight 16-B slots per thread per plane (3 taps x 128 couts x 2 / 256; 7 taps x 32 x 2 / 256 -> 2)
+constexpr int SB_LOADS = 4;       // weight 16-B slots per thread per plane (3 taps x 128 couts x 2 / 256 -> 3; 7 taps x 64 x 2 / 256 -> 4)
 
 struct SplitParams {
   const float* src[GPEMSR_MAX_SRC];
@@ -486,7 +487,10 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   P.res_vec = d->residual && (d->res_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->residual) & 15) == 0);
   const int KW = tr ? 2 : (gemm ? 2 : d->ksize);                  // GEMM: 2 sub-chunks of 16 channels per stage
   // 7x7: 32-cout blocks of 4x32 pixels keep the (larger) halo + 7-tap weight images at two workgroups per CU
-  const int BN = tr ? 128 : (gemm ? (d->cout <= 64 ? 64 : 128) : (KW == 7 ? 32 : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128))));
+  // 7x7: 32-cout blocks; plain bf16 (one plane) has room for 64-cout blocks at two workgroups per CU (the fp32 halo tile is then
+  // staged and converted once per 64 couts instead of twice) -- GPEMSR_SPLIT_NO_7x7_BN64 restores 32
+  const bool bn64_7 = (nsplit == 1 && d->cout >= 64 && getenv("GPEMSR_SPLIT_NO_7x7_BN64") == nullptr);
+  const int BN = tr ? 128 : (gemm ? (d->cout <= 64 ? 64 : 128) : (KW == 7 ? (bn64_7 ? 64 : 32) : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128))));
   const int TH = (BN == 128 || KW == 7 || gemm) ? 4 : 8;
   P.pad = (tr || gemm) ? 0 : KW / 2;
   // narrow maps (16x16 latents of training crops): 2*TH x 16-pixel tiles instead of half-empty 32-wide ones
@@ -517,6 +521,7 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
     if (BN == 64) return nsplit == 2 ? launch_split<64, 2, 2, 4, 2, 2, false, true>(P, lds, st) : launch_split<64, 2, 2, 4, 1, 2, false, true>(P, lds, st);
     return nsplit == 2 ? launch_split<128, 2, 2, 4, 2, 2, false, true>(P, lds, st) : launch_split<128, 2, 2, 4, 1, 2, false, true>(P, lds, st);
   }
+  if (KW == 7 && BN == 64) return launch_split<64, 4, 1, 4, 1, 7>(P, lds, st);
   if (KW == 7) return nsplit == 2 ? launch_split<32, 4, 1, 4, 2, 7>(P, lds, st) : launch_split<32, 4, 1, 4, 1, 7>(P, lds, st);
   if (nsplit == 2) {
     if (BN == 32) return launch_split<32, 4, 1, 8, 2, 3>(P, lds, st);
