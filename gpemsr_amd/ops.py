@@ -192,6 +192,8 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
     use_direct = (not force_mfma and pc.cout <= 16 and (pc.cout <= 2 or pc.cin <= 16) and len(srcs) == 1 and k >= 3
                   and pc.ck == 8 and not pc.transposed
                   and not pc.pixel_shuffle and pixmul is None and weight_image_stride == 0 and src_image_stride is None)
+    if use_direct and precision == "bf16" and pc.w16 is not None and k == 7 and stride == 1 and s0.c % 16 == 0 and residual is not None:
+        use_direct = False          # SpyNet's 16 -> 2 7x7 output conv: even padded to 32 couts the bf16 matrix pipe beats the VALU kernel
     if stride == 4:
         assert use_direct, "stride 4 is only available through the direct kernel"
     use_stem = (not force_mfma and len(srcs) == 1 and s0.c == 1 and s0.ld == 1 and k == 3 and stride == 1 and pc.ck == 8
