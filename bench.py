@@ -3,15 +3,18 @@
 (5-slice 1x128x128 LR windows -> 1024x1024 HR tiles) on 1/2/4/8 MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-A "step" is one pass of the hot path over one batch of synthetic tiles: at N=1 the
-workload is BASELINE.json configs[1] (batch = 16 tiles, fp32, forward only); at N>1
-every rank runs the same 16 tiles/GPU (weak scaling) and the step ends with the RCCL
-all-gather of the HR output slabs (the north_star's only exchange step).  Inputs are
-resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with the
-`roofline` (conv implicit-GEMM kernel: algorithmic FLOPs / HIP-event time, against the
-fp32 matrix peak) and `cpu_baseline` (the CPU oracle timed on the host cores) objects.
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env), or started
+plainly -- then this process only PARSES the arguments and starts N fresh rank processes of itself (one per GPU,
+env:// rendezvous on 127.0.0.1: the one-process-per-GPU launch of R:train_stage3.py:20-27); the parent never touches
+the GPU, forwards rank 0's JSON line and exits non-zero if any rank fails.
+
+A "step" is one pass of the hot path over one batch of synthetic tiles: at N=1 the workload is BASELINE.json configs[1]
+(batch = 16 tiles, fp32, forward only); at N>1 every rank runs the same 16 tiles/GPU (weak scaling) and the step ends
+with the RCCL all-gather of the HR output slabs (the north_star's only exchange step).  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line with the `roofline` (dominant kernel family: algorithmic FLOPs /
+HIP-event time on the launch stream, against the matrix-pipe peak of the dtype) and `cpu_baseline` (the CPU oracle timed
+on the host cores) objects.  `extras` carries the bf16 configurations (BASELINE configs[2]) measured in the same run.
 """
 from __future__ import annotations
 
@@ -24,10 +27,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 ESSENTIAL_GFLOP_PER_TILE = {8: 5901.7, 16: 4882.3}
+CHILD_ENV = "GPEMSR_BENCH_CHILD"
 
 
 def effective_cores() -> int:
@@ -42,7 +45,7 @@ def effective_cores() -> int:
     return max(1, n)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -50,41 +53,323 @@ def main():
     ap.add_argument("--tiles", type=int, default=16, help="tiles (5-slice windows) per GPU per step")
     ap.add_argument("--lr", type=int, default=128)
     ap.add_argument("--scale", type=int, default=8, choices=(8, 16))
-    ap.add_argument("--precision", type=str, default="fp32", choices=("fp32", "bf16x3", "bf16"),
-                    help="fp32 = exact fp32 MFMA (BASELINE configs[1], the default); bf16x3 = 3x3 convs on the bf16 matrix pipe with "
-                         "split hi+lo operands (fp32-grade, ~1e-5/op); bf16 = plain bf16 operands")
+    ap.add_argument("--precision", type=str, default="fp32", choices=("fp32", "bf16x3", "bf16", "bf16op"),
+                    help="fp32 = exact fp32 MFMA (BASELINE configs[1], the default); bf16 = bf16 activations in HBM + bf16 MFMA "
+                         "(BASELINE configs[2]); bf16x3 = fp32 activations, convs on the bf16 pipe with split hi+lo operands "
+                         "(fp32-grade); bf16op = fp32 activations, bf16 operands (round 1's bf16 mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-by-the-driver) bf16x3 measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-by-the-driver) measurements")
+    ap.add_argument("--extras", type=str, default="bf16", help="comma list of precisions measured beside the official fp32 number")
     ap.add_argument("--cpu-lr", type=int, default=128, help="LR size of the CPU-oracle sample tile")
     ap.add_argument("--layer-report", type=str, default="", help="write a per-layer conv timing table to this file")
     ap.add_argument("--mode", type=str, default="forward", choices=("forward", "train", "train2"),
-                    help="forward = BASELINE configs[1]/[2]/[3] (the headline metric, default); train = configs[4], the stage-3 training step; train2 = the stage-2 (indexer) training step")
+                    help="forward = BASELINE configs[1]/[2]/[3] (the headline metric, default); train = configs[4], the stage-3 "
+                         "training step; train2 = the stage-2 (indexer) training step")
     ap.add_argument("--no-profile", action="store_true", help="--mode train: no per-launch HIP events (roofline fields become 0)")
     ap.add_argument("--train-batch", type=int, default=8, help="--mode train: samples per GPU per step")
-    ap.add_argument("--stage2-lr", type=int, default=128, help="--mode train2: LR size (GT is scale x larger; train_stage2_x8.yml: 1024 / 8)")
+    ap.add_argument("--stage2-lr", type=int, default=128, help="--mode train2: LR size (GT is scale x larger)")
     ap.add_argument("--train-lr", type=int, default=32, help="--mode train: LR crop size (option/train_stage3_x8.yml LQ_size)")
-    args = ap.parse_args()
-    if args.mode == "train":
-        import bench_train
-        return bench_train.run(args, ROOT, effective_cores)
-    if args.mode == "train2":
-        import bench_train
-        return bench_train.run_stage2(args, ROOT, effective_cores)
+    ap.add_argument("--backend", type=str, default="", help="torch.distributed backend (default: nccl = RCCL on GPUs)")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test (tests/test_bench_launcher_cpu.py): a per-tile stand-in model on the CPU with "
+                         "--backend gloo; exercises spawn, rendezvous, barrier, all-gather and max-over-ranks timing only")
+    ap.add_argument("--rank-timeout", type=float, default=3000.0, help="seconds the launcher waits for its ranks")
+    return ap.parse_args(argv)
 
-    from gpemsr_amd import dist as gdist, ops
-    from gpemsr_amd.config import build_model, load_options
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts its own N ranks
+# ----------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv) -> int:
+    """Start args.gpus rank processes of this script (fresh interpreters; this parent initialises no GPU state), wait,
+    forward rank 0's stdout.  Returns the exit code: 0 only if every rank exited 0 and rank 0 printed its JSON line."""
+    import socket
+    import subprocess
+    import tempfile
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ)
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    base[CHILD_ENV] = "1"
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")                 # rank 0's stdout (a file, so a long line can never block it)
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + args.rank_timeout
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending and rc == 0:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0:
+                        print(f"[bench launcher] rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                        rc = code if code > 0 else 1
+            if pending and rc == 0:
+                if time.time() > deadline:
+                    print(f"[bench launcher] ranks {sorted(pending)} still running after {args.rank_timeout:.0f} s", file=sys.stderr, flush=True)
+                    rc = 124
+                else:
+                    time.sleep(0.2)
+    finally:
+        for p in procs:                      # the exact PIDs started above, never a pattern
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    out0.seek(0)
+    text = out0.read()
+    out0.close()
+    if rc == 0:
+        line = None
+        for ln in text.splitlines():
+            if ln.startswith("{"):
+                try:
+                    line = json.loads(ln)
+                except Exception:
+                    pass
+        if line is None or line.get("n_gpus") != n:
+            print("[bench launcher] rank 0 printed no JSON line for n_gpus=%d" % n, file=sys.stderr, flush=True)
+            rc = 1
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# rank body
+# ----------------------------------------------------------------------------------------------------------------------
+class _StubModel:
+    """Per-tile stand-in (launcher self-test on the CPU): out depends on the tile only, so sharded == unsharded."""
+    precision = "stub"
+
+    def __call__(self, x):
+        b = x.shape[0]
+        return (x[:, 2].mean(dim=(1, 2, 3)).view(b, 1, 1, 1) + x[:, 2, :, :8, :8]).contiguous(), x
+
+
+def timed_steps(step, steps: int, world: int, dev, sync):
+    """EXACTLY `steps` steps between barrier + synchronize pairs; returns (max over ranks of the wall time, last output)."""
+    import torch
+    if world > 1:
+        torch.distributed.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    sync()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, out
+
+
+def _family(summ, names):
+    d = {"launches": 0, "ms": 0.0, "flops": 0.0}
+    for k in names:
+        if k in summ:
+            for f in d:
+                d[f] += summ[k][f]
+    return d
+
+
+def _tf(d):
+    return d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+
+
+def pmc_traffic(tag: str, launches_per_step: int):
+    """HBM bytes per launch of the dominant kernel family from the rocprofv3 --pmc summary committed for THIS tree
+    (profiles/r02_<tag>_pmc_summary.json, scripts/pmc_round.sh; separate passes, FETCH_SIZE x2 gfx950 correction).  The
+    summary records the family's launches per step; a mismatch means it was taken on another tree -> null."""
+    path = os.path.join(ROOT, "profiles", f"r02_{tag}_pmc_summary.json")
+    try:
+        doc = json.load(open(path))
+        fam = doc["dominant_family"]
+        if int(fam["launches_per_step"]) != int(launches_per_step):
+            return None, None
+        return round(fam["hbm_bytes_per_launch"]), {"file": os.path.relpath(path, ROOT),
+                                                     "hbm_bytes_per_step_all_kernels": doc.get("hbm_bytes_per_step_all_kernels")}
+    except Exception:
+        return None, None
+
+
+FAMILIES = {
+    "fp32": (("conv_mfma",), "conv_mfma_kernel (implicit-GEMM conv/GEMM family, v_mfma_f32_32x32x2_f32)", PEAK_F32_MATRIX_TFLOPS),
+    "bf16": (("conv_bf16", "vgg_mask", "attn_bf16"),
+             "bf16 MFMA family (v_mfma_f32_32x32x16_bf16): conv_bf16_kernel (implicit-GEMM conv / 1x1 / transposed / attention "
+             "products), vgg_mask_kernel (fused VGG relu1_2 + 16x16 patch cosine), attn_bf16 (fused attention)", PEAK_BF16_MATRIX_TFLOPS),
+    "bf16x3": (("conv_split",), "conv_split_kernel (v_mfma_f32_32x32x16_bf16, 3 split products per algorithmic product)", PEAK_BF16_MATRIX_TFLOPS),
+    "bf16op": (("conv_split",), "conv_split_kernel (v_mfma_f32_32x32x16_bf16, bf16 operands rounded in LDS)", PEAK_BF16_MATRIX_TFLOPS),
+}
+
+
+def build_roofline(args, prof, dt, B, s, precision=None):
+    precision = precision or args.precision
+    summ = prof.summary()
+    fam_names, kern, peak = FAMILIES[precision]
+    fam = _family(summ, fam_names)
+    achieved = _tf(fam)
+    launches_per_step = fam["launches"] // max(args.steps, 1)
+    traffic, traffic_src = pmc_traffic(precision, launches_per_step)
+    r = {
+        "bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+        "algorithmic_gflop_per_launch": round(fam["flops"] / 1e9 / max(fam["launches"], 1), 2),
+        "launches_per_step": launches_per_step,
+        "avg_launch_us": round(1e3 * fam["ms"] / max(fam["launches"], 1), 2),
+        "algorithmic_gflop_per_tile_in_kernel": round(fam["flops"] / 1e9 / max(args.steps * B, 1), 1),
+        "essential_gflop_per_tile_survey": ESSENTIAL_GFLOP_PER_TILE[s],
+        "kernel_time_share_of_step": round(fam["ms"] * 1e-3 / dt, 3),
+        "whole_path_tflops_essential": round(ESSENTIAL_GFLOP_PER_TILE[s] * B * args.steps / dt / 1e3, 2),
+    }
+    others = {k: {"tflops": round(_tf(v), 2), "launches_per_step": v["launches"] // max(args.steps, 1),
+                  "time_share_of_step": round(v["ms"] * 1e-3 / dt, 3)} for k, v in summ.items() if k not in fam_names}
+    if others:
+        r["other_profiled_kernels"] = others
+    return r
+
+
+def write_layer_report(prof, path):
+    rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
+    with open(path, "w") as f:
+        f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\n")
+        for (kern, tag), d in rows:
+            f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{_tf(d):.1f}\n")
+
+
+def _volume_bench(model, fr, win, steps):
+    import torch
+    model.forward_volume(fr, win)
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    for _ in range(steps):
+        model.forward_volume(fr, win)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - tv) / steps
+
+
+def run_extras(args, model, opt, x, out, dt, dev):
+    """Measured beside the official number, never replacing it: volume mode (what output_GPEMSR.py runs) and
+    the bf16 configurations (BASELINE configs[2] names "bf16 MFMA"), each with its own roofline object and its error
+    against this run's fp32 outputs (teacher-forced = the fp32 run's code indices, free-running = its own)."""
+    import torch
+    from gpemsr_amd import ops
+    from gpemsr_amd.config import build_model
     from gpemsr_amd.synth import synth_lr_tiles
-
-    rank, world, local = gdist.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{args.scale}.yml"))
-    model = build_model(opt, load_prior_files=False, precision=args.precision).eval().to(dev)
     B, s, lr = args.tiles, args.scale, args.lr
-    x = synth_lr_tiles(B, 5, lr, lr, seed=1000 + rank, kind="uniform").to(dev)     # resident in HBM before timing
+    T = B + 4
+    fr = synth_lr_tiles(1, T, lr, lr, seed=77, kind="smooth")[0].to(dev)
+    rows = [[min(max(c + o, 0), T - 1) for o in (-2, -1, 0, 1, 2)] for c in range(T)]
+    win = torch.tensor(rows, dtype=torch.int32, device=dev)
+    value = B * (lr * s) ** 2 / 1e6 * args.steps / dt
+    dv = _volume_bench(model, fr, win, args.steps)
+    extras = {"volume_mode": {"value": round(T * (lr * s) ** 2 / 1e6 / dv, 3), "unit": "MP/s", "ms_per_volume": round(1e3 * dv, 2),
+                              "workload": f"{T} consecutive {lr}x{lr} LR slices -> {T} HR slices of {lr * s}^2 (sliding 5-slice windows, "
+                                          "per-slice features cached; output_GPEMSR.py's loop)", "precision": args.precision,
+                              "speedup_vs_independent_windows": round(T * (lr * s) ** 2 / 1e6 / dv / value, 3)}}
+    if args.precision != "fp32":
+        return extras
+    out_ref = out[:B].clone()
+    tr_ref = {}
+    o2_ref, _ = model(x[:2], trace=tr_ref)                  # two windows, for the teacher-forced comparison
+    idx_ref = torch.cat(tr_ref["code_idx"])
+    del model
+    for mode in [m for m in args.extras.split(",") if m]:
+        torch.cuda.empty_cache()
+        m3 = build_model(opt, load_prior_files=False, precision=mode).eval().to(dev)
+
+        def step3():
+            return m3(x)[0]
+        for _ in range(max(args.warmup, 2)):          # the allocator re-grows its pools after empty_cache(): keep that out of the timing
+            step3()
+        prof = ops.LaunchProfiler()
+        ops.PROFILER = prof
+        d3, o3 = timed_steps(step3, args.steps, 1, dev, torch.cuda.synchronize)
+        ops.PROFILER = None
+        rel = float((o3[:B] - out_ref).abs().max() / out_ref.abs().max())
+        tr3 = {}
+        o2_tf, _ = m3(x[:2], forced_code_idx=idx_ref)
+        m3(x[:2], trace=tr3)
+        rel_tf = float((o2_tf - o2_ref).abs().max() / o2_ref.abs().max())
+        agree = float((torch.cat(tr3["code_idx"]) == idx_ref).float().mean())
+        vol = _volume_bench(m3, fr, win, args.steps)
+        extras[mode] = {"value": round(B * (lr * s) ** 2 / 1e6 * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
+                        "volume_mode_value": round(T * (lr * s) ** 2 / 1e6 / vol, 3),
+                        "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
+                        "code_index_agreement_free_running_2_windows": agree,
+                        "rel_err_vs_fp32_path_free_running_all_windows": rel,
+                        "speedup_vs_fp32_path": round(dt / d3, 3),
+                        "roofline": build_roofline(args, prof, d3, B, s, precision=mode)}
+        del m3, o3
+    return extras
+
+
+def run_cpu_baseline(args, model_sd, x, out):
+    """Bounded sample of the same workload: ONE 5-slice window through the CPU oracle on the host cores, a same-size
+    warm-up pass + 2 timed passes."""
+    import torch
+    from gpemsr_amd.synth import synth_lr_tiles
+    from oracle import gpemsr_oracle as orc
+    s, lr = args.scale, args.lr
+    cores = effective_cores()
+    torch.set_num_threads(cores)
+    xc = x[:1].cpu() if args.cpu_lr == lr else synth_lr_tiles(1, 5, args.cpu_lr, args.cpu_lr, seed=1000)
+    times = []
+    with torch.no_grad():
+        for i in range(3):
+            t1 = time.perf_counter()
+            o_cpu, _ = orc.gpemsr_forward(model_sd, xc, scale=s)
+            if i > 0:
+                times.append(time.perf_counter() - t1)
+    cdt = sum(times) / len(times)
+    cpu_mp = (args.cpu_lr * s) ** 2 / 1e6 / cdt
+    cb = {"value": round(cpu_mp, 5), "unit": "output megapixels/s", "cores": torch.get_num_threads(), "kind": "port",
+          "sample": f"1 window [1,5,1,{args.cpu_lr},{args.cpu_lr}] -> {args.cpu_lr * s}^2: same-size warm-up pass + 2 timed passes "
+                    f"({times[0]:.1f} s, {times[1]:.1f} s) of oracle/gpemsr_oracle.py (torch CPU fp32; SpyNet de-duplicated, VGG slice1 only)"}
+    if args.cpu_lr == lr and args.precision == "fp32":
+        err = float((out[:1].cpu() - o_cpu).abs().max() / o_cpu.abs().max())
+        cb["gpu_vs_cpu_rel_err_free_running"] = float(f"{err:.3e}")
+    return cb
+
+
+def run_forward(args) -> int:
+    import torch
+    from gpemsr_amd import dist as gdist
+
+    rank, world, local = gdist.init_from_env(backend=args.backend or None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    B, s, lr = args.tiles, args.scale, args.lr
+    if args.stub:
+        dev = torch.device("cpu")
+        sync = lambda: None                                                        # noqa: E731
+        model = _StubModel()
+        x = torch.rand(B, 5, 1, lr, lr, generator=torch.Generator().manual_seed(1000 + rank))
+    else:
+        from gpemsr_amd import ops
+        from gpemsr_amd.config import build_model, load_options
+        from gpemsr_amd.synth import synth_lr_tiles
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
+        opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{s}.yml"))
+        model = build_model(opt, load_prior_files=False, precision=args.precision).eval().to(dev)
+        x = synth_lr_tiles(B, 5, lr, lr, seed=1000 + rank, kind="uniform").to(dev)     # resident in HBM before timing
 
     def step():
         out, _ = gdist.forward_sharded(model, x, rank, world, already_local=True, gather=True)
@@ -92,193 +377,71 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    prof = ops.LaunchProfiler()
-    ops.PROFILER = prof
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    ops.PROFILER = None
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    prof = None
+    if not args.stub:
+        prof = ops.LaunchProfiler()
+        ops.PROFILER = prof
+    dt, out = timed_steps(step, args.steps, world, dev, sync)
+    if not args.stub:
+        ops.PROFILER = None
     assert out.shape[0] == B * world
+    rccl_world = torch.distributed.get_world_size() if world > 1 else 1           # the group the all-gathers above ran on
 
-    mp_per_step = world * B * (lr * s) * (lr * s) / 1e6
+    opix = out.shape[-1] * out.shape[-2]
+    mp_per_step = world * B * opix / 1e6
     value = mp_per_step * args.steps / dt
-    summ = prof.summary()
-    conv = summ.get("conv_mfma", {"launches": 0, "ms": 0.0, "flops": 0.0})
-    split = summ.get("conv_split")
-    achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
-    alg_gflop_tile = conv["flops"] / 1e9 / (args.steps * B) if args.steps * B else 0.0
-    # HBM bytes per launch of the same kernel family from the separate rocprofv3 --pmc passes committed under profiles/
-    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); PMC cannot be collected inside this process.
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01c_fp32_pmc_summary.json")
-    if s == 8 and lr == 128 and B == 16 and os.path.exists(pmc_file):
-        try:
-            fam = json.load(open(pmc_file))["conv_mfma_family"]
-            traffic, traffic_src = round(fam["hbm_bytes_per_launch"]), "profiles/r01c_fp32_pmc_summary.json (separate --pmc passes of the same command, scripts/pmc_round.sh)"
-        except Exception:
-            pass
-    roofline = {
-        "bound": "mfma", "kernel": "conv_mfma_kernel (implicit-GEMM conv/GEMM family, v_mfma_f32_32x32x2_f32)",
-        "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-        "traffic_source": traffic_src,
-        "algorithmic_gflop_per_launch": round(conv["flops"] / 1e9 / max(conv["launches"], 1), 2),
-        "launches_per_step": conv["launches"] // max(args.steps, 1),
-        "avg_launch_us": round(1e3 * conv["ms"] / max(conv["launches"], 1), 2),
-        "algorithmic_gflop_per_tile_in_kernel": round(alg_gflop_tile, 1),
-        "essential_gflop_per_tile_survey": ESSENTIAL_GFLOP_PER_TILE[s],
-        "kernel_time_share_of_step": round(conv["ms"] * 1e-3 / dt, 3),
-        "whole_path_tflops_essential": round(ESSENTIAL_GFLOP_PER_TILE[s] * B * args.steps / dt / 1e3, 2),
-    }
-    if split is not None:
-        roofline["split_bf16_kernel"] = {
-            "kernel": "conv_split_kernel (3x3 convs, v_mfma_f32_32x32x16_bf16, %s)" % args.precision,
-            "achieved_algorithmic_tflops": round(split["flops"] / (split["ms"] * 1e-3) / 1e12, 2),
-            "peak_bf16_dense_tflops": 2500.0, "mfma_products_per_algorithmic_product": 3 if args.precision == "bf16x3" else 1,
-            "launches_per_step": split["launches"] // max(args.steps, 1),
-            "time_share_of_step": round(split["ms"] * 1e-3 / dt, 3)}
-    if args.layer_report and rank == 0:
-        rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
-        with open(args.layer_report, "w") as f:
-            f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\n")
-            for (kern, tag), d in rows:
-                tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0
-                f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{tf:.1f}\n")
-
-    # Extra, reported beside the official number (never replaces it): the same step with precision='bf16x3'
-    # (3x3/7x7 convs on the bf16 matrix pipe with split hi+lo operands; meets the same 1e-3 parity bar, see tests).
-    extras = None
-    if world == 1 and not args.no_extras:
-        # Volume mode (what output_GPEMSR.py runs): T consecutive slices, one sliding 5-slice window per
-        # slice (edges replicated); the per-slice half runs once per slice.  Same arithmetic, bit-identical outputs.
-        T = B + 4
-        fr = synth_lr_tiles(1, T, lr, lr, seed=77, kind="smooth")[0].to(dev)
-        rows = [[min(max(c + o, 0), T - 1) for o in (-2, -1, 0, 1, 2)] for c in range(T)]
-        win = torch.tensor(rows, dtype=torch.int32, device=dev)
-        model.forward_volume(fr, win)
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        for _ in range(args.steps):
-            ov, _ = model.forward_volume(fr, win)
-        torch.cuda.synchronize()
-        dv = (time.perf_counter() - tv) / args.steps
-        extras = {"volume_mode": {"value": round(T * (lr * s) ** 2 / 1e6 / dv, 3), "unit": "MP/s", "ms_per_volume": round(1e3 * dv, 2),
-                                  "workload": f"{T} consecutive {lr}x{lr} LR slices -> {T} HR slices of {lr * s}^2 (sliding 5-slice windows, "
-                                              "per-slice features cached; output_GPEMSR.py's loop)", "precision": args.precision,
-                                  "speedup_vs_independent_windows": round(T * (lr * s) ** 2 / 1e6 / dv / value, 3)}}
-        del ov
-    if args.precision == "fp32" and not args.no_extras:
-        # The same step on the bf16 matrix pipe, reported beside the official number (never replaces it):
-        #   bf16x3 = split hi+lo operands, fp32-grade (meets the same 1e-3 bar, see tests); bf16 = plain bf16 operands
-        #   (BASELINE configs[2] names "bf16 MFMA"), bounded at 2e-2 by its test.
-        out_ref = out[:B].clone()
-        tr_ref = {}
-        o2_ref, _ = model(x[:2], trace=tr_ref)                  # two windows, for the teacher-forced comparison
-        idx_ref = torch.cat(tr_ref["code_idx"])
-        del model
-        extras = dict(extras or {})
-        dtypes = {"bf16x3": "bf16x3: fp32 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate "
-                            "(1x1/3x3/7x7 convs, transposed convs, attention products); f32 elsewhere and in HBM",
-                  "bf16": "bf16 operands (rounded in the kernel), v_mfma_f32_32x32x16_bf16, fp32 accumulate (same layers); f32 elsewhere and in HBM"}
-        for mode in ("bf16x3", "bf16"):
-            torch.cuda.empty_cache()
-            m3 = build_model(opt, load_prior_files=False, precision=mode).eval().to(dev)
-            def step3():
-                o, _ = gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True)
-                return o
-            for _ in range(max(args.warmup, 2)):          # the allocator re-grows its pools after empty_cache(): keep that out of the timing
-                step3()
-            if world > 1:
-                torch.distributed.barrier()
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            for _ in range(args.steps):
-                o3 = step3()
-            torch.cuda.synchronize()
-            if world > 1:
-                torch.distributed.barrier()
-            d3 = time.perf_counter() - t3
-            if world > 1:
-                tt = torch.tensor([d3], dtype=torch.float64, device=dev)
-                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-                d3 = float(tt.item())
-            rel = float((o3[:B] - out_ref).abs().max() / out_ref.abs().max())
-            tr3 = {}
-            o2_tf, _ = m3(x[:2], forced_code_idx=idx_ref)
-            m3(x[:2], trace=tr3)
-            rel_tf = float((o2_tf - o2_ref).abs().max() / o2_ref.abs().max())
-            agree = float((torch.cat(tr3["code_idx"]) == idx_ref).float().mean())
-            vol = None
-            if world == 1:
-                m3.forward_volume(fr, win)
-                torch.cuda.synchronize()
-                tv = time.perf_counter()
-                for _ in range(args.steps):
-                    m3.forward_volume(fr, win)
-                torch.cuda.synchronize()
-                vol = round(T * (lr * s) ** 2 / 1e6 / ((time.perf_counter() - tv) / args.steps), 3)
-            extras[mode] = {"value": round(mp_per_step * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
-                            "volume_mode_value": vol,
-                            "dtype": dtypes[mode],
-                            "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
-                            "code_index_agreement_free_running_2_windows": agree,
-                            "rel_err_vs_fp32_path_free_running_all_windows": rel,
-                            "speedup_vs_fp32_path": round((dt / args.steps) / (d3 / args.steps), 3)}
-            model = m3
-            del o3
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # bounded sample of the same workload: ONE 5-slice window through the CPU oracle on the host cores
-        from oracle import gpemsr_oracle as orc
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cores = effective_cores()
-        torch.set_num_threads(cores)
-        xc = x[:1].cpu() if args.cpu_lr == lr else synth_lr_tiles(1, 5, args.cpu_lr, args.cpu_lr, seed=1000)
-        with torch.no_grad():
-            orc.gpemsr_forward(sd, synth_lr_tiles(1, 5, 16, 16, seed=1), scale=s)      # warm-up (tiny tile)
-            t1 = time.perf_counter()
-            o_cpu, _ = orc.gpemsr_forward(sd, xc, scale=s)
-            cdt = time.perf_counter() - t1
-        cpu_mp = (args.cpu_lr * s) ** 2 / 1e6 / cdt
-        cpu_baseline = {"value": round(cpu_mp, 5), "unit": "output megapixels/s", "cores": torch.get_num_threads(),
-                        "kind": "port",
-                        "sample": f"1 window [1,5,1,{args.cpu_lr},{args.cpu_lr}] -> {args.cpu_lr * s}^2, one pass "
-                                  f"({cdt:.1f} s) of oracle/gpemsr_oracle.py (torch CPU fp32; SpyNet de-duplicated, VGG slice1 only)"}
-        if args.cpu_lr == lr:
-            err = float((out[:1].cpu() - o_cpu).abs().max() / o_cpu.abs().max())
-            cpu_baseline["gpu_vs_cpu_rel_err_free_running"] = float(f"{err:.3e}")
+    roofline, extras, cpu_baseline = None, None, None
+    if not args.stub:
+        roofline = build_roofline(args, prof, dt, B, s)
+        if args.layer_report and rank == 0:
+            write_layer_report(prof, args.layer_report)
+        model_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        if world == 1 and not args.no_extras:
+            extras = run_extras(args, model, opt, x, out, dt, dev)
+        if model_sd is not None:
+            cpu_baseline = run_cpu_baseline(args, model_sd, x, out)
 
     if rank == 0:
+        cfg_name = {8: "BASELINE.json configs[1]" if args.precision == "fp32" else "BASELINE.json configs[2], one GPU's share",
+                    16: "BASELINE.json configs[3], one GPU's share"}[s]
+        dtype = {"fp32": "f32", "bf16": "bf16 (bf16 activations in HBM, bf16 MFMA, fp32 accumulate; indexer logits + argmax fp32)",
+                 "bf16x3": "bf16x3 (fp32 activations; convs as 3 split hi+lo bf16 MFMA products, fp32 accumulate)",
+                 "bf16op": "bf16 operands rounded in the kernel (fp32 activations in HBM), fp32 accumulate"}[args.precision]
         line = {
             "metric": "output megapixels/sec, 8x EMSR 128->1024 tiles" if s == 8 else "output megapixels/sec, 16x EMSR 64->1024 tiles",
-            "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split hi+lo bf16 MFMA, fp32 accumulate) for 3x3 convs, f32 elsewhere",
-                      "bf16": "bf16 MFMA (fp32 accumulate) for 3x3 convs, f32 elsewhere"}[args.precision], "data": "synthetic",
-            "config": {"workload": f"{s}x EMSR stage-3 forward, batch={B} synthetic 5x1x{lr}x{lr} LR windows per GPU -> "
-                                   f"{lr * s}x{lr * s} HR tiles, fp32 (BASELINE.json configs[1])",
+            "vs_baseline": None, "dtype": "stub" if args.stub else dtype, "data": "synthetic",
+            "config": {"workload": ("launcher self-test (stub model, CPU, gloo)" if args.stub else
+                                    f"{s}x EMSR stage-3 forward, batch={B} synthetic 5x1x{lr}x{lr} LR windows per GPU -> "
+                                    f"{lr * s}x{lr * s} HR tiles, {args.precision} ({cfg_name})"),
                        "tiles_per_gpu": B, "global_tiles": B * world, "lr": lr, "scale": s,
                        "weights": "deterministic synthetic init (reference checkpoints are not redistributable)",
-                       "parallelism": f"tiles sharded over {world} GPU(s), RCCL all-gather of HR slabs" if world > 1 else "single GPU"},
+                       "parallelism": f"tiles sharded over {world} GPU(s), one process per GPU, RCCL all-gather of HR slabs" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    return 0
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world == 1 and not os.environ.get(CHILD_ENV):
+        return spawn_ranks(args, argv)                   # plain `python bench.py --gpus N`: start our own ranks
+    if args.mode == "train":
+        import bench_train
+        bench_train.run(args, ROOT, effective_cores)
+        return 0
+    if args.mode == "train2":
+        import bench_train
+        bench_train.run_stage2(args, ROOT, effective_cores)
+        return 0
+    return run_forward(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -23,8 +23,8 @@ def run(args, root: str, effective_cores):
     from gpemsr_amd.synth import synth_lr_tiles
     from gpemsr_amd.train import Stage3Trainer
 
-    rank, world, local = gdist.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rank, world, local = gdist.init_from_env(backend=getattr(args, "backend", "") or None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -135,7 +135,8 @@ def run(args, root: str, effective_cores):
     if rank == 0:
         line = {
             "metric": f"stage-3 training samples/sec, {s}x EMSR (LR {lr}x{lr} -> {lr * s}x{lr * s} crops), batch {B}/GPU",
-            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
+            "rccl_world": torch.distributed.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "forward convolutions bf16x3 (split hi+lo bf16 MFMA, fp32 accumulate, fp32-grade); gradients f32",
             "data": "synthetic",
@@ -161,8 +162,8 @@ def run_stage2(args, root: str, effective_cores):
     from gpemsr_amd.synth import synth_lr_tiles
     from gpemsr_amd.train_stage2 import Stage2Trainer
 
-    rank, world, local = gdist.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1
+    rank, world, local = gdist.init_from_env(backend=getattr(args, "backend", "") or None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -225,7 +226,8 @@ def run_stage2(args, root: str, effective_cores):
     if rank == 0:
         print(json.dumps({
             "metric": f"stage-2 (indexer) training samples/sec, {s}x (GT {lr * s}x{lr * s} -> LR {lr}x{lr}), batch {B}/GPU",
-            "value": round(world * B * args.steps / dt, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(world * B * args.steps / dt, 3), "unit": "samples/s", "n_gpus": world,
+            "rccl_world": torch.distributed.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"stage-2 training step (train_stage2.py:351-366): frozen Encoder(GT) + nearest codebook vector -> targets; "

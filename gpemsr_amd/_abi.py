@@ -16,7 +16,7 @@ _lib = None
 MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_LRELU_SIGMOID = 0, 1, 2, 3, 4
 
-# every symbol include/gpemsr_hip.h declares (checked by tests/test_abi_cpu.py)
+# every symbol include/gpemsr_hip.h declares (checked by tests/test_host_cpu.py::test_c_abi_library_exports_every_declared_symbol)
 SYMBOLS = [
     "gpemsr_abi_version", "gpemsr_last_error", "gpemsr_device_info", "gpemsr_conv2d", "gpemsr_conv2d_split", "gpemsr_split_pack_rows", "gpemsr_conv2d_direct", "gpemsr_conv2d_stem1",
     "gpemsr_groupnorm_stats", "gpemsr_groupnorm_apply", "gpemsr_softmax_rows", "gpemsr_softmax_rows_ld", "gpemsr_argmax_rows",

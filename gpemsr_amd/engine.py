@@ -55,7 +55,7 @@ class Engine:
         self.center = nframes // 2
         self.dec_nrb = dec_num_res_blocks
         self.frame_chunk, self.tile_chunk = frame_chunk, tile_chunk
-        assert precision in ("fp32", "bf16x3", "bf16"), precision
+        assert precision in ("fp32", "bf16x3", "bf16", "bf16op"), precision
         # fp32: exact fp32 MFMA everywhere (default).  bf16x3 / bf16: 3x3 stride-1 convolutions whose sources are all
         # multiples of 16 channels run on the bf16 matrix pipe (split hi+lo = fp32-grade, or plain bf16); every other
         # op stays fp32 (incl. the indexer's logits GEMM + argmax).
@@ -65,6 +65,7 @@ class Engine:
         self.pc: Dict[str, ops.PackedConv] = {}
         self.par: Dict[str, torch.Tensor] = {}
         self._pack_all()
+        self._sig = self._signature(sd)
 
     # ------------------------------------------------------------------ packing
     def _pack_all(self):
@@ -86,6 +87,38 @@ class Engine:
         m, s = sd.get("align_module.spynet.mean"), sd.get("align_module.spynet.std")
         self.spy_mean = tuple(float(v) for v in m.flatten()) if m is not None else _SPY_MEAN
         self.spy_std = tuple(float(v) for v in s.flatten()) if s is not None else _SPY_STD
+
+    # ------------------------------------------------------------------ weight lifecycle
+    @staticmethod
+    def _signature(tensors: Dict[str, torch.Tensor]):
+        """(storage address, torch version counter) per entry: moves whenever torch writes a tensor in place or rebinds it."""
+        return {k: (v.data_ptr(), v._version) for k, v in tensors.items()}
+
+    def sync_weights(self, live: Dict[str, torch.Tensor], force=()):
+        """Bring the packed copies up to date with the live parameters: every entry whose storage or version counter moved
+        since it was packed (an optimizer step, ``p.data = ...``, a sub-module ``load_state_dict``) and every name in
+        ``force`` (weights written by a HIP kernel through the raw pointer, which torch's counters cannot see) is repacked.
+        The reference re-reads its Parameters on every forward (R:train_stage3.py:197-312 validates between optimizer
+        steps); a packed copy must therefore never outlive the weights it was made from."""
+        sig = self._signature(live)
+        changed = {k for k in sig if sig[k] != self._sig.get(k)} | {k for k in force if k in live}
+        if not changed:
+            return 0
+        bases = set()
+        for k in changed:
+            self.sd[k] = live[k].detach()
+            bases.add(k.rsplit(".", 1)[0])
+        for b in bases:
+            for nm in [n for n in self.pc if n == b or n.startswith(b + "@")]:
+                del self.pc[nm]                               # incl. lazily packed variants (model.vgg's "@rgb" entry)
+            if (b + ".weight") in self.sd:
+                self._pack_one(b + ".weight", self.sd[b + ".weight"])
+        if any(k.startswith("align_module.spynet.") and k.endswith((".mean", ".std")) for k in changed):
+            m, sdv = self.sd.get("align_module.spynet.mean"), self.sd.get("align_module.spynet.std")
+            self.spy_mean = tuple(float(v) for v in m.flatten()) if m is not None else _SPY_MEAN
+            self.spy_std = tuple(float(v) for v in sdv.flatten()) if sdv is not None else _SPY_STD
+        self._sig = sig
+        return len(changed)
 
     def _pack_one(self, k: str, w: torch.Tensor):
         """Repack one state-dict entry into its kernel-native form (called for all at load, and again for the trainable

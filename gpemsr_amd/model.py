@@ -70,10 +70,16 @@ class GPEMSR(nn.Module):
             _register(self, name, synth_tensor(name, spec, init_seed), spec.trainable, spec.is_buffer)
         self._engine = None
         self._train_state = None
-        # the reference loads the frozen prior at construction (model/GPEMSR.py:275-276, 283-284)
-        if ref_path_G is not None and os.path.exists(str(ref_path_G)):
+        self._hip_written = set()     # parameter names a HIP kernel updated in place (trainers): see _get_engine
+        # the reference loads the frozen prior at construction and raises if a file is missing (model/GPEMSR.py:275-276,
+        # 283-284); None (build_model(load_prior_files=False)) keeps the deterministic synthetic prior
+        for path, what in ((ref_path_G, "ref_path_G"), (ref_path_Indexer, "ref_path_Indexer")):
+            if path is not None and not os.path.exists(str(path)):
+                raise FileNotFoundError(f"gpemsr_amd.GPEMSR: {what}={path!r} does not exist (pass None to keep the "
+                                        "synthetic prior, e.g. config.build_model(load_prior_files=False))")
+        if ref_path_G is not None:
             self.refmodel.load_state_dict(torch.load(ref_path_G, map_location="cpu"), strict=False)
-        if ref_path_Indexer is not None and os.path.exists(str(ref_path_Indexer)):
+        if ref_path_Indexer is not None:
             self.refmodel.indexer.load_state_dict(torch.load(ref_path_Indexer, map_location="cpu"), strict=True)
 
     # -- weight lifecycle: any change of the parameters invalidates the packed copies
@@ -99,6 +105,7 @@ class GPEMSR(nn.Module):
         memo[id(self)] = new
         for k, v in self.__dict__.items():
             new.__dict__[k] = None if k in ("_engine", "_train_state") else copy.deepcopy(v, memo)
+        new._hip_written = set()
         new._rebind()
         return new
 
@@ -120,14 +127,24 @@ class GPEMSR(nn.Module):
         return super().train(mode)
 
     def _get_engine(self, device):
+        live = self.state_dict(keep_vars=True)
         if self._engine is None or self._engine.dev != device:
             from . import _abi
             from .engine import Engine
             _abi.load()                        # fail loudly if the HIP library is missing
-            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            sd = {k: v.detach() for k, v in live.items()}
             self._engine = Engine(sd, device, self.scale, self.nframes, self.groups, self.nf, self._dec_nrb,
                                   frame_chunk=self._chunks[0], tile_chunk=self._chunks[1], precision=self.precision)
+        else:
+            # validation between optimizer steps (R:train_stage3.py:197-312), torch optimizers on the autograd path,
+            # model.refmodel.indexer.load_state_dict(...): repack whatever changed since the packs were made
+            self._engine.sync_weights(live, force=self._hip_written)
+        self._hip_written = set()
         return self._engine
+
+    def mark_weights_written(self, names):
+        """Called by the trainers after a HIP kernel (Adam on the flat buffer) wrote these parameters in place."""
+        self._hip_written = set(getattr(self, "_hip_written", ())) | set(names)
 
     def _get_train_state(self, device):
         """State of the torch.autograd path (gpemsr_amd/autograd.py): built on the first differentiable forward."""

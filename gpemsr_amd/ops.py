@@ -192,7 +192,7 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
     use_direct = (not force_mfma and pc.cout <= 16 and (pc.cout <= 2 or pc.cin <= 16) and len(srcs) == 1 and k >= 3
                   and pc.ck == 8 and not pc.transposed
                   and not pc.pixel_shuffle and pixmul is None and weight_image_stride == 0 and src_image_stride is None)
-    if use_direct and precision == "bf16" and pc.w16 is not None and k == 7 and stride == 1 and s0.c % 16 == 0 and residual is not None:
+    if use_direct and precision in ("bf16", "bf16op") and pc.w16 is not None and k == 7 and stride == 1 and s0.c % 16 == 0 and residual is not None:
         use_direct = False          # SpyNet's 16 -> 2 7x7 output conv: even padded to 32 couts the bf16 matrix pipe beats the VALU kernel
     if stride == 4:
         assert use_direct, "stride 4 is only available through the direct kernel"
@@ -242,7 +242,7 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
     d.pixel_shuffle = int(pc.pixel_shuffle)
     d.out, d.out_ld = out.ptr, out.ld
     gemm16 = (k == 1 and stride == 1 and not pc.transposed and not pc.pixel_shuffle)
-    use_split = (precision in ("bf16x3", "bf16") and pc.w16 is not None and (k in (3, 7) or gemm16) and (stride == 1 or pc.transposed)
+    use_split = (precision in ("bf16x3", "bf16", "bf16op") and pc.w16 is not None and (k in (3, 7) or gemm16) and (stride == 1 or pc.transposed)
                  and not (pc.transposed and pixmul is not None) and (weight_image_stride == 0 or gemm16) and src_image_stride is None
                  and all(s.c % (32 if gemm16 else 16) == 0 and s.ld % 4 == 0 and s.ptr % 16 == 0 for s in srcs))
     if use_split:

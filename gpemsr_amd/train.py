@@ -52,9 +52,12 @@ class CosineAnnealingLRRestart:
         self.T_period = list(T_period)
         self.T_max = self.T_period[0]
         self.eta_min = float(eta_min)
-        self.restarts = [v + 1 for v in (restarts if restarts else [0])]
-        self.restart_weights = list(weights) if weights else [1]
+        # no `restarts` = no restarts (the reference's default [0] -> [1] indexes T_period[1] at the first step and
+        # raises for a one-period schedule, model/lr_scheduler.py:42-47,58)
+        self.restarts = [v + 1 for v in restarts] if restarts else []
+        self.restart_weights = (list(weights) if weights else [1] * len(self.restarts))[:len(self.restarts)] if self.restarts else []
         assert len(self.restarts) == len(self.restart_weights), 'restarts and their weights do not match.'
+        assert not self.restarts or len(self.T_period) > len(self.restarts), 'T_period needs one entry more than restarts'
         self.last_restart = 0
         self.last_epoch = 0
 
@@ -81,8 +84,8 @@ class MultiStepLRRestart:
         self.milestones = {}
         for m in milestones:
             self.milestones[m] = self.milestones.get(m, 0) + 1
-        self.restarts = [v + 1 for v in (restarts if restarts else [0])]
-        self.restart_weights = list(weights) if weights else [1]
+        self.restarts = [v + 1 for v in restarts] if restarts else []
+        self.restart_weights = (list(weights) if weights else [1] * len(self.restarts)) if self.restarts else []
         self.last_epoch = 0
 
     def step(self) -> float:
@@ -507,6 +510,8 @@ class _TrainerState:
 
     def load_state_dict(self, st: dict):
         assert st["exp_avg"].numel() == self.flat_m.numel(), "optimizer state belongs to a different parameter set"
+        mine = self.state_dict()["param_names"] if "param_names" in st else None
+        assert mine is None or list(st["param_names"]) == mine, "optimizer state was saved for other parameters / another order"
         self.step_count, self.lr = int(st["step_count"]), float(st["lr"])
         for k, v in st["scheduler"].items():
             setattr(self.sched, k, v)
@@ -535,6 +540,7 @@ class Stage3Trainer(_TrainerState):
         named = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
         self.flat_p, self.flat_g, self.flat_m, self.flat_v, gw, gb, names = flatten_parameters(named, device)
         self.n_params = sum(p.numel() for _, p in named)
+        self._param_keys = [k for k, _ in named]
         model._engine = None
         model._train_state = None
         sd = {k: v.detach() for k, v in model.state_dict().items()}
@@ -620,4 +626,5 @@ class Stage3Trainer(_TrainerState):
                       1e-8, float(o.get("weight_decay_G") or 0.0), self.step_count)
         self.lr = self.sched.step()
         self.eng.refresh_weights()
+        self.model.mark_weights_written(self._param_keys)     # the inference engine's packs are stale now (validation!)
         return {"rec_loss": rec, "ref_loss": ref, "lr": self.lr}

@@ -183,6 +183,7 @@ class Stage2Trainer(_TrainerState):
         named = [(k, p) for k, p in model.named_parameters() if k.startswith("refmodel.indexer.")]     # train_stage2.py:152-176
         self.flat_p, self.flat_g, self.flat_m, self.flat_v, gw, gb, names = flatten_parameters(named, device)
         self.n_params = sum(p.numel() for _, p in named)
+        self._param_keys = [k for k, _ in named]
         model._engine = None
         model._train_state = None
         sd = {k: v.detach() for k, v in model.state_dict().items()}
@@ -236,4 +237,5 @@ class Stage2Trainer(_TrainerState):
                       1e-8, float(o.get("weight_decay_G") or 0.0), self.step_count)
         self.lr = self.sched.step()
         self.eng.refresh_weights()
+        self.model.mark_weights_written(self._param_keys)     # the inference engine's packs are stale now
         return {"loss": loss, "lr": self.lr}

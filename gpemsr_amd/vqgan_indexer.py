@@ -123,10 +123,13 @@ class _LRGenerator(nn.Module):
             if self._state is None or self._state.eng.dev != device:
                 self._state = _State(self, device)
             return self._state
+        live = {_PFX + k: v for k, v in self.state_dict(keep_vars=True).items()}
         if self._infer is None or self._infer.dev != device:
             from .train_stage2 import Stage2Engine
-            sd = {_PFX + k: v.detach() for k, v in self.state_dict().items()}
+            sd = {k: v.detach() for k, v in live.items()}
             self._infer = Stage2Engine(sd, device, self.scale, 5, 8, 64, self._dec_nrb, (), {}, {})
+        else:
+            self._infer.sync_weights(live)       # optimizer steps since the packs were made (validation between steps)
         return self._infer
 
     def forward(self, lr: torch.Tensor, gt: torch.Tensor):

@@ -143,7 +143,12 @@ def main():
         raise RuntimeError("output_GPEMSR.py (gpemsr_amd) needs an MI355X / HIP device: there is no CPU path")
     torch.cuda.set_device(max(local, 0))
     device = torch.device("cuda", max(local, 0))
-    model = build_model(opt).eval().to(device)
+    # the reference raises when a prior file is missing (model/GPEMSR.py:275-276); only the explicit opt-in below may
+    # fall back to the deterministic synthetic prior
+    syn = bool(opt.get('synthetic_weights_if_missing', False))
+    net = opt['network']
+    have_prior = all(p and osp.exists(str(p)) for p in (net['ref_path_G'], net['ref_path_Indexer']))
+    model = build_model(opt, load_prior_files=have_prior or not syn).eval().to(device)
     pretrain_path = opt['pretrain_path']
     if pretrain_path and osp.exists(pretrain_path):
         model.load_state_dict(torch.load(pretrain_path, map_location="cpu"), strict=True)   # output_GPEMSR.py:52

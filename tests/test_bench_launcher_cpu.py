@@ -1,0 +1,60 @@
+"""`python bench.py --gpus N` must start its own N ranks (the one-process-per-GPU launch of
+R:train_stage3.py:20-27).  Driven here on the CPU: --backend gloo with the per-tile stub model, so the launcher, the
+env:// rendezvous, the barrier + max-over-ranks timing and the all-gather of the output slabs all really run."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GPEMSR_BENCH_CHILD")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--backend", "gloo", "--tiles", "3", "--lr", "16",
+                           "--steps", "2", "--warmup", "1"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_plain_invocation_spawns_two_ranks():
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world"] == 2 and d["config"]["global_tiles"] == 6
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_single_rank_runs_in_process():
+    r = _run(["--gpus", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["rccl_world"] == 1
+
+
+def test_failing_rank_fails_the_launcher():
+    # a bogus backend makes every rank raise in init_process_group: the parent must report failure, not hang or print a line
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GPEMSR_BENCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--backend", "no_such_backend", "--gpus", "2", "--tiles", "2",
+                        "--lr", "16", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_under_torchrun_env_it_is_a_rank_not_a_launcher():
+    # the driver's N>1 form sets WORLD_SIZE itself (python -m torch.distributed.run ...): no second level of spawning
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    base = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    env0 = {k: v for k, v in os.environ.items() if k != "GPEMSR_BENCH_CHILD"}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--backend", "gloo", "--gpus", "2", "--tiles", "2", "--lr", "16",
+           "--steps", "1", "--warmup", "0"]
+    procs = [subprocess.Popen(cmd, env=dict(env0, **base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    d = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["rccl_world"] == 2
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]

@@ -19,6 +19,11 @@ def _opt(scale):
     return load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{scale}.yml"))
 
 
+def build_model(*a, **k):
+    from gpemsr_amd.config import build_model as bm
+    return bm(*a, **k)
+
+
 @pytest.mark.parametrize("scale", [8, 16])
 def test_param_specs_match_reference_manifest(scale, golden_dir):
     """Key names, shapes, parameter counts == the reference model's state_dict (565 / 575 tensors)."""
@@ -228,3 +233,57 @@ def test_cli_index_windows_dedupes_slices(tmp_path):
     # a block in the middle of the volume only needs its own slices (+ halo)
     files2, win2 = cli.index_windows(wp[3:5])
     assert len(files2) == 6 and int(win2.max()) == 5 and win2[0].tolist() == [0, 1, 2, 3, 4]
+
+
+def test_missing_prior_file_raises_like_the_reference(tmp_path):
+    """R:model/GPEMSR.py:275-276 torch.load()s the prior files unconditionally: a mistyped path must not silently train
+    against the synthetic prior."""
+    import pytest
+    opt = _opt(8)
+    net = dict(opt["network"])
+    net["ref_path_G"] = str(tmp_path / "no_such_stage1.pth")
+    opt = dict(opt, network=net)
+    with pytest.raises(FileNotFoundError):
+        build_model(opt, load_prior_files=True)
+    build_model(opt, load_prior_files=False)        # explicit opt-out keeps the synthetic prior
+
+
+def test_scheduler_defaults_do_not_index_past_t_period():
+    """A trainer built from an option dict without `restarts`: T_period = [1 << 30], no restarts."""
+    from gpemsr_amd.train import CosineAnnealingLRRestart, MultiStepLRRestart
+    s = CosineAnnealingLRRestart(4e-4, [1 << 30], None, None, eta_min=1e-7)
+    lrs = [s.step() for _ in range(5)]
+    assert all(0 < v <= 4e-4 for v in lrs) and lrs[0] == pytest.approx(4e-4, rel=1e-6)
+    m = MultiStepLRRestart(1e-3, [2, 4], None, None, gamma=0.5)
+    assert [round(m.step(), 9) for _ in range(5)] == [1e-3, 5e-4, 5e-4, 2.5e-4, 2.5e-4]
+    # with restarts the recurrence still follows R:model/lr_scheduler.py:36-68
+    c = CosineAnnealingLRRestart(1.0, [4, 4], [4], [0.5], eta_min=0.0)
+    seq = [c.step() for _ in range(6)]
+    assert seq[4] == pytest.approx(0.5)              # e = 5 = restarts[0] + 1 -> base_lr * weight
+
+
+def test_packed_weights_follow_in_place_parameter_updates():
+    """validation between optimizer steps must see the current weights.  Packing runs on the CPU too
+    (only the kernels need a GPU), so the life-cycle is checked here: in-place update, p.data rebinding, sub-module
+    load_state_dict and the trainers' HIP-written marker all refresh the packed copies; untouched entries are not repacked."""
+    import torch
+    m = build_model(_opt(8), load_prior_files=False)
+    dev = torch.device("cpu")
+    eng = m._get_engine(dev)
+    w0 = eng.pc["conv_last"].w.clone()
+    keep = eng.pc["HRconv"].w
+    with torch.no_grad():
+        m.conv_last.weight.mul_(2.0)                                   # what torch.optim does
+    eng2 = m._get_engine(dev)
+    assert eng2 is eng and torch.equal(eng.pc["conv_last"].w, 2.0 * w0)
+    assert eng.pc["HRconv"].w is keep                                   # unchanged layers keep their packs
+    m.conv_last.weight.data = m.conv_last.weight.data * 0.5             # rebinding the storage
+    assert torch.equal(m._get_engine(dev).pc["conv_last"].w, w0)
+    g0 = eng.par["refmodel.indexer.feat_extract.0.block.1.weight"].clone()
+    sd = {k: v * 3.0 for k, v in m.refmodel.indexer.state_dict().items()}
+    m.refmodel.indexer.load_state_dict(sd)                              # bypasses GPEMSR.load_state_dict
+    assert torch.equal(m._get_engine(dev).par["refmodel.indexer.feat_extract.0.block.1.weight"], 3.0 * g0)
+    # a HIP kernel writing through the raw pointer leaves torch's counters alone: the trainers mark such names
+    m.HRconv.bias.data.view(-1)[0] = 123.0                              # .data writes do not bump _version
+    m.mark_weights_written(["HRconv.bias"])
+    assert float(m._get_engine(dev).pc["HRconv"].b[0]) == 123.0
