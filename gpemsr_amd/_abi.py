@@ -33,6 +33,12 @@ SYMBOLS = [
     "gpemsr_transpose_images", "gpemsr_adam_step",
     # stage-2 (indexer) training step
     "gpemsr_groupnorm_bwd", "gpemsr_softmax_bwd_rows", "gpemsr_cross_entropy",
+    # bf16 data path
+    "gpemsr_conv2d_bf16", "gpemsr_conv2d_bf16_gn_parts", "gpemsr_groupnorm_stats_bf16", "gpemsr_groupnorm_finish", "gpemsr_groupnorm_apply_bf16",
+    "gpemsr_softmax_rows_bf16", "gpemsr_gather_rows_bf16", "gpemsr_pack_rows_bf16", "gpemsr_cast_f32_bf16", "gpemsr_cast_bf16_f32",
+    "gpemsr_bilinear_bf16", "gpemsr_pool3s2_maxavg_bf16", "gpemsr_spynet_prep_bf16", "gpemsr_dcn_columns_bf16", "gpemsr_patch_cosine_bf16",
+    "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
+    "gpemsr_copy_channels_f32_bf16", "gpemsr_conv2d_stem1_bf16", "gpemsr_conv2d_direct_bf16",
 ]
 
 
@@ -51,6 +57,23 @@ class ConvDesc(C.Structure):
         ("residual", C.c_void_p), ("res_ld", C.c_int32),
         ("pixmul", C.c_void_p), ("pixel_shuffle", C.c_int32),
         ("out", C.c_void_p), ("out_ld", C.c_int32),
+    ]
+
+
+class ConvDesc16(C.Structure):
+    """gpemsr_conv16_desc (include/gpemsr_hip.h), field by field."""
+    _fields_ = [
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("nsrc", C.c_int32),
+        ("src", Src * MAX_SRC),
+        ("src_image_stride", C.c_int64 * MAX_SRC),
+        ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("transposed", C.c_int32),
+        ("weight", C.c_void_p), ("weight_image_stride", C.c_int64),
+        ("bias", C.c_void_p), ("act", C.c_int32),
+        ("residual", C.c_void_p), ("res_ld", C.c_int32), ("res_f32", C.c_int32),
+        ("pixmul", C.c_void_p), ("pixel_shuffle", C.c_int32), ("kpack", C.c_int32),
+        ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_f32", C.c_int32),
+        ("out32", C.c_void_p), ("out32_ld", C.c_int32),
+        ("gn_partials", C.c_void_p), ("variant", C.c_int32),
     ]
 
 
@@ -133,6 +156,28 @@ def load():
     lib.gpemsr_softmax_bwd_rows.argtypes = [p, p, i64, i32, p]
     lib.gpemsr_cross_entropy.argtypes = [p, p, i64, i32, f32, p, p, p, p]
     lib.gpemsr_device_info.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    lib.gpemsr_conv2d_bf16.argtypes = [C.POINTER(ConvDesc16), p]
+    lib.gpemsr_conv2d_bf16_gn_parts.argtypes = [C.POINTER(ConvDesc16)]
+    lib.gpemsr_groupnorm_stats_bf16.argtypes = [p, i32, i32, i32, i32, p, i32, p]
+    lib.gpemsr_groupnorm_finish.argtypes = [p, i32, i32, i32, i32, i32, f32, p, p]
+    lib.gpemsr_groupnorm_apply_bf16.argtypes = [p, i32, i32, i32, i32, i32, p, p, p, i32, p, i32, p, i32, p]
+    lib.gpemsr_softmax_rows_bf16.argtypes = [p, i32, i64, i32, i32, p, i32, p]
+    lib.gpemsr_gather_rows_bf16.argtypes = [p, i32, p, i64, p, i32, p]
+    lib.gpemsr_pack_rows_bf16.argtypes = [p, i32, i32, i32, i32, i64, p, p]
+    lib.gpemsr_cast_f32_bf16.argtypes = [p, i64, i32, i32, p, i32, p]
+    lib.gpemsr_cast_bf16_f32.argtypes = [p, i64, i32, i32, p, i32, p]
+    lib.gpemsr_bilinear_bf16.argtypes = [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, i32, p]
+    lib.gpemsr_pool3s2_maxavg_bf16.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
+    lib.gpemsr_spynet_prep_bf16.argtypes = [p, p, p, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), p, p, p]
+    lib.gpemsr_dcn_columns_bf16.argtypes = [p, i32, i32, i32, i32, i32, p, i32, i32, p, p]
+    lib.gpemsr_patch_cosine_bf16.argtypes = [p, p, i32, i32, i32, i32, p, p]
+    lib.gpemsr_temporal_gate_bf16.argtypes = [p, p, p, i32, i32, i32, i32, p, p]
+    lib.gpemsr_frame_mix_lrelu_bf16.argtypes = [p, i64, i32, i32, p, p, p, p]
+    lib.gpemsr_threeda_combine_bf16.argtypes = [p, p, p, p, p, i64, p, p]
+    lib.gpemsr_copy_channels_bf16.argtypes = [p, i32, p, i32, i64, i32, p]
+    lib.gpemsr_copy_channels_f32_bf16.argtypes = [p, i32, p, i32, i64, i32, p]
+    lib.gpemsr_conv2d_stem1_bf16.argtypes = [p, i32, i32, i32, p, p, i32, i32, p, i32, p]
+    lib.gpemsr_conv2d_direct_bf16.argtypes = [p, i32, i32, i32, i32, i32, i32, p, p, i32, i32, i32, i32, p, i32, p, i32, i32, p]
     _lib = lib
     return lib
 

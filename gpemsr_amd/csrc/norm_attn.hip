@@ -194,6 +194,12 @@ extern "C" int gpemsr_groupnorm_stats(const float* x, int n, int hw, int c, int 
   return check_launch("groupnorm_stats");
 }
 
+extern "C" int gpemsr_groupnorm_finish(const float* ws, int n, int hw, int c, int groups, int parts, float eps, float* mean_rstd, void* stream) {
+  GP_REQUIRE(ws && mean_rstd && n > 0 && hw > 0 && c % groups == 0 && parts >= 1, "groupnorm_finish: bad args");
+  hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(n * groups, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws, n, hw, c, groups, parts, eps, mean_rstd);
+  return check_launch("groupnorm_finish");
+}
+
 extern "C" int gpemsr_groupnorm_apply(const float* x, int n, int hw, int c, int ld, int groups, const float* mean_rstd,
                                       const float* gamma, const float* beta, int relu,
                                       const float* residual, int res_ld, float* out, int out_ld, void* stream) {

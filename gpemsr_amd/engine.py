@@ -27,7 +27,8 @@ import torch
 
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
-from .packing import pack_conv, pack_conv_split, pack_convT, pack_convT_split, pack_dcn, pack_linear, pack_vgg_first
+from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear,
+                      pack_vgg_first)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -56,10 +57,14 @@ class Engine:
         self.dec_nrb = dec_num_res_blocks
         self.frame_chunk, self.tile_chunk = frame_chunk, tile_chunk
         assert precision in ("fp32", "bf16x3", "bf16", "bf16op"), precision
-        # fp32: exact fp32 MFMA everywhere (default).  bf16x3 / bf16: 3x3 stride-1 convolutions whose sources are all
-        # multiples of 16 channels run on the bf16 matrix pipe (split hi+lo = fp32-grade, or plain bf16); every other
-        # op stays fp32 (incl. the indexer's logits GEMM + argmax).
+        # fp32: exact fp32 MFMA everywhere (default).
+        # bf16: bf16 NHWC activations in HBM + bf16 MFMA (BASELINE configs[2]); 1-channel images, flows, deformable offsets
+        #       and the indexer's logits GEMM + argmax stay fp32.
+        # bf16x3 / bf16op: fp32 activations; convolutions whose sources are multiples of 16 channels run on the bf16 matrix
+        #       pipe with operands converted in LDS (split hi+lo = fp32-grade, or plain bf16 operands).
         self.precision = precision
+        self.bf16 = precision == "bf16"
+        self.split = precision in ("bf16x3", "bf16op")
         self._forced_flow = None
         self.o = ops            # operator namespace; the training engine swaps in a recording proxy (gpemsr_amd/train.py)
         self.pc: Dict[str, ops.PackedConv] = {}
@@ -70,14 +75,15 @@ class Engine:
     # ------------------------------------------------------------------ packing
     def _pack_all(self):
         sd, dev, nf = self.sd, self.dev, self.nf
+        self._ffc = 64 if self.bf16 else 48      # channels of the flow/frame concat buffer (34 used; bf16: 32-channel chunks)
         splits = {
             "reffusionconv1": (nf, 64), "reffusionconv2": (nf, 128, nf), "down_fea_conv2": (nf, nf),
             "reffusionconv3": (nf, 256, 2 * nf), "down_fea_conv3": (nf, 2 * nf), "reffusionconv4": (nf, 512, 3 * nf),
             "reduce_dim_conv": (nf, 3 * nf, nf) if self.scale == 16 else (nf, 2 * nf, nf),
             # [nbr_fea, ref_fea, flow1|flow2|nbr_frame|ref_frame]: the 16+16 flow features and the 2 frames share ONE
             # 48-channel buffer (14 zero channels, zero weight columns), so every source is a multiple of 16 channels
-            "align_module.L3_offset_conv1": (nf, nf, 48), "align_module.L2_offset_conv1": (nf, nf, 48),
-            "align_module.L1_offset_conv1": (nf, nf, 48), "align_module.L2_offset_conv2": (nf, nf),
+            "align_module.L3_offset_conv1": (nf, nf, self._ffc), "align_module.L2_offset_conv1": (nf, nf, self._ffc),
+            "align_module.L1_offset_conv1": (nf, nf, self._ffc), "align_module.L2_offset_conv2": (nf, nf),
             "align_module.L1_offset_conv2": (nf, nf), "align_module.L2_fea_conv": (nf, nf),
             "align_module.L1_fea_conv": (nf, nf), "align_module.cas_offset_conv1": (nf, nf),
         }
@@ -134,29 +140,37 @@ class Engine:
         b = sd.get(name + ".bias")
         if w.dim() == 4 and name.endswith("dcnpack"):
             self.pc[name] = pack_dcn(w, b, dev)
+            if self.bf16:       # 1x1 over the tap-major column tensor [9*cin]
+                self.pc[name].wb = pack_conv_bf16(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1, 1, 1), dev)
         elif w.dim() == 4 and (name.startswith("reffea_L") or name.endswith(".upblock")):
             self.pc[name] = pack_convT(w, b, dev)
-            if self.precision != "fp32" and w.shape[0] % 16 == 0:
+            if self.split and w.shape[0] % 16 == 0:
                 self.pc[name].w16 = pack_convT_split(self.pc[name], dev)
+            if self.bf16:
+                self.pc[name].wb = pack_convT_bf16(w, dev)
         elif name == "vgg.slice1.0":
             self.pc[name] = pack_vgg_first(w, b, dev)
         elif w.dim() == 4 and name.endswith((".q",)) and ".feat_extract." in name:
             c = w.shape[0]
             sc = float(int(c) ** (-0.5))
             self.pc[name] = pack_conv(w, b, dev, scale=sc)                        # fold C^-1/2 (blocks.py:76)
-            if self.precision != "fp32" and c % 32 == 0:
+            if self.split and c % 32 == 0:
                 self.pc[name].w16 = pack_conv_split(self.pc[name], w.detach().to(torch.float32) * sc, dev)
+            if self.bf16:
+                self.pc[name].wb = pack_conv_bf16(w, dev, scale=sc)
         elif w.dim() == 4:
             if name.endswith("_offset_conv1") and w.shape[1] == 2 * nf + 34:
-                w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 14))       # 162 -> 176 input channels
+                w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, self._ffc - 34))   # 162 -> 176 (bf16: 192) input channels
             if self.precision != "fp32" and w.shape[1] == 8 and w.shape[2] == 7 and ".spynet." in name:
                 # SpyNet stems (8 -> 32, 7x7): zero-pad cin to 16 so they run on the split-bf16 kernel too
                 w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 8))
             self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
             kk = w.shape[2]
-            if self.precision != "fp32" and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
-                                             or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
+            if self.split and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
+                               or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
                 self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
+            if self.bf16 and all(c % 16 == 0 for c in self.pc[name].splits):
+                self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
         elif w.dim() == 2 and name.endswith("indexer.embedding"):
             self.pc[name] = pack_linear(w, b, dev)
         elif w.dim() == 2 and name.endswith("codebook.embedding"):
@@ -170,7 +184,8 @@ class Engine:
 
     # ------------------------------------------------------------------ helpers
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
-        return self.o.conv2d(srcs, self.pc[name], act, tag=name, precision=self.precision, **kw)
+        kw.setdefault("precision", self.precision)
+        return self.o.conv2d(srcs, self.pc[name], act, tag=name, **kw)
 
     def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:
         """basicsr ResidualBlockNoBN chain; ``pixmul`` multiplies the output of the LAST block
@@ -183,9 +198,10 @@ class Engine:
 
     # ------------------------------------------------------------------ VQGAN prior
     def vq_resblock(self, x: Act, p: str) -> Act:
-        t = self.conv(x, p + ".block.0")
+        # bf16 path: the conv epilogue leaves the GroupNorm partial sums (no statistics pass over the tensor)
+        t = self.conv(x, p + ".block.0", gn_stats=self.bf16)
         self.o.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
-        u = self.conv(t, p + ".block.3")
+        u = self.conv(t, p + ".block.3", gn_stats=self.bf16)
         skip = self.conv(x, p + ".channel_up") if (p + ".channel_up") in self.pc else x
         return self.o.groupnorm_relu(u, self.par[p + ".block.4.weight"], self.par[p + ".block.4.bias"], True, residual=skip, out=u)
 
@@ -195,6 +211,8 @@ class Engine:
         T = h * w
         if c % 32 != 0 or T % 4 != 0:
             raise RuntimeError(f"gpemsr_amd: non-local block needs channels ({c}) % 32 == 0 and latent tokens ({T}) % 4 == 0")
+        if self.bf16:
+            return self._nonlocal_bf16(x, p)
         if T % 32 != 0:
             return self._nonlocal_ragged(x, p)
         hn = self.o.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
@@ -211,16 +229,47 @@ class Engine:
             qa = q.images(f0, m).reshape_hw(gh, gw)
             kf, vf = k.images(f0, m), vT.images(f0, m)
             # bf16x3 / bf16: the B operands (k, v^T) are activations, so they are split + re-ordered on the device
-            k16 = self.o.split_pack_rows(kf) if self.precision != "fp32" else None
+            k16 = self.o.split_pack_rows(kf) if self.split else None
             S = self.o.conv2d([qa], self.o.PackedConv(kf.buf, None, 1, T, (c,), 32, w16=k16), ACT_NONE,
                            weight_image_stride=T * c, tag=p + ".qk", precision=self.precision)
             del k16
             self.o.softmax_rows_(S.buf, m * T, T)
-            v16 = self.o.split_pack_rows(vf) if self.precision != "fp32" else None
+            v16 = self.o.split_pack_rows(vf) if self.split else None
             self.o.conv2d([S], self.o.PackedConv(vf.buf, wv.b, 1, c, (T,), 32, w16=v16), ACT_NONE,
                        weight_image_stride=c * T, out=out.images(f0, m).reshape_hw(gh, gw), tag=p + ".pv",
                        precision=self.precision)
             del v16
+        return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
+
+    def _nonlocal_bf16(self, x: Act, p: str) -> Act:
+        """model/blocks.py:61-83 on the bf16 path.  q, k and v^T are 1x1 products; k and v^T leave their epilogues already in
+        the B-operand layout of the next product ("kpack"), the score matrix and P are bf16, softmax arithmetic is fp32."""
+        n, h, w, c = x.n, x.h, x.w, x.c
+        T = h * w
+        if T % 16 != 0:
+            raise RuntimeError(f"gpemsr_amd: the bf16 non-local block needs latent tokens ({T}) % 16 == 0")
+        o = self.o
+        hn = o.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
+        q = self.conv(hn, p + ".q")                                    # [n][T][C], C^-1/2 folded in
+        kp = self.conv(hn, p + ".k", kpack=True)                        # [n][C/8][T][8]
+        wv = self.pc[p + ".v"]
+        if not hasattr(wv, "_wa"):                                      # W_v as the A operand of v^T = W_v . hn^T: [C rows][C]
+            wv._wa = self.sd[p + ".v.weight"].detach().reshape(c, c).to(torch.bfloat16).contiguous().to(self.dev)
+        hnp = o.pack_rows_bf16(hn)                                      # hn as B operand: [n][C/8][T][8]
+        wa = Act(wv._wa, n, 1, c, c, c, 0)                              # n "images" that alias the one weight matrix
+        vtp = o.conv2d([wa], o.PackedConv(None, None, 1, T, (c,), 32, wb=hnp), ACT_NONE, weight_image_stride=T * c,
+                       src_image_stride=[0], kpack=True, tag="nonlocal.vT", precision="bf16")     # v^T: [n][T/8][C][8]
+        del hnp, hn
+        out = o.new_act(n, h, w, c, device=self.dev, bf16=True)
+        fc = max(1, min(n, (1 << 30) // (T * T)))                        # frames per score-matrix chunk (<= 2 GiB of bf16)
+        for f0 in range(0, n, fc):
+            m = min(fc, n - f0)
+            S = o.conv2d([q.images(f0, m)], o.PackedConv(None, None, 1, T, (c,), 32, wb=kp[f0:f0 + m]), ACT_NONE,
+                         weight_image_stride=T * c, tag=p + ".qk", precision="bf16")
+            P = o.softmax_rows_bf16(S)
+            o.conv2d([P], o.PackedConv(None, wv.b, 1, c, (T,), 32, wb=vtp[f0:f0 + m]), ACT_NONE, weight_image_stride=c * T,
+                     out=out.images(f0, m), tag=p + ".pv", precision="bf16")
+            del S, P
         return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
 
     def _nonlocal_ragged(self, x: Act, p: str) -> Act:
@@ -276,9 +325,16 @@ class Engine:
         h = self.conv(xf, p + ".input_layer.0", ACT_RELU)
         for i in range(_seq_len(self.sd, p + ".feat_extract")):
             h = self.vq_layer(h, f"{p}.feat_extract.{i}")
-        for i in range(_seq_len(self.sd, p + ".output_layer")):
-            h = self.vq_layer(h, f"{p}.output_layer.{i}")
-        return self.conv(h, p + ".embedding")              # nn.Linear on NHWC == 1x1 conv (indexer.py:100)
+        n_out = _seq_len(self.sd, p + ".output_layer")
+        for i in range(n_out):
+            name = f"{p}.output_layer.{i}"
+            if self.bf16 and i == n_out - 1 and name in self.pc:
+                h = self.conv(h, name, out_f32=True)       # the logits GEMM + argmax stay fp32
+            else:
+                h = self.vq_layer(h, name)
+        if h.bf16:
+            h = self.o.cast_f32(h)
+        return self.conv(h, p + ".embedding", precision="fp32")    # nn.Linear on NHWC == 1x1 conv (indexer.py:100)
 
     def ref_extract(self, xf: Act, forced_idx: Optional[torch.Tensor], trace: Optional[dict]) -> List[Act]:
         logits = self.indexer_logits(xf)
@@ -286,7 +342,8 @@ class Engine:
         if trace is not None:
             trace.setdefault("logits", []).append(logits.torch().clone())
             trace.setdefault("code_idx", []).append(idx.clone())
-        x = self.o.gather_rows(self.par["refmodel.codebook.embedding.weight"], idx, logits.n, logits.h, logits.w)
+        gather = self.o.gather_rows_bf16 if self.bf16 else self.o.gather_rows
+        x = gather(self.par["refmodel.codebook.embedding.weight"], idx, logits.n, logits.h, logits.w)
         del logits
         p = "refmodel.decoder"
         for i in range(_seq_len(self.sd, p + ".input_layer")):
@@ -372,12 +429,15 @@ class Engine:
         flow = None
         p = "align_module.spynet.basic_module"
         for lvl in range(6):
-            up, inp = self.o.spynet_prep(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std, pad16=self.precision != "fp32")
+            if self.bf16:
+                up, inp = self.o.spynet_prep_bf16(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std)
+            else:
+                up, inp = self.o.spynet_prep(rp[lvl], sp[lvl], flow, self.spy_mean, self.spy_std, pad16=self.split)
             t = self.conv(inp, f"{p}.{lvl}.basic_module.0", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.2", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.4", ACT_RELU)
             t = self.conv(t, f"{p}.{lvl}.basic_module.6", ACT_RELU)
-            flow = self.conv(t, f"{p}.{lvl}.basic_module.8", ACT_NONE, residual=up)
+            flow = self.conv(t, f"{p}.{lvl}.basic_module.8", ACT_NONE, residual=up, out_f32=self.bf16)   # flows stay fp32
         if (hf, wf) != (h, w):
             out = self.o.new_act(flow.n, h, w, 2, device=self.dev)
             self.o.bilinear(flow.slice(0, 1), h, w, mul=float(w) / float(wf), out=out.slice(0, 1))
@@ -386,7 +446,7 @@ class Engine:
         return flow
 
     def dcn(self, x: Act, feat: Act, name: str, act: int) -> Act:
-        om = self.conv(feat, name + ".conv_offset", force_mfma=True)
+        om = self.conv(feat, name + ".conv_offset", force_mfma=True, out_f32=self.bf16)    # sampling coordinates stay fp32
         col = self.o.dcn_columns(x, om, self.groups)
         return self.conv(col, name, act)
 
@@ -401,8 +461,10 @@ class Engine:
             flow = self.spynet(self.o.bilinear(nbr_frame, 4 * H, 4 * W), self.o.bilinear(ref_frame, 4 * H, 4 * W))
         if trace is not None:
             trace.setdefault("flow", []).append(flow.nchw())
-        def flow_frames(h, w):      # [flow1 16 | flow2 16 | nbr_frame | ref_frame | 14 zeros]
-            return Act(torch.zeros(P * h * w * 48, dtype=torch.float32, device=self.dev), P, h, w, 48, 48, 0)
+        ffc = self._ffc
+
+        def flow_frames(h, w):      # [flow1 16 | flow2 16 | nbr_frame | ref_frame | zeros up to ffc]
+            return self.o.new_act(P, h, w, ffc, device=self.dev, bf16=self.bf16, zero=True)
         fl1 = flow_frames(H, W)
         self.conv(flow, p + ".flowdsconv0_1", stride=4, out=fl1.slice(0, 16))
         self.conv(flow, p + ".flowdsconv0_2", stride=4, out=fl1.slice(16, 16))
@@ -412,10 +474,18 @@ class Engine:
         fl3 = flow_frames(H // 4, W // 4)
         self.conv(fl2.slice(0, 16), p + ".flowdsconv2_1", stride=2, out=fl3.slice(0, 16))
         self.conv(fl2.slice(16, 16), p + ".flowdsconv2_2", stride=2, out=fl3.slice(16, 16))
-        fr1 = fl1.slice(32, 2)
-        self.o.copy_channels(nbr_frame, fr1.slice(0, 1)); self.o.copy_channels(ref_frame, fr1.slice(1, 1))
-        self.o.bilinear(fr1, H // 2, W // 2, out=fl2.slice(32, 2))
-        self.o.bilinear(fl2.slice(32, 2), H // 4, W // 4, out=fl3.slice(32, 2))
+        if self.bf16:
+            # the two frames are 1-channel fp32 images: resize them in fp32 (channel by channel == the 2-channel resize of
+            # model/GPEMSR.py:107-110), then drop them into the bf16 concat buffers
+            for fl, (hh, ww) in ((fl1, (H, W)), (fl2, (H // 2, W // 2)), (fl3, (H // 4, W // 4))):
+                if (hh, ww) != (H, W):
+                    nbr_frame, ref_frame = self.o.bilinear(nbr_frame, hh, ww), self.o.bilinear(ref_frame, hh, ww)
+                self.o.copy_channels_f32_bf16(nbr_frame, fl.slice(32, 1)); self.o.copy_channels_f32_bf16(ref_frame, fl.slice(33, 1))
+        else:
+            fr1 = fl1.slice(32, 2)
+            self.o.copy_channels(nbr_frame, fr1.slice(0, 1)); self.o.copy_channels(ref_frame, fr1.slice(1, 1))
+            self.o.bilinear(fr1, H // 2, W // 2, out=fl2.slice(32, 2))
+            self.o.bilinear(fl2.slice(32, 2), H // 4, W // 4, out=fl3.slice(32, 2))
 
         o3 = self.conv([nbr[2], ref[2], fl3], p + ".L3_offset_conv1", ACT_LRELU)
         o3 = self.conv(o3, p + ".L3_offset_conv2", ACT_LRELU)
@@ -478,9 +548,9 @@ class Engine:
     def _front_all(self, xa: Act, forced_idx, trace):
         """Per-frame half (everything up to the L1/L2/L3 pyramid, model/GPEMSR.py:325-426) for all frames of ``xa``."""
         nfr, H, W, s = xa.n, xa.h, xa.w, self.scale
-        L1 = self.o.new_act(nfr, H, W, 64, device=self.dev)
-        L2 = self.o.new_act(nfr, H // 2, W // 2, 64, device=self.dev)
-        L3 = self.o.new_act(nfr, H // 4, W // 4, 64, device=self.dev)
+        L1 = self.o.new_act(nfr, H, W, 64, device=self.dev, bf16=self.bf16)
+        L2 = self.o.new_act(nfr, H // 2, W // 2, 64, device=self.dev, bf16=self.bf16)
+        L3 = self.o.new_act(nfr, H // 4, W // 4, 64, device=self.dev, bf16=self.bf16)
         ref_img = torch.empty(nfr, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
         ref_act = Act(ref_img, nfr, H * s, W * s, 1, 1, 0)
         lat = (H // 2) * (W // 2) if s == 8 else H * W

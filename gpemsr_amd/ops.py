@@ -24,12 +24,22 @@ class Act:
     Training (gpemsr_amd/train.py): every view remembers the ``root`` allocation it was cut from; the root owns one
     zero-initialised gradient buffer of the same size (``gbuf``, created on first use) and a ``rg`` flag ("some
     producer of this memory depends on a trainable parameter"), so ``a.grad()`` is the same view over the gradient."""
-    __slots__ = ("buf", "n", "h", "w", "c", "ld", "off", "_root", "gbuf", "rg")
+    __slots__ = ("buf", "n", "h", "w", "c", "ld", "off", "_root", "gbuf", "rg", "gn")
 
     def __init__(self, buf: torch.Tensor, n: int, h: int, w: int, c: int, ld: int, off: int = 0, root: "Act" = None):
         self.buf, self.n, self.h, self.w, self.c, self.ld, self.off = buf, n, h, w, c, ld, off
         self._root = root            # None for a root allocation (no self reference: buffers must die by ref-count, not by gc)
         self.gbuf, self.rg = None, False
+        self.gn = None               # bf16 path: (workspace, parts) GroupNorm partial sums written by the producing convolution
+
+    @property
+    def bf16(self) -> bool:
+        """bf16 NHWC tensor of the precision="bf16" data path (else float32)."""
+        return self.buf.dtype == torch.bfloat16
+
+    @property
+    def esize(self) -> int:
+        return 2 if self.buf.dtype == torch.bfloat16 else 4
 
     @property
     def root(self) -> "Act":
@@ -37,7 +47,7 @@ class Act:
 
     @property
     def ptr(self) -> int:
-        return self.buf.data_ptr() + 4 * self.off
+        return self.buf.data_ptr() + self.esize * self.off
 
     @property
     def pixels(self) -> int:
@@ -87,17 +97,19 @@ class Act:
         return v[..., self.off:self.off + self.c]
 
     def nchw(self) -> torch.Tensor:
-        return self.torch().permute(0, 3, 1, 2).contiguous()
+        """float32 NCHW copy (tests / traces / module boundary), whatever the storage format."""
+        return self.torch().permute(0, 3, 1, 2).contiguous().to(torch.float32)
 
 
-def new_act(n: int, h: int, w: int, c: int, ld: Optional[int] = None, device=None) -> Act:
+def new_act(n: int, h: int, w: int, c: int, ld: Optional[int] = None, device=None, bf16: bool = False, zero: bool = False) -> Act:
     ld = c if ld is None else ld
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    return Act(torch.empty(n * h * w * ld, dtype=torch.float32, device=dev), n, h, w, c, ld, 0)
+    alloc = torch.zeros if zero else torch.empty
+    return Act(alloc(n * h * w * ld, dtype=torch.bfloat16 if bf16 else torch.float32, device=dev), n, h, w, c, ld, 0)
 
 
 def from_nhwc(t: torch.Tensor) -> Act:
-    assert t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous()
+    assert t.dtype in (torch.float32, torch.bfloat16) and t.dim() == 4 and t.is_contiguous()
     n, h, w, c = t.shape
     return Act(t, n, h, w, c, c, 0)
 
@@ -162,6 +174,7 @@ class PackedConv:
     transposed: bool = False
     pixel_shuffle: bool = False
     w16: Optional[torch.Tensor] = None     # split-bf16 weights [2][tap][cout][cin] (packing.pack_conv_split), optional
+    wb: Optional[torch.Tensor] = None      # bf16 data path: staged-order weights (packing.pack_conv_bf16 / pack_convT_bf16)
 
     @property
     def cin(self) -> int:
@@ -171,13 +184,16 @@ class PackedConv:
 def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
            pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
            src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
-           precision: str = "fp32") -> Act:
+           precision: str = "fp32", **kw16) -> Act:
     lib = _abi.load()
     if isinstance(srcs, Act):
         srcs = [srcs]
     _require_gpu(*srcs)
     assert len(srcs) == len(pc.splits) and all(s.c == c for s, c in zip(srcs, pc.splits)), \
         f"source channels {[s.c for s in srcs]} != packed splits {pc.splits}"
+    if precision == "bf16":
+        return conv2d_bf16(srcs, pc, act, stride, residual, pixmul, out, weight_image_stride, src_image_stride, force_mfma, tag, **kw16)
+    assert not kw16 or not any(kw16.values()), f"{sorted(kw16)} are options of the bf16 data path"
     s0 = srcs[0]
     n, h, w = s0.n, s0.h, s0.w
     k = pc.ksize
@@ -272,6 +288,25 @@ def groupnorm_relu(x: Act, gamma: torch.Tensor, beta: torch.Tensor, relu: bool =
     lib = _abi.load()
     _require_gpu(x)
     hw = x.h * x.w
+    if x.bf16:
+        # first pass: from the producing convolution's epilogue when it left partial sums (x.gn), else one read of x
+        dev = x.buf.device
+        if x.gn is not None:
+            ws, parts = x.gn
+        else:
+            parts = max(1, min(64, hw // 64))
+            ws = torch.empty(x.n * parts * x.c * 2, dtype=torch.float32, device=dev)
+            _abi.check(lib.gpemsr_groupnorm_stats_bf16(x.ptr, x.n, hw, x.c, x.ld, ws.data_ptr(), parts, _stream()), "groupnorm_stats_bf16")
+        mr = torch.empty(x.n * groups * 2, dtype=torch.float32, device=dev)
+        _abi.check(lib.gpemsr_groupnorm_finish(ws.data_ptr(), x.n, hw, x.c, groups, parts, eps, mr.data_ptr(), _stream()), "groupnorm_finish")
+        if out is None:
+            out = new_act(x.n, x.h, x.w, x.c, device=dev, bf16=True)
+        assert out.bf16 and (residual is None or residual.bf16)
+        _abi.check(lib.gpemsr_groupnorm_apply_bf16(x.ptr, x.n, hw, x.c, x.ld, groups, mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                   int(relu), residual.ptr if residual is not None else None,
+                                                   residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()), "groupnorm_apply_bf16")
+        out.gn = None
+        return out
     parts = max(1, min(64, hw // 64))
     ws = torch.empty(x.n * parts * x.c * 2 + x.n * groups * 2, dtype=torch.float32, device=x.buf.device)
     mr = ws[x.n * parts * x.c * 2:]
@@ -310,6 +345,12 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor, n: int, h: int, w: int) 
 
 def bilinear(x: Act, oh: int, ow: int, align_corners: bool = False, mul: float = 1.0, out: Optional[Act] = None) -> Act:
     _require_gpu(x)
+    if x.bf16:
+        if out is None:
+            out = new_act(x.n, oh, ow, x.c, device=x.buf.device, bf16=True)
+        _abi.check(_abi.load().gpemsr_bilinear_bf16(x.ptr, x.n, x.h, x.w, x.c, x.ld, oh, ow, int(align_corners), mul, out.ptr,
+                                                    out.ld, _stream()), "bilinear_bf16")
+        return out
     if out is None:
         out = new_act(x.n, oh, ow, x.c, device=x.buf.device)
     _abi.check(_abi.load().gpemsr_bilinear(x.ptr, x.n, x.h, x.w, x.c, x.ld, oh, ow, int(align_corners), mul, out.ptr,
@@ -325,6 +366,10 @@ def avgpool2(x: Act) -> Act:
 
 def pool3s2_maxavg(x: Act) -> Act:
     oh, ow = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
+    if x.bf16:
+        out = new_act(x.n, oh, ow, 2 * x.c, device=x.buf.device, bf16=True)
+        _abi.check(_abi.load().gpemsr_pool3s2_maxavg_bf16(x.ptr, x.n, x.h, x.w, x.c, x.ld, out.ptr, out.ld, _stream()), "pool3s2_bf16")
+        return out
     out = new_act(x.n, oh, ow, 2 * x.c, device=x.buf.device)
     _abi.check(_abi.load().gpemsr_pool3s2_maxavg(x.ptr, x.n, x.h, x.w, x.c, x.ld, out.ptr, out.ld, _stream()), "pool3s2")
     return out
@@ -344,6 +389,12 @@ def spynet_prep(ref: Act, supp: Act, flow_coarse: Optional[Act], mean3, std3, pa
 
 
 def dcn_columns(x: Act, om: Act, groups: int) -> Act:
+    if x.bf16:
+        assert not om.bf16, "deformable offsets / mask logits stay fp32"
+        col = new_act(x.n, x.h, x.w, 9 * x.c, device=x.buf.device, bf16=True)
+        _abi.check(_abi.load().gpemsr_dcn_columns_bf16(x.ptr, x.n, x.h, x.w, x.c, x.ld, om.ptr, om.ld, groups, col.ptr, _stream()),
+                   "dcn_columns_bf16")
+        return col
     col = new_act(x.n, x.h, x.w, 9 * x.c, device=x.buf.device)
     _abi.check(_abi.load().gpemsr_dcn_columns(x.ptr, x.n, x.h, x.w, x.c, x.ld, om.ptr, om.ld, groups, col.ptr, _stream()),
                "dcn_columns")
@@ -353,6 +404,10 @@ def dcn_columns(x: Act, om: Act, groups: int) -> Act:
 def patch_cosine(a: Act, b: Act) -> Act:
     assert a.ld == a.c and b.ld == b.c
     out = new_act(a.n, a.h // 16, a.w // 16, 1, device=a.buf.device)
+    if a.bf16:
+        assert b.bf16
+        _abi.check(_abi.load().gpemsr_patch_cosine_bf16(a.ptr, b.ptr, a.n, a.h, a.w, a.c, out.ptr, _stream()), "patch_cosine_bf16")
+        return out
     _abi.check(_abi.load().gpemsr_patch_cosine(a.ptr, b.ptr, a.n, a.h, a.w, a.c, out.ptr, _stream()), "patch_cosine")
     return out
 
@@ -360,6 +415,12 @@ def patch_cosine(a: Act, b: Act) -> Act:
 def temporal_gate(aligned: Act, emb: Act, emb_ref: Act, b: int, t: int) -> Act:
     """aligned/emb: [b*t,h,w,c]; emb_ref: [b,h,w,c] -> af [b,h,w,t*c]."""
     assert aligned.ld == aligned.c and emb.ld == emb.c and emb_ref.ld == emb_ref.c
+    if aligned.bf16:
+        assert emb.bf16 and emb_ref.bf16
+        af = new_act(b, aligned.h, aligned.w, t * aligned.c, device=aligned.buf.device, bf16=True)
+        _abi.check(_abi.load().gpemsr_temporal_gate_bf16(aligned.ptr, emb.ptr, emb_ref.ptr, b, t, aligned.h * aligned.w, aligned.c,
+                                                         af.ptr, _stream()), "temporal_gate_bf16")
+        return af
     af = new_act(b, aligned.h, aligned.w, t * aligned.c, device=aligned.buf.device)
     _abi.check(_abi.load().gpemsr_temporal_gate(aligned.ptr, emb.ptr, emb_ref.ptr, b, t, aligned.h * aligned.w, aligned.c,
                                                 af.ptr, _stream()), "temporal_gate")
@@ -368,6 +429,11 @@ def temporal_gate(aligned: Act, emb: Act, emb_ref: Act, b: int, t: int) -> Act:
 
 def frame_mix_lrelu(af: Act, t: int, m: torch.Tensor, bias: torch.Tensor) -> Act:
     assert af.ld == af.c and af.c % t == 0
+    if af.bf16:
+        out = new_act(af.n, af.h, af.w, af.c, device=af.buf.device, bf16=True)
+        _abi.check(_abi.load().gpemsr_frame_mix_lrelu_bf16(af.ptr, af.pixels, t, af.c // t, m.data_ptr(), bias.data_ptr(), out.ptr,
+                                                           _stream()), "frame_mix_bf16")
+        return out
     out = new_act(af.n, af.h, af.w, af.c, device=af.buf.device)
     _abi.check(_abi.load().gpemsr_frame_mix_lrelu(af.ptr, af.pixels, t, af.c // t, m.data_ptr(), bias.data_ptr(), out.ptr,
                                                   _stream()), "frame_mix")
@@ -377,6 +443,12 @@ def frame_mix_lrelu(af: Act, t: int, m: torch.Tensor, bias: torch.Tensor) -> Act
 def threeda_combine(feat: Act, attn: Act, attn_add: Act, f2: Act, f3: Act) -> Act:
     for a in (feat, attn, attn_add, f2, f3):
         assert a.ld == a.c
+    if feat.bf16:
+        assert all(a.bf16 for a in (attn, attn_add, f2, f3))
+        out = new_act(feat.n, feat.h, feat.w, feat.c, device=feat.buf.device, bf16=True)
+        _abi.check(_abi.load().gpemsr_threeda_combine_bf16(feat.ptr, attn.ptr, attn_add.ptr, f2.ptr, f3.ptr, feat.pixels * feat.c,
+                                                           out.ptr, _stream()), "threeda_combine_bf16")
+        return out
     out = new_act(feat.n, feat.h, feat.w, feat.c, device=feat.buf.device)
     _abi.check(_abi.load().gpemsr_threeda_combine(feat.ptr, attn.ptr, attn_add.ptr, f2.ptr, f3.ptr, feat.pixels * feat.c,
                                                   out.ptr, _stream()), "threeda_combine")
@@ -393,6 +465,10 @@ def tensor2img_u8(x: torch.Tensor) -> torch.Tensor:
 
 def copy_channels(src: Act, dst: Act):
     assert src.pixels == dst.pixels and src.c == dst.c
+    if src.bf16 or dst.bf16:
+        assert src.bf16 and dst.bf16
+        _abi.check(_abi.load().gpemsr_copy_channels_bf16(src.ptr, src.ld, dst.ptr, dst.ld, src.pixels, src.c, _stream()), "copy_channels_bf16")
+        return
     _abi.check(_abi.load().gpemsr_copy_channels(src.ptr, src.ld, dst.ptr, dst.ld, src.pixels, src.c, _stream()),
                "copy_channels")
 
@@ -465,8 +541,9 @@ def gather_images(src: Act, idx: torch.Tensor) -> Act:
     assert src.ld == src.c and src.off == 0
     assert idx.dtype == torch.int32 and idx.is_cuda and idx.is_contiguous()
     n_dst = idx.numel()
-    dst = new_act(n_dst, src.h, src.w, src.c, device=src.buf.device)
-    _abi.check(_abi.load().gpemsr_gather_images(src.ptr, idx.data_ptr(), dst.ptr, n_dst, src.h * src.w * src.c, _stream()),
+    dst = new_act(n_dst, src.h, src.w, src.c, device=src.buf.device, bf16=src.bf16)
+    units = src.h * src.w * src.c * src.esize // 4            # a raw copy in 4-byte units (bf16 images: c % 8 == 0)
+    _abi.check(_abi.load().gpemsr_gather_images(src.ptr, idx.data_ptr(), dst.ptr, n_dst, units, _stream()),
                "gather_images")
     return dst
 
@@ -474,8 +551,8 @@ def gather_images(src: Act, idx: torch.Tensor) -> Act:
 def copy_images(src: Act, n_dst: int, div: int, mul: int, add: int) -> Act:
     """dst image j = src image (j // div) * mul + add (dense NHWC images, ld == c)."""
     assert src.ld == src.c and src.off == 0
-    dst = new_act(n_dst, src.h, src.w, src.c, device=src.buf.device)
-    _abi.check(_abi.load().gpemsr_copy_images(src.ptr, dst.ptr, n_dst, src.h * src.w * src.c, div, mul, add, _stream()),
+    dst = new_act(n_dst, src.h, src.w, src.c, device=src.buf.device, bf16=src.bf16)
+    _abi.check(_abi.load().gpemsr_copy_images(src.ptr, dst.ptr, n_dst, src.h * src.w * src.c * src.esize // 4, div, mul, add, _stream()),
                "copy_images")
     return dst
 
@@ -634,3 +711,172 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
               weight_decay: float, step: int):
     _abi.check(_abi.load().gpemsr_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(beta1),
                                             float(beta2), float(eps), float(weight_decay), int(step), _stream()), "adam_step")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bf16 data path (precision = "bf16"): include/gpemsr_hip.h, "bf16 data path".  bf16 NHWC activations; 1-channel images,
+# flows, deformable offsets and logits stay fp32.  The functions above dispatch here when they are handed bf16 Acts.
+# ----------------------------------------------------------------------------------------------------------------------
+def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
+                pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
+                src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
+                out_f32: bool = False, out32: Optional[Act] = None, gn_stats: bool = False, kpack: bool = False,
+                variant: int = 0) -> Act:
+    """Convolution of the bf16 path.  out_f32: fp32 result (logits input, deformable offsets, flows, 1-channel images);
+    out32: additionally store the un-rounded fp32 result there; gn_stats: leave GroupNorm partial sums on the result
+    (``out.gn``); kpack: store as the B operand [n][cout/8][pixels][8] of a later 1x1 product (returns the raw tensor)."""
+    lib = _abi.load()
+    s0 = srcs[0]
+    n, h, w = s0.n, s0.h, s0.w
+    k = pc.ksize
+    dev = s0.buf.device
+    if pc.transposed:
+        oh, ow = 2 * h, 2 * w
+    else:
+        oh, ow = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    OH, OW, oc = (2 * oh, 2 * ow, pc.cout // 4) if pc.pixel_shuffle else (oh, ow, pc.cout)
+    plain = (not pc.transposed and not pc.pixel_shuffle and pixmul is None and weight_image_stride == 0 and src_image_stride is None
+             and out32 is None and not gn_stats and not kpack and len(srcs) == 1)
+    # 1 -> C stem: fp32 1-channel image in, bf16 out
+    if (plain and not force_mfma and not s0.bf16 and s0.c == 1 and s0.ld == 1 and k == 3 and stride == 1 and pc.cout % 8 == 0 and pc.cout > 16
+            and residual is None and not out_f32):
+        if out is None:
+            out = new_act(n, OH, OW, oc, device=dev, bf16=True)
+        assert out.bf16 and (out.n, out.h, out.w, out.c) == (n, OH, OW, oc)
+
+        def _go_stem():
+            _abi.check(lib.gpemsr_conv2d_stem1_bf16(s0.ptr, n, h, w, pc.w.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
+                                                    pc.cout, act, out.ptr, out.ld, _stream()), "conv2d_stem1_bf16")
+        if PROFILER is not None:
+            PROFILER.run("conv_stem1", tag, 2.0 * n * oh * ow * pc.cout * 9, _go_stem)
+        else:
+            _go_stem()
+        return out
+    taps = 9.0 / 4.0 if pc.transposed else float(k * k)
+    flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps
+    # tiny channel counts: VALU kernel with fp32 packed weights (1-channel results are fp32 images)
+    use_direct = (plain and not force_mfma and pc.cout <= 16 and (pc.cout <= 2 or pc.cin <= 16) and k >= 3 and pc.ck == 8
+                  and (residual is None or (pc.cin == 64 and pc.cout == 1 and k == 3 and stride == 1 and not residual.bf16)))
+    if use_direct:
+        o32 = out_f32 or pc.cout <= 2
+        if out is None:
+            out = new_act(n, OH, OW, oc, device=dev, bf16=not o32)
+        assert (out.n, out.h, out.w, out.c) == (n, OH, OW, oc) and out.bf16 == (not o32)
+
+        def _go_direct():
+            _abi.check(lib.gpemsr_conv2d_direct_bf16(s0.ptr, int(not s0.bf16), n, h, w, s0.ld, s0.c, pc.w.data_ptr(),
+                                                     pc.b.data_ptr() if pc.b is not None else None, pc.cout, k, stride, act,
+                                                     residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
+                                                     out.ptr, int(o32), out.ld, _stream()), "conv2d_direct_bf16")
+        if PROFILER is not None:
+            PROFILER.run("conv_direct", tag, flops, _go_direct)
+        else:
+            _go_direct()
+        return out
+    assert pc.wb is not None, f"{tag}: no bf16 weights packed for this layer"
+    assert all(s.bf16 for s in srcs), f"{tag}: the bf16 MFMA kernel takes bf16 sources"
+    d = _abi.ConvDesc16()
+    d.n, d.h, d.w, d.nsrc = n, h, w, len(srcs)
+    for i, s in enumerate(srcs):
+        assert (s.n, s.h, s.w) == (n, h, w) or (src_image_stride is not None)
+        d.src[i].ptr, d.src[i].ld, d.src[i].c = s.ptr, s.ld, s.c
+        d.src_image_stride[i] = -1 if src_image_stride is None else int(src_image_stride[i])
+    d.cout, d.ksize, d.stride, d.transposed = pc.cout, k, stride, int(pc.transposed)
+    d.weight, d.weight_image_stride = pc.wb.data_ptr(), int(weight_image_stride)
+    d.bias = pc.b.data_ptr() if pc.b is not None else None
+    d.act = act
+    if residual is not None:
+        assert (residual.n, residual.h, residual.w, residual.c) == (n, OH, OW, oc)
+        d.residual, d.res_ld, d.res_f32 = residual.ptr, residual.ld, int(not residual.bf16)
+    if pixmul is not None:
+        assert not pixmul.bf16 and pixmul.c == 1 and pixmul.ld == 1 and (pixmul.n, pixmul.h, pixmul.w) == (n, OH, OW)
+        d.pixmul = pixmul.ptr
+    d.pixel_shuffle = int(pc.pixel_shuffle)
+    d.kpack = int(kpack)
+    d.variant = int(variant)
+    ret = None
+    if kpack:
+        assert out is None and not out_f32
+        ret = torch.empty(n, oc // 8, OH * OW, 8, dtype=torch.bfloat16, device=dev)
+        d.out, d.out_ld, d.out_f32 = ret.data_ptr(), 8, 0
+    else:
+        if out is None:
+            out = new_act(n, OH, OW, oc, device=dev, bf16=not out_f32)
+        assert (out.n, out.h, out.w, out.c) == (n, OH, OW, oc), f"out geometry {(out.n, out.h, out.w, out.c)} != {(n, OH, OW, oc)}"
+        assert out.bf16 == (not out_f32), f"{tag}: output format mismatch"
+        d.out, d.out_ld, d.out_f32 = out.ptr, out.ld, int(out_f32)
+        ret = out
+    if out32 is not None:
+        assert not out32.bf16 and (out32.n, out32.h, out32.w, out32.c) == (n, OH, OW, oc)
+        d.out32, d.out32_ld = out32.ptr, out32.ld
+    if gn_stats:
+        parts = lib.gpemsr_conv2d_bf16_gn_parts(C.byref(d))
+        if parts < 1:
+            _abi.check(parts, "conv2d_bf16_gn_parts")
+        ws = torch.empty(n * parts * pc.cout * 2, dtype=torch.float32, device=dev)
+        d.gn_partials = ws.data_ptr()
+        out.gn = (ws, parts)
+
+    def _go():
+        _abi.check(lib.gpemsr_conv2d_bf16(C.byref(d), _stream()), "conv2d_bf16")
+    if PROFILER is not None:
+        PROFILER.run("conv_bf16", tag, flops, _go)
+    else:
+        _go()
+    return ret
+
+
+def cast_bf16(x: Act) -> Act:
+    out = new_act(x.n, x.h, x.w, x.c, device=x.buf.device, bf16=True)
+    _abi.check(_abi.load().gpemsr_cast_f32_bf16(x.ptr, x.pixels, x.c, x.ld, out.ptr, out.ld, _stream()), "cast_f32_bf16")
+    return out
+
+
+def cast_f32(x: Act) -> Act:
+    out = new_act(x.n, x.h, x.w, x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_cast_bf16_f32(x.ptr, x.pixels, x.c, x.ld, out.ptr, out.ld, _stream()), "cast_bf16_f32")
+    return out
+
+
+def pack_rows_bf16(a: Act) -> torch.Tensor:
+    """bf16 rows [n][h*w][c] -> [n][c/8][h*w][8]: the per-image B operand of a 1x1 product (attention)."""
+    assert a.bf16 and a.c % 8 == 0
+    rows = a.h * a.w
+    out = torch.empty(a.n, a.c // 8, rows, 8, dtype=torch.bfloat16, device=a.buf.device)
+    _abi.check(_abi.load().gpemsr_pack_rows_bf16(a.ptr, a.n, rows, a.c, a.ld, rows * a.ld, out.data_ptr(), _stream()), "pack_rows_bf16")
+    return out
+
+
+def softmax_rows_bf16(s: Act) -> Act:
+    """Row softmax of a score tensor [n][rows][cols] (fp32 or bf16) -> P bf16 (in place when S is bf16)."""
+    rows, cols = s.pixels, s.c
+    out = s if s.bf16 else new_act(s.n, s.h, s.w, s.c, device=s.buf.device, bf16=True)
+    _abi.check(_abi.load().gpemsr_softmax_rows_bf16(s.ptr, int(not s.bf16), rows, cols, s.ld, out.ptr, out.ld, _stream()), "softmax_rows_bf16")
+    return out
+
+
+def gather_rows_bf16(table: torch.Tensor, idx: torch.Tensor, n: int, h: int, w: int) -> Act:
+    dim = table.shape[1]
+    out = new_act(n, h, w, dim, device=table.device, bf16=True)
+    _abi.check(_abi.load().gpemsr_gather_rows_bf16(table.data_ptr(), dim, idx.data_ptr(), n * h * w, out.ptr, out.ld, _stream()),
+               "gather_rows_bf16")
+    return out
+
+
+def copy_channels_f32_bf16(src: Act, dst: Act):
+    assert not src.bf16 and dst.bf16 and src.pixels == dst.pixels and src.c == dst.c
+    _abi.check(_abi.load().gpemsr_copy_channels_f32_bf16(src.ptr, src.ld, dst.ptr, dst.ld, src.pixels, src.c, _stream()),
+               "copy_channels_f32_bf16")
+
+
+def spynet_prep_bf16(ref: Act, supp: Act, flow_coarse: Optional[Act], mean3, std3):
+    assert ref.c == 1 and ref.ld == 1 and supp.c == 1 and supp.ld == 1 and not ref.bf16
+    up = new_act(ref.n, ref.h, ref.w, 2, device=ref.buf.device)
+    inp = new_act(ref.n, ref.h, ref.w, 16, device=ref.buf.device, bf16=True)
+    m = (C.c_float * 3)(*[float(v) for v in mean3])
+    s = (C.c_float * 3)(*[float(v) for v in std3])
+    if flow_coarse is not None:
+        assert flow_coarse.ld == 2 and not flow_coarse.bf16 and flow_coarse.h == ref.h // 2 and flow_coarse.w == ref.w // 2
+    _abi.check(_abi.load().gpemsr_spynet_prep_bf16(ref.ptr, supp.ptr, flow_coarse.ptr if flow_coarse is not None else None,
+                                                   ref.n, ref.h, ref.w, m, s, up.ptr, inp.ptr, _stream()), "spynet_prep_bf16")
+    return up, inp

@@ -122,3 +122,52 @@ def pack_convT_split(pc: PackedConv, device) -> torch.Tensor:
     wt = pc.w.detach().to(torch.float32).cpu()
     assert pc.transposed and wt.shape[2] % 16 == 0
     return _split_planes(wt, device)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bf16 data path (gpemsr_conv2d_bf16): weights in the kernel's staged order [cin/CK][tap][CK/8][cout][8] bf16
+# ----------------------------------------------------------------------------------------------------------------------
+def bf16_chunk(splits: Sequence[int]) -> int:
+    """Channel chunk of a launch: 32 when every source is a multiple of 32 channels, else 16."""
+    assert all(c % 16 == 0 for c in splits), f"bf16 convolutions need source channels % 16 == 0, got {splits}"
+    return 32 if all(c % 32 == 0 for c in splits) else 16
+
+
+def _stage_order_bf16(w3: torch.Tensor, ck: int) -> torch.Tensor:
+    """[tap][cout][cin] -> [cin/ck][tap][ck/8][cout][8]: for a chunk, a tap and an 8-channel piece the couts are contiguous, so
+    one LDS-DMA instruction reads 1 KiB of consecutive memory and lands as the [tap][piece][cout][8] image the MFMA B
+    fragments are read from."""
+    t, cout, cin = w3.shape
+    assert cin % ck == 0
+    return w3.reshape(t, cout, cin // ck, ck // 8, 8).permute(2, 0, 3, 1, 4).contiguous()
+
+
+def pack_conv_bf16(w: torch.Tensor, device, splits: Optional[Sequence[int]] = None, pixel_shuffle: bool = False,
+                   scale: float = 1.0) -> torch.Tensor:
+    """OIHW conv weight -> staged bf16 (same tap / row order as pack_conv, incl. the PixelShuffle row permutation)."""
+    cout, cin, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3, 7)
+    splits = tuple(splits) if splits is not None else (cin,)
+    assert sum(splits) == cin
+    wt = w.detach().to(torch.float32).cpu().permute(2, 3, 0, 1).reshape(kh * kw, cout, cin) * scale
+    if pixel_shuffle:
+        cq = cout // 4
+        perm = torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)
+        wt = wt[:, perm]
+    return _stage_order_bf16(wt, bf16_chunk(splits)).to(torch.bfloat16).to(device)
+
+
+def pack_convT_bf16(w: torch.Tensor, device) -> torch.Tensor:
+    """ConvTranspose2d(k3,s2,p1,op1) [Cin,Cout,3,3] -> phase-stacked 2x2-tap rows (pack_convT) in staged bf16 order."""
+    cin, cout, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cout % 32 == 0 and cin % 16 == 0
+    wf = w.detach().to(torch.float32).cpu()
+    out = torch.zeros(4, 4 * cout, cin, dtype=torch.float32)
+    co = torch.arange(cout)
+    for dy in range(2):
+        for dx in range(2):
+            for py in range(dy, 2):
+                for px in range(dx, 2):
+                    rows = (co // 32) * 128 + (2 * py + px) * 32 + (co % 32)
+                    out[2 * dy + dx, rows] = wf[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()
+    return _stage_order_bf16(out, bf16_chunk((cin,))).to(torch.bfloat16).to(device)

@@ -103,6 +103,95 @@ int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight_bf16, int6
  * stride rows*k). */
 int gpemsr_split_pack_rows(const float* src, int n, int rows, int k, int ld, int64_t img_stride, void* dst_bf16, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * bf16 data path (precision = "bf16": BASELINE.json configs[2], "bf16 MFMA").  Activations are bf16 NHWC in HBM
+ * ([n][h][w][ld], ld % 8 == 0, channel counts multiples of 16), 1-channel images (LR slices, prior image, masks, flows)
+ * and the indexer's logits stay fp32.  Entry points mirror the fp32 ones above and replace the same reference calls.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  const void* ptr;   /* bf16 NHWC base of this source */
+  int32_t ld;        /* elements between consecutive pixels (multiple of 8) */
+  int32_t c;         /* channels taken from this source (multiple of 16; every source of a launch a multiple of 32, or 16-granular) */
+} gpemsr_src16_t;
+
+typedef struct {
+  int32_t n, h, w;
+  int32_t nsrc;
+  gpemsr_src16_t src[GPEMSR_MAX_SRC];      /* virtual concat along C, in order */
+  int64_t src_image_stride[GPEMSR_MAX_SRC]; /* elements between images; 0 = shared by all n; <0 = dense (h*w*ld) */
+  int32_t cout;
+  int32_t ksize;                   /* 1, 3 or 7 */
+  int32_t stride;                  /* 1, or 2 for 3x3 with cout > 32 (ignored when transposed) */
+  int32_t transposed;              /* 1 = ConvTranspose2d(k=3,s=2,p=1,op=1) */
+  const void* weight;              /* bf16, staged order [cin_total/CK][tap][CK/8][cout][8] (CK = 32, or 16 when a source is an odd
+                                      multiple of 16); transposed: tap = 2*dy+dx of the phase-stacked 2x2 form, cout -> 4*cout rows
+                                      (gpemsr_amd/packing.py::pack_conv_bf16 / pack_convT_bf16) */
+  int64_t weight_image_stride;     /* elements; != 0: image i uses weight + i*stride (1x1 only: attention products) */
+  const float* bias;               /* fp32 [cout] or NULL */
+  int32_t act;                     /* GPEMSR_ACT_* */
+  const void* residual;            /* added after act; bf16 (res_f32 = 0) or fp32 (res_f32 = 1); NULL = none */
+  int32_t res_ld, res_f32;
+  const float* pixmul;             /* fp32 [n][oh][ow] multiplier applied last; NULL = none */
+  int32_t pixel_shuffle;           /* same meaning as in the fp32 descriptor; cout % 32 == 0 */
+  int32_t kpack;                   /* 1: store the bf16 result as the B operand of a later product: [n][cout/8][oh*ow][8] */
+  void* out; int32_t out_ld;       /* bf16 (out_f32 = 0) or fp32 (out_f32 = 1) */
+  int32_t out_f32;
+  float* out32; int32_t out32_ld;  /* optional: the un-rounded fp32 result as well (master copy of residual trunks); NULL = none */
+  float* gn_partials;              /* optional: per (tile, channel) sum / sum of squares of (conv + bias) -- the first pass of
+                                      GroupNorm (model/blocks.py:5-6) -- as [n][parts][cout][2], parts = gpemsr_conv2d_bf16_gn_parts();
+                                      feed to gpemsr_groupnorm_finish.  NULL = none */
+  int32_t variant;                 /* 0 = default tile choice; other values select alternative tilings (tuning only) */
+} gpemsr_conv16_desc;
+
+int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream);
+/* rows of the gn_partials workspace per image for this launch geometry (>= 1), or a negative error code */
+int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d);
+
+/* GroupNorm on bf16 tensors (model/blocks.py:5-6,13-28).  The first pass (per-channel sum / sum of squares) comes either from
+ * the producing convolution's epilogue (gpemsr_conv16_desc.gn_partials) or from gpemsr_groupnorm_stats_bf16; both fill
+ * ws[n][parts][c][2].  gpemsr_groupnorm_finish folds it into mean_rstd[n][groups][2] (fixed order, deterministic);
+ * gpemsr_groupnorm_apply_bf16 normalises (+ReLU, + bf16 residual). */
+int gpemsr_groupnorm_stats_bf16(const void* x, int n, int hw, int c, int ld, float* ws, int parts, void* stream);
+int gpemsr_groupnorm_finish(const float* ws, int n, int hw, int c, int groups, int parts, float eps, float* mean_rstd, void* stream);
+int gpemsr_groupnorm_apply_bf16(const void* x, int n, int hw, int c, int ld, int groups, const float* mean_rstd,
+                                const float* gamma, const float* beta, int relu, const void* residual, int res_ld,
+                                void* out, int out_ld, void* stream);
+/* row softmax (blocks.py:77): s[rows][cols] fp32 (s_f32 = 1) or bf16 -> p bf16; cols % 8 == 0, <= 8192 */
+int gpemsr_softmax_rows_bf16(const void* s, int s_f32, int64_t rows, int cols, int s_ld, void* p, int p_ld, void* stream);
+/* codebook lookup (codebook.py:41): out[r] = bf16(table[idx[r]]), fp32 table */
+int gpemsr_gather_rows_bf16(const float* table, int dim, const int32_t* idx, int64_t rows, void* out, int out_ld, void* stream);
+/* bf16 rows [n][rows][c] -> B-operand layout [n][c/8][rows][8] of gpemsr_conv2d_bf16's 1x1 form (attention: k, v^T) */
+int gpemsr_pack_rows_bf16(const void* src, int n, int rows, int c, int ld, int64_t img_stride, void* dst, void* stream);
+/* format changes at the module boundary / between the fp32 and bf16 parts of the path */
+int gpemsr_cast_f32_bf16(const float* x, int64_t pixels, int c, int x_ld, void* out, int out_ld, void* stream);
+int gpemsr_cast_bf16_f32(const void* x, int64_t pixels, int c, int x_ld, float* out, int out_ld, void* stream);
+/* bf16 counterparts of gpemsr_bilinear / _pool3s2_maxavg / _spynet_prep (16-channel bf16 level input, channels 8..15 zero; flows
+ * stay fp32) / _dcn_columns (x and columns bf16, offsets + mask logits fp32) / _patch_cosine / _temporal_gate /
+ * _frame_mix_lrelu / _threeda_combine / _copy_channels (c % 8 == 0) */
+int gpemsr_bilinear_bf16(const void* x, int n, int h, int w, int c, int ld, int oh, int ow, int align_corners, float mul,
+                         void* out, int out_ld, void* stream);
+int gpemsr_pool3s2_maxavg_bf16(const void* x, int n, int h, int w, int c, int ld, void* out, int out_ld, void* stream);
+int gpemsr_spynet_prep_bf16(const float* ref, const float* supp, const float* flow_coarse, int n, int h, int w,
+                            const float* mean3, const float* std3, float* up_flow, void* inp16, void* stream);
+int gpemsr_dcn_columns_bf16(const void* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
+                            void* col, void* stream);
+int gpemsr_patch_cosine_bf16(const void* a, const void* b, int n, int h, int w, int c, float* out, void* stream);
+int gpemsr_temporal_gate_bf16(const void* aligned, const void* emb, const void* emb_ref, int b, int t, int hw, int c,
+                              void* af, void* stream);
+int gpemsr_frame_mix_lrelu_bf16(const void* af, int64_t pixels, int t, int c, const float* m, const float* bias, void* out,
+                                void* stream);
+int gpemsr_threeda_combine_bf16(const void* feat, const void* attn, const void* attn_add, const void* f2, const void* f3,
+                                int64_t count, void* out, void* stream);
+int gpemsr_copy_channels_bf16(const void* src, int src_ld, void* dst, int dst_ld, int64_t pixels, int c, void* stream);
+int gpemsr_copy_channels_f32_bf16(const float* src, int src_ld, void* dst, int dst_ld, int64_t pixels, int c, void* stream);
+/* gpemsr_conv2d_stem1 with bf16 output (cout % 8 == 0); gpemsr_conv2d_direct with fp32 or bf16 input / output (fp32 packed
+ * weights as for gpemsr_conv2d_direct; the 64 -> 1 3x3 form takes an fp32 residual) */
+int gpemsr_conv2d_stem1_bf16(const float* x, int n, int h, int w, const float* weight, const float* bias, int cout, int act,
+                             void* out, int out_ld, void* stream);
+int gpemsr_conv2d_direct_bf16(const void* x, int x_f32, int n, int h, int w, int ld, int cin, const float* weight,
+                              const float* bias, int cout, int ksize, int stride, int act, const float* residual, int res_ld,
+                              void* out, int out_f32, int out_ld, void* stream);
+
 /* Direct (VALU) convolution for tiny channel counts: cout <= 16, any k<=7, stride 1/2/4.
  * replaces: POD.flowdsconv* (model/GPEMSR.py:70-75,101-106), SpyNet's last 16->2 conv,
  * conv_last / decoder.output_layer / refmaskconv3 (cout = 1).  weight layout as above. */

@@ -1,0 +1,332 @@
+"""bf16 data path (precision = "bf16", BASELINE configs[2]): every entry point of the "bf16 data path" section of
+include/gpemsr_hip.h against torch CPU functional ops.  The comparison operands are the bf16-ROUNDED inputs and weights
+evaluated in fp32 (so only accumulation order and the final bf16 rounding of the result differ): fp32 outputs must match
+to 1e-4, bf16 outputs to 2^-8 relative (half an ulp is 2^-9)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = 2.0 ** -8
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda", 0)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def _r(x):
+    """round to bf16 and back (what the device tensor holds)"""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _act16(x_nchw, dev, ld=None, off=0):
+    from gpemsr_amd import ops
+    n, c, h, w = x_nchw.shape
+    ld = c if ld is None else ld
+    buf = torch.full((n, h, w, ld), 7.0)
+    buf[..., off:off + c] = x_nchw.permute(0, 2, 3, 1)
+    return ops.Act(buf.to(torch.bfloat16).to(dev).contiguous().view(-1), n, h, w, c, ld, off)
+
+
+def _act32(x_nchw, dev):
+    from gpemsr_amd import ops
+    return ops.from_nhwc(x_nchw.permute(0, 2, 3, 1).contiguous().to(dev))
+
+
+def _close(got, want, tol, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    ref = max(want.abs().max().item(), 1e-6)
+    assert err <= tol * ref + 1e-6, f"{what}: max err {err:.3e} vs ref max {ref:.3e} (tol {tol:.1e})"
+
+
+def _apply_act(t, act):
+    return {0: lambda v: v, 1: F.relu, 2: lambda v: F.leaky_relu(v, 0.1), 3: torch.sigmoid,
+            4: lambda v: torch.sigmoid(F.leaky_relu(v, 0.1))}[act](t)
+
+
+def _pc(wt, b, dev, splits=None, pixel_shuffle=False):
+    from gpemsr_amd.packing import pack_conv, pack_conv_bf16
+    pc = pack_conv(wt, b, dev, splits, pixel_shuffle=pixel_shuffle)
+    pc.wb = pack_conv_bf16(wt, dev, splits, pixel_shuffle=pixel_shuffle)
+    return pc
+
+
+CASES = [
+    # (n, cins, cout, k, stride, h, w, act, residual: 0 none / 1 bf16 / 2 fp32, pixmul, out_f32, variant)
+    (2, (64,), 64, 3, 1, 16, 32, 1, 1, False, False, 0),
+    (1, (64,), 64, 3, 1, 37, 70, 2, 2, True, False, 0),
+    (1, (64,), 64, 3, 1, 37, 70, 0, 0, False, True, 1),
+    (2, (64, 64), 64, 3, 1, 17, 19, 0, 1, True, False, 0),
+    (1, (64, 128, 64), 64, 3, 1, 16, 40, 0, 0, False, False, 0),
+    (1, (64, 64, 64), 64, 3, 1, 9, 33, 2, 0, False, False, 0),
+    (1, (128,), 256, 3, 1, 20, 36, 0, 1, False, False, 0),
+    (1, (128,), 256, 3, 1, 20, 36, 1, 0, False, False, 1),
+    (1, (128,), 256, 3, 1, 20, 36, 1, 0, False, True, 2),
+    (1, (256,), 256, 3, 1, 16, 32, 0, 0, False, False, 0),
+    (1, (64,), 216, 3, 1, 16, 16, 0, 0, False, True, 0),
+    (1, (32,), 32, 3, 1, 12, 50, 1, 0, False, False, 0),
+    (1, (16,), 32, 3, 1, 12, 50, 1, 0, False, False, 0),
+    (1, (48,), 64, 3, 1, 10, 34, 0, 0, False, False, 0),
+    (2, (64,), 64, 3, 2, 32, 64, 2, 0, False, False, 0),
+    (1, (256,), 512, 3, 2, 16, 32, 0, 0, False, False, 0),
+    (1, (64, 64), 64, 3, 2, 18, 66, 0, 0, False, False, 0),
+    (1, (16,), 32, 7, 1, 32, 40, 1, 0, False, False, 0),
+    (1, (32,), 64, 7, 1, 16, 48, 1, 0, False, False, 0),
+    (1, (64,), 32, 7, 1, 9, 37, 1, 0, False, False, 0),
+    (1, (32,), 16, 7, 1, 12, 32, 1, 0, False, False, 0),
+    (2, (512,), 512, 1, 1, 8, 16, 0, 1, False, False, 0),
+    (1, (64, 128, 64), 64, 1, 1, 16, 16, 0, 0, False, False, 0),
+    (1, (320,), 64, 1, 1, 12, 20, 2, 1, False, False, 0),
+    (1, (576,), 64, 1, 1, 10, 13, 2, 0, False, False, 0),
+    (1, (512,), 512, 1, 1, 8, 8, 0, 0, False, True, 0),
+    (1, (64,), 20, 3, 1, 16, 16, 3, 0, False, True, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_bf16(case):
+    from gpemsr_amd import ops
+    n, cins, cout, k, stride, h, w, act, res_mode, use_mul, out_f32, variant = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _r(_rand(n, cin, h, w, seed=1))
+    wt = _r(_rand(cout, cin, k, k, seed=2, scale=1.0 / np.sqrt(cin * k * k)))
+    b = _rand(cout, seed=3, scale=0.1)
+    want = _apply_act(F.conv2d(x, wt, b, stride, k // 2), act)
+    oh, ow = want.shape[2:]
+    res = _rand(n, cout, oh, ow, seed=4) if res_mode else None
+    if res_mode == 1:
+        res = _r(res)
+    mul = torch.rand(n, 1, oh, ow, generator=torch.Generator().manual_seed(5)) if use_mul else None
+    if res is not None:
+        want = want + res
+    if mul is not None:
+        want = want * mul
+    srcs, o = [], 0
+    for i, c in enumerate(cins):
+        srcs.append(_act16(x[:, o:o + c], dev, ld=c + (8 if i == 0 else 0), off=8 if i == 0 else 0))
+        o += c
+    pc = _pc(wt, b, dev, cins)
+    r_act = None if res is None else (_act16(res, dev) if res_mode == 1 else _act32(res, dev))
+    m_act = None if mul is None else ops.Act(mul.reshape(-1).to(dev), n, oh, ow, 1, 1, 0)
+    got = ops.conv2d(srcs, pc, act, stride=stride, residual=r_act, pixmul=m_act, precision="bf16", out_f32=out_f32, variant=variant,
+                     force_mfma=True)
+    assert got.bf16 == (not out_f32)
+    _close(got.nchw(), want, 1e-4 if out_f32 else BF, str(case))
+
+
+def test_conv2d_bf16_dual_output_and_gn_partials():
+    """out32 = the un-rounded result; gn partial sums + finish == the statistics torch's group_norm uses; apply == group_norm."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    for (cin, cout, h, w, variant) in ((64, 64, 24, 40, 0), (128, 256, 16, 48, 0), (128, 256, 16, 48, 1), (64, 128, 9, 33, 2)):
+        n = 2
+        x = _r(_rand(n, cin, h, w, seed=11))
+        wt = _r(_rand(cout, cin, 3, 3, seed=12, scale=1.0 / np.sqrt(cin * 9)))
+        b = _rand(cout, seed=13, scale=0.3)
+        conv = F.conv2d(x, wt, b, 1, 1)
+        pc = _pc(wt, b, dev)
+        o32 = ops.new_act(n, h, w, cout, device=dev)
+        got = ops.conv2d([_act16(x, dev)], pc, 0, precision="bf16", out32=o32, gn_stats=True, variant=variant)
+        _close(o32.nchw(), conv, 1e-4, "out32")
+        _close(got.nchw(), conv, BF, "bf16 out")
+        assert got.gn is not None
+        gamma, beta = _rand(cout, seed=14) + 1.5, _rand(cout, seed=15)
+        res = _r(_rand(n, cout, h, w, seed=16))
+        y = ops.groupnorm_relu(got, gamma.to(dev), beta.to(dev), True, residual=_act16(res, dev))
+        want = F.relu(F.group_norm(conv, 32, gamma, beta, eps=1e-6)) + res
+        # the normalised tensor is computed from the bf16-rounded conv output: 2^-8 of |conv| scaled by rstd*gamma
+        _close(y.nchw(), want, 3 * BF, f"groupnorm after conv {cin}->{cout} v{variant}")
+        # standalone statistics pass (no producing conv)
+        z = ops.groupnorm_relu(_act16(_r(conv), dev), gamma.to(dev), beta.to(dev), False)
+        _close(z.nchw(), F.group_norm(_r(conv), 32, gamma, beta, eps=1e-6), 2 * BF, "groupnorm standalone")
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 16, 32), (128, 64, 9, 20), (512, 256, 8, 8), (64, 32, 5, 33)])
+def test_conv_transpose_bf16(cin, cout, h, w):
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_convT, pack_convT_bf16
+    dev = _dev()
+    x = _r(_rand(2, cin, h, w, seed=21))
+    wt = _r(_rand(cin, cout, 3, 3, seed=22, scale=1.0 / np.sqrt(cin * 2.25)))
+    b = _rand(cout, seed=23, scale=0.1)
+    want = F.leaky_relu(F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1), 0.1)
+    pc = pack_convT(wt, b, dev)
+    pc.wb = pack_convT_bf16(wt, dev)
+    got = ops.conv2d([_act16(x, dev)], pc, 2, precision="bf16")
+    _close(got.nchw(), want, BF, "convT")
+
+
+def test_pixel_shuffle_bf16():
+    from gpemsr_amd import ops
+    dev = _dev()
+    x = _r(_rand(2, 64, 12, 34, seed=31))
+    wt = _r(_rand(256, 64, 3, 3, seed=32, scale=1.0 / 24))
+    b = _rand(256, seed=33, scale=0.1)
+    want = F.leaky_relu(F.pixel_shuffle(F.conv2d(x, wt, b, 1, 1), 2), 0.1)
+    got = ops.conv2d([_act16(x, dev)], _pc(wt, b, dev, pixel_shuffle=True), 2, precision="bf16")
+    _close(got.nchw(), want, BF, "pixel shuffle")
+
+
+def test_spynet_flow_conv_fp32_out_with_fp32_residual():
+    """SpyNet's 16 -> 2 7x7 output conv: bf16 in, fp32 flow out, + the fp32 up-sampled flow (2-channel rows, scalar path)."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    x = _r(_rand(2, 16, 24, 40, seed=41))
+    wt = _r(_rand(2, 16, 7, 7, seed=42, scale=1.0 / 28))
+    b = _rand(2, seed=43, scale=0.1)
+    up = _rand(2, 2, 24, 40, seed=44, scale=3.0)
+    want = F.conv2d(x, wt, b, 1, 3) + up
+    got = ops.conv2d([_act16(x, dev)], _pc(wt, b, dev), 0, residual=_act32(up, dev), precision="bf16", out_f32=True)
+    _close(got.nchw(), want, 1e-4, "flow conv")
+
+
+def test_attention_products_bf16():
+    """The three products of model/blocks.py:75-80 with per-image B operands in the kpack layout: S = q.k^T, v^T = W_v.hn^T,
+    A = P.v (+ v bias), against torch.bmm on the bf16-rounded operands."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    n, h, w, c = 2, 8, 12, 64
+    T = h * w
+    hn = _r(_rand(n, c, h, w, seed=51))
+    wq, wk, wv = (_r(_rand(c, c, 1, 1, seed=s, scale=1.0 / 8)) for s in (52, 53, 54))
+    bq, bk, bv = (_rand(c, seed=s, scale=0.1) for s in (55, 56, 57))
+    hn_a = _act16(hn, dev)
+    q = ops.conv2d([hn_a], _pc(wq, bq, dev), 0, precision="bf16")
+    kp = ops.conv2d([hn_a], _pc(wk, bk, dev), 0, precision="bf16", kpack=True)
+    q_ref = _r(F.conv2d(hn, wq, bq)).permute(0, 2, 3, 1).reshape(n, T, c)
+    k_ref = _r(F.conv2d(hn, wk, bk)).permute(0, 2, 3, 1).reshape(n, T, c)
+    # kpack layout [n][c/8][T][8]
+    _close(kp.float().permute(0, 2, 1, 3).reshape(n, T, c), k_ref, 1e-6, "kpack of k")
+    S = ops.conv2d([q], ops.PackedConv(None, None, 1, T, (c,), 32, wb=kp), 0, weight_image_stride=T * c, precision="bf16", out_f32=True)
+    _close(S.torch().reshape(n, T, T), torch.bmm(q_ref, k_ref.transpose(1, 2)), 1e-4, "q.k^T")
+    Sb = ops.conv2d([q], ops.PackedConv(None, None, 1, T, (c,), 32, wb=kp), 0, weight_image_stride=T * c, precision="bf16")
+    P = ops.softmax_rows_bf16(Sb)
+    p_ref = torch.softmax(_r(torch.bmm(q_ref, k_ref.transpose(1, 2))), dim=2)
+    _close(P.torch().float().reshape(n, T, T), p_ref, 2 * BF, "softmax")
+    hnp = ops.pack_rows_bf16(hn_a)
+    wa = ops.Act(wv.reshape(c, c).to(torch.bfloat16).to(dev).contiguous().view(-1), n, 1, c, c, c, 0)
+    vtp = ops.conv2d([wa], ops.PackedConv(None, None, 1, T, (c,), 32, wb=hnp), 0, weight_image_stride=T * c, src_image_stride=[0],
+                     kpack=True, precision="bf16")
+    v_ref = _r(F.conv2d(hn, wv)).permute(0, 2, 3, 1).reshape(n, T, c)                 # without bias
+    _close(vtp.float().permute(0, 2, 1, 3).reshape(n, c, T), v_ref.transpose(1, 2), 1e-6, "v^T kpack")
+    p_dev = _r(P.torch().float().reshape(n, T, T).cpu())
+    out = ops.conv2d([P], ops.PackedConv(None, bv.to(dev), 1, c, (T,), 32, wb=vtp), 0, weight_image_stride=c * T, precision="bf16", out_f32=True)
+    _close(out.torch().reshape(n, T, c), torch.bmm(p_dev, v_ref) + bv, 1e-4, "P.v")
+
+
+def test_elementwise_bf16_kernels():
+    from gpemsr_amd import ops
+    dev = _dev()
+    # bilinear (x2 up, x1/2 down, align_corners, mul) and the 3x3 stride-2 max|avg pool
+    x = _r(_rand(2, 64, 9, 14, seed=61))
+    a = _act16(x, dev)
+    _close(ops.bilinear(a, 18, 28).nchw(), F.interpolate(x, size=(18, 28), mode="bilinear", align_corners=False), BF, "bilinear up")
+    _close(ops.bilinear(a, 18, 28, mul=2.0).nchw(), 2 * F.interpolate(x, size=(18, 28), mode="bilinear", align_corners=False), BF, "bilinear mul")
+    p = ops.pool3s2_maxavg(a).nchw()
+    _close(p[:, :64], F.max_pool2d(x, 3, 2, 1), 1e-6, "maxpool")
+    _close(p[:, 64:], F.avg_pool2d(x, 3, 2, 1), BF, "avgpool")
+    # casts and channel copies
+    y = _rand(2, 16, 5, 7, seed=62)
+    _close(ops.cast_bf16(_act32(y, dev)).nchw(), _r(y), 1e-7, "cast to bf16")
+    _close(ops.cast_f32(_act16(_r(y), dev)).nchw(), _r(y), 1e-7, "cast to f32")
+    dst = ops.new_act(2, 5, 7, 64, device=dev, bf16=True, zero=True)
+    ops.copy_channels(_act16(_r(y), dev), dst.slice(16, 16))
+    ops.copy_channels_f32_bf16(_act32(y[:, :1], dev), dst.slice(33, 1))
+    full = dst.nchw()
+    _close(full[:, 16:32], _r(y), 1e-7, "copy slice")
+    _close(full[:, 33:34], _r(y[:, :1]), 1e-7, "copy f32 -> bf16 slice")
+    assert float(full[:, :16].abs().max()) == 0 and float(full[:, 34:].abs().max()) == 0
+    # codebook gather
+    table = _rand(50, 64, seed=63)
+    idx = torch.randint(0, 50, (2 * 3 * 4,), generator=torch.Generator().manual_seed(64), dtype=torch.int32)
+    g = ops.gather_rows_bf16(table.to(dev), idx.to(dev), 2, 3, 4)
+    _close(g.torch().float().reshape(-1, 64), _r(table[idx.long()]), 1e-7, "gather rows")
+    # image regrouping is a raw copy
+    imgs = _act16(_r(_rand(6, 64, 4, 8, seed=65)), dev)
+    gi = ops.gather_images(imgs, torch.tensor([5, 0, 0, 3], dtype=torch.int32, device=dev))
+    _close(gi.nchw(), imgs.nchw()[[5, 0, 0, 3]], 0.0, "gather images")
+    ci = ops.copy_images(imgs, 2, 1, 3, 2)
+    _close(ci.nchw(), imgs.nchw()[[2, 5]], 0.0, "copy images")
+    # ThreeDA pieces
+    b, t, hh, ww, c = 2, 5, 6, 10, 64
+    al = _r(_rand(b * t, c, hh, ww, seed=66)); em = _r(_rand(b * t, c, hh, ww, seed=67, scale=0.3)); er = _r(_rand(b, c, hh, ww, seed=68, scale=0.3))
+    af = ops.temporal_gate(_act16(al, dev), _act16(em, dev), _act16(er, dev), b, t)
+    cor = torch.sigmoid((em.view(b, t, c, hh, ww) * er.view(b, 1, c, hh, ww)).sum(2, keepdim=True))
+    want_af = (al.view(b, t, c, hh, ww) * cor).reshape(b, t * c, hh, ww)
+    _close(af.nchw(), want_af, BF, "temporal gate")
+    m = _rand(t, t, seed=69, scale=0.5); mb = _rand(t, seed=70, scale=0.1)
+    fm = ops.frame_mix_lrelu(_act16(_r(want_af), dev), t, m.to(dev), mb.to(dev))
+    wf = F.leaky_relu(torch.einsum("ik,bkchw->bichw", m, _r(want_af).view(b, t, c, hh, ww)) + mb.view(1, t, 1, 1, 1), 0.1).reshape(b, t * c, hh, ww)
+    _close(fm.nchw(), wf, BF, "frame mix")
+    f5 = [_r(_rand(b, c, hh, ww, seed=71 + i)) for i in range(5)]
+    tc = ops.threeda_combine(*[_act16(v, dev) for v in f5])
+    _close(tc.nchw(), f5[0] * torch.sigmoid(f5[1]) * 2 + f5[2] + f5[3] + f5[4], BF, "threeda combine")
+    # 16x16 patch cosine
+    fa, fb = _r(_rand(2, 64, 32, 48, seed=80).abs()), _r(_rand(2, 64, 32, 48, seed=81).abs())
+    pcs = ops.patch_cosine(_act16(fa, dev), _act16(fb, dev)).nchw()
+    ua = F.unfold(fa, 16, stride=16); ub = F.unfold(fb, 16, stride=16)
+    wantc = (F.normalize(ua, dim=1) * F.normalize(ub, dim=1)).sum(1).view(2, 1, 2, 3)
+    _close(pcs, wantc, 1e-5, "patch cosine")
+
+
+def test_stem_direct_and_dcn_bf16():
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv
+    dev = _dev()
+    # 1 -> 64 stem: fp32 image in, bf16 out
+    img = torch.rand(2, 1, 20, 36, generator=torch.Generator().manual_seed(90))
+    wt = _rand(64, 1, 3, 3, seed=91, scale=0.3); b = _rand(64, seed=92, scale=0.1)
+    got = ops.conv2d([ops.Act(img.reshape(-1).to(dev), 2, 20, 36, 1, 1, 0)], pack_conv(wt, b, dev), 2, precision="bf16")
+    assert got.bf16
+    _close(got.nchw(), F.leaky_relu(F.conv2d(img, wt, b, 1, 1), 0.1), BF, "stem")
+    # 64 -> 1 (bf16 in, fp32 out, fp32 residual, sigmoid(lrelu)) and flow down-convs (fp32 in -> bf16 slice; bf16 -> bf16 stride 2)
+    x = _r(_rand(2, 64, 16, 24, seed=93))
+    w1 = _rand(1, 64, 3, 3, seed=94, scale=1.0 / 24); b1 = _rand(1, seed=95)
+    base = _rand(2, 1, 16, 24, seed=96)
+    g1 = ops.conv2d([_act16(x, dev)], pack_conv(w1, b1, dev), 0, residual=_act32(base, dev), precision="bf16")
+    assert not g1.bf16
+    _close(g1.nchw(), F.conv2d(x, w1, b1, 1, 1) + base, 1e-4, "64 -> 1 with residual")
+    g2 = ops.conv2d([_act16(x, dev)], pack_conv(w1, b1, dev), 4, precision="bf16")
+    _close(g2.nchw(), torch.sigmoid(F.leaky_relu(F.conv2d(x, w1, b1, 1, 1), 0.1)), 1e-4, "mask head")
+    flow = _rand(2, 2, 32, 48, seed=97, scale=2.0)
+    wf = _rand(16, 2, 3, 3, seed=98, scale=0.3); bf = _rand(16, seed=99, scale=0.1)
+    buf = ops.new_act(2, 8, 12, 64, device=dev, bf16=True, zero=True)
+    ops.conv2d([_act32(flow, dev)], pack_conv(wf, bf, dev), 0, stride=4, out=buf.slice(16, 16), precision="bf16")
+    want = F.conv2d(flow, wf, bf, 4, 1)
+    _close(buf.nchw()[:, 16:32], want, BF, "flow conv stride 4 into a slice")
+    w2 = _rand(16, 16, 3, 3, seed=100, scale=0.1)
+    buf2 = ops.new_act(2, 4, 6, 64, device=dev, bf16=True, zero=True)
+    ops.conv2d([buf.slice(16, 16)], pack_conv(w2, None, dev), 0, stride=2, out=buf2.slice(0, 16), precision="bf16")
+    _close(buf2.nchw()[:, :16], F.conv2d(buf.nchw()[:, 16:32].cpu(), w2, None, 2, 1), BF, "flow conv stride 2 bf16 -> bf16")
+    # deformable columns: bf16 features, fp32 offsets / mask logits; compare with the fp32 kernel on the same rounded features
+    xf = _r(_rand(2, 64, 12, 16, seed=101))
+    om = _rand(2, 216, 12, 16, seed=102, scale=2.0)
+    c16 = ops.dcn_columns(_act16(xf, dev), _act32(om, dev), 8)
+    c32 = ops.dcn_columns(_act32(xf, dev), _act32(om, dev), 8)
+    assert c16.bf16 and not c32.bf16
+    _close(c16.nchw(), c32.nchw(), BF, "dcn columns")
+
+
+def test_spynet_prep_bf16_matches_fp32_kernel():
+    from gpemsr_amd import ops
+    dev = _dev()
+    ref = torch.rand(2, 1, 16, 24, generator=torch.Generator().manual_seed(110))
+    sup = torch.rand(2, 1, 16, 24, generator=torch.Generator().manual_seed(111))
+    fc = _rand(2, 2, 8, 12, seed=112, scale=1.5)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    A = lambda t: ops.Act(t.permute(0, 2, 3, 1).contiguous().reshape(-1).to(dev), t.shape[0], t.shape[2], t.shape[3], t.shape[1], t.shape[1], 0)   # noqa: E731
+    up16, in16 = ops.spynet_prep_bf16(A(ref), A(sup), A(fc), mean, std)
+    up32, in32 = ops.spynet_prep(A(ref), A(sup), A(fc), mean, std, pad16=True)
+    _close(up16.nchw(), up32.nchw(), 0.0, "up flow")
+    _close(in16.nchw(), in32.nchw(), BF, "level input")

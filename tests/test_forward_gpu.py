@@ -243,20 +243,64 @@ def test_bf16x3_mode_meets_the_fp32_parity_bar(tag, golden_dir):
     assert abs(calculate_psnr(u8, base_u8) - float(d["psnr_vs_base"])) < 0.01
 
 
-def test_bf16_mode_is_within_its_looser_bar(golden_dir):
-    """precision='bf16' (plain bf16 operands): not parity-grade -- bounded at 2e-2 relative, |dPSNR| < 0.01 dB."""
+def test_bf16op_mode_is_within_its_looser_bar(golden_dir):
+    """precision='bf16op' (round 1's bf16 mode: fp32 activations, bf16 operands rounded in LDS): bounded at 2e-3 relative
+    (observed 6e-4), |dPSNR| < 0.01 dB."""
     d = np.load(os.path.join(golden_dir, "x8_lr32_b1_smooth.npz"))
-    model = _pmodel(8, "bf16")
+    model = _pmodel(8, "bf16op")
     out, ref_img = model(torch.from_numpy(d["x"]).cuda(), forced_code_idx=torch.from_numpy(d["code_idx"]).cuda())
     torch.cuda.synchronize()
-    _cmp(out, d, "out", tol=2e-2)
+    _cmp(out, d, "out", tol=2e-3)
     _cmp(ref_img, d, "ref_img", tol=2e-2)
+    _psnr_check(out, d, 8)
+
+
+def _psnr_check(out, d, scale):
     from gpemsr_amd import ops
     from gpemsr_amd.imgutil import calculate_psnr
     u8 = ops.tensor2img_u8(out[0, 0]).cpu().numpy()
-    base = torch.nn.functional.interpolate(torch.from_numpy(d["x"])[0:1, 2], scale_factor=8, mode="bilinear", align_corners=False)
+    base = torch.nn.functional.interpolate(torch.from_numpy(d["x"])[0:1, 2], scale_factor=scale, mode="bilinear", align_corners=False)
     base_u8 = (base.squeeze().clamp(0, 1).numpy() * 255.0).round().astype(np.uint8)
     assert abs(calculate_psnr(u8, base_u8) - float(d["psnr_vs_base"])) < 0.01
+    return u8
+
+
+@pytest.mark.parametrize("tag", ["x8_lr32_b1_smooth", "x8_lr16_b1_uniform", "x16_lr16_b1_smooth"])
+def test_bf16_data_path_against_the_reference_golden(tag, golden_dir):
+    """precision='bf16' = BASELINE configs[2] ("bf16 MFMA"): bf16 NHWC activations in HBM, bf16 MFMA with fp32 accumulation,
+    the indexer's logits GEMM + argmax in fp32.  Against the vectors emitted by the unmodified reference, with the
+    reference's code indices teacher-forced (SURVEY section 7 protocol): the SR output within 1e-3 relative (the fp32
+    bar; bf16 rounding of the 64-channel trunks is ~2^-9 per tensor but the output adds the fp32 bilinear base), every
+    hooked intermediate within 2e-2 (bf16 tensors: 2^-8 per element and layer), uint8 image within 1 grey level and
+    |dPSNR| < 0.01 dB.  Free-running code-index agreement is reported and must hold wherever the reference's top-2 logit
+    margin exceeds four times the measured logit error (bf16 activations in the indexer move logits by ~1e-2 relative)."""
+    d = np.load(os.path.join(golden_dir, tag + ".npz"))
+    scale = int(d["scale"])
+    model = _pmodel(scale, "bf16")
+    x = torch.from_numpy(d["x"]).cuda()
+    tr = {}
+    out, ref_img = model(x, forced_code_idx=torch.from_numpy(d["code_idx"]).cuda(), trace=tr)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float32 and ref_img.dtype == torch.float32
+    errs = {}
+    for name, t, tol in (("out", out, 1e-3), ("ref_img", ref_img, 2e-2), ("L1_fea", torch.cat(tr["L1_fea"]), 2e-2),
+                         ("L1_fused", tr["L1_fused"], 2e-2), ("mask_cos", torch.cat(tr["mask_cos"]), 2e-2),
+                         ("flow", torch.cat(tr["flow"]), 2e-2), ("aligned", torch.cat(tr["aligned"]), 2e-2),
+                         ("fused", torch.cat(tr["fused"]), 2e-2), ("logits", torch.cat(tr["logits"]), 5e-2)):
+        errs[name] = _cmp(t, d, name, tol=tol)
+    u8 = _psnr_check(out, d, scale)
+    assert np.abs(u8.astype(np.int32) - d["out_u8"].astype(np.int32)).max() <= 1
+    tr2 = {}
+    model(x, trace=tr2)
+    idx = torch.cat(tr2["code_idx"]).cpu().numpy()
+    agree = float((idx == d["code_idx"]).mean())
+    # a code can only flip where the reference's top-2 margin is within twice the logit error; require agreement elsewhere
+    lg_want, lg_stride = _golden(d, "logits")
+    abs_err = errs["logits"] * float(np.abs(lg_want).max())
+    safe = d["logit_margin"] > 4.0 * abs_err
+    print(f"bf16 path {tag}: rel err " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()) +
+          f"; code agreement {agree:.4f} ({int(safe.sum())}/{safe.size} cells have a margin > 4 x the logit error {abs_err:.1e})")
+    assert (idx[safe] == d["code_idx"][safe]).all() and agree > 0.9
 
 
 def test_volume_mode_equals_independent_windows():

@@ -465,7 +465,7 @@ def test_conv_split_bf16x3(case):
     out3 = ops.conv2d(srcs, pc, act, precision="bf16x3", **kw)
     torch.cuda.synchronize()
     _close(out3.nchw(), want.float(), tol=3e-5, what=f"bf16x3 {case}")
-    out1 = ops.conv2d(srcs, pc, act, precision="bf16", **kw)
+    out1 = ops.conv2d(srcs, pc, act, precision="bf16op", **kw)
     torch.cuda.synchronize()
     _close(out1.nchw(), want.float(), tol=2e-2, what=f"bf16 {case}")
     again = ops.conv2d(srcs, pc, act, precision="bf16x3", **kw)
@@ -500,7 +500,7 @@ def test_conv_split_1x1(case):
     out = ops.conv2d(srcs, pc, act, precision="bf16x3", residual=_to_act(res, dev) if use_res else None)
     torch.cuda.synchronize()
     _close(out.nchw(), want.float(), tol=3e-5, what=f"bf16x3 1x1 {case}")
-    out1 = ops.conv2d(srcs, pc, act, precision="bf16", residual=_to_act(res, dev) if use_res else None)
+    out1 = ops.conv2d(srcs, pc, act, precision="bf16op", residual=_to_act(res, dev) if use_res else None)
     torch.cuda.synchronize()
     _close(out1.nchw(), want.float(), tol=2e-2, what=f"bf16 1x1 {case}")
 
