@@ -40,8 +40,15 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #ifdef GP16_STAMP
 __device__ unsigned long long g_xstamps[8 * 65536];
 #define XST(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) g_xstamps[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// segment accounting (wave 0 of every workgroup): XSEG(k) adds the cycles since the previous mark to bucket k
+#define XSEG_DECL unsigned long long xs_t = __builtin_amdgcn_s_memtime(), xs_acc[6] = {0, 0, 0, 0, 0, 0}
+#define XSEG(k) do { const unsigned long long xs_n = __builtin_amdgcn_s_memtime(); xs_acc[k] += xs_n - xs_t; xs_t = xs_n; } while (0)
+#define XSEG_FLUSH do { if (threadIdx.x == 0 && blockIdx.x < 65536) { for (int k = 0; k < 6; ++k) g_xstamps[8 * blockIdx.x + k] = xs_acc[k]; g_xstamps[8 * blockIdx.x + 6] = T_me; } } while (0)
 #else
 #define XST(i)
+#define XSEG_DECL
+#define XSEG(k)
+#define XSEG_FLUSH
 #endif
 
 constexpr int XA_LOADS = 6;       // 16-B A slots per thread (halo_px * R / 256)
@@ -76,6 +83,8 @@ struct XParams {
   int n_abuf;                                // A images in LDS: GEMM: ring; conv: 2 (1 when there is a single chunk)
   int spc;                                   // stages per chunk = kk / TPS
   int nblocks;
+  int nbias;                                 // true output channels (bias entries)
+  int gpt, ns;                               // resident kernel: workgroups per cout slab, spatial tiles
 };
 
 __device__ __forceinline__ void xglds16(unsigned voff, const void* base, unsigned lds_addr) {
@@ -83,6 +92,14 @@ __device__ __forceinline__ void xglds16(unsigned voff, const void* base, unsigne
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
+
+// make a wave-uniform value provably uniform for the "s" operands of the DMA statement (guide 5.7 / T20)
+__device__ __forceinline__ const void* xuni_ptr(const void* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned xuni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ void xwait_vmcnt(int n) {
   switch (n) {
@@ -102,9 +119,193 @@ __device__ __forceinline__ unsigned xcvt_pk_bf16(float a, float b) {
 __device__ __forceinline__ float xbf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float xbf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 
+
+struct XGeo { int img, oy0, ox0, n0, tile_in_img; };
+
+// Epilogue of one wave's MT x NT accumulator tiles, straight from registers.  The accumulators are D^T (registers = 16 couts
+// (r&3) + 8 (r>>2) + 4 lh of a 32-cout tile, lanes = 32 pixels): bias (from LDS: a global load here would drain the DMA
+// prefetches through the in-order vmcnt) and activation are applied per register, then two v_permlane32_swap per register
+// pair give lane (li, lh) the 8 consecutive couts 8 (gp + lh) .. + 7 of its pixel: residual, per-pixel multiplier, optional
+// fp32 copy, 16-byte store.  GroupNorm partial sums (conv + bias, valid pixels): butterfly over the 32 pixel lanes.
+template <int MT, int NT, bool GEMM>
+__device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x16 (&acc)[MT][NT], int pix_base, int cout_base, int gn_part,
+                                           const float* bias_lds, int li, int lh) {
+  const long long img_pix0 = (long long)g.img * P.OH * P.OW;
+  const bool up = P.store_mode == XS_PIXSHUF || P.store_mode == XS_CONVT;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int p = pix_base + mt * 32 + li;
+    int oy, ox; bool pok;
+    if (GEMM) { oy = 0; ox = g.ox0 + p; pok = ox < P.oh * P.ow; }
+    else { oy = g.oy0 + (p >> 5); ox = g.ox0 + (p & 31); pok = oy < P.oh && ox < P.ow; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cb0 = g.n0 + cout_base + nt * 32;            // first cout (GEMM column) of this 32-row accumulator tile
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[mt][nt][r];
+      if (P.bias) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int c0 = cb0 + 8 * gq + 4 * lh;
+          int bc = c0;
+          if (P.store_mode == XS_CONVT) bc = (c0 >> 7) * 32 + (c0 & 31);     // bias is per true output channel
+          if (c0 < P.cout) {                                                    // (the LDS copy is zero-padded to a multiple of 8)
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + bc);
+            v[4 * gq] += b4.x; v[4 * gq + 1] += b4.y; v[4 * gq + 2] += b4.z; v[4 * gq + 3] += b4.w;
+          }
+        }
+      }
+      if (P.act == GPEMSR_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (P.act == GPEMSR_ACT_LRELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.1f * v[r]);
+      } else if (P.act != GPEMSR_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], P.act);
+      }
+      // two register pairs of groups (0,1) and (2,3): after the half-wave swaps lane (li, lh) owns couts 8*(gp + lh) .. +7
+#pragma unroll
+      for (int gp = 0; gp < 4; gp += 2) {
+        float w8[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * gp + j]), __float_as_uint(v[4 * gp + 4 + j]), false, false);
+          w8[j] = __uint_as_float(sw[0]); w8[4 + j] = __uint_as_float(sw[1]);
+        }
+        const int nidx = cb0 + 8 * (gp + lh);
+        const int nvalid = (P.cout - nidx) < 8 ? (P.cout - nidx) : 8;
+        if (!pok || nvalid <= 0) continue;
+        int ch = nidx, sy = 0, sx = 0;
+        if (P.store_mode == XS_PIXSHUF) { const int q = nidx / P.cq; ch = nidx - q * P.cq; sy = q >> 1; sx = q & 1; }
+        else if (P.store_mode == XS_CONVT) { const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); sy = q >> 1; sx = q & 1; }
+        const int opix = GEMM ? ox : (up ? (2 * oy + sy) * P.OW + 2 * ox + sx : oy * P.OW + ox);
+        const bool full = nvalid == 8;
+        if (P.residual) {
+          if (P.res_f32) {
+            const float* rp = reinterpret_cast<const float*>(P.residual) + (img_pix0 + opix) * P.res_ld + ch;
+            if (full) {
+              const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+              w8[0] += r0.x; w8[1] += r0.y; w8[2] += r0.z; w8[3] += r0.w; w8[4] += r1.x; w8[5] += r1.y; w8[6] += r1.z; w8[7] += r1.w;
+            } else {
+              for (int k = 0; k < nvalid; ++k) w8[k] += rp[k];
+            }
+          } else {
+            const unsigned short* rp = reinterpret_cast<const unsigned short*>(P.residual) + (img_pix0 + opix) * P.res_ld + ch;
+            if (full) {
+              const uint4 u = *reinterpret_cast<const uint4*>(rp);
+              w8[0] += xbf_lo(u.x); w8[1] += xbf_hi(u.x); w8[2] += xbf_lo(u.y); w8[3] += xbf_hi(u.y);
+              w8[4] += xbf_lo(u.z); w8[5] += xbf_hi(u.z); w8[6] += xbf_lo(u.w); w8[7] += xbf_hi(u.w);
+            } else {
+              for (int k = 0; k < nvalid; ++k) w8[k] += __uint_as_float((unsigned)rp[k] << 16);
+            }
+          }
+        }
+        if (P.pixmul) {
+          const float m = P.pixmul[img_pix0 + opix];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w8[k] *= m;
+        }
+        if (P.out32) {
+          float* o32 = P.out32 + (img_pix0 + opix) * P.out32_ld + ch;
+          if (full) {
+            *reinterpret_cast<float4*>(o32) = make_float4(w8[0], w8[1], w8[2], w8[3]);
+            *reinterpret_cast<float4*>(o32 + 4) = make_float4(w8[4], w8[5], w8[6], w8[7]);
+          } else {
+            for (int k = 0; k < nvalid; ++k) o32[k] = w8[k];
+          }
+        }
+        if (P.out_f32) {
+          float* op = reinterpret_cast<float*>(P.out) + (img_pix0 + opix) * P.out_ld + ch;
+          if (full) {
+            *reinterpret_cast<float4*>(op) = make_float4(w8[0], w8[1], w8[2], w8[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(w8[4], w8[5], w8[6], w8[7]);
+          } else {
+            for (int k = 0; k < nvalid; ++k) op[k] = w8[k];
+          }
+        } else {
+          const uint4 pk = make_uint4(xcvt_pk_bf16(w8[0], w8[1]), xcvt_pk_bf16(w8[2], w8[3]), xcvt_pk_bf16(w8[4], w8[5]), xcvt_pk_bf16(w8[6], w8[7]));
+          unsigned short* op;
+          if (P.store_mode == XS_KPACK) op = reinterpret_cast<unsigned short*>(P.out) + (long long)g.img * P.kpack_img_stride + ((long long)(ch >> 3) * (P.OH * P.OW) + opix) * 8;
+          else op = reinterpret_cast<unsigned short*>(P.out) + (img_pix0 + opix) * P.out_ld + ch;
+          if (full) {
+            *reinterpret_cast<uint4*>(op) = pk;
+          } else {
+            const unsigned wv[4] = {pk.x, pk.y, pk.z, pk.w};
+            for (int k = 0; k < nvalid; ++k) op[k] = (unsigned short)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xFFFFu));
+          }
+        }
+      }
+    }
+  }
+  if (P.gn_ws) {
+#pragma unroll 1
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cb0 = g.n0 + cout_base + nt * 32;
+      float bs[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        bs[r] = (P.bias && co < P.cout) ? bias_lds[co] : 0.f;
+      }
+      float gsum[16], gsq[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { gsum[r] = 0.f; gsq[r] = 0.f; }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int p = pix_base + mt * 32 + li;
+        bool pok;
+        if (GEMM) pok = g.ox0 + p < P.oh * P.ow;
+        else pok = (g.oy0 + (p >> 5)) < P.oh && (g.ox0 + (p & 31)) < P.ow;
+        // static register indexing (guide rule 20): select the accumulator tile with a compile-time index
+#pragma unroll
+        for (int n2 = 0; n2 < NT; ++n2)
+          if (n2 == nt && pok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[mt][n2][r] + bs[r]; gsum[r] += v; gsq[r] = fmaf(v, v, gsq[r]); }
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = gsum[r], b = gsq[r];
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        const int co = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (li == 0 && co < P.cout) {
+          float* wsp = P.gn_ws + (((long long)g.img * P.gn_parts + gn_part) * P.cout + co) * 2;
+          wsp[0] = a; wsp[1] = b;
+        }
+      }
+    }
+  }
+}
+
+// bias -> LDS (zero-padded to a multiple of 8 floats); nbias = number of true output channels
+__device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, int nbias, int nthreads) {
+  const int npad = (nbias + 7) & ~7;
+  for (int i = threadIdx.x; i < npad; i += nthreads) bias_lds[i] = (P.bias && i < nbias) ? P.bias[i] : 0.f;
+}
+
 // CK: channels per chunk (32; 16 for sources that are odd multiples of 16).  TPS: taps per stage.  CONVT / GEMM: see above.
+// Filter width and stride follow from the instantiation: GEMM -> 1x1, CONVT -> 2x2 taps, TPS == 7 -> 7x7, TH == 2 -> 3x3 stride 2.
+//
+// PERSISTENT workgroups: a workgroup walks tiles  blockIdx.x, +gridDim.x, ...  and treats their chunks / stages as ONE stream:
+// the weights of the next tile's first stages and its first halo image are already in flight while the current tile's last
+// stages are multiplied and while its results are stored, so the per-tile prologue (DMA round trip) and epilogue overlap
+// with matrix work instead of adding to it (in-kernel stamps of the first version: 8k cycles set-up + 20k cycles epilogue
+// around 15k cycles of main loop on 64-channel layers).  The accumulators are kept TRANSPOSED (D^T = W . In^T: couts on
+// the register axis, pixels on the lanes), so after bias / activation a pair of v_permlane32_swap gives every lane 8
+// consecutive output channels of one pixel: the epilogue stores 16-byte pieces straight from registers -- no LDS staging,
+// no barrier, each wave on its own.
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
+  constexpr int KW = GEMM ? 1 : (CONVT ? 2 : (TPS == 7 ? 7 : 3));
+  constexpr int S = (!GEMM && !CONVT && TH == 2) ? 2 : 1;
+  constexpr int KK = KW * KW;
+  constexpr int SPC = KK / TPS;        // stages per chunk
+  static_assert(KK % TPS == 0, "taps per stage must divide the tap count");
   constexpr int R = CK / 8;            // 16-byte pieces per pixel row
   constexpr int KS = CK / 16;          // MFMA k-steps per tap
   constexpr int NPIX = TH * 32;
@@ -114,115 +315,172 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
   constexpr int NT = WNT / 32;
   constexpr int ROWB = R * 16;         // bytes per pixel row of the A image
   constexpr int SWZ_SH = (R == 4) ? 2 : 3, SWZ_MK = R - 1;
+  constexpr int HALO_W = GEMM ? NPIX : 31 * S + KW;
+  constexpr int HALO_H = GEMM ? 1 : (TH - 1) * S + KW;
+  constexpr int HALO_PX = HALO_W * HALO_H;
+  constexpr int NA = (HALO_PX * R + 255) / 256;       // A slots (16 B) per thread
+  constexpr int NB = (TPS * R * BN + 255) / 256;      // B slots per thread per stage
+  constexpr int A_BYTES = HALO_PX * R * 16;
+  constexpr int B_BYTES = TPS * R * BN * 16;
+  static_assert(NA <= XA_LOADS && NB <= XB_LOADS, "tile too large");
 
   extern __shared__ __attribute__((aligned(16))) char xsm[];
-  XST(0);
+  XSEG_DECL;
   const int n_abuf = P.n_abuf;
+  const int RING = P.ring;             // <= 4
   char* const a_base = xsm;
-  char* const b_base = xsm + n_abuf * P.a_bytes;
+  char* const b_base = xsm + n_abuf * A_BYTES;
+  float* const bias_lds = reinterpret_cast<float*>(b_base + RING * B_BYTES);
+  x_stage_bias(P, bias_lds, P.nbias, 256);            // (published by the prologue barrier)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-
-  int bid = blockIdx.x;
-  {
-    const int nwg = P.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
-  int t = bid;
-  const int tn = t % P.tiles_n; t /= P.tiles_n;
-  const int tx = t % P.tiles_x; t /= P.tiles_x;
-  const int ty = t % P.tiles_y; t /= P.tiles_y;
-  const int img = t;
-  const int tw_lg = P.tw_lg, tw_mask = (1 << tw_lg) - 1;
-  const int n0 = tn * BN;
-  const int S = P.stride;
-  // conv: tile rows oy0.., cols ox0..; GEMM: NPIX consecutive pixels of the flattened image starting at ox0 (oy0 = 0)
-  const int oy0 = GEMM ? 0 : ty * (NPIX >> tw_lg), ox0 = GEMM ? tx * NPIX : (tx << tw_lg);
-  const int iy0 = oy0 * S - P.pad, ix0 = ox0 * S - P.pad;
   const int hw_in = P.h * P.w;
 
-  // ---- per-thread DMA slots ----
-  int a_goff[XA_LOADS];        // element offset of the slot's 8 channels inside the source image, chunk base excluded; -1: none
+  // ---- sources (static copies: no dependent scalar loads in the loop) ----
+  const unsigned short* srcp[GPEMSR_MAX_SRC];
+  long long src_istride[GPEMSR_MAX_SRC];
+  unsigned src_pixb[GPEMSR_MAX_SRC];
+  int src_c[GPEMSR_MAX_SRC];
+  int nchunks = 0;
 #pragma unroll
-  for (int i = 0; i < XA_LOADS; ++i) {
-    const int e = tid + i * 256;
-    a_goff[i] = -1;
-    if (i < P.na && e < P.halo_px * R) {
-      const int hp = e / R, pp = e % R;
-      const int q = pp ^ ((hp >> SWZ_SH) & SWZ_MK);               // logical piece held at physical piece pp
-      int pix = -1;
-      if (GEMM) { const int p = ox0 + hp; if (p < hw_in) pix = p; }
-      else {
-        const int iy = iy0 + hp / P.halo_w, ix = ix0 + hp % P.halo_w;
-        if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) pix = iy * P.w + ix;
-      }
-      if (pix >= 0) a_goff[i] = (pix << 8) | q;                   // pixel index (<= 2^23) and piece; the source ld is per chunk
-    }
+  for (int s = 0; s < GPEMSR_MAX_SRC; ++s) {
+    srcp[s] = P.src[s]; src_istride[s] = P.img_stride[s]; src_pixb[s] = (unsigned)P.ld[s] * 2u; src_c[s] = s < P.nsrc ? P.c[s] : 0;
+    nchunks += src_c[s] / CK;
   }
-  int b_goff[XB_LOADS];        // element offset inside the weight tensor relative to (chunk, first tap of the stage); -1: none
+  const int G = nchunks * SPC;                        // stages per tile
+
+  // ---- slot geometry (recomputed where needed: registers are better spent on accumulators) ----
+  // A slot i of this thread = 16-B piece e = tid + 256 i of the halo image: halo pixel hp = e / R holds, at physical piece
+  // e % R, the logical piece (e % R) ^ swizzle(hp).  B slot i = piece e of the stage image [tap][piece][BN][8].
+  auto a_slot_exists = [&](int i) -> bool { return tid + i * 256 < HALO_PX * R; };
+  auto a_slot_piece = [&](int i) -> unsigned { const int e = tid + i * 256, hp = e / R; return (unsigned)((e % R) ^ ((hp >> SWZ_SH) & SWZ_MK)); };
+  // DMA instructions per image THIS WAVE issues for the weights (rows past cout are clamped, not masked: they only feed
+  // accumulator rows that are never stored) -- wave-uniform and constant
+  int nb_w = 0;
 #pragma unroll
-  for (int i = 0; i < XB_LOADS; ++i) {
-    const int e = tid + i * 256;
-    b_goff[i] = -1;
-    if (i < P.nb && e < TPS * R * BN) {
-      const int nn = e % BN, tq = e / BN;                         // LDS image [tap][piece][BN][8]
-      if (n0 + nn < P.cout) b_goff[i] = (tq * P.cout + n0 + nn) * 8;
-    }
-  }
-  int na_w = 0, nb_w = 0;
-#pragma unroll
-  for (int i = 0; i < XA_LOADS; ++i) na_w += (__ballot(a_goff[i] >= 0) != 0ull) ? 1 : 0;
-#pragma unroll
-  for (int i = 0; i < XB_LOADS; ++i) nb_w += (__ballot(b_goff[i] >= 0) != 0ull) ? 1 : 0;
+  for (int i = 0; i < NB; ++i) nb_w += (i * 256 + wave * 64 < TPS * R * BN) ? 1 : 0;
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)xsm + (unsigned)wave * 1024u);
 
-  // zero the slots no DMA ever writes (out-of-image halo pixels, rows past cout): once, in every buffer
-  {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < XA_LOADS; ++i)
-      if (i < P.na && (tid + i * 256) < P.halo_px * R && a_goff[i] < 0)
-        for (int bsel = 0; bsel < n_abuf; ++bsel) *reinterpret_cast<float4*>(a_base + bsel * P.a_bytes + (tid + i * 256) * 16) = z;
-#pragma unroll
-    for (int i = 0; i < XB_LOADS; ++i)
-      if (i < P.nb && (tid + i * 256) < TPS * R * BN && b_goff[i] < 0)
-        for (int bsel = 0; bsel < P.ring; ++bsel) *reinterpret_cast<float4*>(b_base + bsel * P.b_bytes + (tid + i * 256) * 16) = z;
-  }
+  // ---- tiles of this workgroup ----
+  const int ntiles = P.nblocks;                        // total tiles of the launch; gridDim.x <= ntiles
+  const int grid = gridDim.x;
+  const int T_me = (ntiles - (int)blockIdx.x + grid - 1) / grid;
+  const int TS = T_me * G, TC = T_me * nchunks;        // stages / chunks of this workgroup's whole stream
 
-  // ---- chunk / stage bookkeeping ----
-  int nchunks = 0;
-  for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / CK;
-  const int spc = P.spc;
-  const int nstages = nchunks * spc;
-  const int RING = P.ring;
-
-  int an_src = 0, an_c0 = 0, an_chunk = 0;                       // A cursor: next chunk image to issue
-  int bn_chunk = 0, bn_grp = 0, bn_stage = 0;                    // B cursor: next stage to issue
-  const unsigned short* wimg = P.weight + (long long)img * P.w_img_stride;
-
-  auto issue_a = [&]() -> int {
-    const unsigned short* sp = P.src[an_src] + (long long)img * P.img_stride[an_src] + an_c0;
-    const unsigned pixb = (unsigned)P.ld[an_src] * 2u;
-    const unsigned la = lds0 + (unsigned)((an_chunk % n_abuf) * P.a_bytes);
-#pragma unroll
-    for (int i = 0; i < XA_LOADS; ++i)
-      if (a_goff[i] >= 0) xglds16((unsigned)(a_goff[i] >> 8) * pixb + 16u * (unsigned)(a_goff[i] & 255), sp, la + i * 4096u);
-    ++an_chunk; an_c0 += CK;
-    if (an_c0 >= P.c[an_src] && an_src + 1 < P.nsrc) { an_c0 = 0; ++an_src; }
-    return na_w;
+  typedef XGeo Geo;
+  auto tile_geo = [&](int ti) -> Geo {
+    int t = (int)blockIdx.x + ti * grid;
+    {   // XCD-aware remap (bijective): consecutive logical tiles of concurrently running workgroups share an XCD / L2
+      const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + t / 8;
+    }
+    const int tn = t % P.tiles_n; t /= P.tiles_n;
+    const int tx = t % P.tiles_x; t /= P.tiles_x;
+    const int ty = t % P.tiles_y; t /= P.tiles_y;
+    Geo g;
+    g.img = t; g.n0 = tn * BN;
+    g.oy0 = GEMM ? 0 : ty * TH; g.ox0 = GEMM ? tx * NPIX : tx * 32;
+    g.tile_in_img = GEMM ? tx : ty * P.tiles_x + tx;
+    return g;
   };
-  auto issue_b = [&]() -> int {
-    const unsigned short* wp = wimg + ((long long)bn_chunk * P.kk + bn_grp * TPS) * (R * 8) * P.cout;
-    const unsigned lb = lds0 + (unsigned)(n_abuf * P.a_bytes + (bn_stage % RING) * P.b_bytes);
+  // `cur` = the tile being multiplied, `nxt` = the one after it.  The DMA cursors run at most one tile ahead (host: ring <=
+  // stages per tile, images <= chunks per tile) and copy what they need from `nxt` when they cross into it.
+  Geo cur = tile_geo(0);
+  Geo nxt = T_me > 1 ? tile_geo(1) : cur;
+  int a_pix[NA];                                       // A cursor's tile: pixel index inside the source image per slot, -1: padding
+  int na_w = 0, a_img = 0;                             // ... DMA instructions this wave issues per chunk image, image number
+  bool a_pad = false;                                  // ... tile has padding slots (zero-fill needed)
+  auto a_enter_tile = [&](const Geo& g) {
+    const int iy0 = g.oy0 * S - P.pad, ix0 = g.ox0 * S - P.pad;
+    int cnt = 0; bool pad = false;
 #pragma unroll
-    for (int i = 0; i < XB_LOADS; ++i)
-      if (b_goff[i] >= 0) xglds16((unsigned)b_goff[i] * 2u, wp, lb + i * 4096u);
-    ++bn_stage;
-    if (++bn_grp == spc) { bn_grp = 0; ++bn_chunk; }
-    return nb_w;
+    for (int i = 0; i < NA; ++i) {
+      int pix = -1;
+      if (a_slot_exists(i)) {
+        const int hp = (tid + i * 256) / R;
+        if (GEMM) { const int pp = g.ox0 + hp; if (pp < hw_in) pix = pp; }
+        else {
+          const int iy = iy0 + hp / HALO_W, ix = ix0 + hp % HALO_W;
+          if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) pix = iy * P.w + ix;
+        }
+        pad = pad || pix < 0;
+      }
+      a_pix[i] = pix;
+      cnt += (__ballot(pix >= 0) != 0ull) ? 1 : 0;
+    }
+    na_w = cnt; a_img = g.img;
+    a_pad = __ballot(pad) != 0ull;
+  };
+  int b_img = cur.img, b_n0 = cur.n0;                  // B cursor's tile
+  // A cursor that has issued the last item of its tile crosses into the next one LAZILY, when it issues that tile's first
+  // item: that moment always lies inside the main loop's current tile (ring <= stages per tile, images <= chunks per tile),
+  // where `nxt` is the tile in question; the moment of the wrap itself may still lie in the tile before.
+  bool a_cross = false, b_cross = false;
+
+  // ---- DMA cursors over the whole stream ----
+  int issued_total = 0;
+  int markB[4] = {0, 0, 0, 0}, markA[4] = {0, 0, 0, 0};
+  auto set4 = [&](int (&m)[4], int idx, int v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j == (idx & 3)) m[j] = v;
+  };
+  auto get4 = [&](const int (&m)[4], int idx) -> int {
+    int v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j == (idx & 3)) v = m[j];
+    return v;
+  };
+  int a_next = 0, a_ti = 0, a_chunk = 0, a_src = 0, a_c0 = 0;           // next chunk image to issue: stream index, tile, position
+  int b_next = 0, b_ti = 0, b_chunk = 0, b_grp = 0;                      // next weight stage to issue
+  auto issue_a = [&]() {
+    if (a_cross) { a_enter_tile(nxt); a_cross = false; }
+    const unsigned short* sp = nullptr; unsigned pixb = 0; int cs = 0;
+#pragma unroll
+    for (int s = 0; s < GPEMSR_MAX_SRC; ++s)
+      if (s == a_src) { sp = srcp[s] + (long long)a_img * src_istride[s] + a_c0; pixb = src_pixb[s]; cs = src_c[s]; }
+    const unsigned la = xuni(lds0 + (unsigned)((a_next % n_abuf) * A_BYTES));
+    sp = reinterpret_cast<const unsigned short*>(xuni_ptr(sp));
+    pixb = xuni(pixb);
+    if (a_pad && a_chunk < n_abuf) {                    // padding slots of this tile: zero once per LDS image
+      char* ab = a_base + (a_next % n_abuf) * A_BYTES;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (a_slot_exists(i) && a_pix[i] < 0) *reinterpret_cast<float4*>(ab + (tid + i * 256) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (a_pix[i] >= 0)
+        xglds16((unsigned)a_pix[i] * pixb + 16u * a_slot_piece(i), sp, la + i * 4096u);
+    issued_total += na_w;
+    set4(markA, a_next, issued_total);
+    ++a_next; a_c0 += CK;
+    if (a_c0 >= cs) { a_c0 = 0; ++a_src; }
+    if (++a_chunk == nchunks) { a_chunk = 0; a_src = 0; a_c0 = 0; ++a_ti; a_cross = true; }
+  };
+  auto issue_b = [&]() {
+    if (b_cross) { b_img = nxt.img; b_n0 = nxt.n0; b_cross = false; }
+    const unsigned short* wp = P.weight + (long long)b_img * P.w_img_stride + ((long long)b_chunk * KK + b_grp * TPS) * (R * 8) * P.cout;
+    wp = reinterpret_cast<const unsigned short*>(xuni_ptr(wp));
+    const unsigned lb = xuni(lds0 + (unsigned)(n_abuf * A_BYTES + (b_next % RING) * B_BYTES));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + i * 256;
+      if (e < TPS * R * BN) {
+        int row = b_n0 + e % BN;
+        row = row < P.cout ? row : P.cout - 1;
+        xglds16((unsigned)((e / BN) * P.cout + row) * 16u, wp, lb + i * 4096u);
+      }
+    }
+    issued_total += nb_w;
+    set4(markB, b_next, issued_total);
+    ++b_next;
+    if (++b_grp == SPC) {
+      b_grp = 0;
+      if (++b_chunk == nchunks) { b_chunk = 0; ++b_ti; b_cross = true; }
+    }
   };
 
   // ---- fragment addressing ----
@@ -230,267 +488,294 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    hp0[mt] = GEMM ? p : ((p >> tw_lg) * S) * P.halo_w + (p & tw_mask) * S;
+    hp0[mt] = GEMM ? p : ((p >> 5) * S) * HALO_W + (p & 31) * S;
   }
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
 
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  // ---- prologue: A(0) [+ GEMM: A(1..RING-2)], B(0..RING-2) ----
-  // issue log: iss[j] = DMA instructions this wave has issued in total once stage j's images are on their way.
-  // A stage may be read after  issued_total - iss[stage]  instructions at most are still in flight (vmcnt is in order).
-  int issued_total = 0;
-  int iss_ring[8];                   // iss of stages s+1 .. (static indexing below: RING <= 8)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) iss_ring[j] = 0;
-  auto log_stage = [&](int stage) {  // called right after the issues that complete `stage`
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (j == (stage & 7)) iss_ring[j] = issued_total;
-  };
-  auto iss_of = [&](int stage) -> int {
-    int v = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (j == (stage & 7)) v = iss_ring[j];
-    return v;
-  };
-  if (GEMM) {
-    for (int j = 0; j < RING - 1 && j < nstages; ++j) { issued_total += issue_a(); issued_total += issue_b(); log_stage(j); }
-  } else {
-    issued_total += issue_a();
-    for (int j = 0; j < RING - 1 && j < nstages; ++j) { issued_total += issue_b(); log_stage(j); }
+  // ---- prologue: tile 0 (and 1) geometry, A(0) [A(1)], B(0 .. RING-1) ----
+  a_enter_tile(cur);
+  issue_a();
+  issue_b();
+  for (int j = 1; j < n_abuf && a_next < TC; ++j) issue_a();
+  for (int j = 1; j < RING && b_next < TS; ++j) issue_b();
+  XSEG(0);
+  {
+    const int ma = get4(markA, 0), mb = get4(markB, 0);
+    xwait_vmcnt(issued_total - (ma > mb ? ma : mb));
   }
-  XST(1);
-  xwait_vmcnt(issued_total - iss_of(0));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  XST(2);
+  XSEG(1);
 
-  int chunk = 0, grp = 0;
-  for (int stage = 0; stage < nstages; ++stage) {
-    // top of the stage: everybody is past the barrier that ended stage-1, so ring slot (stage-1) % RING and the A buffer of
-    // chunk-1 are free.  Issue order: next chunk's A image first, then the weights of stage + RING - 1.
-    if (!GEMM && grp == 0 && an_chunk < nchunks && an_chunk == chunk + 1) issued_total += issue_a();
-    if (stage + RING - 1 < nstages) {
-      if (GEMM) issued_total += issue_a();
-      issued_total += issue_b();
-      log_stage(stage + RING - 1);
+  int gs = 0, gc = 0;               // stream position: stage, chunk
+  for (int ti = 0; ti < T_me; ++ti) {
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    int grp = 0;
+    for (int s = 0; s < G; ++s, ++gs) {
+      const char* A = a_base + (gc % n_abuf) * A_BYTES;
+      const char* B = b_base + (gs % RING) * B_BYTES + b_frag;
+      const int tap0 = grp * TPS;
+      bf16x8 fa[2][MT], fb[2][NT];
+      auto tap_mask = [&](int tap) -> unsigned {       // CONVT: N tiles (phases q = 2py+px) fed by tap (dy,dx) = (tap>>1, tap&1)
+        if (!CONVT) return 0xFu;
+        return (tap >> 1) ? ((tap & 1) ? 0x8u : 0xCu) : ((tap & 1) ? 0xAu : 0xFu);
+      };
+      auto load_step = [&](int set, int tt, int ks) {
+        const int tap = tap0 + tt;
+        const int ky = GEMM ? 0 : tap / KW, kx = GEMM ? 0 : tap - ky * KW;
+        const int toff = ky * HALO_W + kx;
+        const unsigned mask = tap_mask(tap);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int hp = hp0[mt] + toff;
+          const int pp = (2 * ks + lh) ^ ((hp >> SWZ_SH) & SWZ_MK);
+          fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + hp * ROWB + pp * 16);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (CONVT && !((mask >> nt) & 1u)) continue;
+          fb[set][nt] = *reinterpret_cast<const bf16x8*>(B + (tt * R + 2 * ks) * (BN * 16) + nt * 512);
+        }
+      };
+      auto mma_step = [&](int set, int tt) {
+        const unsigned mask = tap_mask(tap0 + tt);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if (CONVT && !((mask >> nt) & 1u)) continue;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)       // D^T: weights are the row operand, pixels the column operand
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][nt], fa[set][mt], acc[mt][nt], 0, 0, 0);
+        }
+      };
+      constexpr int NSTEP = TPS * KS;
+      load_step(0, 0, 0);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {            // software pipelined by two (static register sets)
+        if (st + 1 < NSTEP) load_step((st + 1) & 1, (st + 1) / KS, (st + 1) % KS);
+        mma_step(st & 1, st / KS);
+      }
+
+      // ---- end of the stage ----
+      XSEG(2);
+      const bool chunk_end = (grp == SPC - 1);
+      if (gs + 1 < TS) {      // the next stage's weights (and, at a chunk boundary, the next chunk's halo image) must have landed
+        int need = get4(markB, gs + 1);
+        if (chunk_end && n_abuf >= 2) { const int ma = get4(markA, gc + 1); need = ma > need ? ma : need; }
+        xwait_vmcnt(issued_total - need);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();        // every wave is done with this stage's ring slot (and, at a chunk end, with the A image)
+      asm volatile("" ::: "memory");
+      XSEG(3);
+      // the freed slot / image are refilled at once: weights of stage gs + RING, halo image of chunk gc + n_abuf
+      if (b_next < TS) issue_b();
+      if (chunk_end) {
+        if (a_next < TC) issue_a();
+        ++gc;
+        if (n_abuf < 2 && gc < TC) {       // single A image: the refill could only start now -- wait for it before the next stage
+          xwait_vmcnt(issued_total - get4(markA, a_next - 1));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+      }
+      if (++grp == SPC) grp = 0;
+      XSEG(4);
     }
 
-    const char* A = a_base + (chunk % n_abuf) * P.a_bytes;
-    const char* B = b_base + (stage % RING) * P.b_bytes + b_frag;
-    const int tap0 = grp * TPS;
-    bf16x8 fa[2][MT], fb[2][NT];
-    auto tap_mask = [&](int tap) -> unsigned {       // CONVT: N tiles (phases q = 2py+px) fed by tap (dy,dx) = (tap>>1, tap&1)
-      if (!CONVT) return 0xFu;
-      return (tap >> 1) ? ((tap & 1) ? 0x8u : 0xCu) : ((tap & 1) ? 0xAu : 0xFu);
-    };
-    // step = (tap tt of the stage, k-step ks)
-    auto load_step = [&](int set, int tt, int ks) {
-      const int tap = tap0 + tt;
-      const int ky = GEMM ? 0 : tap / P.kw, kx = GEMM ? 0 : tap - ky * P.kw;
-      const int toff = ky * P.halo_w + kx;
-      const unsigned mask = tap_mask(tap);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int hp = hp0[mt] + toff;
-        const int pp = (2 * ks + lh) ^ ((hp >> SWZ_SH) & SWZ_MK);
-        fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + hp * ROWB + pp * 16);
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (CONVT && !((mask >> nt) & 1u)) continue;
-        fb[set][nt] = *reinterpret_cast<const bf16x8*>(B + (tt * R + 2 * ks) * (BN * 16) + nt * 512);
-      }
-    };
-    auto mma_step = [&](int set, int tt) {
-      const unsigned mask = tap_mask(tap0 + tt);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (CONVT && !((mask >> nt) & 1u)) continue;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][mt], fb[set][nt], acc[mt][nt], 0, 0, 0);
-      }
-    };
-    constexpr int NSTEP = TPS * KS;
-    load_step(0, 0, 0);
-#pragma unroll
-    for (int st = 0; st < NSTEP; ++st) {            // software pipelined by two (static register sets)
-      if (st + 1 < NSTEP) load_step((st + 1) & 1, (st + 1) / KS, (st + 1) % KS);
-      mma_step(st & 1, st / KS);
-    }
+    // both DMA cursors have crossed into the next tile by now: advance the tile window
+    const Geo g = cur;
+    cur = nxt;
+    if (ti + 2 < T_me) nxt = tile_geo(ti + 2);
 
-    // end of the stage: stage+1's images must have landed (this wave's pieces; the barrier covers the other waves') and
-    // every wave must be done reading this stage's slot before the next top-of-stage overwrites it.
-    if (stage + 1 < nstages) xwait_vmcnt(issued_total - iss_of(stage + 1));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (++grp == spc) { grp = 0; ++chunk; }
+    // ---- epilogue, straight from the accumulators (D^T: lane = pixel, registers = couts) ----
+    x_epilogue<MT, NT, GEMM>(P, g, acc, wm * PM, wn * WNT, g.tile_in_img * WM + wm, bias_lds, li, lh);
+    XSEG(5);
+  }
+  XSEG_FLUSH;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with 64 input channels -- the most common layer of the network (feature extraction, fusion
+// blocks, reconstruction trunk, up-convs, HRconv, the 64-channel VQGAN blocks) -- with the WEIGHTS RESIDENT IN LDS.
+// In-kernel stamps of the ring kernel above show those layers bound by global -> LDS staging, not by the matrix pipe: a CU
+// stages ~25-30 B/clk, and with K = 576 the weights (73.7 KB per 64 couts) were re-staged for every 256-pixel tile.  Here a
+// 512-thread workgroup (8 waves, one per CU) keeps the [2 chunks][9 taps][4 pieces][64 couts][8] weight slab of ITS 64 couts
+// in LDS for its whole life and streams only halo images: tile = 16 x 32 pixels, every wave owns two pixel rows x all 64
+// couts (64 accumulator registers), the halo image of a 32-channel chunk (18 x 34 pixels, 39 KB) is double buffered, so
+// chunk c + 1 (or the next tile's chunk 0) lands while chunk c is multiplied: 72 MFMAs per wave between barriers, two
+// barriers per tile, no DMA accounting beyond vmcnt(0) (each image was issued a whole phase earlier).
+// Staged bytes per FLOP drop 2.7x against the ring kernel (78 KB per 37.7 MFLOP instead of 117 KB per 18.9).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
+  constexpr int TH = 16, HALO_W = 34, HALO_H = 18, HALO_PX = HALO_W * HALO_H, R = 4;
+  constexpr int A_BYTES = HALO_PX * R * 16;            // 39,168
+  constexpr int W_BYTES = 2 * 9 * 4 * 64 * 16;         // 73,728
+  constexpr int NA = (HALO_PX * R + 511) / 512;        // 5 slots per thread per chunk image
+  constexpr int NW = W_BYTES / 16 / 512;               // 9 slots per thread for the weight slab
+  constexpr int MT = 2, NT = 2;
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  char* const w_base = xsm;
+  char* const a_base = xsm + W_BYTES;
+  float* const bias_lds = reinterpret_cast<float*>(xsm + W_BYTES + 2 * A_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int tn = (int)blockIdx.x % P.tiles_n, sg = (int)blockIdx.x / P.tiles_n;
+  const int n0 = tn * 64;
+  const int gpt = P.gpt, NS = P.ns;
+  const int T_me = (NS - sg + gpt - 1) / gpt;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)xsm + (unsigned)wave * 1024u);
+
+  x_stage_bias(P, bias_lds, P.nbias, 512);
+  // weight slab of this workgroup: rows n0 .. n0+63 of every (chunk, tap, piece) -- 72 runs of 1 KiB (rows past cout clamped)
+  {
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.weight));
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tid + i * 512;                      // 16-B piece: (chunk*9 + tap)*4 + piece = e / 64, cout row = e % 64
+      int row = n0 + (e & 63);
+      row = row < P.cout ? row : P.cout - 1;
+      xglds16((unsigned)((e >> 6) * P.cout + row) * 16u, wp, lds0 + i * 8192u);
+    }
   }
 
-  XST(3);
-  // ---- epilogue: accumulators -> LDS [128 px][EW + 4] fp32 -> rows of 8 channels per thread ----
-  constexpr int EW = BN < 64 ? BN : 64;
-  constexpr int EPIX = EW + 4;
-  constexpr int NCP = BN / EW;
-  constexpr int EP = NPIX < 128 ? NPIX : 128; // pixels per pass
-  constexpr int NPP = NPIX / EP;
-  constexpr int NV = EW / 8;                  // 8-channel groups per pixel per pass
-  constexpr int ITER = (EP * NV) / 256;       // items per thread per pass (4 for 128 px x 64 columns)
-  constexpr int PSTEP = 256 / NV;
-  static_assert(ITER >= 1, "epilogue pass smaller than the workgroup");
-  float* E = reinterpret_cast<float*>(xsm);
-  const int ej = tid % NV, ep0 = tid / NV;
-  const long long img_pix0 = (long long)img * P.OH * P.OW;
-  const char* res_img = P.residual ? reinterpret_cast<const char*>(P.residual) + img_pix0 * P.res_ld * (P.res_f32 ? 4 : 2) : nullptr;
-  const float* mul_img = P.pixmul ? P.pixmul + img_pix0 : nullptr;
-  char* out_img = reinterpret_cast<char*>(P.out) + (P.store_mode == XS_KPACK ? (long long)img * P.kpack_img_stride * 2
-                                                                             : img_pix0 * P.out_ld * (P.out_f32 ? 4 : 2));
-  float* out32_img = P.out32 ? P.out32 + img_pix0 * P.out32_ld : nullptr;
-  const int tile_in_img = GEMM ? tx : ty * P.tiles_x + tx;
+  XGeo g;
+  int a_pix[NA];
+  bool a_pad = false;
+  auto enter_tile = [&](int ti) {
+    int t = sg + ti * gpt;
+    const int tx = t % P.tiles_x; t /= P.tiles_x;
+    const int ty = t % P.tiles_y; t /= P.tiles_y;
+    g.img = t; g.n0 = n0; g.oy0 = ty * TH; g.ox0 = tx * 32; g.tile_in_img = ty * P.tiles_x + tx;
+    bool pad = false;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 512;
+      int pix = -1;
+      if (e < HALO_PX * R) {
+        const int hp = e / R;
+        const int iy = g.oy0 - 1 + hp / HALO_W, ix = g.ox0 - 1 + hp % HALO_W;
+        if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) pix = iy * P.w + ix;
+        pad = pad || pix < 0;
+      }
+      a_pix[i] = pix;
+    }
+    a_pad = __ballot(pad) != 0ull;
+  };
+  const unsigned pixb = (unsigned)P.ld[0] * 2u;
+  auto issue_a = [&](int chunk) {       // halo image of `chunk` of the tile described by g / a_pix -> buffer `chunk`
+    const unsigned short* sp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.src[0] + (long long)g.img * P.img_stride[0] + chunk * 32));
+    const unsigned la = lds0 + (unsigned)(W_BYTES + chunk * A_BYTES);
+    if (a_pad) {
+      char* ab = a_base + chunk * A_BYTES;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (tid + i * 512 < HALO_PX * R && a_pix[i] < 0) *reinterpret_cast<float4*>(ab + (tid + i * 512) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (a_pix[i] >= 0) {
+        const int e = tid + i * 512, hp = e / R;
+        const unsigned q = (unsigned)((e % R) ^ ((hp >> 2) & 3));
+        xglds16((unsigned)a_pix[i] * pixb + 16u * q, sp, la + i * 8192u);
+      }
+  };
+
+  int hp0[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) hp0[mt] = (2 * wave + mt) * HALO_W + li;
+  const int b_frag = li * 16 + lh * 1024;
+
+  XSEG_DECL;
+  enter_tile(0);
+  issue_a(0);
+  issue_a(1);
+  XSEG(0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  XSEG(1);
+
+  int n_st = 0;                       // result stores this wave issued in the previous tile's epilogue (lower bound)
+  for (int ti = 0; ti < T_me; ++ti) {
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    const XGeo gcur = g;
+    auto compute = [&](int chunk) {
+      const char* A = a_base + chunk * A_BYTES;
+      const char* B = w_base + chunk * (9 * 4 * 1024) + b_frag;
+      bf16x8 fa[2][MT], fb[2][NT];
+      auto load_step = [&](int set, int st) {
+        const int tap = st >> 1, ks = st & 1;
+        const int toff = (tap / 3) * HALO_W + tap % 3;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int hp = hp0[mt] + toff;
+          const int pp = (2 * ks + lh) ^ ((hp >> 2) & 3);
+          fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + hp * 64 + pp * 16);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const bf16x8*>(B + (tap * 4 + 2 * ks) * 1024 + nt * 512);
+      };
+      load_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        if (st + 1 < 18) load_step((st + 1) & 1, st + 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st & 1][nt], fa[st & 1][mt], acc[mt][nt], 0, 0, 0);
+      }
+    };
+    const bool more = ti + 1 < T_me;
 #pragma unroll 1
-  for (int pass = 0; pass < NCP * NPP; ++pass) {
-    const int cpass = pass % NCP, ppass = pass / NCP;
-    const int nidx = n0 + cpass * EW + 8 * ej;
-    int ch = nidx, bidx = nidx, sy = 0, sx = 0;
-    if (P.store_mode == XS_PIXSHUF) { const int q = nidx / P.cq; ch = nidx - q * P.cq; sy = q >> 1; sx = q & 1; }
-    else if (P.store_mode == XS_CONVT) { const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); bidx = ch; sy = q >> 1; sx = q & 1; }
-    const int nvalid = (P.cout - nidx) < 8 ? (P.cout - nidx) : 8;
-    const bool full = nvalid == 8;
-    const bool up = P.store_mode == XS_PIXSHUF || P.store_mode == XS_CONVT;
-    int opix[ITER];
-    float rres[ITER][8];
-    float rmul[ITER];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int p = ppass * EP + ep0 + it * PSTEP;
-      int oy, ox; bool ok;
-      if (GEMM) { oy = 0; ox = ox0 + p; ok = ox < P.oh * P.ow; }
-      else { oy = oy0 + (p >> tw_lg); ox = ox0 + (p & tw_mask); ok = oy < P.oh && ox < P.ow; }
-      opix[it] = -1; rmul[it] = 1.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) rres[it][k] = 0.f;
-      if (ok && nvalid > 0) {
-        const int Y = up ? 2 * oy + sy : oy, X = up ? 2 * ox + sx : ox;
-        opix[it] = GEMM ? ox : Y * P.OW + X;
-        if (P.residual) {
-          if (P.res_f32) {
-            const float* rp = reinterpret_cast<const float*>(res_img) + (long long)opix[it] * P.res_ld + ch;
-            if (full) {
-              const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-              rres[it][0] = r0.x; rres[it][1] = r0.y; rres[it][2] = r0.z; rres[it][3] = r0.w;
-              rres[it][4] = r1.x; rres[it][5] = r1.y; rres[it][6] = r1.z; rres[it][7] = r1.w;
-            } else {
-              for (int k = 0; k < nvalid; ++k) rres[it][k] = rp[k];
-            }
-          } else {
-            const unsigned short* rp = reinterpret_cast<const unsigned short*>(res_img) + (long long)opix[it] * P.res_ld + ch;
-            if (full) {
-              const uint4 u = *reinterpret_cast<const uint4*>(rp);
-              rres[it][0] = xbf_lo(u.x); rres[it][1] = xbf_hi(u.x); rres[it][2] = xbf_lo(u.y); rres[it][3] = xbf_hi(u.y);
-              rres[it][4] = xbf_lo(u.z); rres[it][5] = xbf_hi(u.z); rres[it][6] = xbf_lo(u.w); rres[it][7] = xbf_hi(u.w);
-            } else {
-              for (int k = 0; k < nvalid; ++k) rres[it][k] = __uint_as_float((unsigned)rp[k] << 16);
-            }
-          }
-        }
-        if (P.pixmul) rmul[it] = mul_img[opix[it]];
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      compute(chunk);
+      XSEG(2);
+      // The image needed next (chunk 1 of this tile / chunk 0 of the next) was issued a whole phase ago; after the barrier
+      // everybody is done with this chunk's buffer, which is refilled at once.  Chunk 1's image is OLDER than the previous
+      // tile's result stores (vmcnt retires in issue order), so that wait leaves `n_st` operations in flight and the stores
+      // drain under this tile's matrix work instead of in front of it; n_st is a lower bound of the stores really issued
+      // (an instruction counts when at least one lane is active), which keeps the wait on the safe side.
+      if (chunk == 0) xwait_vmcnt(n_st); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      XSEG(3);
+      if (more) {
+        if (chunk == 0) enter_tile(ti + 1);
+        issue_a(chunk);
       }
+      XSEG(4);
     }
-    float bv[8];
+    x_epilogue<MT, NT, false>(P, gcur, acc, wave * 64, 0, gcur.tile_in_img * 8 + wave, bias_lds, li, lh);
+    n_st = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bv[k] = (P.bias && k < nvalid) ? P.bias[bidx + k] : 0.f;
-    __syncthreads();                            // main loop / previous pass done with the LDS
+    for (int mt = 0; mt < MT; ++mt) {
+      const int p = wave * 64 + mt * 32 + li;
+      const bool pok = (gcur.oy0 + (p >> 5)) < P.oh && (gcur.ox0 + (p & 31)) < P.ow;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col0 = wn * WNT + nt * 32;
-      if (col0 / EW != cpass) continue;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int prow0 = wm * PM + mt * 32;
-        if (prow0 / EP != ppass) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          E[(prow0 - ppass * EP + row) * EPIX + (col0 - cpass * EW) + li] = acc[mt][nt][r];
-        }
-      }
+      for (int k = 0; k < 2 * NT; ++k) n_st += (__ballot(pok && (n0 + 16 * k + 8 * lh) < P.cout) != 0ull) ? 1 : 0;
     }
-    __syncthreads();
-    float gs[8], gq[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { gs[k] = 0.f; gq[k] = 0.f; }
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      if (opix[it] < 0) continue;
-      const float* er = E + (ep0 + it * PSTEP) * EPIX + 8 * ej;
-      const float4 a0 = *reinterpret_cast<const float4*>(er), a1 = *reinterpret_cast<const float4*>(er + 4);
-      float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        v[k] += bv[k];
-        gs[k] += v[k]; gq[k] = fmaf(v[k], v[k], gq[k]);
-        v[k] = apply_act(v[k], P.act);
-        v[k] = (v[k] + rres[it][k]) * rmul[it];
-      }
-      if (out32_img) {
-        float* o32 = out32_img + (long long)opix[it] * P.out32_ld + ch;
-        if (full) {
-          *reinterpret_cast<float4*>(o32) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          for (int k = 0; k < nvalid; ++k) o32[k] = v[k];
-        }
-      }
-      if (P.out_f32) {
-        float* op = reinterpret_cast<float*>(out_img) + (long long)opix[it] * P.out_ld + ch;
-        if (full) {
-          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          for (int k = 0; k < nvalid; ++k) op[k] = v[k];
-        }
-      } else {
-        const uint4 pk = make_uint4(xcvt_pk_bf16(v[0], v[1]), xcvt_pk_bf16(v[2], v[3]), xcvt_pk_bf16(v[4], v[5]), xcvt_pk_bf16(v[6], v[7]));
-        unsigned short* op;
-        if (P.store_mode == XS_KPACK) op = reinterpret_cast<unsigned short*>(out_img) + ((long long)(ch >> 3) * (P.OH * P.OW) + opix[it]) * 8;
-        else op = reinterpret_cast<unsigned short*>(out_img) + (long long)opix[it] * P.out_ld + ch;
-        if (full) {
-          *reinterpret_cast<uint4*>(op) = pk;
-        } else {
-          const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
-          for (int k = 0; k < nvalid; ++k) op[k] = (unsigned short)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xFFFFu));
-        }
-      }
-    }
-    if (P.gn_ws) {
-      // per-(tile, channel) sum / sum of squares of (conv + bias): threads with the same ej hold the same 8 channels
-      __syncthreads();                          // everybody is done reading E
-      float* G = E;                             // [PSTEP rows][EW channels][2]
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { G[((ep0 * EW) + 8 * ej + k) * 2] = gs[k]; G[((ep0 * EW) + 8 * ej + k) * 2 + 1] = gq[k]; }
-      __syncthreads();
-      if (tid < EW * 2) {
-        const int chn = tid >> 1, st = tid & 1;
-        float s = 0.f;
-        for (int r = 0; r < PSTEP; ++r) s += G[((r * EW) + chn) * 2 + st];         // fixed order
-        const int co = n0 + cpass * EW + chn;
-        if (co < P.cout) {
-          float* wsp = P.gn_ws + (((long long)img * P.gn_parts + tile_in_img * NPP + ppass) * P.cout + co) * 2 + st;
-          *wsp = s;
-        }
-      }
-    }
+    XSEG(5);
   }
-  XST(4);
+  XSEG_FLUSH;
 }
 
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false>
@@ -504,7 +789,17 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
       done = true;
     }
   }
-  hipLaunchKernelGGL(kfn, dim3(P.nblocks), dim3(256), lds, st, P);
+  // persistent workgroups: as many as the chip holds at once (two per CU when the LDS footprint allows), each walking
+  // tiles blockIdx.x, +gridDim.x, ...
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(GPEMSR_ELAUNCH, "conv2d_bf16: device query failed");
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int slots = cus * (lds <= 80 * 1024 ? 2 : 1);
+  const int grid = P.nblocks < slots ? P.nblocks : slots;
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, P);
   return check_launch("conv_bf16_kernel");
 }
 
@@ -513,7 +808,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
 using namespace gpemsr;
 
 namespace {
-struct XPlan { int CK, BN, TH, TPS, WM, WN; bool tr, gemm; size_t lds; };
+struct XPlan { int CK, BN, TH, TPS, WM, WN; bool tr, gemm, resident; size_t lds; };
 
 // geometry + tile choice of one launch (shared by the launcher and by gpemsr_conv2d_bf16_gn_parts)
 int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
@@ -548,12 +843,15 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.res_f32 = d->res_f32; P.pixmul = d->pixmul;
   P.out = d->out; P.out_ld = d->out_ld; P.out_f32 = d->out_f32; P.out32 = d->out32; P.out32_ld = d->out32_ld;
   P.gn_ws = d->gn_partials;
+  P.nbias = d->cout;
+  const int bias_bytes = ((d->cout + 7) & ~7) * 4;
   int BN, TH, TPS, WM, WN;
+  L.resident = false;
   const int var = d->variant;                // 0 = default tile choice; > 0: alternatives (A/B tuning, scripts/conv16_microbench.py)
   if (tr) {
     P.kw = 2; P.kk = 4; P.stride = 1; P.pad = 0; P.cout = 4 * d->cout;
     P.oh = d->h; P.ow = d->w; P.OH = 2 * d->h; P.OW = 2 * d->w;
-    P.store_mode = XS_CONVT; P.cq = d->cout; BN = 128; TH = 8; TPS = 2; WM = 4; WN = 1;
+    P.store_mode = XS_CONVT; P.cq = d->cout; BN = 128; TH = 4; TPS = 2; WM = 4; WN = 1;
   } else {
     P.kw = d->ksize; P.kk = d->ksize * d->ksize; P.stride = d->stride; P.pad = d->ksize / 2; P.cout = d->cout;
     P.oh = (d->h + 2 * P.pad - d->ksize) / P.stride + 1; P.ow = (d->w + 2 * P.pad - d->ksize) / P.stride + 1;
@@ -568,9 +866,9 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     }
     else if (d->stride == 2) { TH = 2; WM = 2; WN = 2; TPS = (BN == 128) ? 1 : 3; }
     else if (BN == 128) {
-      if (var == 1) { TH = 4; TPS = 3; WM = 2; WN = 2; }          // 4x32 px, row stages, 2-deep ring
+      if (var == 1) { TH = 8; TPS = 1; WM = 4; WN = 1; }          // 8x32 px, wave = 64 px x 128 couts, tap stages
       else if (var == 2) { TH = 8; TPS = 1; WM = 2; WN = 2; }     // 8x32 px, wave = 128 px x 64 couts
-      else { TH = 8; TPS = 1; WM = 4; WN = 1; }                   // 8x32 px, wave = 64 px x 128 couts, tap stages
+      else { TH = 4; TPS = 3; WM = 2; WN = 2; }                   // 4x32 px, wave = 64 px x 64 couts, row stages
     }
     else { TH = 8; TPS = (var == 1) ? 1 : 3; WM = 4; WN = 1; }
   }
@@ -597,7 +895,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d_bf16: grid too large");
   P.nblocks = (int)nb;
-  P.gn_parts = P.tiles_y * P.tiles_x * (NPIX > 128 ? NPIX / 128 : 1);
+  P.gn_parts = P.tiles_y * P.tiles_x * WM;                   // one row of partial sums per wave row of a tile
   if (d->gn_partials) GP_REQUIRE(P.store_mode == XS_PLAIN && !tr, "conv2d_bf16: gn partial sums need the plain store");
   const int R = CK / 8;
   P.na = cdiv((long long)P.halo_px * R, 256);
@@ -607,21 +905,31 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.b_bytes = TPS * R * BN * 16;
   GP_REQUIRE(P.kk % TPS == 0, "conv2d_bf16: taps per stage must divide the tap count");
   P.spc = P.kk / TPS;
-  // ring depth: as deep as 80 KiB per workgroup (two workgroups per CU) allows, at most spc + 1 (then the next chunk's A image,
-  // issued at the chunk's first stage, is always older than the weights the end-of-stage wait retires) and at most 8
-  const int budget = 80 * 1024;
-  const int n_abuf_conv = nchunk_total > 1 ? 2 : 1;
-  int ring = gemm ? 4 : 8;
-  if (!gemm && ring > P.spc + 1) ring = P.spc + 1;
-  if (ring > nchunk_total * P.spc) ring = nchunk_total * P.spc > 2 ? nchunk_total * P.spc : 2;
-  if (ring < 2) ring = 2;
-  while (ring > 2 && (gemm ? ring * (P.a_bytes + P.b_bytes) : n_abuf_conv * P.a_bytes + ring * P.b_bytes) > budget) --ring;
+  // Ring depth / number of halo images: as deep as 80 KiB per workgroup (two workgroups per CU) allows, at most 4; the
+  // persistent stream looks at most ONE tile ahead, hence ring <= stages per tile and images <= chunks per tile.
+  const int budget = 80 * 1024 - bias_bytes;
+  const int stages = nchunk_total * P.spc;
+  int ring = stages < 4 ? (stages < 2 ? 2 : stages) : 4;
+  int n_abuf = gemm ? (nchunk_total < 4 ? nchunk_total : 4) : (nchunk_total < 2 ? 1 : 2);
+  while (ring > 2 && n_abuf * P.a_bytes + ring * P.b_bytes > budget) --ring;
+  while (gemm && n_abuf > 2 && n_abuf * P.a_bytes + ring * P.b_bytes > budget) --n_abuf;
+  if (stages < 2) ring = 2;                                  // (a second slot that is simply never filled)
   P.ring = ring;
-  P.n_abuf = gemm ? ring : n_abuf_conv;
-  size_t lds = (size_t)P.n_abuf * P.a_bytes + (size_t)ring * P.b_bytes;
-  const size_t epi = (size_t)(NPIX < 128 ? NPIX : 128) * (size_t)((BN < 64 ? BN : 64) + 4) * 4;
-  if (epi > lds) lds = epi;
+  P.n_abuf = n_abuf;
+  size_t lds = (size_t)n_abuf * P.a_bytes + (size_t)ring * P.b_bytes + bias_bytes;
   GP_REQUIRE(lds <= 160 * 1024, "conv2d_bf16: LDS %zu too large", lds);
+  // 64 input channels, 3x3, stride 1, one source: the weights-resident kernel (one 64-cout slab per workgroup)
+  if (!tr && !gemm && d->ksize == 3 && d->stride == 1 && d->nsrc == 1 && d->src[0].c == 64 && d->weight_image_stride == 0 && var != 3 &&
+      bias_bytes <= 8 * 1024) {
+    L.resident = true;
+    P.tiles_n = cdiv(P.cout, 64);
+    P.tiles_x = cdiv(P.ow, 32); P.tiles_y = cdiv(P.oh, 16);
+    const long long ns = (long long)d->n * P.tiles_y * P.tiles_x;
+    GP_REQUIRE(ns < (1ll << 31), "conv2d_bf16: grid too large");
+    P.ns = (int)ns;
+    P.gn_parts = P.tiles_y * P.tiles_x * 8;
+    lds = 73728 + 2 * 39168 + bias_bytes;
+  }
   L.lds = lds;
   return GPEMSR_OK;
 }
@@ -635,16 +943,42 @@ extern "C" int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d) {
   return rc == GPEMSR_OK ? P.gn_parts : rc;
 }
 
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
 extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
   XParams P{}; XPlan L{};
   const int rc = plan_x(d, P, L);
   if (rc != GPEMSR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = L.lds;
+  if (L.resident) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return fail(GPEMSR_ELAUNCH, "conv2d_bf16: cannot raise the dynamic LDS limit");
+      attr = true;
+    }
+    // one workgroup per CU; workgroups of a cout slab split the spatial tiles between them
+    const int cus = device_cus();
+    int gpt = cus / P.tiles_n;
+    if (gpt < 1) gpt = 1;
+    if (gpt > P.ns) gpt = P.ns;
+    P.gpt = gpt;
+    hipLaunchKernelGGL(conv64_resident_kernel, dim3(gpt * P.tiles_n), dim3(512), lds, st, P);
+    return check_launch("conv64_resident_kernel");
+  }
 #define GP_X(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
   (L.CK == 32 ? launch_x<32, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv>(P, lds, st) : launch_x<16, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv>(P, lds, st))
 #define GP_IS(BNv, WMv, WNv, THv, TPSv) (L.BN == BNv && L.WM == WMv && L.WN == WNv && L.TH == THv && L.TPS == TPSv)
-  if (L.tr) return GP_X(128, 4, 1, 8, 2, true, false);
+  if (L.tr) return GP_X(128, 4, 1, 4, 2, true, false);
   if (L.gemm) {
     if (GP_IS(32, 4, 1, 4, 1)) return GP_X(32, 4, 1, 4, 1, false, true);
     if (GP_IS(64, 2, 2, 4, 1)) return GP_X(64, 2, 2, 4, 1, false, true);

@@ -64,6 +64,10 @@ def _pc(wt, b, dev, splits=None, pixel_shuffle=False):
 CASES = [
     # (n, cins, cout, k, stride, h, w, act, residual: 0 none / 1 bf16 / 2 fp32, pixmul, out_f32, variant)
     (2, (64,), 64, 3, 1, 16, 32, 1, 1, False, False, 0),
+    (2, (64,), 64, 3, 1, 16, 32, 1, 1, False, False, 3),          # variant 3: the ring kernel instead of the weights-resident one
+    (3, (64,), 64, 3, 1, 50, 70, 2, 1, True, False, 0),           # several tiles per workgroup, ragged edges
+    (1, (64,), 256, 3, 1, 33, 40, 0, 0, False, False, 0),         # four cout slabs
+    (1, (64,), 32, 3, 1, 20, 33, 1, 2, False, True, 0),           # half-filled slab, fp32 out + fp32 residual
     (1, (64,), 64, 3, 1, 37, 70, 2, 2, True, False, 0),
     (1, (64,), 64, 3, 1, 37, 70, 0, 0, False, True, 1),
     (2, (64, 64), 64, 3, 1, 17, 19, 0, 1, True, False, 0),
@@ -123,6 +127,49 @@ def test_conv2d_bf16(case):
                      force_mfma=True)
     assert got.bf16 == (not out_f32)
     _close(got.nchw(), want, 1e-4 if out_f32 else BF, str(case))
+
+
+STREAM_CASES = [
+    # more tiles than the chip holds workgroups (512): every workgroup streams several tiles, the DMA cursors cross tile
+    # (and image, and cout-tile) boundaries while the previous tile is still being multiplied
+    # (n, cins, cout, k, stride, h, w, transposed)
+    (10, (64, 64), 64, 3, 1, 96, 96, False),        # 2 sources x 2 chunks, ring == 3 stages of a 12-stage tile
+    (6, (32,), 64, 3, 1, 128, 96, False),           # ONE chunk per tile: single halo image, refilled at every tile end
+    (3, (128,), 256, 3, 1, 96, 128, False),         # two cout tiles per pixel tile
+    (12, (64,), 64, 3, 1, 64, 64, True),            # transposed: 4 stages per tile == ring depth
+    (5, (64,), 64, 1, 1, 192, 160, False),          # 1x1: two chunks, two stages per tile
+    (6, (64,), 64, 3, 2, 192, 128, False),          # stride 2
+    (4, (32,), 64, 7, 1, 128, 160, False),          # 7x7, single chunk
+    (40, (64,), 128, 3, 1, 64, 96, False),          # weights-resident kernel: several tiles per workgroup and cout slab
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_conv2d_bf16_streams_many_tiles_per_workgroup(case):
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_convT, pack_convT_bf16
+    n, cins, cout, k, stride, h, w, tr = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _r(_rand(n, cin, h, w, seed=1))
+    b = _rand(cout, seed=3, scale=0.1)
+    if tr:
+        wt = _r(_rand(cin, cout, 3, 3, seed=2, scale=1.0 / np.sqrt(cin * 2.25)))
+        want = F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1)
+        pc = pack_convT(wt, b, dev)
+        pc.wb = pack_convT_bf16(wt, dev)
+    else:
+        wt = _r(_rand(cout, cin, k, k, seed=2, scale=1.0 / np.sqrt(cin * k * k)))
+        want = F.conv2d(x, wt, b, stride, k // 2)
+        pc = _pc(wt, b, dev, cins)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(_act16(x[:, o:o + c], dev))
+        o += c
+    got = ops.conv2d(srcs, pc, 0, stride=stride, precision="bf16", force_mfma=True)
+    _close(got.nchw(), want, BF, str(case))
+    again = ops.conv2d(srcs, pc, 0, stride=stride, precision="bf16", force_mfma=True)
+    assert torch.equal(got.buf, again.buf), "not bit-stable run to run"
 
 
 def test_conv2d_bf16_dual_output_and_gn_partials():
