@@ -30,7 +30,7 @@ def _stale(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(REPO, "include", "gpemsr_hip.h"), os.path.join(CSRC, "common.h")]
+    hdrs = [os.path.join(REPO, "include", "gpemsr_hip.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bf16_common.h")]
     objs, jobs = [], []
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")

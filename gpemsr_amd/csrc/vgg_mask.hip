@@ -1,0 +1,281 @@
+// Fused mask front end of the prior fusion (R:model/GPEMSR.py:385-395):
+//     a = relu1_2(vgg(ref_img x3)),  b = relu1_2(vgg(bilinear_s(LR) x3)),
+//     mask[p] = <a_p, b_p> / (max(|a_p|, 1e-12) max(|b_p|, 1e-12))        per 16x16x64 patch p
+// in ONE kernel: neither the two [n,64,sH,sW] feature maps (1.3 GB each per 5 slices at 1024^2 in fp32; SURVEY section 2.3 says
+// they must never reach HBM) nor the up-sampled LR image are ever materialised.  VGG relu1_2 is 13.7 % of the essential
+// FLOPs of the forward and was 25 % of the bf16 step (stem 1->64 write + conv1_2 read/write + patch reduction read).
+//
+// Structure = conv64_resident_kernel (conv_bf16.hip): a 512-thread workgroup keeps conv1_2's 64x64x3x3 bf16 weights in LDS
+// and walks 16x32-pixel tiles (= one patch row x two patches).  Per tile and per image (prior image, then up-sampled LR):
+//   1. the 20x36 fp32 image window goes to LDS (the LR window is bilinearly resampled on the fly, torch's align_corners=False
+//      rule); zero outside the image = conv1_1's padding;
+//   2. conv1_1 (1 -> 64, the three identical input channels folded into the weights) on the matrix pipe: im2col K = 9 taps as
+//      hi + lo bf16 halves of the fp32 pixel (18 of 32 k slots, so the INPUT keeps fp32 accuracy), D^T = W1 . im2col^T per
+//      32 pixels x 32 couts, + bias, ReLU, -> bf16, written straight into the swizzled A images of conv1_2 (both 32-channel
+//      chunks); halo pixels outside the image are conv1_2's zero padding;
+//   3. conv1_2: 2 chunks x 9 taps x 2 k-steps x 4 MFMAs per wave from LDS only, accumulators D^T (lane = pixel);
+//   4. after both images: relu(acc + bias) products reduced per patch (lanes of a 16-column half, registers, waves) in a fixed
+//      order -> deterministic.
+// No HBM traffic besides the two 1-channel images and 4 bytes per patch.
+#include "bf16_common.h"
+
+namespace gpemsr {
+
+struct VggParams {
+  const float* ref; const float* lr;       // [n][H][W] prior image, [n][h][w] LR slice
+  int n, H, W, h, w;
+  float sh, sw;                              // h / H, w / W as torch computes them
+  const float* w1; const float* b1;          // conv1_1: [64][9] (cin-summed), [64]
+  const unsigned short* w2; const float* b2; // conv1_2: staged bf16 [2][9][4][64][8], [64]
+  float* out;                                // [n][H/16][W/16]
+  int tiles_x, tiles_y, ns;
+};
+
+__device__ __forceinline__ void vsrc_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float s = fmaxf(scale * (dst + 0.5f) - 0.5f, 0.f);            // aten area_pixel_compute_source_index, align_corners=False
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - i0;
+}
+
+__global__ __launch_bounds__(512, 2) void vgg_mask_kernel(VggParams P) {
+  constexpr int HALO_W = 34, HALO_H = 18, HALO_PX = HALO_W * HALO_H;      // conv1_2 input window of a 16x32 tile
+  constexpr int PW = 36, PH = 20;                                        // conv1_1 input window
+  constexpr int A_BYTES = HALO_PX * 64;                                   // one 32-channel chunk image, 64-B pixel rows
+  constexpr int W_BYTES = 2 * 9 * 4 * 64 * 16;
+  constexpr int NW = W_BYTES / 16 / 512;
+  extern __shared__ __attribute__((aligned(16))) char vsm[];
+  char* const w_base = vsm;
+  char* const a_base = vsm + W_BYTES;                                     // chunk 0, chunk 1
+  float* const patch = reinterpret_cast<float*>(vsm + W_BYTES + 2 * A_BYTES);          // [PH][PW]
+  float* const cst = patch + PH * PW;                                     // b1[64], b2[64]
+  float* const red = cst + 128;                                           // [8 waves][2 patches][3]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)vsm + (unsigned)wave * 1024u);
+
+  // ---- once per workgroup: conv1_2 weights -> LDS, biases -> LDS, conv1_1 weights -> MFMA row fragments in registers ----
+  {
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.w2));
+#pragma unroll
+    for (int i = 0; i < NW; ++i) xglds16((unsigned)(tid + i * 512) * 16u, wp, lds0 + i * 8192u);
+  }
+  if (tid < 64) { cst[tid] = P.b1[tid]; cst[64 + tid] = P.b2[tid]; }
+  // W1 fragments: row operand of D^T = W1 . im2col^T.  k slots: 0..8 = taps (for the hi half of the pixel), 9..17 = the same
+  // taps again (lo half), 18..31 = 0.  Lane (li = cout within the 32-row tile ct, lh) holds k = 16 s + 8 lh + j.
+  bf16x8 w1f[2][2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * s + 8 * lh + j;
+        const int tap = k < 9 ? k : k - 9;
+        const float v = k < 18 ? P.w1[(ct * 32 + li) * 9 + tap] : 0.f;
+        w1f[ct][s][j] = (short)(xcvt_pk_bf16(v, 0.f) & 0xFFFFu);
+      }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  int hp0[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) hp0[mt] = (2 * wave + mt) * HALO_W + li;
+  const int b_frag = li * 16 + lh * 1024;
+
+  for (int t = (int)blockIdx.x; t < P.ns; t += (int)gridDim.x) {
+    int q = t;
+    const int tx = q % P.tiles_x; q /= P.tiles_x;
+    const int ty = q % P.tiles_y; q /= P.tiles_y;
+    const int img = q;
+    const int oy0 = ty * 16, ox0 = tx * 32;
+    f32x16 acc[2][2];                 // [pixel tile][cout tile] of the image being convolved
+    unsigned pa[2][2][8];             // relu1_2 features of the prior image, packed bf16 pairs (registers 2k, 2k+1)
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+      // ---- 1. image window -> LDS (zero outside the image) ----
+      for (int e = tid; e < PH * PW; e += 512) {
+        const int py = e / PW, px = e % PW;
+        const int Y = oy0 - 2 + py, X = ox0 - 2 + px;
+        float v = 0.f;
+        if (Y >= 0 && Y < P.H && X >= 0 && X < P.W) {
+          if (which == 0) v = P.ref[((long long)img * P.H + Y) * P.W + X];
+          else {
+            int y0, y1, x0, x1; float ly, lx;
+            vsrc_index(Y, P.sh, P.h, y0, y1, ly);
+            vsrc_index(X, P.sw, P.w, x0, x1, lx);
+            const float* b = P.lr + (long long)img * P.h * P.w;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            v = hy * (hx * b[y0 * P.w + x0] + lx * b[y0 * P.w + x1]) + ly * (hx * b[y1 * P.w + x0] + lx * b[y1 * P.w + x1]);
+          }
+        }
+        patch[e] = v;
+      }
+      __syncthreads();                 // also: everybody is done reading the A images of the previous phase
+      // ---- 2. conv1_1 on the matrix pipe -> A images of conv1_2 ----
+      for (int grp = wave; grp < (HALO_PX + 31) / 32; grp += 8) {
+        const int hp = grp * 32 + li;
+        const int hy = hp / HALO_W, hx = hp % HALO_W;           // halo pixel; its 3x3 window starts at patch (hy, hx)
+        const bool exists = hp < HALO_PX;
+        float pv[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) pv[tp] = exists ? patch[(hy + tp / 3) * PW + hx + tp % 3] : 0.f;
+        unsigned hi[9], lo[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          hi[tp] = xcvt_pk_bf16(pv[tp], 0.f) & 0xFFFFu;
+          lo[tp] = xcvt_pk_bf16(pv[tp] - xbf_lo(hi[tp]), 0.f) & 0xFFFFu;
+        }
+        // column operand: k = 16 s + 8 lh + j  ->  s = 0: lh = 0: hi0..hi7 | lh = 1: hi8, lo0..lo6 ;  s = 1: lh = 0: lo7, lo8, 0.. | lh = 1: 0
+        bf16x8 f0, f1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned v0 = lh == 0 ? hi[j] : (j == 0 ? hi[8] : lo[j - 1]);
+          const unsigned v1 = lh == 0 ? (j == 0 ? lo[7] : (j == 1 ? lo[8] : 0u)) : 0u;
+          f0[j] = (short)v0; f1[j] = (short)v1;
+        }
+        const int Y = oy0 - 1 + hy, X = ox0 - 1 + hx;
+        const bool inside = exists && Y >= 0 && Y < P.H && X >= 0 && X < P.W;        // else: conv1_2's zero padding
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ct][0], f0, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ct][1], f1, d, 0, 0, 0);
+          if (exists) {
+            char* arow = a_base + ct * A_BYTES + hp * 64;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                       // registers 4g..4g+3 = couts 32 ct + 8 g + 4 lh + (0..3)
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = inside ? fmaxf(d[4 * g + j] + cst[ct * 32 + 8 * g + 4 * lh + j], 0.f) : 0.f;
+              *reinterpret_cast<uint2*>(arow + ((g ^ ((hp >> 2) & 3)) * 16) + lh * 8) = make_uint2(xcvt_pk_bf16(v[0], v[1]), xcvt_pk_bf16(v[2], v[3]));
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- 3. conv1_2 from LDS ----
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll 1
+      for (int chunk = 0; chunk < 2; ++chunk) {
+        const char* A = a_base + chunk * A_BYTES;
+        const char* B = w_base + chunk * (9 * 4 * 1024) + b_frag;
+        bf16x8 fa[2][2], fb[2][2];
+        auto load_step = [&](int set, int st) {
+          const int tap = st >> 1, ks = st & 1;
+          const int toff = (tap / 3) * HALO_W + tap % 3;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const int hp = hp0[mt] + toff;
+            fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + hp * 64 + (((2 * ks + lh) ^ ((hp >> 2) & 3)) * 16));
+          }
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) fb[set][nt] = *reinterpret_cast<const bf16x8*>(B + (tap * 4 + 2 * ks) * 1024 + nt * 512);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+          if (st + 1 < 18) load_step((st + 1) & 1, st + 1);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st & 1][nt], fa[st & 1][mt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+      if (which == 0) {                // keep a = relu(conv1_2 + bias) as bf16 (what the layer-by-layer path stores in HBM)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float b0 = cst[64 + nt * 32 + ((2 * k) & 3) + 8 * ((2 * k) >> 2) + 4 * lh];
+              const float b1v = cst[64 + nt * 32 + ((2 * k + 1) & 3) + 8 * ((2 * k + 1) >> 2) + 4 * lh];
+              pa[mt][nt][k] = xcvt_pk_bf16(fmaxf(acc[mt][nt][2 * k] + b0, 0.f), fmaxf(acc[mt][nt][2 * k + 1] + b1v, 0.f));
+            }
+      }
+    }
+    // ---- 4. patch cosine: lane = pixel (column li -> patch li >> 4), registers = couts ----
+    // (pixels beyond the image -- ragged last tile -- carry relu(bias) of zero features: masked out)
+    float dot = 0.f, na = 0.f, nb = 0.f;
+    {
+      const bool colok = ox0 + li < P.W;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float bias = cst[64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const float okf = (colok && oy0 + 2 * wave + mt < P.H) ? 1.f : 0.f;
+            const float a = okf * ((r & 1) ? xbf_hi(pa[mt][nt][r >> 1]) : xbf_lo(pa[mt][nt][r >> 1]));
+            const float b = okf * fmaxf(acc[mt][nt][r] + bias, 0.f);
+            dot = fmaf(a, b, dot); na = fmaf(a, a, na); nb = fmaf(b, b, nb);
+          }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o <= 8; o <<= 1) { dot += __shfl_xor(dot, o); na += __shfl_xor(na, o); nb += __shfl_xor(nb, o); }
+    dot += __shfl_xor(dot, 32); na += __shfl_xor(na, 32); nb += __shfl_xor(nb, 32);
+    if (lane == 0 || lane == 16) {
+      float* rp = red + (wave * 2 + (lane >> 4)) * 3;
+      rp[0] = dot; rp[1] = na; rp[2] = nb;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      float d = 0.f, x = 0.f, y = 0.f;
+      for (int wv = 0; wv < 8; ++wv) { d += red[(wv * 2 + tid) * 3]; x += red[(wv * 2 + tid) * 3 + 1]; y += red[(wv * 2 + tid) * 3 + 2]; }
+      const int pxx = tx * 2 + tid;
+      if (pxx < P.W / 16)
+        P.out[((long long)img * (P.H / 16) + ty) * (P.W / 16) + pxx] = d / (fmaxf(sqrtf(x), 1e-12f) * fmaxf(sqrtf(y), 1e-12f));   // F.normalize eps
+    }
+    // (the next tile's first __syncthreads orders the reuse of `red`, `patch` and the A images)
+  }
+}
+
+}  // namespace gpemsr
+
+using namespace gpemsr;
+
+extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n, int h, int w, int scale, const float* w1, const float* b1,
+                                    const void* w2_bf16, const float* b2, float* out, void* stream) {
+  GP_REQUIRE(ref_img && lr && w1 && b1 && w2_bf16 && b2 && out && n > 0 && h > 0 && w > 0 && scale > 0, "vgg_mask_bf16: bad args");
+  const int H = h * scale, W = w * scale;
+  GP_REQUIRE(H % 16 == 0 && W % 16 == 0, "vgg_mask_bf16: the HR size must be a multiple of 16 (the reflect 'same' padding of "
+             "model/GPEMSR.py:14-30 is not implemented; the forward asserts LR sizes that never need it)");
+  GP_REQUIRE((reinterpret_cast<uintptr_t>(w2_bf16) & 15) == 0, "vgg_mask_bf16: weight alignment");
+  VggParams P{};
+  P.ref = ref_img; P.lr = lr; P.n = n; P.H = H; P.W = W; P.h = h; P.w = w;
+  P.sh = (float)((double)h / (double)H); P.sw = (float)((double)w / (double)W);
+  P.w1 = w1; P.b1 = b1; P.w2 = reinterpret_cast<const unsigned short*>(w2_bf16); P.b2 = b2; P.out = out;
+  P.tiles_x = cdiv(W, 32); P.tiles_y = H / 16;
+  const long long ns = (long long)n * P.tiles_x * P.tiles_y;
+  GP_REQUIRE(ns < (1ll << 31), "vgg_mask_bf16: grid too large");
+  P.ns = (int)ns;
+  const size_t lds = 73728 + 2 * (18 * 34 * 64) + (20 * 36 + 128 + 48) * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return fail(GPEMSR_ELAUNCH, "vgg_mask_bf16: cannot raise the dynamic LDS limit");
+    attr = true;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int grid = P.ns < cus ? P.ns : cus;
+  hipLaunchKernelGGL(vgg_mask_kernel, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), P);
+  return check_launch("vgg_mask_kernel");
+}

@@ -64,6 +64,7 @@ class Engine:
         #       pipe with operands converted in LDS (split hi+lo = fp32-grade, or plain bf16 operands).
         self.precision = precision
         self.bf16 = precision == "bf16"
+        self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.split = precision in ("bf16x3", "bf16op")
         self._forced_flow = None
         self.o = ops            # operator namespace; the training engine swaps in a recording proxy (gpemsr_amd/train.py)
@@ -114,6 +115,8 @@ class Engine:
         for k in changed:
             self.sd[k] = live[k].detach()
             bases.add(k.rsplit(".", 1)[0])
+        if any(b.startswith("vgg.slice1.0") for b in bases):
+            self.par.pop("vgg.w1", None); self.par.pop("vgg.b1", None)
         for b in bases:
             for nm in [n for n in self.pc if n == b or n.startswith(b + "@")]:
                 del self.pc[nm]                               # incl. lazily packed variants (model.vgg's "@rgb" entry)
@@ -373,6 +376,15 @@ class Engine:
             self.o.copy_channels(o, out.images(i0, m))
         return out
 
+    def vgg_mask_fused(self, ref_img: Act, xf: Act) -> Act:
+        """The same from the LR slices themselves, in one kernel (bf16 path): no up-sampled image, no feature maps in HBM."""
+        if "vgg.w1" not in self.par:
+            w = self.sd["vgg.slice1.0.weight"].detach().to(torch.float32)
+            self.par["vgg.w1"] = w.sum(dim=1).reshape(w.shape[0], 9).contiguous().to(self.dev)      # 3 identical input channels
+            self.par["vgg.b1"] = self.sd["vgg.slice1.0.bias"].detach().to(torch.float32).contiguous().to(self.dev)
+        pc2 = self.pc["vgg.slice1.2"]
+        return self.o.vgg_mask_bf16(ref_img, xf, self.scale, self.par["vgg.w1"], self.par["vgg.b1"], pc2.wb, pc2.b)
+
     # ------------------------------------------------------------------ per-frame front half
     def front(self, xf: Act, forced_idx, trace) -> Dict[str, Act]:
         s, H, W = self.scale, xf.h, xf.w
@@ -384,9 +396,12 @@ class Engine:
         Lr3 = self.conv(Lr2, "reffea_L3_conv1", ACT_LRELU)
         Lr4 = self.conv(Lr3, "reffea_L4_conv1", ACT_LRELU) if s == 16 else None
         ref_x16, ref_x8, ref_x4, ref_x2, ref_img = self.ref_extract(xf, forced_idx, trace)
-        up_lr = self.o.bilinear(xf, s * H, s * W)
-        mask = self.vgg_mask(ref_img, up_lr)
-        del up_lr
+        if self.bf16 and (s * H) % 16 == 0 and (s * W) % 16 == 0 and self.fuse_vgg:
+            mask = self.vgg_mask_fused(ref_img, xf)
+        else:
+            up_lr = self.o.bilinear(xf, s * H, s * W)
+            mask = self.vgg_mask(ref_img, up_lr)
+            del up_lr
         if trace is not None:
             trace.setdefault("mask_cos", []).append(mask.nchw())
         mask = self.conv(mask, "refmaskconv1", ACT_LRELU)

@@ -880,3 +880,22 @@ def spynet_prep_bf16(ref: Act, supp: Act, flow_coarse: Optional[Act], mean3, std
     _abi.check(_abi.load().gpemsr_spynet_prep_bf16(ref.ptr, supp.ptr, flow_coarse.ptr if flow_coarse is not None else None,
                                                    ref.n, ref.h, ref.w, m, s, up.ptr, inp.ptr, _stream()), "spynet_prep_bf16")
     return up, inp
+
+
+def vgg_mask_bf16(ref_img: Act, lr: Act, scale: int, w1: torch.Tensor, b1: torch.Tensor, w2b: torch.Tensor, b2: torch.Tensor, tag: str = "vgg_mask") -> Act:
+    """model/GPEMSR.py:385-395 fused: VGG relu1_2 of the prior image and of the bilinearly up-sampled LR slice + 16x16 patch
+    cosine -> [n, sH/16, sW/16, 1] fp32; no feature map in HBM."""
+    assert not ref_img.bf16 and not lr.bf16 and ref_img.c == 1 and lr.c == 1 and ref_img.ld == 1 and lr.ld == 1
+    n, h, w = lr.n, lr.h, lr.w
+    assert (ref_img.n, ref_img.h, ref_img.w) == (n, h * scale, w * scale)
+    out = new_act(n, h * scale // 16, w * scale // 16, 1, device=lr.buf.device)
+
+    def _go():
+        _abi.check(_abi.load().gpemsr_vgg_mask_bf16(ref_img.ptr, lr.ptr, n, h, w, scale, w1.data_ptr(), b1.data_ptr(), w2b.data_ptr(), b2.data_ptr(),
+                                                    out.ptr, _stream()), "vgg_mask_bf16")
+    flops = 2.0 * 2 * n * (h * scale) * (w * scale) * 64 * (64 * 9 + 9)          # both images: conv1_2 + conv1_1
+    if PROFILER is not None:
+        PROFILER.run("vgg_mask", tag, flops, _go)
+    else:
+        _go()
+    return out

@@ -184,6 +184,14 @@ int gpemsr_threeda_combine_bf16(const void* feat, const void* attn, const void* 
                                 int64_t count, void* out, void* stream);
 int gpemsr_copy_channels_bf16(const void* src, int src_ld, void* dst, int dst_ld, int64_t pixels, int c, void* stream);
 int gpemsr_copy_channels_f32_bf16(const float* src, int src_ld, void* dst, int dst_ld, int64_t pixels, int c, void* stream);
+/* Fused mask front end (model/GPEMSR.py:385-395): VGG19 relu1_2 of the prior image `ref_img` [n][s*h][s*w] and of the bilinearly
+ * up-sampled (align_corners=False) LR slice `lr` [n][h][w], both fp32 1-channel images (the reference expands them to 3 identical
+ * channels; w1 = conv1_1 weights summed over the input channels, [64][9], tap = 3*ky + kx), and the cosine similarity of their
+ * co-located 16x16x64 patches -> out [n][s*h/16][s*w/16].  conv1_1 runs with fp32-accurate inputs (hi + lo bf16 halves), conv1_2
+ * with bf16 operands (w2_bf16 = vgg.slice1.2 in the staged order of gpemsr_conv2d_bf16), fp32 accumulation and reduction.
+ * Neither feature map nor the up-sampled image touches HBM. */
+int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n, int h, int w, int scale, const float* w1, const float* b1,
+                         const void* w2_bf16, const float* b2, float* out, void* stream);
 /* gpemsr_conv2d_stem1 with bf16 output (cout % 8 == 0); gpemsr_conv2d_direct with fp32 or bf16 input / output (fp32 packed
  * weights as for gpemsr_conv2d_direct; the 64 -> 1 3x3 form takes an fp32 residual) */
 int gpemsr_conv2d_stem1_bf16(const float* x, int n, int h, int w, const float* weight, const float* bias, int cout, int act,

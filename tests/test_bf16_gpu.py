@@ -377,3 +377,32 @@ def test_spynet_prep_bf16_matches_fp32_kernel():
     up32, in32 = ops.spynet_prep(A(ref), A(sup), A(fc), mean, std, pad16=True)
     _close(up16.nchw(), up32.nchw(), 0.0, "up flow")
     _close(in16.nchw(), in32.nchw(), BF, "level input")
+
+
+@pytest.mark.parametrize("n,h,w,scale", [(2, 16, 24, 8), (1, 32, 32, 8), (3, 8, 12, 16), (1, 10, 6, 8)])
+def test_vgg_mask_fused_matches_the_layered_form(n, h, w, scale):
+    """gpemsr_vgg_mask_bf16 (conv1_1 -> conv1_2 -> 16x16 patch cosine in one kernel, R:model/GPEMSR.py:385-395) against torch:
+    relu1_2 of the image expanded to 3 identical channels, F.interpolate for the LR slice, unfold + normalize + sum."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv_bf16
+    dev = _dev()
+    H, W = h * scale, w * scale
+    g = torch.Generator().manual_seed(7)
+    ref = torch.rand(n, 1, H, W, generator=g)
+    lr = torch.rand(n, 1, h, w, generator=g)
+    w1 = _rand(64, 3, 3, 3, seed=8, scale=0.4); b1 = _rand(64, seed=9, scale=0.2)
+    w2 = _r(_rand(64, 64, 3, 3, seed=10, scale=1.0 / 24)); b2 = _rand(64, seed=11, scale=0.1)
+    w1s = _r(w1.sum(dim=1, keepdim=True))                                   # the kernel folds the 3 channels and rounds W1 to bf16
+
+    def relu1_2(img):
+        f = _r(F.relu(F.conv2d(img, w1s, b1, 1, 1)))                        # conv1_2's input is bf16 in the kernel
+        return F.relu(F.conv2d(f, w2, b2, 1, 1))
+    fa = relu1_2(ref)
+    fb = relu1_2(F.interpolate(lr, scale_factor=scale, mode="bilinear", align_corners=False))
+    ua, ub = F.unfold(fa, 16, stride=16), F.unfold(fb, 16, stride=16)
+    want = (F.normalize(ua, dim=1) * F.normalize(ub, dim=1)).sum(1).view(n, 1, H // 16, W // 16)
+    A = lambda t: ops.Act(t.reshape(-1).to(dev), t.shape[0], t.shape[2], t.shape[3], 1, 1, 0)   # noqa: E731
+    got = ops.vgg_mask_bf16(A(ref), A(lr), scale, w1.sum(dim=1).reshape(64, 9).contiguous().to(dev), b1.to(dev), pack_conv_bf16(w2, dev), b2.to(dev))
+    _close(got.nchw(), want, 2e-3, "fused vgg mask")
+    again = ops.vgg_mask_bf16(A(ref), A(lr), scale, w1.sum(dim=1).reshape(64, 9).contiguous().to(dev), b1.to(dev), pack_conv_bf16(w2, dev), b2.to(dev))
+    assert torch.equal(got.buf, again.buf)
