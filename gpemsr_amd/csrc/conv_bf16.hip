@@ -48,7 +48,7 @@ __device__ unsigned long long g_xstamps[8 * 65536];
 #define XSEG_FLUSH
 #endif
 
-constexpr int XA_LOADS = 6;       // 16-B A slots per thread (halo_px * R / 256)
+constexpr int XA_LOADS = 7;       // 16-B A slots per thread (halo_px * R / threads; 7x7 big tile: 7)
 constexpr int XB_LOADS = 7;       // 16-B B slots per thread per stage (TPS * R * BN / 256; 7x7 row stage of 64 couts: 7)
 
 enum { XS_PLAIN = 0, XS_PIXSHUF = 1, XS_CONVT = 2, XS_KPACK = 3 };
@@ -202,6 +202,9 @@ __device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x
           }
         }
       }
+      // keep the accumulator tiles' epilogues sequential: hoisting the loads of later tiles costs more registers than a wave
+      // with 128 accumulator registers has (the stores are fire-and-forget, the loads are few)
+      asm volatile("" ::: "memory");
     }
   }
   if (P.gn_ws) {
@@ -264,7 +267,8 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
 // consecutive output channels of one pixel: the epilogue stores 16-byte pieces straight from registers -- no LDS staging,
 // no barrier, each wave on its own.
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM>
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
+  constexpr int NTH = WM * WN * 64;    // 256 threads: two workgroups per CU; 512 threads ("big tile" forms): one
   constexpr int KW = GEMM ? 1 : (CONVT ? 2 : (TPS == 7 ? 7 : 3));
   constexpr int S = (!GEMM && !CONVT && TH == 2) ? 2 : 1;
   constexpr int KK = KW * KW;
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
   constexpr int HALO_W = GEMM ? NPIX : 31 * S + KW;
   constexpr int HALO_H = GEMM ? 1 : (TH - 1) * S + KW;
   constexpr int HALO_PX = HALO_W * HALO_H;
-  constexpr int NA = (HALO_PX * R + 255) / 256;       // A slots (16 B) per thread
-  constexpr int NB = (TPS * R * BN + 255) / 256;      // B slots per thread per stage
+  constexpr int NA = (HALO_PX * R + NTH - 1) / NTH;   // A slots (16 B) per thread
+  constexpr int NB = (TPS * R * BN + NTH - 1) / NTH;  // B slots per thread per stage
   constexpr int A_BYTES = HALO_PX * R * 16;
   constexpr int B_BYTES = TPS * R * BN * 16;
   static_assert(NA <= XA_LOADS && NB <= XB_LOADS, "tile too large");
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
   char* const a_base = xsm;
   char* const b_base = xsm + n_abuf * A_BYTES;
   float* const bias_lds = reinterpret_cast<float*>(b_base + RING * B_BYTES);
-  x_stage_bias(P, bias_lds, P.nbias, 256);            // (published by the prologue barrier)
+  x_stage_bias(P, bias_lds, P.nbias, NTH);            // (published by the prologue barrier)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -318,13 +322,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
   // ---- slot geometry (recomputed where needed: registers are better spent on accumulators) ----
   // A slot i of this thread = 16-B piece e = tid + 256 i of the halo image: halo pixel hp = e / R holds, at physical piece
   // e % R, the logical piece (e % R) ^ swizzle(hp).  B slot i = piece e of the stage image [tap][piece][BN][8].
-  auto a_slot_exists = [&](int i) -> bool { return tid + i * 256 < HALO_PX * R; };
-  auto a_slot_piece = [&](int i) -> unsigned { const int e = tid + i * 256, hp = e / R; return (unsigned)((e % R) ^ ((hp >> SWZ_SH) & SWZ_MK)); };
+  auto a_slot_exists = [&](int i) -> bool { return tid + i * NTH < HALO_PX * R; };
+  auto a_slot_piece = [&](int i) -> unsigned { const int e = tid + i * NTH, hp = e / R; return (unsigned)((e % R) ^ ((hp >> SWZ_SH) & SWZ_MK)); };
   // DMA instructions per image THIS WAVE issues for the weights (rows past cout are clamped, not masked: they only feed
   // accumulator rows that are never stored) -- wave-uniform and constant
   int nb_w = 0;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) nb_w += (i * 256 + wave * 64 < TPS * R * BN) ? 1 : 0;
+  for (int i = 0; i < NB; ++i) nb_w += (i * NTH + wave * 64 < TPS * R * BN) ? 1 : 0;
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)xsm + (unsigned)wave * 1024u);
 
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
     for (int i = 0; i < NA; ++i) {
       int pix = -1;
       if (a_slot_exists(i)) {
-        const int hp = (tid + i * 256) / R;
+        const int hp = (tid + i * NTH) / R;
         if (GEMM) { const int pp = g.ox0 + hp; if (pp < hw_in) pix = pp; }
         else {
           const int iy = iy0 + hp / HALO_W, ix = ix0 + hp % HALO_W;
@@ -399,60 +403,102 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
   };
   int a_next = 0, a_ti = 0, a_chunk = 0, a_src = 0, a_c0 = 0;           // next chunk image to issue: stream index, tile, position
   int b_next = 0, b_ti = 0, b_chunk = 0, b_grp = 0;                      // next weight stage to issue
-  auto issue_a = [&]() {
+  int a_dst = 0, b_dst = 0;                                              // their destinations: a_next % n_abuf, b_next % RING
+  // Issue of one image = begin (operands), one DMA instruction per slot, end (book-keeping).  In the main loop the slot
+  // instructions are spread over the MFMA steps of the NEXT stage instead of being fired in one burst after the barrier:
+  // an LDS-DMA instruction holds the issuing wave for 100-200 cycles while the CU's address path accepts it (in-kernel
+  // stamps: a third of a wide layer's time was spent in that burst, with the matrix pipe idle), so it must go between MFMAs.
+  const unsigned short* ia_sp = nullptr; unsigned ia_pixb = 0, ia_la = 0; int ia_cs = 0;
+  auto issue_a_begin = [&]() {
     if (a_cross) { a_enter_tile(nxt); a_cross = false; }
     const unsigned short* sp = nullptr; unsigned pixb = 0; int cs = 0;
 #pragma unroll
     for (int s = 0; s < GPEMSR_MAX_SRC; ++s)
       if (s == a_src) { sp = srcp[s] + (long long)a_img * src_istride[s] + a_c0; pixb = src_pixb[s]; cs = src_c[s]; }
-    const unsigned la = xuni(lds0 + (unsigned)((a_next % n_abuf) * A_BYTES));
-    sp = reinterpret_cast<const unsigned short*>(xuni_ptr(sp));
-    pixb = xuni(pixb);
+    ia_la = xuni(lds0 + (unsigned)(a_dst * A_BYTES));
+    ia_sp = reinterpret_cast<const unsigned short*>(xuni_ptr(sp));
+    ia_pixb = xuni(pixb); ia_cs = cs;
     if (a_pad && a_chunk < n_abuf) {                    // padding slots of this tile: zero once per LDS image
-      char* ab = a_base + (a_next % n_abuf) * A_BYTES;
+      char* ab = a_base + a_dst * A_BYTES;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        if (a_slot_exists(i) && a_pix[i] < 0) *reinterpret_cast<float4*>(ab + (tid + i * 256) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_slot_exists(i) && a_pix[i] < 0) *reinterpret_cast<float4*>(ab + (tid + i * NTH) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (a_pix[i] >= 0)
-        xglds16((unsigned)a_pix[i] * pixb + 16u * a_slot_piece(i), sp, la + i * 4096u);
+  };
+  auto issue_a_slot = [&](int i) {
+    if (a_pix[i] >= 0) xglds16((unsigned)a_pix[i] * ia_pixb + 16u * a_slot_piece(i), ia_sp, ia_la + i * (NTH * 16u));
+  };
+  auto issue_a_end = [&]() {
     issued_total += na_w;
     set4(markA, a_next, issued_total);
+    if (++a_dst == n_abuf) a_dst = 0;
     ++a_next; a_c0 += CK;
-    if (a_c0 >= cs) { a_c0 = 0; ++a_src; }
+    if (a_c0 >= ia_cs) { a_c0 = 0; ++a_src; }
     if (++a_chunk == nchunks) { a_chunk = 0; a_src = 0; a_c0 = 0; ++a_ti; a_cross = true; }
   };
-  auto issue_b = [&]() {
+  auto issue_a = [&]() {
+    issue_a_begin();
+#pragma unroll
+    for (int i = 0; i < NA; ++i) issue_a_slot(i);
+    issue_a_end();
+  };
+  const unsigned short* ib_wp = nullptr; unsigned ib_lb = 0;
+  auto issue_b_begin = [&]() {
     if (b_cross) { b_img = nxt.img; b_n0 = nxt.n0; b_cross = false; }
     const unsigned short* wp = P.weight + (long long)b_img * P.w_img_stride + ((long long)b_chunk * KK + b_grp * TPS) * (R * 8) * P.cout;
-    wp = reinterpret_cast<const unsigned short*>(xuni_ptr(wp));
-    const unsigned lb = xuni(lds0 + (unsigned)(n_abuf * A_BYTES + (b_next % RING) * B_BYTES));
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int e = tid + i * 256;
-      if (e < TPS * R * BN) {
-        int row = b_n0 + e % BN;
-        row = row < P.cout ? row : P.cout - 1;
-        xglds16((unsigned)((e / BN) * P.cout + row) * 16u, wp, lb + i * 4096u);
-      }
+    ib_wp = reinterpret_cast<const unsigned short*>(xuni_ptr(wp));
+    ib_lb = xuni(lds0 + (unsigned)(n_abuf * A_BYTES + b_dst * B_BYTES));
+  };
+  auto issue_b_slot = [&](int i) {
+    const int e = tid + i * NTH;
+    if (e < TPS * R * BN) {
+      int row = b_n0 + e % BN;
+      row = row < P.cout ? row : P.cout - 1;
+      xglds16((unsigned)((e / BN) * P.cout + row) * 16u, ib_wp, ib_lb + i * (NTH * 16u));
     }
+  };
+  auto issue_b_end = [&]() {
     issued_total += nb_w;
     set4(markB, b_next, issued_total);
+    if (++b_dst == RING) b_dst = 0;
     ++b_next;
     if (++b_grp == SPC) {
       b_grp = 0;
       if (++b_chunk == nchunks) { b_chunk = 0; ++b_ti; b_cross = true; }
     }
   };
+  auto issue_b = [&]() {
+    issue_b_begin();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) issue_b_slot(i);
+    issue_b_end();
+  };
 
   // ---- fragment addressing ----
+  // PMC of the first versions: 8 VALU + 10 SALU instructions per MFMA, nearly all of it fragment address arithmetic redone for
+  // every read -- the vector ALU was as busy as the matrix pipe.  The byte offsets are tile-invariant, so they are formed
+  // ONCE: for filters up to 3x3 a table a_off[mt][tap] (k-step 0; k-step s > 0 flips piece bits: offset ^ (32 s)); the 7x7
+  // filter (49 taps) keeps one filter row (= one stage) of offsets, rebuilt per stage.  Taps are compile-time (the stage loop
+  // is unrolled over a chunk's stages), weight fragment offsets are immediates on one per-stage base.
   int hp0[MT];                       // halo pixel of this lane's A row at tap (0,0)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
     hp0[mt] = GEMM ? p : ((p >> 5) * S) * HALO_W + (p & 31) * S;
+  }
+  auto a_offset2 = [&](int mt, int ky, int kx) -> int {     // byte offset of k-step 0 of tap (ky,kx) inside a halo image
+    const int hp = hp0[mt] + ky * HALO_W + kx;
+    return hp * ROWB + ((lh ^ ((hp >> SWZ_SH) & SWZ_MK)) * 16);
+  };
+  auto a_offset = [&](int mt, int tap) -> int { return GEMM ? a_offset2(mt, 0, 0) : a_offset2(mt, tap / KW, tap % KW); };
+  constexpr bool TABLE = KK <= 9;
+  constexpr int NTAB = TABLE ? KK : TPS;
+  int a_off[MT][NTAB];
+  if (TABLE) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int tap = 0; tap < NTAB; ++tap) a_off[mt][tap] = a_offset(mt, tap);
   }
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
 
@@ -473,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
   XSEG(1);
 
   int gs = 0, gc = 0;               // stream position: stage, chunk
+  int a_slot = 0, b_slot = 0;       // LDS image / ring slot of the current chunk / stage (gc % n_abuf, gs % RING)
   for (int ti = 0; ti < T_me; ++ti) {
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -482,26 +529,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    int grp = 0;
-    for (int s = 0; s < G; ++s, ++gs) {
-      const char* A = a_base + (gc % n_abuf) * A_BYTES;
-      const char* B = b_base + (gs % RING) * B_BYTES + b_frag;
+    auto stage = [&](const int grp) {                  // grp is a compile-time constant in the unrolled (TABLE) form
+      const char* A = a_base + a_slot * A_BYTES;
+      const char* B = b_base + b_slot * B_BYTES + b_frag;
       const int tap0 = grp * TPS;
       bf16x8 fa[2][MT], fb[2][NT];
+      if (!TABLE) {                                    // 7x7: a stage is filter row ky = grp
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int tt = 0; tt < TPS; ++tt) a_off[mt][tt] = a_offset2(mt, grp, tt);
+      }
       auto tap_mask = [&](int tap) -> unsigned {       // CONVT: N tiles (phases q = 2py+px) fed by tap (dy,dx) = (tap>>1, tap&1)
         if (!CONVT) return 0xFu;
         return (tap >> 1) ? ((tap & 1) ? 0x8u : 0xCu) : ((tap & 1) ? 0xAu : 0xFu);
       };
       auto load_step = [&](int set, int tt, int ks) {
-        const int tap = tap0 + tt;
-        const int ky = GEMM ? 0 : tap / KW, kx = GEMM ? 0 : tap - ky * KW;
-        const int toff = ky * HALO_W + kx;
-        const unsigned mask = tap_mask(tap);
+        const unsigned mask = tap_mask(tap0 + tt);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const int hp = hp0[mt] + toff;
-          const int pp = (2 * ks + lh) ^ ((hp >> SWZ_SH) & SWZ_MK);
-          fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + hp * ROWB + pp * 16);
+          const int o = a_off[mt][TABLE ? tap0 + tt : tt];
+          fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + (ks ? (o ^ (32 * ks)) : o));
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -529,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
 
       // ---- end of the stage ----
       XSEG(2);
-      const bool chunk_end = (grp == SPC - 1);
+      const bool chunk_end = (grp == SPC - 1);         // compile-time after unrolling
       if (gs + 1 < TS) {      // the next stage's weights (and, at a chunk boundary, the next chunk's halo image) must have landed
         int need = get4(markB, gs + 1);
         if (chunk_end && n_abuf >= 2) { const int ma = get4(markA, gc + 1); need = ma > need ? ma : need; }
@@ -539,20 +587,34 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(XParams P) {
       __builtin_amdgcn_s_barrier();        // every wave is done with this stage's ring slot (and, at a chunk end, with the A image)
       asm volatile("" ::: "memory");
       XSEG(3);
-      // the freed slot / image are refilled at once: weights of stage gs + RING, halo image of chunk gc + n_abuf
+      // the freed slot / image are refilled at once: weights of stage gs + RING, halo image of chunk gc + n_abuf.  (Spreading
+      // these DMA instructions over the next stage's MFMA steps was tried and lost 2-10 %: a DMA instruction stalls the wave
+      // in front of its own MFMAs.)
       if (b_next < TS) issue_b();
+      if (++b_slot == RING) b_slot = 0;
       if (chunk_end) {
-        if (a_next < TC) issue_a();
+        if (n_abuf >= 2 && a_next < TC) issue_a();
         ++gc;
-        if (n_abuf < 2 && gc < TC) {       // single A image: the refill could only start now -- wait for it before the next stage
+        if (++a_slot == n_abuf) a_slot = 0;
+        if (n_abuf < 2 && gc < TC) {       // single A image: needed by the very next stage -- issue now and wait for it
+          issue_a();
           xwait_vmcnt(issued_total - get4(markA, a_next - 1));
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
         }
       }
-      if (++grp == SPC) grp = 0;
       XSEG(4);
+      ++gs;
+    };
+    for (int cc = 0; cc < nchunks; ++cc) {
+      if (TABLE) {
+#pragma unroll
+        for (int grp = 0; grp < SPC; ++grp) stage(grp);      // unrolled: taps, tap masks, table indices are compile-time
+      } else {
+#pragma unroll 1
+        for (int grp = 0; grp < SPC; ++grp) stage(grp);
+      }
     }
 
     // both DMA cursors have crossed into the next tile by now: advance the tile window
@@ -637,27 +699,43 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
     a_pad = __ballot(pad) != 0ull;
   };
   const unsigned pixb = (unsigned)P.ld[0] * 2u;
-  auto issue_a = [&](int chunk) {       // halo image of `chunk` of the tile described by g / a_pix -> buffer `chunk`
-    const unsigned short* sp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.src[0] + (long long)g.img * P.img_stride[0] + chunk * 32));
-    const unsigned la = lds0 + (unsigned)(W_BYTES + chunk * A_BYTES);
+  // halo image of `chunk` of the tile described by g / a_pix -> buffer `chunk`: begin (operands, padding), one DMA instruction
+  // per slot (spread over the MFMA steps of the following phase: an LDS-DMA instruction holds the wave for 100-200 cycles)
+  const unsigned short* ia_sp = nullptr; unsigned ia_la = 0;
+  auto issue_a_begin = [&](int chunk) {
+    ia_sp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.src[0] + (long long)g.img * P.img_stride[0] + chunk * 32));
+    ia_la = xuni(lds0 + (unsigned)(W_BYTES + chunk * A_BYTES));
     if (a_pad) {
       char* ab = a_base + chunk * A_BYTES;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         if (tid + i * 512 < HALO_PX * R && a_pix[i] < 0) *reinterpret_cast<float4*>(ab + (tid + i * 512) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto issue_a_slot = [&](int i) {
+    if (a_pix[i] >= 0) {
+      const int e = tid + i * 512, hp = e / R;
+      const unsigned q = (unsigned)((e % R) ^ ((hp >> 2) & 3));
+      xglds16((unsigned)a_pix[i] * pixb + 16u * q, ia_sp, ia_la + i * 8192u);
+    }
+  };
+  auto issue_a = [&](int chunk) {
+    issue_a_begin(chunk);
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (a_pix[i] >= 0) {
-        const int e = tid + i * 512, hp = e / R;
-        const unsigned q = (unsigned)((e % R) ^ ((hp >> 2) & 3));
-        xglds16((unsigned)a_pix[i] * pixb + 16u * q, sp, la + i * 8192u);
-      }
+    for (int i = 0; i < NA; ++i) issue_a_slot(i);
   };
 
-  int hp0[MT];
+  // Fragment byte offsets are tile-invariant: computed ONCE (PMC of the first version: 8 VALU + 4 SALU instructions per MFMA,
+  // most of them this address arithmetic -- the vector ALU was as busy as the matrix pipe).  aoff[mt][tap] = k-step 0 of
+  // tap (ky,kx) for pixel row mt; k-step 1 is the same address with bit 5 flipped (piece ^ 2).
+  int aoff[MT][9];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) hp0[mt] = (2 * wave + mt) * HALO_W + li;
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hp = (2 * wave + mt) * HALO_W + li + (tap / 3) * HALO_W + tap % 3;
+      aoff[mt][tap] = hp * 64 + ((lh ^ ((hp >> 2) & 3)) * 16);
+    }
   const int b_frag = li * 16 + lh * 1024;
 
   XSEG_DECL;
@@ -680,19 +758,14 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     const XGeo gcur = g;
-    auto compute = [&](int chunk) {
+    auto compute = [&](int chunk, bool pend) {       // pend: the halo image begun by issue_a_begin goes out between the MFMAs
       const char* A = a_base + chunk * A_BYTES;
       const char* B = w_base + chunk * (9 * 4 * 1024) + b_frag;
       bf16x8 fa[2][MT], fb[2][NT];
       auto load_step = [&](int set, int st) {
         const int tap = st >> 1, ks = st & 1;
-        const int toff = (tap / 3) * HALO_W + tap % 3;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int hp = hp0[mt] + toff;
-          const int pp = (2 * ks + lh) ^ ((hp >> 2) & 3);
-          fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + hp * 64 + pp * 16);
-        }
+        for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + (ks ? (aoff[mt][tap] ^ 32) : aoff[mt][tap]));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const bf16x8*>(B + (tap * 4 + 2 * ks) * 1024 + nt * 512);
       };
@@ -708,9 +781,11 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
       }
     };
     const bool more = ti + 1 < T_me;
+    bool pend = false;
 #pragma unroll 1
     for (int chunk = 0; chunk < 2; ++chunk) {
-      compute(chunk);
+      compute(chunk, pend);
+      pend = false;
       XSEG(2);
       // The image needed next (chunk 1 of this tile / chunk 0 of the next) was issued a whole phase ago; after the barrier
       // everybody is done with this chunk's buffer, which is refilled at once.  Chunk 1's image is OLDER than the previous
@@ -723,6 +798,7 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
       asm volatile("" ::: "memory");
       XSEG(3);
       if (more) {
+        // buffer 0 is refilled between the MFMAs of this tile's second phase; buffer 1 at once (the epilogue follows)
         if (chunk == 0) enter_tile(ti + 1);
         issue_a(chunk);
       }
@@ -761,9 +837,10 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(GPEMSR_ELAUNCH, "conv2d_bf16: device query failed");
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int slots = cus * (lds <= 80 * 1024 ? 2 : 1);
+  constexpr int NTH = WM * WN * 64;
+  const int slots = cus * ((NTH == 256 && lds <= 80 * 1024) ? 2 : 1);
   const int grid = P.nblocks < slots ? P.nblocks : slots;
-  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, P);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTH), lds, st, P);
   return check_launch("conv_bf16_kernel");
 }
 
@@ -824,15 +901,22 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     BN = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
     if (gemm) { TH = 4; TPS = 1; WM = BN == 32 ? 4 : 2; WN = BN == 32 ? 1 : 2; }
     else if (d->ksize == 7) {
-      // single-chunk layers (cin <= 32) keep ONE A image and a 2-deep ring of 7-tap row stages; wider inputs use 32-cout blocks
-      TH = 4; TPS = 7;
-      if (nchunk_total > 1 || BN == 32) { BN = 32; WM = 4; WN = 1; } else { BN = 64; WM = 2; WN = 2; }
+      if (var == 1) {
+        // 256-thread form: single-chunk layers (cin <= 32) keep ONE A image and a 2-deep ring of 7-tap row stages; wider inputs
+        // use 32-cout blocks
+        TH = 4; TPS = 7;
+        if (nchunk_total > 1 || BN == 32) { BN = 32; WM = 4; WN = 1; } else { BN = 64; WM = 2; WN = 2; }
+      } else {
+        // big tile: 16x32 pixels, 8 waves (one workgroup per CU): the 49-tap weights are staged once per 512 pixels
+        TH = 16; TPS = 7; WM = 8; WN = 1;
+        if (BN == 128) BN = 64;
+      }
     }
     else if (d->stride == 2) { TH = 2; WM = 2; WN = 2; TPS = (BN == 128) ? 1 : 3; }
     else if (BN == 128) {
       if (var == 1) { TH = 8; TPS = 1; WM = 4; WN = 1; }          // 8x32 px, wave = 64 px x 128 couts, tap stages
-      else if (var == 2) { TH = 8; TPS = 1; WM = 2; WN = 2; }     // 8x32 px, wave = 128 px x 64 couts
-      else { TH = 4; TPS = 3; WM = 2; WN = 2; }                   // 4x32 px, wave = 64 px x 64 couts, row stages
+      else if (var == 2) { TH = 4; TPS = 3; WM = 2; WN = 2; }     // 4x32 px x 128 couts, 256 threads, row stages
+      else { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; }          // big tile: 16x32 px x 64 couts, 8 waves, row stages
     }
     else { TH = 8; TPS = (var == 1) ? 1 : 3; WM = 4; WN = 1; }
   }
@@ -862,8 +946,9 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.gn_parts = P.tiles_y * P.tiles_x * WM;                   // one row of partial sums per wave row of a tile
   if (d->gn_partials) GP_REQUIRE(P.store_mode == XS_PLAIN && !tr, "conv2d_bf16: gn partial sums need the plain store");
   const int R = CK / 8;
-  P.na = cdiv((long long)P.halo_px * R, 256);
-  P.nb = cdiv((long long)TPS * R * BN, 256);
+  const int nth = WM * WN * 64;
+  P.na = cdiv((long long)P.halo_px * R, nth);
+  P.nb = cdiv((long long)TPS * R * BN, nth);
   GP_REQUIRE(P.na <= XA_LOADS && P.nb <= XB_LOADS, "conv2d_bf16: tile too large (na=%d nb=%d)", P.na, P.nb);
   P.a_bytes = P.halo_px * R * 16;                          // lanes past the image are masked: no padding to whole DMA pieces
   P.b_bytes = TPS * R * BN * 16;
@@ -871,7 +956,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.spc = P.kk / TPS;
   // Ring depth / number of halo images: as deep as 80 KiB per workgroup (two workgroups per CU) allows, at most 4; the
   // persistent stream looks at most ONE tile ahead, hence ring <= stages per tile and images <= chunks per tile.
-  const int budget = 80 * 1024 - bias_bytes;
+  const int budget = (nth == 512 ? 158 : 80) * 1024 - bias_bytes;      // 512 threads: one workgroup per CU
   const int stages = nchunk_total * P.spc;
   int ring = stages < 4 ? (stages < 2 ? 2 : stages) : 4;
   int n_abuf = gemm ? (nchunk_total < 4 ? nchunk_total : 4) : (nchunk_total < 2 ? 1 : 2);
@@ -948,6 +1033,9 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (GP_IS(64, 2, 2, 4, 1)) return GP_X(64, 2, 2, 4, 1, false, true);
     return GP_X(128, 2, 2, 4, 1, false, true);
   }
+  if (GP_IS(64, 8, 1, 16, 3)) return GP_X(64, 8, 1, 16, 3, false, false);
+  if (GP_IS(64, 8, 1, 16, 7)) return GP_X(64, 8, 1, 16, 7, false, false);
+  if (GP_IS(32, 8, 1, 16, 7)) return GP_X(32, 8, 1, 16, 7, false, false);
   if (GP_IS(32, 4, 1, 4, 7)) return GP_X(32, 4, 1, 4, 7, false, false);
   if (GP_IS(64, 2, 2, 4, 7)) return GP_X(64, 2, 2, 4, 7, false, false);
   if (GP_IS(64, 2, 2, 2, 3)) return GP_X(64, 2, 2, 2, 3, false, false);
@@ -957,7 +1045,6 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
   if (GP_IS(64, 4, 1, 8, 3)) return GP_X(64, 4, 1, 8, 3, false, false);
   if (GP_IS(64, 4, 1, 8, 1)) return GP_X(64, 4, 1, 8, 1, false, false);
   if (GP_IS(128, 2, 2, 4, 3)) return GP_X(128, 2, 2, 4, 3, false, false);
-  if (GP_IS(128, 2, 2, 8, 1)) return GP_X(128, 2, 2, 8, 1, false, false);
   if (GP_IS(128, 4, 1, 8, 1)) return GP_X(128, 4, 1, 8, 1, false, false);
   return fail(GPEMSR_EUNSUPPORTED, "conv2d_bf16: no kernel for BN=%d WM=%d WN=%d TH=%d TPS=%d", L.BN, L.WM, L.WN, L.TH, L.TPS);
 #undef GP_X

@@ -81,9 +81,15 @@ __global__ __launch_bounds__(512, 2) void vgg_mask_kernel(VggParams P) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  int hp0[2];
+  // tile-invariant fragment offsets, formed once (see conv64_resident_kernel): k-step 1 = offset ^ 32
+  int aoff[2][9];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) hp0[mt] = (2 * wave + mt) * HALO_W + li;
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hp = (2 * wave + mt) * HALO_W + li + (tap / 3) * HALO_W + tap % 3;
+      aoff[mt][tap] = hp * 64 + ((lh ^ ((hp >> 2) & 3)) * 16);
+    }
   const int b_frag = li * 16 + lh * 1024;
 
   for (int t = (int)blockIdx.x; t < P.ns; t += (int)gridDim.x) {
@@ -173,12 +179,8 @@ __global__ __launch_bounds__(512, 2) void vgg_mask_kernel(VggParams P) {
         bf16x8 fa[2][2], fb[2][2];
         auto load_step = [&](int set, int st) {
           const int tap = st >> 1, ks = st & 1;
-          const int toff = (tap / 3) * HALO_W + tap % 3;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const int hp = hp0[mt] + toff;
-            fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + hp * 64 + (((2 * ks + lh) ^ ((hp >> 2) & 3)) * 16));
-          }
+          for (int mt = 0; mt < 2; ++mt) fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + (ks ? (aoff[mt][tap] ^ 32) : aoff[mt][tap]));
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) fb[set][nt] = *reinterpret_cast<const bf16x8*>(B + (tap * 4 + 2 * ks) * 1024 + nt * 512);
         };
