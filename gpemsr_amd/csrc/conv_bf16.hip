@@ -48,7 +48,7 @@ __device__ unsigned long long g_xstamps[8 * 65536];
 #define XSEG_FLUSH
 #endif
 
-constexpr int XA_LOADS = 7;       // 16-B A slots per thread (halo_px * R / threads; 7x7 big tile: 7)
+constexpr int XA_LOADS = 10;      // 16-B A slots per DMA thread (halo_px * R / DMA threads; 16x32 tile on 4 loader waves: 10)
 constexpr int XB_LOADS = 7;       // 16-B B slots per thread per stage (TPS * R * BN / 256; 7x7 row stage of 64 couts: 7)
 
 enum { XS_PLAIN = 0, XS_PIXSHUF = 1, XS_CONVT = 2, XS_KPACK = 3 };
@@ -266,9 +266,19 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
 // the register axis, pixels on the lanes), so after bias / activation a pair of v_permlane32_swap gives every lane 8
 // consecutive output channels of one pixel: the epilogue stores 16-byte pieces straight from registers -- no LDS staging,
 // no barrier, each wave on its own.
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
-  constexpr int NTH = WM * WN * 64;    // 256 threads: two workgroups per CU; 512 threads ("big tile" forms): one
+//
+// NL > 0: WAVE SPECIALISATION.  In-kernel stamps of the 8-wave big tile on a 256 -> 256 layer: 26 % of a tile in the MFMA
+// stages, 30 % issuing refill DMA (the CU's global -> LDS path takes ~25-30 B/clk, so a 1-KiB instruction holds its wave for
+// hundreds of cycles), 30 % waiting + barrier -- serialised, because every wave did every job and all waves are in the same
+// phase.  With NL loader waves beside the WM x WN multiplying waves the DMA issue stalls and the counted waits sit on waves
+// that have nothing else to do: per stage the multiplying waves run  MFMAs -> barrier , the loader waves  wait for stage
+// s + 1 -> barrier -> refill the slot the barrier freed , and both meet at the one barrier per stage.
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0>
+__global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) void conv_bf16_kernel(XParams P) {
+  constexpr int NC = WM * WN;          // multiplying waves
+  constexpr bool SPEC = NL > 0;
+  constexpr int NTH = (NC + NL) * 64;  // 256 threads: two workgroups per CU; 512 threads ("big tile" forms): one
+  constexpr int DTH = SPEC ? NL * 64 : NTH;   // threads that issue DMA
   constexpr int KW = GEMM ? 1 : (CONVT ? 2 : (TPS == 7 ? 7 : 3));
   constexpr int S = (!GEMM && !CONVT && TH == 2) ? 2 : 1;
   constexpr int KK = KW * KW;
@@ -286,8 +296,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
   constexpr int HALO_W = GEMM ? NPIX : 31 * S + KW;
   constexpr int HALO_H = GEMM ? 1 : (TH - 1) * S + KW;
   constexpr int HALO_PX = HALO_W * HALO_H;
-  constexpr int NA = (HALO_PX * R + NTH - 1) / NTH;   // A slots (16 B) per thread
-  constexpr int NB = (TPS * R * BN + NTH - 1) / NTH;  // B slots per thread per stage
+  constexpr int NA = (HALO_PX * R + DTH - 1) / DTH;   // A slots (16 B) per DMA thread
+  constexpr int NB = (TPS * R * BN + DTH - 1) / DTH;  // B slots per DMA thread per stage
   constexpr int A_BYTES = HALO_PX * R * 16;
   constexpr int B_BYTES = TPS * R * BN * 16;
   static_assert(NA <= XA_LOADS && NB <= XB_LOADS, "tile too large");
@@ -302,6 +312,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
   x_stage_bias(P, bias_lds, P.nbias, NTH);            // (published by the prologue barrier)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = !SPEC || wave >= NC, is_mul = !SPEC || wave < NC;     // wave-uniform roles
+  const int dtid = SPEC ? tid - NC * 64 : tid, dwave = SPEC ? wave - NC : wave;  // DMA thread / wave index (loaders)
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   const int hw_in = P.h * P.w;
@@ -322,15 +334,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
   // ---- slot geometry (recomputed where needed: registers are better spent on accumulators) ----
   // A slot i of this thread = 16-B piece e = tid + 256 i of the halo image: halo pixel hp = e / R holds, at physical piece
   // e % R, the logical piece (e % R) ^ swizzle(hp).  B slot i = piece e of the stage image [tap][piece][BN][8].
-  auto a_slot_exists = [&](int i) -> bool { return tid + i * NTH < HALO_PX * R; };
-  auto a_slot_piece = [&](int i) -> unsigned { const int e = tid + i * NTH, hp = e / R; return (unsigned)((e % R) ^ ((hp >> SWZ_SH) & SWZ_MK)); };
+  auto a_slot_exists = [&](int i) -> bool { return dtid + i * DTH < HALO_PX * R; };
+  auto a_slot_piece = [&](int i) -> unsigned { const int e = dtid + i * DTH, hp = e / R; return (unsigned)((e % R) ^ ((hp >> SWZ_SH) & SWZ_MK)); };
   // DMA instructions per image THIS WAVE issues for the weights (rows past cout are clamped, not masked: they only feed
   // accumulator rows that are never stored) -- wave-uniform and constant
   int nb_w = 0;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) nb_w += (i * NTH + wave * 64 < TPS * R * BN) ? 1 : 0;
+  for (int i = 0; i < NB; ++i) nb_w += (i * DTH + dwave * 64 < TPS * R * BN) ? 1 : 0;
 
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)xsm + (unsigned)wave * 1024u);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)xsm + (unsigned)dwave * 1024u);
 
   // ---- tiles of this workgroup ----
   const int ntiles = P.nblocks;                        // total tiles of the launch; gridDim.x <= ntiles
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
     for (int i = 0; i < NA; ++i) {
       int pix = -1;
       if (a_slot_exists(i)) {
-        const int hp = (tid + i * NTH) / R;
+        const int hp = (dtid + i * DTH) / R;
         if (GEMM) { const int pp = g.ox0 + hp; if (pp < hw_in) pix = pp; }
         else {
           const int iy = iy0 + hp / HALO_W, ix = ix0 + hp % HALO_W;
@@ -422,11 +434,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
       char* ab = a_base + a_dst * A_BYTES;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        if (a_slot_exists(i) && a_pix[i] < 0) *reinterpret_cast<float4*>(ab + (tid + i * NTH) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_slot_exists(i) && a_pix[i] < 0) *reinterpret_cast<float4*>(ab + (dtid + i * DTH) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto issue_a_slot = [&](int i) {
-    if (a_pix[i] >= 0) xglds16((unsigned)a_pix[i] * ia_pixb + 16u * a_slot_piece(i), ia_sp, ia_la + i * (NTH * 16u));
+    if (a_pix[i] >= 0) xglds16((unsigned)a_pix[i] * ia_pixb + 16u * a_slot_piece(i), ia_sp, ia_la + i * (DTH * 16u));
   };
   auto issue_a_end = [&]() {
     issued_total += na_w;
@@ -450,11 +462,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
     ib_lb = xuni(lds0 + (unsigned)(n_abuf * A_BYTES + b_dst * B_BYTES));
   };
   auto issue_b_slot = [&](int i) {
-    const int e = tid + i * NTH;
+    const int e = dtid + i * DTH;
     if (e < TPS * R * BN) {
       int row = b_n0 + e % BN;
       row = row < P.cout ? row : P.cout - 1;
-      xglds16((unsigned)((e / BN) * P.cout + row) * 16u, ib_wp, ib_lb + i * (NTH * 16u));
+      xglds16((unsigned)((e / BN) * P.cout + row) * 16u, ib_wp, ib_lb + i * (DTH * 16u));
     }
   };
   auto issue_b_end = [&]() {
@@ -490,26 +502,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
     const int hp = hp0[mt] + ky * HALO_W + kx;
     return hp * ROWB + ((lh ^ ((hp >> SWZ_SH) & SWZ_MK)) * 16);
   };
-  auto a_offset = [&](int mt, int tap) -> int { return GEMM ? a_offset2(mt, 0, 0) : a_offset2(mt, tap / KW, tap % KW); };
+  // A wave's 32-pixel tiles are consecutive tile rows, so tap (ky, kx) of tile mt reads halo row  mt * S + ky : the table holds
+  // one entry per (halo row, kx) -- (MT - 1) S + KW rows instead of MT * KW.
   constexpr bool TABLE = KK <= 9;
-  constexpr int NTAB = TABLE ? KK : TPS;
-  int a_off[MT][NTAB];
+  constexpr int AR = !TABLE || GEMM ? MT : (MT - 1) * S + KW, AC = !TABLE ? TPS : (GEMM ? 1 : KW);
+  int a_off[AR][AC];
   if (TABLE) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int rr = 0; rr < AR; ++rr)
 #pragma unroll
-      for (int tap = 0; tap < NTAB; ++tap) a_off[mt][tap] = a_offset(mt, tap);
+      for (int kx = 0; kx < AC; ++kx) a_off[rr][kx] = GEMM ? a_offset2(rr, 0, 0) : a_offset2(0, rr, kx);
   }
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
 
   // ---- prologue: tile 0 (and 1) geometry, A(0) [A(1)], B(0 .. RING-1) ----
-  a_enter_tile(cur);
-  issue_a();
-  issue_b();
-  for (int j = 1; j < n_abuf && a_next < TC; ++j) issue_a();
-  for (int j = 1; j < RING && b_next < TS; ++j) issue_b();
+  if (is_loader) {
+    a_enter_tile(cur);
+    issue_a();
+    issue_b();
+    for (int j = 1; j < n_abuf && a_next < TC; ++j) issue_a();
+    for (int j = 1; j < RING && b_next < TS; ++j) issue_b();
+  }
   XSEG(0);
-  {
+  if (is_loader) {
     const int ma = get4(markA, 0), mb = get4(markB, 0);
     xwait_vmcnt(issued_total - (ma > mb ? ma : mb));
   }
@@ -520,6 +535,54 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
 
   int gs = 0, gc = 0;               // stream position: stage, chunk
   int a_slot = 0, b_slot = 0;       // LDS image / ring slot of the current chunk / stage (gc % n_abuf, gs % RING)
+
+  // ---- end of a stage: DMA == true on the waves that load (all of them without specialisation) ----
+  auto stage_end = [&](const bool chunk_end, const bool DMA) {
+    if (DMA && gs + 1 < TS) {      // the next stage's weights (and, at a chunk boundary, the next chunk's halo image) must have landed
+      int need = get4(markB, gs + 1);
+      if (chunk_end && n_abuf >= 2) { const int ma = get4(markA, gc + 1); need = ma > need ? ma : need; }
+      xwait_vmcnt(issued_total - need);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // every wave is done with this stage's ring slot (and, at a chunk end, with the A image)
+    asm volatile("" ::: "memory");
+    XSEG(3);
+    // the freed slot / image are refilled at once: weights of stage gs + RING, halo image of chunk gc + n_abuf.  (Spreading
+    // these DMA instructions over the next stage's MFMA steps was tried and lost 2-10 %: a DMA instruction stalls the wave
+    // in front of its own MFMAs -- hence the loader waves of the specialised form.)
+    if (DMA && b_next < TS) issue_b();
+    if (++b_slot == RING) b_slot = 0;
+    if (chunk_end) {
+      if (DMA && n_abuf >= 2 && a_next < TC) issue_a();
+      ++gc;
+      if (++a_slot == n_abuf) a_slot = 0;
+      if (n_abuf < 2 && gc < TC) {       // single A image: needed by the very next stage -- issue now and wait for it
+        if (DMA) {
+          issue_a();
+          xwait_vmcnt(issued_total - get4(markA, a_next - 1));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    XSEG(4);
+    ++gs;
+  };
+
+  if (SPEC && !is_mul) {
+    // ---- loader waves: the same stage / barrier sequence, no arithmetic ----
+    for (int ti = 0; ti < T_me; ++ti) {
+      for (int cc = 0; cc < nchunks; ++cc) {
+#pragma unroll 1
+        for (int grp = 0; grp < SPC; ++grp) stage_end(grp == SPC - 1, true);
+      }
+      cur = nxt;
+      if (ti + 2 < T_me) nxt = tile_geo(ti + 2);
+    }
+    return;
+  }
+
   for (int ti = 0; ti < T_me; ++ti) {
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -530,7 +593,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     auto stage = [&](const int grp) {                  // grp is a compile-time constant in the unrolled (TABLE) form
-      const char* A = a_base + a_slot * A_BYTES;
+      // TABLE: a_off already points into the current halo image (moved once per chunk, below) -- adding the image base per
+      // read gave the compiler 2 x 18 more loop invariants to keep (and spill) on the 168-register budget of the 12-wave form
+      const char* A = TABLE ? a_base : a_base + a_slot * A_BYTES;
       const char* B = b_base + b_slot * B_BYTES + b_frag;
       const int tap0 = grp * TPS;
       bf16x8 fa[2][MT], fb[2][NT];
@@ -548,7 +613,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
         const unsigned mask = tap_mask(tap0 + tt);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const int o = a_off[mt][TABLE ? tap0 + tt : tt];
+          const int tap = tap0 + tt;
+          const int o = !TABLE ? a_off[mt][tt] : (GEMM ? a_off[mt][0] : a_off[mt * S + tap / KW][tap % KW]);
           fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + (ks ? (o ^ (32 * ks)) : o));
         }
 #pragma unroll
@@ -574,38 +640,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_bf16_kernel(XParams P) {
         if (st + 1 < NSTEP) load_step((st + 1) & 1, (st + 1) / KS, (st + 1) % KS);
         mma_step(st & 1, st / KS);
       }
-
-      // ---- end of the stage ----
       XSEG(2);
-      const bool chunk_end = (grp == SPC - 1);         // compile-time after unrolling
-      if (gs + 1 < TS) {      // the next stage's weights (and, at a chunk boundary, the next chunk's halo image) must have landed
-        int need = get4(markB, gs + 1);
-        if (chunk_end && n_abuf >= 2) { const int ma = get4(markA, gc + 1); need = ma > need ? ma : need; }
-        xwait_vmcnt(issued_total - need);
+      const int a_before = a_slot;
+      stage_end(grp == SPC - 1, !SPEC);               // (compile-time after unrolling)
+      if (TABLE && grp == SPC - 1 && a_slot != a_before) {
+        const int delta = (a_slot - a_before) * A_BYTES;
+#pragma unroll
+        for (int rr = 0; rr < AR; ++rr)
+#pragma unroll
+          for (int kx = 0; kx < AC; ++kx) a_off[rr][kx] += delta;
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();        // every wave is done with this stage's ring slot (and, at a chunk end, with the A image)
-      asm volatile("" ::: "memory");
-      XSEG(3);
-      // the freed slot / image are refilled at once: weights of stage gs + RING, halo image of chunk gc + n_abuf.  (Spreading
-      // these DMA instructions over the next stage's MFMA steps was tried and lost 2-10 %: a DMA instruction stalls the wave
-      // in front of its own MFMAs.)
-      if (b_next < TS) issue_b();
-      if (++b_slot == RING) b_slot = 0;
-      if (chunk_end) {
-        if (n_abuf >= 2 && a_next < TC) issue_a();
-        ++gc;
-        if (++a_slot == n_abuf) a_slot = 0;
-        if (n_abuf < 2 && gc < TC) {       // single A image: needed by the very next stage -- issue now and wait for it
-          issue_a();
-          xwait_vmcnt(issued_total - get4(markA, a_next - 1));
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-        }
-      }
-      XSEG(4);
-      ++gs;
     };
     for (int cc = 0; cc < nchunks; ++cc) {
       if (TABLE) {
@@ -818,9 +862,9 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
   XSEG_FLUSH;
 }
 
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false>
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0>
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM>;
+  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -837,7 +881,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(GPEMSR_ELAUNCH, "conv2d_bf16: device query failed");
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  constexpr int NTH = WM * WN * 64;
+  constexpr int NTH = (WM * WN + NL) * 64;
   const int slots = cus * ((NTH == 256 && lds <= 80 * 1024) ? 2 : 1);
   const int grid = P.nblocks < slots ? P.nblocks : slots;
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTH), lds, st, P);
@@ -849,7 +893,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
 using namespace gpemsr;
 
 namespace {
-struct XPlan { int CK, BN, TH, TPS, WM, WN; bool tr, gemm, resident; size_t lds; };
+struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident; size_t lds; };
 
 // geometry + tile choice of one launch (shared by the launcher and by gpemsr_conv2d_bf16_gn_parts)
 int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
@@ -886,7 +930,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.gn_ws = d->gn_partials;
   P.nbias = d->cout;
   const int bias_bytes = ((d->cout + 7) & ~7) * 4;
-  int BN, TH, TPS, WM, WN;
+  int BN, TH, TPS, WM, WN, NL = 0;
   L.resident = false;
   const int var = d->variant;                // 0 = default tile choice; > 0: alternatives (A/B tuning, scripts/conv16_microbench.py)
   if (tr) {
@@ -916,11 +960,12 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     else if (BN == 128) {
       if (var == 1) { TH = 8; TPS = 1; WM = 4; WN = 1; }          // 8x32 px, wave = 64 px x 128 couts, tap stages
       else if (var == 2) { TH = 4; TPS = 3; WM = 2; WN = 2; }     // 4x32 px x 128 couts, 256 threads, row stages
-      else { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; }          // big tile: 16x32 px x 64 couts, 8 waves, row stages
+      else if (var == 4) { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; }   // big tile, 8 waves that all load and multiply
+      else { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; NL = 4; }  // big tile: 16x32 px x 64 couts, 8 multiplying + 4 loader waves
     }
     else { TH = 8; TPS = (var == 1) ? 1 : 3; WM = 4; WN = 1; }
   }
-  L.BN = BN; L.TH = TH; L.TPS = TPS; L.WM = WM; L.WN = WN;
+  L.BN = BN; L.TH = TH; L.TPS = TPS; L.WM = WM; L.WN = WN; L.NL = NL;
   GP_REQUIRE(!(P.store_mode == XS_PIXSHUF) || P.cq % 8 == 0, "conv2d_bf16: pixel_shuffle needs cout%%32==0");
   // 16-byte vector accesses are used by threads that own 8 valid channels; with cout < 8 every access is scalar
   const bool vec = d->cout >= 8;
@@ -946,9 +991,10 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.gn_parts = P.tiles_y * P.tiles_x * WM;                   // one row of partial sums per wave row of a tile
   if (d->gn_partials) GP_REQUIRE(P.store_mode == XS_PLAIN && !tr, "conv2d_bf16: gn partial sums need the plain store");
   const int R = CK / 8;
-  const int nth = WM * WN * 64;
-  P.na = cdiv((long long)P.halo_px * R, nth);
-  P.nb = cdiv((long long)TPS * R * BN, nth);
+  const int nth = (WM * WN + NL) * 64;
+  const int dth = NL ? NL * 64 : nth;                       // threads that issue DMA
+  P.na = cdiv((long long)P.halo_px * R, dth);
+  P.nb = cdiv((long long)TPS * R * BN, dth);
   GP_REQUIRE(P.na <= XA_LOADS && P.nb <= XB_LOADS, "conv2d_bf16: tile too large (na=%d nb=%d)", P.na, P.nb);
   P.a_bytes = P.halo_px * R * 16;                          // lanes past the image are masked: no padding to whole DMA pieces
   P.b_bytes = TPS * R * BN * 16;
@@ -1033,6 +1079,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (GP_IS(64, 2, 2, 4, 1)) return GP_X(64, 2, 2, 4, 1, false, true);
     return GP_X(128, 2, 2, 4, 1, false, true);
   }
+  if (GP_IS(64, 8, 1, 16, 3) && L.NL == 4)
+    return L.CK == 32 ? launch_x<32, 64, 8, 1, 16, 3, false, false, 4>(P, lds, st) : launch_x<16, 64, 8, 1, 16, 3, false, false, 4>(P, lds, st);
   if (GP_IS(64, 8, 1, 16, 3)) return GP_X(64, 8, 1, 16, 3, false, false);
   if (GP_IS(64, 8, 1, 16, 7)) return GP_X(64, 8, 1, 16, 7, false, false);
   if (GP_IS(32, 8, 1, 16, 7)) return GP_X(32, 8, 1, 16, 7, false, false);

@@ -28,7 +28,7 @@ import torch
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
 from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear,
-                      pack_vgg_first)
+                      pack_vgg_first, pack_cout1_taps, pack_upconv_out)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -115,6 +115,8 @@ class Engine:
         for k in changed:
             self.sd[k] = live[k].detach()
             bases.add(k.rsplit(".", 1)[0])
+        if any(b.startswith("refmodel.decoder.") for b in bases):
+            self.par.pop("@upout.frag", None); self.par.pop("@upout.consts", None)
         if any(b.startswith("vgg.slice1.0") for b in bases):
             self.par.pop("vgg.w1", None); self.par.pop("vgg.b1", None)
         for b in bases:
@@ -174,6 +176,8 @@ class Engine:
                 self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             if self.bf16 and all(c % 16 == 0 for c in self.pc[name].splits):
                 self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
+            if self.bf16 and tuple(w.shape) == (1, 64, 3, 3):
+                self.pc[name].wtap = pack_cout1_taps(w, dev)            # 64 -> 1 on the matrix cores (csrc/tap_sum.hip)
         elif w.dim() == 2 and name.endswith("indexer.embedding"):
             self.pc[name] = pack_linear(w, b, dev)
         elif w.dim() == 2 and name.endswith("codebook.embedding"):
@@ -355,11 +359,23 @@ class Engine:
         feats = []
         x = self.vq_layer(x, f"{p}.feat_extract.0")
         nrb = self.dec_nrb
-        for i in range(n_fe - 1):
+        # bf16: the last up-block (64 -> 64) and the output layer (64 -> 1) have nothing in between and the 64-channel tensor at
+        # the full resolution has no other reader: they run as one composed operator (csrc/tap_sum.hip)
+        last = f"{p}.feat_extract.{n_fe - 1}.upblock"
+        fuse_tail = (self.bf16 and n_fe >= 2 and last in self.pc and tuple(self.sd[last + ".weight"].shape) == (64, 64, 3, 3)
+                     and tuple(self.sd[p + ".output_layer.weight"].shape) == (1, 64, 3, 3) and (n_fe - 2 - nrb + 1) % (nrb + 1) != 0)
+        for i in range(n_fe - 1 - int(fuse_tail)):
             x = self.vq_layer(x, f"{p}.feat_extract.{i + 1}")
             if (i - nrb + 1) % (nrb + 1) == 0:
                 feats.append(x)
-        feats.append(self.conv(x, p + ".output_layer"))
+        if fuse_tail:
+            if "@upout.frag" not in self.par:
+                self.par["@upout.frag"], self.par["@upout.consts"] = pack_upconv_out(
+                    self.sd[last + ".weight"], self.sd.get(last + ".bias"), self.sd[p + ".output_layer.weight"],
+                    self.sd.get(p + ".output_layer.bias"), self.dev)
+            feats.append(self.o.upconv_out_bf16(x, self.par["@upout.frag"], self.par["@upout.consts"], tag=last + "+output_layer"))
+        else:
+            feats.append(self.conv(x, p + ".output_layer"))
         return feats
 
     # ------------------------------------------------------------------ mask

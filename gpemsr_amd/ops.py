@@ -175,6 +175,7 @@ class PackedConv:
     pixel_shuffle: bool = False
     w16: Optional[torch.Tensor] = None     # split-bf16 weights [2][tap][cout][cin] (packing.pack_conv_split), optional
     wb: Optional[torch.Tensor] = None      # bf16 data path: staged-order weights (packing.pack_conv_bf16 / pack_convT_bf16)
+    wtap: Optional[torch.Tensor] = None    # bf16 data path, 64 -> 1 3x3: tap fragments (packing.pack_cout1_taps)
 
     @property
     def cin(self) -> int:
@@ -763,6 +764,18 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
             out = new_act(n, OH, OW, oc, device=dev, bf16=not o32)
         assert (out.n, out.h, out.w, out.c) == (n, OH, OW, oc) and out.bf16 == (not o32)
 
+        def _go_taps():
+            _abi.check(lib.gpemsr_conv_c64_cout1_bf16(s0.ptr, n, h, w, s0.ld, pc.wtap.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
+                                                      act, residual.ptr if residual is not None else None,
+                                                      residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()),
+                       "conv_c64_cout1_bf16")
+        if pc.wtap is not None and s0.bf16 and pc.cin == 64 and pc.cout == 1 and k == 3 and stride == 1:
+            if PROFILER is not None:
+                PROFILER.run("tap_sum", tag, flops, _go_taps)
+            else:
+                _go_taps()
+            return out
+
         def _go_direct():
             _abi.check(lib.gpemsr_conv2d_direct_bf16(s0.ptr, int(not s0.bf16), n, h, w, s0.ld, s0.c, pc.w.data_ptr(),
                                                      pc.b.data_ptr() if pc.b is not None else None, pc.cout, k, stride, act,
@@ -824,6 +837,26 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
     else:
         _go()
     return ret
+
+
+def upconv_out_bf16(x: Act, frag: torch.Tensor, consts: torch.Tensor, out: Optional[Act] = None, tag: str = "") -> Act:
+    """ConvTranspose2d(64 -> 64, k3 s2 p1 op1) + Conv2d(64 -> 1, 3x3) as one operator (csrc/tap_sum.hip; packing.pack_upconv_out):
+    bf16 x [n][h][w][64] -> fp32 image [n][2h][2w]."""
+    _require_gpu(x)
+    assert x.bf16 and x.c == 64
+    if out is None:
+        out = new_act(x.n, 2 * x.h, 2 * x.w, 1, device=x.buf.device)
+    assert not out.bf16 and (out.n, out.h, out.w, out.c) == (x.n, 2 * x.h, 2 * x.w, 1)
+
+    def _go():
+        _abi.check(_abi.load().gpemsr_upconv_out_c64_bf16(x.ptr, x.n, x.h, x.w, x.ld, frag.data_ptr(), consts.data_ptr(), out.ptr, out.ld,
+                                                          _stream()), "upconv_out_c64_bf16")
+    if PROFILER is not None:
+        # the arithmetic of the layered form it replaces: 2.25 taps x 64 x 64 for the up-block + 9 x 64 for the output conv
+        PROFILER.run("tap_sum", tag, 2.0 * x.n * 4 * x.h * x.w * (64 * 64 * 2.25 + 64 * 9), _go)
+    else:
+        _go()
+    return out
 
 
 def cast_bf16(x: Act) -> Act:

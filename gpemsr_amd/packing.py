@@ -171,3 +171,63 @@ def pack_convT_bf16(w: torch.Tensor, device) -> torch.Tensor:
                     rows = (co // 32) * 128 + (2 * py + px) * 32 + (co % 32)
                     out[2 * dy + dx, rows] = wf[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()
     return _stage_order_bf16(out, bf16_chunk((cin,))).to(torch.bfloat16).to(device)
+
+
+def _tap_fragments(rows: torch.Tensor) -> torch.Tensor:
+    """rows [R <= 32][64] (bf16-representable fp32) -> the A-operand fragments [4 k-steps][64 lanes][8] of one 32-row MFMA tile:
+    lane l holds row l % 32, channels 16 ks + 8 (l // 32) .. + 8 (csrc/tap_sum.hip)."""
+    full = torch.zeros(32, 64, dtype=torch.float32)
+    full[:rows.shape[0]] = rows
+    return full.reshape(32, 4, 2, 8).permute(1, 2, 0, 3).reshape(4, 64, 8).to(torch.bfloat16)
+
+
+def _hi_lo(w: torch.Tensor):
+    hi = w.to(torch.bfloat16).to(torch.float32)
+    return hi, (w - hi).to(torch.bfloat16).to(torch.float32)
+
+
+def pack_cout1_taps(w: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d(64 -> 1, 3x3) weight [1][64][3][3] -> tap fragments for gpemsr_conv_c64_cout1_bf16: rows 0..8 carry the bf16 hi
+    halves of the nine taps, rows 16..24 their lo halves (one MFMA, summed in the epilogue)."""
+    assert tuple(w.shape) == (1, 64, 3, 3)
+    rows = w.detach().to(torch.float32).cpu()[0].permute(1, 2, 0).reshape(9, 64)
+    hi, lo = _hi_lo(rows)
+    full = torch.zeros(32, 64)
+    full[0:9], full[16:25] = hi, lo
+    return _tap_fragments(full).contiguous().to(device)
+
+
+def compose_upconv_out(w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor]):
+    """ConvTranspose2d(C -> M, k3 s2 p1 op1; w1 [C][M][3][3]) followed by Conv2d(M -> 1, 3x3 pad 1; w2 [1][M][3][3]) as one
+    operator (csrc/tap_sum.hip): returns fp64 (taps [25][C] with t = ty*5+tx and o = 2 i + t - 2, S [9], b2, Wy0 [5][C], Wx0 [5][C],
+    Wc [C])."""
+    w1d, w2d = w1.detach().double().cpu(), w2.detach().double().cpu()[0]
+    C = w1d.shape[0]
+    m = torch.einsum("cmab,mde->cabde", w1d, w2d)              # [C][ky][kx][dy][dx]
+    taps = torch.zeros(5, 5, C, dtype=torch.float64)
+    wy0 = torch.zeros(5, C, dtype=torch.float64)
+    wx0 = torch.zeros(5, C, dtype=torch.float64)
+    for ky in range(3):
+        for dy in range(3):
+            for kx in range(3):
+                for dx in range(3):
+                    ty, tx = ky - dy + 2, kx - dx + 2
+                    taps[ty, tx] += m[:, ky, kx, dy, dx]
+                    if ky == 0 and dy == 0:
+                        wy0[tx] += m[:, ky, kx, dy, dx]
+                    if kx == 0 and dx == 0:
+                        wx0[ty] += m[:, ky, kx, dy, dx]
+    wc = m[:, 0, 0, 0, 0].clone()
+    s = torch.einsum("m,mde->de", b1.detach().double().cpu(), w2d).reshape(9) if b1 is not None else torch.zeros(9, dtype=torch.float64)
+    bb = float(b2.detach().double().cpu()[0]) if b2 is not None else 0.0
+    return taps.reshape(25, C), s, bb, wy0, wx0, wc
+
+
+def pack_upconv_out(w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor], device):
+    """-> (fragments [2 sets: hi, lo][4][64][8] bf16, consts [10 + 5*64 + 5*64 + 64] fp32) for gpemsr_upconv_out_c64_bf16."""
+    assert tuple(w1.shape) == (64, 64, 3, 3) and tuple(w2.shape) == (1, 64, 3, 3)
+    taps, s, bb, wy0, wx0, wc = compose_upconv_out(w1, b1, w2, b2)
+    hi, lo = _hi_lo(taps.to(torch.float32))
+    frag = torch.stack([_tap_fragments(hi), _tap_fragments(lo)]).contiguous().to(device)
+    consts = torch.cat([s, torch.tensor([bb], dtype=torch.float64), wy0.reshape(-1), wx0.reshape(-1), wc]).to(torch.float32).contiguous().to(device)
+    return frag, consts

@@ -199,6 +199,17 @@ int gpemsr_conv2d_stem1_bf16(const float* x, int n, int h, int w, const float* w
 int gpemsr_conv2d_direct_bf16(const void* x, int x_f32, int n, int h, int w, int ld, int cin, const float* weight,
                               const float* bias, int cout, int ksize, int stride, int act, const float* residual, int res_ld,
                               void* out, int out_f32, int out_ld, void* stream);
+/* One-output-channel convolutions over 64 bf16 channels as tap partial products on the matrix cores (csrc/tap_sum.hip): the input
+ * is read from HBM once, fp32 result [n][h][w] with pixel stride out_ld.  wfrag: MFMA A-operand fragments of the taps as bf16
+ * hi + lo halves (packing.pack_cout1_taps / pack_upconv_out).
+ *   conv_c64_cout1: Conv2d(64 -> 1, 3x3, pad 1) + act + fp32 residual -- conv_last (model/GPEMSR.py:318,455).
+ *   upconv_out_c64: ConvTranspose2d(64 -> 64, k3 s2 p1 op1) then Conv2d(64 -> 1, 3x3, pad 1) with nothing in between, composed
+ *                   into one 5x5 stride-2 operator 64 -> 1 (the VQGAN decoder's last up-block + output_layer, model/vqgan.py):
+ *                   x [n][h][w] -> out [n][2h][2w]; consts = [9 bias-through-tap sums, b2, Wy0 5x64, Wx0 5x64, Wc 64] fp32. */
+int gpemsr_conv_c64_cout1_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, int act,
+                               const float* residual, int res_ld, float* out, int out_ld, void* stream);
+int gpemsr_upconv_out_c64_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* consts, float* out,
+                               int out_ld, void* stream);
 
 /* Direct (VALU) convolution for tiny channel counts: cout <= 16, any k<=7, stride 1/2/4.
  * replaces: POD.flowdsconv* (model/GPEMSR.py:70-75,101-106), SpyNet's last 16->2 conv,

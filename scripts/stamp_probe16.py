@@ -16,7 +16,7 @@ from gpemsr_amd.packing import pack_conv, pack_conv_bf16  # noqa: E402
 
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
-for (n, cin, cout, k, h, w, bias) in ((80, 64, 64, 3, 128, 128, True), (4, 64, 64, 3, 1024, 1024, True), (80, 256, 256, 3, 128, 128, True), (80, 512, 512, 1, 64, 64, True)):
+for (n, cin, cout, k, h, w, bias) in ((80, 64, 64, 3, 512, 512, True), (80, 64, 64, 3, 128, 128, True), (4, 64, 64, 3, 1024, 1024, True), (80, 256, 256, 3, 128, 128, True), (80, 512, 512, 1, 64, 64, True)):
     wt = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / (cin * k * k) ** 0.5
     pc = pack_conv(wt, torch.rand(cout) if bias else None, dev)
     pc.wb = pack_conv_bf16(wt, dev)

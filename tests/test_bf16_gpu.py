@@ -76,6 +76,8 @@ CASES = [
     (1, (128,), 256, 3, 1, 20, 36, 0, 1, False, False, 0),
     (1, (128,), 256, 3, 1, 20, 36, 1, 0, False, False, 1),
     (1, (128,), 256, 3, 1, 20, 36, 1, 0, False, True, 2),
+    (1, (128,), 256, 3, 1, 20, 36, 1, 1, False, False, 4),         # variant 4: the 8-wave big tile without loader waves
+    (2, (128, 64), 128, 3, 1, 35, 45, 2, 1, True, False, 0),      # loader-wave form: two sources, six chunks, ragged tiles
     (1, (256,), 256, 3, 1, 16, 32, 0, 0, False, False, 0),
     (1, (64,), 216, 3, 1, 16, 16, 0, 0, False, True, 0),
     (1, (32,), 32, 3, 1, 12, 50, 1, 0, False, False, 0),
@@ -136,6 +138,8 @@ STREAM_CASES = [
     (10, (64, 64), 64, 3, 1, 96, 96, False),        # 2 sources x 2 chunks, ring == 3 stages of a 12-stage tile
     (6, (32,), 64, 3, 1, 128, 96, False),           # ONE chunk per tile: single halo image, refilled at every tile end
     (3, (128,), 256, 3, 1, 96, 128, False),         # two cout tiles per pixel tile
+    (8, (128,), 256, 3, 1, 96, 128, False),         # loader-wave form, three tiles per workgroup
+    (9, (48,), 128, 3, 1, 80, 96, False),           # loader-wave form with 16-channel chunks (three of them)
     (12, (64,), 64, 3, 1, 64, 64, True),            # transposed: 4 stages per tile == ring depth
     (5, (64,), 64, 1, 1, 192, 160, False),          # 1x1: two chunks, two stages per tile
     (6, (64,), 64, 3, 2, 192, 128, False),          # stride 2
@@ -406,3 +410,48 @@ def test_vgg_mask_fused_matches_the_layered_form(n, h, w, scale):
     _close(got.nchw(), want, 2e-3, "fused vgg mask")
     again = ops.vgg_mask_bf16(A(ref), A(lr), scale, w1.sum(dim=1).reshape(64, 9).contiguous().to(dev), b1.to(dev), pack_conv_bf16(w2, dev), b2.to(dev))
     assert torch.equal(got.buf, again.buf)
+
+
+@pytest.mark.parametrize("n,h,w,ld,off", [(2, 16, 24, 64, 0), (1, 37, 131, 96, 16), (3, 5, 62, 64, 0), (1, 70, 63, 64, 0)])
+def test_tap_sum_conv_64_to_1(n, h, w, ld, off):
+    """gpemsr_conv_c64_cout1_bf16 (csrc/tap_sum.hip): hi + lo weight halves keep the weights at fp32 accuracy, so the result is the
+    fp32 convolution of the bf16-rounded input to 1e-5; tiles own 16 x 62 pixels, the cases cross both tile edges."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_cout1_taps
+    dev = _dev()
+    x = _r(_rand(n, 64, h, w, seed=300 + h))
+    wt = _rand(1, 64, 3, 3, seed=301, scale=1.0 / 24); b = _rand(1, seed=302)
+    base = _rand(n, 1, h, w, seed=303)
+    pc = pack_conv(wt, b, dev)
+    pc.wtap = pack_cout1_taps(wt, dev)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    got = ops.conv2d([_act16(x, dev, ld, off)], pc, 0, residual=_act32(base, dev), precision="bf16")
+    assert not got.bf16
+    _close(got.nchw(), want + base.double(), 1e-5, "tap-sum 64 -> 1 with residual")
+    got = ops.conv2d([_act16(x, dev, ld, off)], pc, 4, precision="bf16")
+    _close(got.nchw(), torch.sigmoid(F.leaky_relu(want, 0.1)), 1e-5, "tap-sum 64 -> 1 mask head")
+    pc.b = None
+    got = ops.conv2d([_act16(x, dev, ld, off)], pc, 0, precision="bf16")
+    _close(got.nchw(), want - b.double(), 1e-5, "tap-sum 64 -> 1 without bias")
+
+
+@pytest.mark.parametrize("n,h,w,ld,off", [(2, 8, 12, 64, 0), (1, 19, 67, 96, 32), (2, 3, 62, 64, 0), (1, 33, 125, 64, 0), (1, 1, 1, 64, 0)])
+def test_upconv_out_composed_operator(n, h, w, ld, off):
+    """gpemsr_upconv_out_c64_bf16: ConvTranspose2d(64 -> 64, k3 s2 p1 op1) + Conv2d(64 -> 1, 3x3) as one operator must equal the
+    layered fp64 evaluation on the same bf16-rounded input (no intermediate rounding in either): 1e-5, borders included."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_upconv_out
+    dev = _dev()
+    x = _r(_rand(n, 64, h, w, seed=310 + h))
+    w1 = _rand(64, 64, 3, 3, seed=311, scale=1.0 / 12); b1 = _rand(64, seed=312, scale=0.5)
+    w2 = _rand(1, 64, 3, 3, seed=313, scale=1.0 / 24); b2 = _rand(1, seed=314)
+    want = F.conv2d(F.conv_transpose2d(x.double(), w1.double(), b1.double(), stride=2, padding=1, output_padding=1), w2.double(), b2.double(), padding=1)
+    frag, consts = pack_upconv_out(w1, b1, w2, b2, dev)
+    got = ops.upconv_out_bf16(_act16(x, dev, ld, off), frag, consts)
+    assert not got.bf16 and (got.h, got.w, got.c) == (2 * h, 2 * w, 1)
+    g, wv = got.nchw().cpu().double(), want
+    for name, sl in (("top row", (slice(None), slice(None), slice(0, 1))), ("left column", (slice(None), slice(None), slice(None), slice(0, 1))),
+                     ("bottom row", (slice(None), slice(None), slice(-1, None))), ("right column", (slice(None), slice(None), slice(None), slice(-1, None)))):
+        err = (g[sl] - wv[sl]).abs().max().item()
+        assert err <= 1e-5 * wv.abs().max().item() + 1e-6, f"{name}: {err:.3e}"
+    _close(got.nchw(), want, 1e-5, "composed up-block + output layer")
