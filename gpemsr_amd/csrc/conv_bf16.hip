@@ -48,7 +48,7 @@ __device__ unsigned long long g_xstamps[8 * 65536];
 #define XSEG_FLUSH
 #endif
 
-constexpr int XA_LOADS = 10;      // 16-B A slots per DMA thread (halo_px * R / DMA threads; 16x32 tile on 4 loader waves: 10)
+constexpr int XA_LOADS = 10;      // 16-B A slots per DMA thread (halo_px * R / DMA threads; 3x3 16x32 tile on 4 loader waves: 10)
 constexpr int XB_LOADS = 7;       // 16-B B slots per thread per stage (TPS * R * BN / 256; 7x7 row stage of 64 couts: 7)
 
 enum { XS_PLAIN = 0, XS_PIXSHUF = 1, XS_CONVT = 2, XS_KPACK = 3 };
@@ -514,6 +514,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
       for (int kx = 0; kx < AC; ++kx) a_off[rr][kx] = GEMM ? a_offset2(rr, 0, 0) : a_offset2(0, rr, kx);
   }
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
+  const unsigned xsm_lds = xlds_addr(xsm);
 
   // ---- prologue: tile 0 (and 1) geometry, A(0) [A(1)], B(0 .. RING-1) ----
   if (is_loader) {
@@ -595,8 +596,8 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
     auto stage = [&](const int grp) {                  // grp is a compile-time constant in the unrolled (TABLE) form
       // TABLE: a_off already points into the current halo image (moved once per chunk, below) -- adding the image base per
       // read gave the compiler 2 x 18 more loop invariants to keep (and spill) on the 168-register budget of the 12-wave form
-      const char* A = TABLE ? a_base : a_base + a_slot * A_BYTES;
-      const char* B = b_base + b_slot * B_BYTES + b_frag;
+      const unsigned A = xsm_lds + (TABLE ? 0u : (unsigned)(a_slot * A_BYTES));
+      const unsigned B = xsm_lds + (unsigned)(n_abuf * A_BYTES + b_slot * B_BYTES + b_frag);
       const int tap0 = grp * TPS;
       bf16x8 fa[2][MT], fb[2][NT];
       if (!TABLE) {                                    // 7x7: a stage is filter row ky = grp
@@ -615,12 +616,12 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
         for (int mt = 0; mt < MT; ++mt) {
           const int tap = tap0 + tt;
           const int o = !TABLE ? a_off[mt][tt] : (GEMM ? a_off[mt][0] : a_off[mt * S + tap / KW][tap % KW]);
-          fa[set][mt] = *reinterpret_cast<const bf16x8*>(A + (ks ? (o ^ (32 * ks)) : o));
+          fa[set][mt] = xlds_read16(A + (unsigned)(ks ? (o ^ (32 * ks)) : o));
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           if (CONVT && !((mask >> nt) & 1u)) continue;
-          fb[set][nt] = *reinterpret_cast<const bf16x8*>(B + (tt * R + 2 * ks) * (BN * 16) + nt * 512);
+          fb[set][nt] = xlds_read16(B + (unsigned)((tt * R + 2 * ks) * (BN * 16) + nt * 512));
         }
       };
       auto mma_step = [&](int set, int tt) {
@@ -937,13 +938,18 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     P.kw = 2; P.kk = 4; P.stride = 1; P.pad = 0; P.cout = 4 * d->cout;
     P.oh = d->h; P.ow = d->w; P.OH = 2 * d->h; P.OW = 2 * d->w;
     P.store_mode = XS_CONVT; P.cq = d->cout; BN = 128; TH = 4; TPS = 2; WM = 4; WN = 1;
+    if (var != 1) { TH = 8; WM = 8; NL = 4; }               // 8x32 px x (4 phases x 32 couts), 8 multiplying + 4 loader waves
   } else {
     P.kw = d->ksize; P.kk = d->ksize * d->ksize; P.stride = d->stride; P.pad = d->ksize / 2; P.cout = d->cout;
     P.oh = (d->h + 2 * P.pad - d->ksize) / P.stride + 1; P.ow = (d->w + 2 * P.pad - d->ksize) / P.stride + 1;
     P.store_mode = d->pixel_shuffle ? XS_PIXSHUF : (d->kpack ? XS_KPACK : XS_PLAIN); P.cq = d->cout / 4;
     P.OH = d->pixel_shuffle ? 2 * P.oh : P.oh; P.OW = d->pixel_shuffle ? 2 * P.ow : P.ow;
     BN = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
-    if (gemm) { TH = 4; TPS = 1; WM = BN == 32 ? 4 : 2; WN = BN == 32 ? 1 : 2; }
+    if (gemm) {
+      TH = 4; TPS = 1; WM = BN == 32 ? 4 : 2; WN = BN == 32 ? 1 : 2;
+      if (var != 1 && BN == 128) { TH = 8; WM = 4; WN = 2; NL = 4; }        // 256 px x 128 columns, 8 + 4 waves
+      else if (var != 1 && BN == 64) { TH = 16; WM = 8; WN = 1; NL = 4; }   // 512 px x 64 columns
+    }
     else if (d->ksize == 7) {
       if (var == 1) {
         // 256-thread form: single-chunk layers (cin <= 32) keep ONE A image and a 2-deep ring of 7-tap row stages; wider inputs
@@ -954,6 +960,9 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
         // big tile: 16x32 pixels, 8 waves (one workgroup per CU): the 49-tap weights are staged once per 512 pixels
         TH = 16; TPS = 7; WM = 8; WN = 1;
         if (BN == 128) BN = 64;
+        // loader waves only for 16-channel chunks: with 32-channel chunks a loader thread owns 14 halo slots, the slot loops stop
+        // being unrolled and the whole cursor state goes to scratch (1.1 KB per lane; measured 4x slower)
+        if (var != 4 && CK == 16) NL = 4;
       }
     }
     else if (d->stride == 2) { TH = 2; WM = 2; WN = 2; TPS = (BN == 128) ? 1 : 3; }
@@ -963,7 +972,8 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
       else if (var == 4) { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; }   // big tile, 8 waves that all load and multiply
       else { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; NL = 4; }  // big tile: 16x32 px x 64 couts, 8 multiplying + 4 loader waves
     }
-    else { TH = 8; TPS = (var == 1) ? 1 : 3; WM = 4; WN = 1; }
+    else if (var == 1 || var == 2) { TH = 8; TPS = (var == 1) ? 1 : 3; WM = 4; WN = 1; }   // 256-thread forms
+    else { TH = 16; TPS = 3; WM = 8; WN = 1; NL = 4; }            // couts <= 64 on the same loader-wave big tile
   }
   L.BN = BN; L.TH = TH; L.TPS = TPS; L.WM = WM; L.WN = WN; L.NL = NL;
   GP_REQUIRE(!(P.store_mode == XS_PIXSHUF) || P.cq % 8 == 0, "conv2d_bf16: pixel_shuffle needs cout%%32==0");
@@ -1002,7 +1012,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.spc = P.kk / TPS;
   // Ring depth / number of halo images: as deep as 80 KiB per workgroup (two workgroups per CU) allows, at most 4; the
   // persistent stream looks at most ONE tile ahead, hence ring <= stages per tile and images <= chunks per tile.
-  const int budget = (nth == 512 ? 158 : 80) * 1024 - bias_bytes;      // 512 threads: one workgroup per CU
+  const int budget = (nth >= 512 ? 158 : 80) * 1024 - bias_bytes;      // 512 / 768 threads: one workgroup per CU
   const int stages = nchunk_total * P.spc;
   int ring = stages < 4 ? (stages < 2 ? 2 : stages) : 4;
   int n_abuf = gemm ? (nchunk_total < 4 ? nchunk_total : 4) : (nchunk_total < 2 ? 1 : 2);
@@ -1073,14 +1083,26 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
 #define GP_X(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
   (L.CK == 32 ? launch_x<32, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv>(P, lds, st) : launch_x<16, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv>(P, lds, st))
 #define GP_IS(BNv, WMv, WNv, THv, TPSv) (L.BN == BNv && L.WM == WMv && L.WN == WNv && L.TH == THv && L.TPS == TPSv)
+#define GP_XL(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
+  (L.CK == 32 ? launch_x<32, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st) : launch_x<16, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st))
+  if (L.NL == 4) {            // loader-wave forms
+    if (L.tr) return GP_XL(128, 8, 1, 8, 2, true, false);
+    if (L.gemm) {
+      if (GP_IS(128, 4, 2, 8, 1)) return GP_XL(128, 4, 2, 8, 1, false, true);
+      if (GP_IS(64, 8, 1, 16, 1)) return GP_XL(64, 8, 1, 16, 1, false, true);
+    }
+    else if (GP_IS(64, 8, 1, 16, 3)) return GP_XL(64, 8, 1, 16, 3, false, false);
+    else if (GP_IS(32, 8, 1, 16, 3)) return GP_XL(32, 8, 1, 16, 3, false, false);
+    else if (GP_IS(64, 8, 1, 16, 7) && L.CK == 16) return launch_x<16, 64, 8, 1, 16, 7, false, false, 4>(P, lds, st);
+    else if (GP_IS(32, 8, 1, 16, 7) && L.CK == 16) return launch_x<16, 32, 8, 1, 16, 7, false, false, 4>(P, lds, st);
+    return fail(GPEMSR_EUNSUPPORTED, "conv2d_bf16: no loader-wave kernel for BN=%d WM=%d WN=%d TH=%d TPS=%d", L.BN, L.WM, L.WN, L.TH, L.TPS);
+  }
   if (L.tr) return GP_X(128, 4, 1, 4, 2, true, false);
   if (L.gemm) {
     if (GP_IS(32, 4, 1, 4, 1)) return GP_X(32, 4, 1, 4, 1, false, true);
     if (GP_IS(64, 2, 2, 4, 1)) return GP_X(64, 2, 2, 4, 1, false, true);
     return GP_X(128, 2, 2, 4, 1, false, true);
   }
-  if (GP_IS(64, 8, 1, 16, 3) && L.NL == 4)
-    return L.CK == 32 ? launch_x<32, 64, 8, 1, 16, 3, false, false, 4>(P, lds, st) : launch_x<16, 64, 8, 1, 16, 3, false, false, 4>(P, lds, st);
   if (GP_IS(64, 8, 1, 16, 3)) return GP_X(64, 8, 1, 16, 3, false, false);
   if (GP_IS(64, 8, 1, 16, 7)) return GP_X(64, 8, 1, 16, 7, false, false);
   if (GP_IS(32, 8, 1, 16, 7)) return GP_X(32, 8, 1, 16, 7, false, false);
@@ -1096,6 +1118,7 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
   if (GP_IS(128, 4, 1, 8, 1)) return GP_X(128, 4, 1, 8, 1, false, false);
   return fail(GPEMSR_EUNSUPPORTED, "conv2d_bf16: no kernel for BN=%d WM=%d WN=%d TH=%d TPS=%d", L.BN, L.WM, L.WN, L.TH, L.TPS);
 #undef GP_X
+#undef GP_XL
 #undef GP_IS
 }
 
