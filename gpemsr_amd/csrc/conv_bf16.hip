@@ -292,7 +292,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
   constexpr int WNT = BN / WN;
   constexpr int NT = WNT / 32;
   constexpr int ROWB = R * 16;         // bytes per pixel row of the A image
-  constexpr int SWZ_SH = (R == 4) ? 2 : 3, SWZ_MK = R - 1;
+  constexpr int SWZ_SH = (R == 8) ? 1 : ((R == 4) ? 2 : 3), SWZ_MK = R - 1;   // 256 B of rows share one bank sweep
   constexpr int HALO_W = GEMM ? NPIX : 31 * S + KW;
   constexpr int HALO_H = GEMM ? 1 : (TH - 1) * S + KW;
   constexpr int HALO_PX = HALO_W * HALO_H;
@@ -912,7 +912,9 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   bool ck32 = true;
   int nchunk_total = 0;
   for (int s = 0; s < d->nsrc; ++s) ck32 = ck32 && (d->src[s].c % 32 == 0);
-  const int CK = ck32 ? 32 : 16;
+  bool ck64 = gemm && d->variant != 1 && d->cout > 64;       // 1x1 / matrix products with 128-column tiles: 64-deep stages
+  for (int s = 0; s < d->nsrc; ++s) ck64 = ck64 && (d->src[s].c % 64 == 0);
+  const int CK = ck64 ? 64 : (ck32 ? 32 : 16);
   L.CK = CK;
   for (int s = 0; s < d->nsrc; ++s) {
     GP_REQUIRE(d->src[s].ptr && d->src[s].c > 0 && d->src[s].c % CK == 0 && d->src[s].ld % 8 == 0 && d->src[s].ld >= d->src[s].c &&
@@ -1016,8 +1018,11 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   const int stages = nchunk_total * P.spc;
   int ring = stages < 4 ? (stages < 2 ? 2 : stages) : 4;
   int n_abuf = gemm ? (nchunk_total < 4 ? nchunk_total : 4) : (nchunk_total < 2 ? 1 : 2);
-  while (ring > 2 && n_abuf * P.a_bytes + ring * P.b_bytes > budget) --ring;
-  while (gemm && n_abuf > 2 && n_abuf * P.a_bytes + ring * P.b_bytes > budget) --n_abuf;
+  while (n_abuf * P.a_bytes + ring * P.b_bytes > budget && (ring > 2 || (gemm && n_abuf > 2))) {
+    if (gemm && n_abuf > 2 && n_abuf >= ring) --n_abuf;      // matrix products: both rings advance per stage, keep them level
+    else if (ring > 2) --ring;
+    else --n_abuf;
+  }
   if (stages < 2) ring = 2;                                  // (a second slot that is simply never filled)
   P.ring = ring;
   P.n_abuf = n_abuf;
@@ -1088,6 +1093,7 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
   if (L.NL == 4) {            // loader-wave forms
     if (L.tr) return GP_XL(128, 8, 1, 8, 2, true, false);
     if (L.gemm) {
+      if (GP_IS(128, 4, 2, 8, 1) && L.CK == 64) return launch_x<64, 128, 4, 2, 8, 1, false, true, 4>(P, lds, st);
       if (GP_IS(128, 4, 2, 8, 1)) return GP_XL(128, 4, 2, 8, 1, false, true);
       if (GP_IS(64, 8, 1, 16, 1)) return GP_XL(64, 8, 1, 16, 1, false, true);
     }

@@ -117,6 +117,62 @@ __global__ __launch_bounds__(256) void gn_apply16_kernel(const bf16_t* x, long l
   }
 }
 
+// The same for channel counts whose 16-byte columns divide the workgroup (c/8 in {1,2,4,...,256}): grid (pixel blocks, n); a
+// thread keeps ONE 8-channel column for its whole life, so scale = rstd*gamma and shift = beta - mean*rstd*gamma are formed once
+// and a pixel costs one 16-byte load, 8 FMAs and one 16-byte store (the generic kernel above spends ~20 dependent scalar loads and
+// two 64-bit divisions per 16 bytes: 2.5 TB/s on the VQGAN blocks).  UNR independent pixels are in flight per thread.
+template <int UNR>
+__global__ __launch_bounds__(256) void gn_apply16_cols_kernel(const bf16_t* x, int hw, int c, int ld, int groups, const float* mr, const float* gamma,
+                                                              const float* beta, int relu, const bf16_t* residual, int res_ld, bf16_t* out, int out_ld,
+                                                              int pix_per_block) {
+  const int c8 = c >> 3, cpg = c / groups;
+  const int col = threadIdx.x % c8, row = threadIdx.x / c8, rows = 256 / c8;
+  const int img = blockIdx.y, ch = 8 * col;
+  float sc[8], sh[8];
+  {
+    float g[8], b[8];
+    ld8f(gamma + ch, g); ld8f(beta + ch, b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int grp = (ch + k) / cpg;
+      const float mean = mr[2 * (img * groups + grp)], rstd = mr[2 * (img * groups + grp) + 1];
+      sc[k] = rstd * g[k]; sh[k] = b[k] - mean * rstd * g[k];
+    }
+  }
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(hw, p0 + pix_per_block);
+  const bf16_t* xp = x + (long long)img * hw * ld + ch;
+  const bf16_t* rp = residual ? residual + (long long)img * hw * res_ld + ch : nullptr;
+  bf16_t* op = out + (long long)img * hw * out_ld + ch;
+  for (int p = p0 + row; p < p1; p += rows * UNR) {
+    uint4 raw[UNR], rr[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int q = p + u * rows;
+      if (q < p1) {
+        raw[u] = *reinterpret_cast<const uint4*>(xp + (long long)q * ld);
+        if (rp) rr[u] = *reinterpret_cast<const uint4*>(rp + (long long)q * res_ld);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int q = p + u * rows;
+      if (q >= p1) continue;
+      const unsigned in[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+      const unsigned rs[4] = {rr[u].x, rr[u].y, rr[u].z, rr[u].w};
+      unsigned o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a = fmaf(__uint_as_float(in[k] << 16), sc[2 * k], sh[2 * k]);
+        float b = fmaf(__uint_as_float(in[k] & 0xFFFF0000u), sc[2 * k + 1], sh[2 * k + 1]);
+        if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+        if (rp) { a += __uint_as_float(rs[k] << 16); b += __uint_as_float(rs[k] & 0xFFFF0000u); }
+        o[k] = pk_bf16(a, b);
+      }
+      *reinterpret_cast<uint4*>(op + (long long)q * out_ld) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 // ---- row softmax: S (fp32 or bf16) -> P bf16; one workgroup per row, cols <= 256 * 8 * MAXV ----
 template <int MAXV, typename TS>
 __global__ __launch_bounds__(256) void softmax16_kernel(const TS* s, int cols, int s_ld, bf16_t* p, int p_ld) {
@@ -613,6 +669,79 @@ __global__ __launch_bounds__(256) void conv_direct16_kernel(const TI* x, int n, 
   }
 }
 
+// small 3x3 convolution, cin in {2 (fp32 flow), 16 (bf16)} -> cout <= 16, stride 1/2/4 (the flow down-convs, R:model/GPEMSR.py:70-75):
+// one thread per output pixel holds all couts; the weights sit in LDS as [tap][cin][16 couts] and are read as broadcasts.
+template <typename TI, int CIN, typename TO>
+__global__ __launch_bounds__(256) void conv_small16_kernel(const TI* x, int n, int h, int w, int ld, int cin_pad, const float* weight, const float* bias,
+                                                           int cout, int stride, int oh, int ow, int act, TO* out, int out_ld, int vec_out) {
+  __shared__ __attribute__((aligned(16))) float wsm[9 * CIN * 16];
+  for (int i = threadIdx.x; i < 9 * CIN * 16; i += 256) {
+    const int co = i & 15, ci = (i >> 4) % CIN, tap = i / (16 * CIN);
+    wsm[i] = co < cout ? weight[((long long)tap * cout + co) * cin_pad + ci] : 0.f;
+  }
+  __syncthreads();
+  float bs[16];
+#pragma unroll
+  for (int co = 0; co < 16; ++co) bs[co] = (bias && co < cout) ? bias[co] : 0.f;
+  const long long total = (long long)n * oh * ow;
+  for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+    const int ox = (int)(pix % ow), oy = (int)((pix / ow) % oh), img = (int)(pix / ((long long)ow * oh));
+    float acc[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc[co] = bs[co];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * stride - 1 + ky;
+      if (iy < 0 || iy >= h) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * stride - 1 + kx;
+        if (ix < 0 || ix >= w) continue;
+        const TI* xp = x + (((long long)img * h + iy) * w + ix) * ld;
+        float v[CIN];
+        if (sizeof(TI) == 4) {
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) v[ci] = reinterpret_cast<const float*>(xp)[ci];
+        } else {
+#pragma unroll
+          for (int c8 = 0; c8 < CIN / 8; ++c8) {
+            float t[8];
+            ld8(reinterpret_cast<const bf16_t*>(xp) + 8 * c8, t);
+#pragma unroll
+            for (int z = 0; z < 8; ++z) v[8 * c8 + z] = t[z];
+          }
+        }
+        const float* wp = wsm + (ky * 3 + kx) * CIN * 16;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+          for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wp + ci * 16 + 4 * c4);
+            acc[4 * c4] = fmaf(v[ci], w4.x, acc[4 * c4]); acc[4 * c4 + 1] = fmaf(v[ci], w4.y, acc[4 * c4 + 1]);
+            acc[4 * c4 + 2] = fmaf(v[ci], w4.z, acc[4 * c4 + 2]); acc[4 * c4 + 3] = fmaf(v[ci], w4.w, acc[4 * c4 + 3]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc[co] = apply_act(acc[co], act);
+    TO* op = out + pix * out_ld;
+    if (sizeof(TO) == 2 && vec_out) {
+      float lo[8], hi[8];
+#pragma unroll
+      for (int z = 0; z < 8; ++z) { lo[z] = acc[z]; hi[z] = acc[8 + z]; }
+      st8(reinterpret_cast<bf16_t*>(op), lo); st8(reinterpret_cast<bf16_t*>(op) + 8, hi);
+    } else {
+#pragma unroll
+      for (int co = 0; co < 16; ++co)
+        if (co < cout) {
+          if (sizeof(TO) == 4) reinterpret_cast<float*>(op)[co] = acc[co];
+          else reinterpret_cast<bf16_t*>(op)[co] = to_bf16(acc[co]);
+        }
+    }
+  }
+}
+
 }  // namespace gpemsr
 
 using namespace gpemsr;
@@ -642,6 +771,21 @@ extern "C" int gpemsr_groupnorm_apply_bf16(const void* x, int n, int hw, int c, 
   GP_REQUIRE(x && mean_rstd && gamma && beta && out, "groupnorm_apply_bf16: null pointer");
   GP_REQUIRE(c % 8 == 0 && ld % 8 == 0 && out_ld % 8 == 0 && (!residual || res_ld % 8 == 0) && c % groups == 0 && A16(x) && A16(out) && A16(gamma) && A16(beta),
              "groupnorm_apply_bf16: alignment");
+  const int c8 = c / 8;
+  if (c8 <= 256 && 256 % c8 == 0) {
+    const int rows = 256 / c8;
+    // >= 4 waves of work per CU over the whole launch, >= 4 x UNR pixel rows per thread
+    int blocks = (2048 + n - 1) / n;
+    const int max_blocks = (hw + rows * 16 - 1) / (rows * 16);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+    int per = (hw + blocks - 1) / blocks;
+    per = (per + rows - 1) / rows * rows;
+    blocks = (hw + per - 1) / per;
+    hipLaunchKernelGGL(gn_apply16_cols_kernel<4>, dim3(blocks, n), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), hw, c, ld, groups, mean_rstd, gamma, beta,
+                       relu, reinterpret_cast<const bf16_t*>(residual), res_ld, reinterpret_cast<bf16_t*>(out), out_ld, per);
+    return check_launch("groupnorm_apply_bf16");
+  }
   const long long total8 = (long long)n * hw * (c / 8);
   hipLaunchKernelGGL(gn_apply16_kernel, dim3(grid16(total8)), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), total8, hw, c, ld, groups,
                      mean_rstd, gamma, beta, relu, reinterpret_cast<const bf16_t*>(residual), res_ld, reinterpret_cast<bf16_t*>(out), out_ld);
@@ -789,6 +933,16 @@ extern "C" int gpemsr_conv2d_direct_bf16(const void* x, int x_f32, int n, int h,
     return check_launch("conv_c64_cout1_16_kernel");
   }
   GP_REQUIRE(!residual, "conv2d_direct_bf16: residual only in the 64 -> 1 form");
+  if (ksize == 3 && cout <= 16 && ((x_f32 && cin == 2) || (!x_f32 && cin == 16 && ld % 8 == 0 && A16(x)))) {
+    const unsigned g2 = grid16((long long)n * oh * ow);
+    const int vec = (!out_f32 && cout == 16 && out_ld % 8 == 0 && A16(out)) ? 1 : 0;
+#define GP_S(TI, CI, TO) hipLaunchKernelGGL((conv_small16_kernel<TI, CI, TO>), dim3(g2), dim3(256), 0, st, reinterpret_cast<const TI*>(x), n, h, w, ld, cin_pad, weight, bias, \
+                                            cout, stride, oh, ow, act, reinterpret_cast<TO*>(out), out_ld, vec)
+    if (x_f32) { if (out_f32) GP_S(float, 2, float); else GP_S(float, 2, bf16_t); }
+    else { if (out_f32) GP_S(bf16_t, 16, float); else GP_S(bf16_t, 16, bf16_t); }
+#undef GP_S
+    return check_launch("conv_small16_kernel");
+  }
   const unsigned grid = grid16((long long)n * oh * ow * cout);
 #define GP_D(TI, TO) hipLaunchKernelGGL((conv_direct16_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const TI*>(x), n, h, w, ld, cin, cin_pad, \
                                         weight, bias, cout, ksize, stride, oh, ow, act, reinterpret_cast<TO*>(out), out_ld)
