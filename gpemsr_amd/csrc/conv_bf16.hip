@@ -91,9 +91,21 @@ struct XGeo { int img, oy0, ox0, n0, tile_in_img; };
 // prefetches through the in-order vmcnt) and activation are applied per register, then two v_permlane32_swap per register
 // pair give lane (li, lh) the 8 consecutive couts 8 (gp + lh) .. + 7 of its pixel: residual, per-pixel multiplier, optional
 // fp32 copy, 16-byte store.  GroupNorm partial sums (conv + bias, valid pixels): butterfly over the 32 pixel lanes.
-template <int MT, int NT, bool GEMM>
-__device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x16 (&acc)[MT][NT], int pix_base, int cout_base, int gn_part,
+//
+// CODE SIZE is a first-order cost here: the epilogue is instantiated once per accumulator tile, every store map / residual type /
+// ragged-channel tail multiplies it, and the kernels had grown to 60-90 KB against a 64 KB instruction cache shared by two CUs --
+// in-kernel stamps: the epilogue took 9.4k cycles per tile of the 64-channel kernel and 4.7k once the rarely used paths were
+// compiled out (-21 % per tile; -15 % on a 256 -> 256 layer, -17 % on a 512-deep 1x1).  Hence LEAN: the form nearly every layer
+// of the network uses (plain NHWC bf16 store, cout % 8 == 0, optional bf16 residual, none / ReLU / LeakyReLU, optional GroupNorm
+// partial sums) is compiled without the other paths; the host picks it whenever the descriptor allows (plan_x).  The transposed
+// kernels know their store map at compile time as well.
+template <int MT, int NT, bool GEMM, bool CONVT = false, bool LEAN = false>
+__device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, f32x16 (&acc)[MT][NT], int pix_base, int cout_base, int gn_part,
                                            const float* bias_lds, int li, int lh) {
+  XParams P = Pfull;          // (a by-value view whose fixed fields fold at compile time)
+  if (CONVT) P.store_mode = XS_CONVT;
+  else if (GEMM && P.store_mode != XS_KPACK) P.store_mode = XS_PLAIN;
+  if (LEAN) { P.store_mode = XS_PLAIN; P.pixmul = nullptr; P.out32 = nullptr; P.out_f32 = 0; P.res_f32 = 0; }
   const long long img_pix0 = (long long)g.img * P.OH * P.OW;
   const bool up = P.store_mode == XS_PIXSHUF || P.store_mode == XS_CONVT;
 #pragma unroll
@@ -126,7 +138,7 @@ __device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x
       } else if (P.act == GPEMSR_ACT_LRELU) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.1f * v[r]);
-      } else if (P.act != GPEMSR_ACT_NONE) {
+      } else if (!LEAN && P.act != GPEMSR_ACT_NONE) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], P.act);
       }
@@ -140,7 +152,7 @@ __device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x
           w8[j] = __uint_as_float(sw[0]); w8[4 + j] = __uint_as_float(sw[1]);
         }
         const int nidx = cb0 + 8 * (gp + lh);
-        const int nvalid = (P.cout - nidx) < 8 ? (P.cout - nidx) : 8;
+        const int nvalid = LEAN ? ((P.cout - nidx) > 0 ? 8 : 0) : ((P.cout - nidx) < 8 ? (P.cout - nidx) : 8);
         if (!pok || nvalid <= 0) continue;
         int ch = nidx, sy = 0, sx = 0;
         if (P.store_mode == XS_PIXSHUF) { const int q = nidx / P.cq; ch = nidx - q * P.cq; sy = q >> 1; sx = q & 1; }
@@ -273,7 +285,7 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
 // phase.  With NL loader waves beside the WM x WN multiplying waves the DMA issue stalls and the counted waits sit on waves
 // that have nothing else to do: per stage the multiplying waves run  MFMAs -> barrier , the loader waves  wait for stage
 // s + 1 -> barrier -> refill the slot the barrier freed , and both meet at the one barrier per stage.
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0>
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false>
 __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) void conv_bf16_kernel(XParams P) {
   constexpr int NC = WM * WN;          // multiplying waves
   constexpr bool SPEC = NL > 0;
@@ -668,7 +680,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
     if (ti + 2 < T_me) nxt = tile_geo(ti + 2);
 
     // ---- epilogue, straight from the accumulators (D^T: lane = pixel, registers = couts) ----
-    x_epilogue<MT, NT, GEMM>(P, g, acc, wm * PM, wn * WNT, g.tile_in_img * WM + wm, bias_lds, li, lh);
+    x_epilogue<MT, NT, GEMM, CONVT, LEAN>(P, g, acc, wm * PM, wn * WNT, g.tile_in_img * WM + wm, bias_lds, li, lh);
     XSEG(5);
   }
   XSEG_FLUSH;
@@ -687,6 +699,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
 // barriers per tile, no DMA accounting beyond vmcnt(0) (each image was issued a whole phase earlier).
 // Staged bytes per FLOP drop 2.7x against the ring kernel (78 KB per 37.7 MFLOP instead of 117 KB per 18.9).
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool LEAN>
 __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
   constexpr int TH = 16, HALO_W = 34, HALO_H = 18, HALO_PX = HALO_W * HALO_H, R = 4;
   constexpr int A_BYTES = HALO_PX * R * 16;            // 39,168
@@ -849,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
       }
       XSEG(4);
     }
-    x_epilogue<MT, NT, false>(P, gcur, acc, wave * 64, 0, gcur.tile_in_img * 8 + wave, bias_lds, li, lh);
+    x_epilogue<MT, NT, false, false, LEAN>(P, gcur, acc, wave * 64, 0, gcur.tile_in_img * 8 + wave, bias_lds, li, lh);
     n_st = 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -863,9 +876,9 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
   XSEG_FLUSH;
 }
 
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0>
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false>
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL>;
+  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -894,7 +907,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
 using namespace gpemsr;
 
 namespace {
-struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident; size_t lds; };
+struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean; size_t lds; };
 
 // geometry + tile choice of one launch (shared by the launcher and by gpemsr_conv2d_bf16_gn_parts)
 int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
@@ -1041,6 +1054,9 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     lds = 73728 + 2 * 39168 + bias_bytes;
   }
   L.lds = lds;
+  // the lean epilogue (see x_epilogue) covers this descriptor?
+  L.lean = P.store_mode == XS_PLAIN && !d->out_f32 && !d->out32 && !d->pixmul && (!d->residual || !d->res_f32) && d->cout % 8 == 0 &&
+           (d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU);
   return GPEMSR_OK;
 }
 }  // namespace
@@ -1072,7 +1088,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
   if (L.resident) {
     static bool attr = false;
     if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(GPEMSR_ELAUNCH, "conv2d_bf16: cannot raise the dynamic LDS limit");
       attr = true;
     }
@@ -1082,7 +1099,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (gpt < 1) gpt = 1;
     if (gpt > P.ns) gpt = P.ns;
     P.gpt = gpt;
-    hipLaunchKernelGGL(conv64_resident_kernel, dim3(gpt * P.tiles_n), dim3(512), lds, st, P);
+    if (L.lean) hipLaunchKernelGGL(conv64_resident_kernel<true>, dim3(gpt * P.tiles_n), dim3(512), lds, st, P);
+    else hipLaunchKernelGGL(conv64_resident_kernel<false>, dim3(gpt * P.tiles_n), dim3(512), lds, st, P);
     return check_launch("conv64_resident_kernel");
   }
 #define GP_X(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
@@ -1090,6 +1108,14 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
 #define GP_IS(BNv, WMv, WNv, THv, TPSv) (L.BN == BNv && L.WM == WMv && L.WN == WNv && L.TH == THv && L.TPS == TPSv)
 #define GP_XL(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
   (L.CK == 32 ? launch_x<32, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st) : launch_x<16, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st))
+  if (L.lean) {               // lean-epilogue instantiations of the hottest tiles (anything else falls through to the general ones)
+    if (L.NL == 4 && !L.tr && !L.gemm && GP_IS(64, 8, 1, 16, 3))
+      return L.CK == 32 ? launch_x<32, 64, 8, 1, 16, 3, false, false, 4, true>(P, lds, st) : launch_x<16, 64, 8, 1, 16, 3, false, false, 4, true>(P, lds, st);
+    if (L.NL == 4 && L.gemm && GP_IS(128, 4, 2, 8, 1) && L.CK == 64) return launch_x<64, 128, 4, 2, 8, 1, false, true, 4, true>(P, lds, st);
+    if (L.NL == 0 && !L.tr && !L.gemm && GP_IS(32, 8, 1, 16, 7) && L.CK == 32) return launch_x<32, 32, 8, 1, 16, 7, false, false, 0, true>(P, lds, st);
+    if (L.NL == 0 && !L.tr && !L.gemm && GP_IS(64, 8, 1, 16, 7) && L.CK == 32) return launch_x<32, 64, 8, 1, 16, 7, false, false, 0, true>(P, lds, st);
+    if (L.NL == 4 && !L.tr && !L.gemm && GP_IS(32, 8, 1, 16, 7) && L.CK == 16) return launch_x<16, 32, 8, 1, 16, 7, false, false, 4, true>(P, lds, st);
+  }
   if (L.NL == 4) {            // loader-wave forms
     if (L.tr) return GP_XL(128, 8, 1, 8, 2, true, false);
     if (L.gemm) {
