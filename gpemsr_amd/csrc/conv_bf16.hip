@@ -49,7 +49,7 @@ __device__ unsigned long long g_xstamps[8 * 65536];
 #endif
 
 constexpr int XA_LOADS = 10;      // 16-B A slots per DMA thread (halo_px * R / DMA threads; 3x3 16x32 tile on 4 loader waves: 10)
-constexpr int XB_LOADS = 7;       // 16-B B slots per thread per stage (TPS * R * BN / 256; 7x7 row stage of 64 couts: 7)
+constexpr int XB_LOADS = 9;       // 16-B B slots per thread per stage (TPS * R * BN / 256; 7x7 row stage of 64 couts: 7)
 
 enum { XS_PLAIN = 0, XS_PIXSHUF = 1, XS_CONVT = 2, XS_KPACK = 3 };
 
@@ -985,10 +985,12 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
       if (var == 1) { TH = 8; TPS = 1; WM = 4; WN = 1; }          // 8x32 px, wave = 64 px x 128 couts, tap stages
       else if (var == 2) { TH = 4; TPS = 3; WM = 2; WN = 2; }     // 4x32 px x 128 couts, 256 threads, row stages
       else if (var == 4) { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; }   // big tile, 8 waves that all load and multiply
-      else { BN = 64; TH = 16; TPS = 3; WM = 8; WN = 1; NL = 4; }  // big tile: 16x32 px x 64 couts, 8 multiplying + 4 loader waves
+      // big tile: 16x32 px x 64 couts, 8 multiplying + 4 loader waves; a stage is a whole 32-channel chunk (9 taps: one barrier per
+      // 72 MFMAs of a wave; +10-13 % over row stages), variant 5: row stages
+      else { BN = 64; TH = 16; TPS = (var == 5 || nchunk_total < 2) ? 3 : 9; WM = 8; WN = 1; NL = 4; }
     }
     else if (var == 1 || var == 2) { TH = 8; TPS = (var == 1) ? 1 : 3; WM = 4; WN = 1; }   // 256-thread forms
-    else { TH = 16; TPS = 3; WM = 8; WN = 1; NL = 4; }            // couts <= 64 on the same loader-wave big tile
+    else { TH = 16; TPS = (var == 5 || BN == 32 || nchunk_total < 2) ? 3 : 9; WM = 8; WN = 1; NL = 4; }   // (one chunk: row stages keep the ring busy)   // couts <= 64 on the same loader-wave big tile
   }
   L.BN = BN; L.TH = TH; L.TPS = TPS; L.WM = WM; L.WN = WN; L.NL = NL;
   GP_REQUIRE(!(P.store_mode == XS_PIXSHUF) || P.cq % 8 == 0, "conv2d_bf16: pixel_shuffle needs cout%%32==0");
@@ -1109,6 +1111,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
 #define GP_XL(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
   (L.CK == 32 ? launch_x<32, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st) : launch_x<16, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st))
   if (L.lean) {               // lean-epilogue instantiations of the hottest tiles (anything else falls through to the general ones)
+    if (L.NL == 4 && !L.tr && !L.gemm && GP_IS(64, 8, 1, 16, 9))
+      return L.CK == 32 ? launch_x<32, 64, 8, 1, 16, 9, false, false, 4, true>(P, lds, st) : launch_x<16, 64, 8, 1, 16, 9, false, false, 4, true>(P, lds, st);
     if (L.NL == 4 && !L.tr && !L.gemm && GP_IS(64, 8, 1, 16, 3))
       return L.CK == 32 ? launch_x<32, 64, 8, 1, 16, 3, false, false, 4, true>(P, lds, st) : launch_x<16, 64, 8, 1, 16, 3, false, false, 4, true>(P, lds, st);
     if (L.NL == 4 && L.gemm && GP_IS(128, 4, 2, 8, 1) && L.CK == 64) return launch_x<64, 128, 4, 2, 8, 1, false, true, 4, true>(P, lds, st);
@@ -1123,6 +1127,7 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
       if (GP_IS(128, 4, 2, 8, 1)) return GP_XL(128, 4, 2, 8, 1, false, true);
       if (GP_IS(64, 8, 1, 16, 1)) return GP_XL(64, 8, 1, 16, 1, false, true);
     }
+    else if (GP_IS(64, 8, 1, 16, 9)) return GP_XL(64, 8, 1, 16, 9, false, false);
     else if (GP_IS(64, 8, 1, 16, 3)) return GP_XL(64, 8, 1, 16, 3, false, false);
     else if (GP_IS(32, 8, 1, 16, 3)) return GP_XL(32, 8, 1, 16, 3, false, false);
     else if (GP_IS(64, 8, 1, 16, 7) && L.CK == 16) return launch_x<16, 64, 8, 1, 16, 7, false, false, 4>(P, lds, st);

@@ -19,9 +19,9 @@ SHAPES = [
     ("recon 64->64 3x3 @128^2 x16", "conv", 16, 64, 64, 3, 1, 128, 128, (0, 3)),
     ("mpf 64->64 3x3 @512^2 x8", "conv", 8, 64, 64, 3, 1, 512, 512, (0, 3)),
     ("vgg/HR 64->64 3x3 @1024^2 x4", "conv", 4, 64, 64, 3, 1, 1024, 1024, (0, 3)),
-    ("dec 128->128 3x3 @256^2 x16", "conv", 16, 128, 128, 3, 1, 256, 256, (0, 2, 4)),
-    ("vq 256->256 3x3 @128^2 x80", "conv", 80, 256, 256, 3, 1, 128, 128, (0, 2, 4)),
-    ("vq 512->512 3x3 @64^2 x80", "conv", 80, 512, 512, 3, 1, 64, 64, (0, 2, 4)),
+    ("dec 128->128 3x3 @256^2 x16", "conv", 16, 128, 128, 3, 1, 256, 256, (0, 5)),
+    ("vq 256->256 3x3 @128^2 x80", "conv", 80, 256, 256, 3, 1, 128, 128, (0, 5)),
+    ("vq 512->512 3x3 @64^2 x80", "conv", 80, 512, 512, 3, 1, 64, 64, (0, 5)),
     ("mpf 128->64 3x3 @512^2 x8", "conv", 8, 128, 64, 3, 1, 512, 512, (0, 2)),
     ("up 64->256 3x3+ps @512^2 x4", "ps", 4, 64, 256, 3, 1, 512, 512, (0, 3)),
     ("1x1 512->512 @64^2 x80", "conv", 80, 512, 512, 1, 1, 64, 64, (0, 1)),
