@@ -285,14 +285,14 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
 // phase.  With NL loader waves beside the WM x WN multiplying waves the DMA issue stalls and the counted waits sit on waves
 // that have nothing else to do: per stage the multiplying waves run  MFMAs -> barrier , the loader waves  wait for stage
 // s + 1 -> barrier -> refill the slot the barrier freed , and both meet at the one barrier per stage.
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false>
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false, int SS = 0>
 __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) void conv_bf16_kernel(XParams P) {
   constexpr int NC = WM * WN;          // multiplying waves
   constexpr bool SPEC = NL > 0;
   constexpr int NTH = (NC + NL) * 64;  // 256 threads: two workgroups per CU; 512 threads ("big tile" forms): one
   constexpr int DTH = SPEC ? NL * 64 : NTH;   // threads that issue DMA
   constexpr int KW = GEMM ? 1 : (CONVT ? 2 : (TPS == 7 ? 7 : 3));
-  constexpr int S = (!GEMM && !CONVT && TH == 2) ? 2 : 1;
+  constexpr int S = SS ? SS : ((!GEMM && !CONVT && TH == 2) ? 2 : 1);     // SS: explicit stride (the 4-row stride-2 loader-wave tile)
   constexpr int KK = KW * KW;
   constexpr int SPC = KK / TPS;        // stages per chunk
   static_assert(KK % TPS == 0, "taps per stage must divide the tap count");
@@ -876,9 +876,9 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
   XSEG_FLUSH;
 }
 
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false>
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0>
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN>;
+  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -980,7 +980,11 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
         if (var != 4 && CK == 16) NL = 4;
       }
     }
-    else if (d->stride == 2) { TH = 2; WM = 2; WN = 2; TPS = (BN == 128) ? 1 : 3; }
+    else if (d->stride == 2) {
+      TH = 2; WM = 2; WN = 2; TPS = (BN == 128) ? 1 : 3;
+      // loader-wave form: 4 x 32 output pixels (9 x 65 halo) x 128 / 64 couts on 4 x 2 multiplying waves
+      if (var != 1 && BN >= 64 && CK == 32) { TH = 4; WM = 4; WN = 2; TPS = 3; NL = 4; }
+    }
     else if (BN == 128) {
       if (var == 1) { TH = 8; TPS = 1; WM = 4; WN = 1; }          // 8x32 px, wave = 64 px x 128 couts, tap stages
       else if (var == 2) { TH = 4; TPS = 3; WM = 2; WN = 2; }     // 4x32 px x 128 couts, 256 threads, row stages
@@ -1127,6 +1131,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
       if (GP_IS(128, 4, 2, 8, 1)) return GP_XL(128, 4, 2, 8, 1, false, true);
       if (GP_IS(64, 8, 1, 16, 1)) return GP_XL(64, 8, 1, 16, 1, false, true);
     }
+    else if (GP_IS(128, 4, 2, 4, 3) && L.CK == 32) return launch_x<32, 128, 4, 2, 4, 3, false, false, 4, false, 2>(P, lds, st);
+    else if (GP_IS(64, 4, 2, 4, 3) && L.CK == 32) return launch_x<32, 64, 4, 2, 4, 3, false, false, 4, false, 2>(P, lds, st);
     else if (GP_IS(64, 8, 1, 16, 9)) return GP_XL(64, 8, 1, 16, 9, false, false);
     else if (GP_IS(64, 8, 1, 16, 3)) return GP_XL(64, 8, 1, 16, 3, false, false);
     else if (GP_IS(32, 8, 1, 16, 3)) return GP_XL(32, 8, 1, 16, 3, false, false);
