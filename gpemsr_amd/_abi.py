@@ -74,7 +74,7 @@ class ConvDesc16(C.Structure):
         ("pixmul", C.c_void_p), ("pixel_shuffle", C.c_int32), ("kpack", C.c_int32),
         ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_f32", C.c_int32),
         ("out32", C.c_void_p), ("out32_ld", C.c_int32),
-        ("gn_partials", C.c_void_p), ("variant", C.c_int32),
+        ("gn_partials", C.c_void_p), ("variant", C.c_int32), ("gn_cpg", C.c_int32),
     ]
 
 

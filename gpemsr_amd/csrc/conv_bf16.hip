@@ -69,7 +69,7 @@ struct XParams {
   int store_mode, cq;
   void* out; int out_ld, out_f32;
   float* out32; int out32_ld;
-  float* gn_ws; int gn_parts;                // [n][gn_parts = tiles per image][cout][2]
+  float* gn_ws; int gn_parts, gn_cpg;        // [n][gn_parts = tiles per image][cout][2]; channels per GroupNorm group
   long long kpack_img_stride;                // XS_KPACK: elements between images of the packed output
   int tiles_x, tiles_y, tiles_n;
   int halo_h, halo_w, halo_px;
@@ -220,41 +220,51 @@ __device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, 
     }
   }
   if (P.gn_ws) {
-#pragma unroll 1
+    // Partial sums of (conv + bias) and its square over the tile's valid pixels, per channel -- or per 2 / 4 neighbouring channels
+    // when they belong to one GroupNorm group (gn_cpg): registers 4q .. 4q+3 of a lane are 4 consecutive channels, so that sum is
+    // free, and every value left costs a 32-lane reduction.  The reduction runs on DPP adds (quad swaps, half-row and row mirrors,
+    // one row broadcast: 5 VALU operations per value); the first version's shuffles went through the LDS crossbar and cost the
+    // 64-channel VQGAN layers half of their time again.
+    const int gs = (P.gn_cpg % 4 == 0 && P.gn_cpg > 0) ? 4 : ((P.gn_cpg % 2 == 0 && P.gn_cpg > 0) ? 2 : 1);
+    auto row_sum32 = [](float v) -> float {           // lanes 16-31 (48-63) end up with the sum over lanes 0-31 (32-63)
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast15 into rows 1, 3
+      return v;
+    };
+#pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cb0 = g.n0 + cout_base + nt * 32;
-      float bs[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        bs[r] = (P.bias && co < P.cout) ? bias_lds[co] : 0.f;
-      }
-      float gsum[16], gsq[16];
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = cb0 + 8 * q + 4 * lh;             // this lane's channels c0 .. c0+3 (registers 4q .. 4q+3)
+        float sm[4], sq[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { gsum[r] = 0.f; gsq[r] = 0.f; }
+        for (int j = 0; j < 4; ++j) { sm[j] = 0.f; sq[j] = 0.f; }
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (P.bias && c0 < P.cout) { const float4 t = *reinterpret_cast<const float4*>(bias_lds + c0); b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w; }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int p = pix_base + mt * 32 + li;
-        bool pok;
-        if (GEMM) pok = g.ox0 + p < P.oh * P.ow;
-        else pok = (g.oy0 + (p >> 5)) < P.oh && (g.ox0 + (p & 31)) < P.ow;
-        // static register indexing (guide rule 20): select the accumulator tile with a compile-time index
+        for (int mt = 0; mt < MT; ++mt) {
+          const int p = pix_base + mt * 32 + li;
+          bool pok;
+          if (GEMM) pok = g.ox0 + p < P.oh * P.ow;
+          else pok = (g.oy0 + (p >> 5)) < P.oh && (g.ox0 + (p & 31)) < P.ow;
+          if (pok) {
 #pragma unroll
-        for (int n2 = 0; n2 < NT; ++n2)
-          if (n2 == nt && pok) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float v = acc[mt][n2][r] + bs[r]; gsum[r] += v; gsq[r] = fmaf(v, v, gsq[r]); }
+            for (int j = 0; j < 4; ++j) { const float v = acc[mt][nt][4 * q + j] + b4[j]; sm[j] += v; sq[j] = fmaf(v, v, sq[j]); }
           }
-      }
+        }
+        if (gs == 4) { sm[0] = (sm[0] + sm[1]) + (sm[2] + sm[3]); sq[0] = (sq[0] + sq[1]) + (sq[2] + sq[3]); sm[1] = sm[2] = sm[3] = 0.f; sq[1] = sq[2] = sq[3] = 0.f; }
+        else if (gs == 2) { sm[0] += sm[1]; sq[0] += sq[1]; sm[2] += sm[3]; sq[2] += sq[3]; sm[1] = sm[3] = 0.f; sq[1] = sq[3] = 0.f; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = gsum[r], b = gsq[r];
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        const int co = cb0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (li == 0 && co < P.cout) {
-          float* wsp = P.gn_ws + (((long long)g.img * P.gn_parts + gn_part) * P.cout + co) * 2;
-          wsp[0] = a; wsp[1] = b;
+        for (int j = 0; j < 4; ++j)
+          if (j % gs == 0) { sm[j] = row_sum32(sm[j]); sq[j] = row_sum32(sq[j]); }
+        if (li == 16 && c0 < P.cout) {                    // (couts are a multiple of 4 wherever partial sums are requested: host)
+          float* wsp = P.gn_ws + (((long long)g.img * P.gn_parts + gn_part) * P.cout + c0) * 2;
+          *reinterpret_cast<float4*>(wsp) = make_float4(sm[0], sq[0], sm[1], sq[1]);
+          *reinterpret_cast<float4*>(wsp + 4) = make_float4(sm[2], sq[2], sm[3], sq[3]);
         }
       }
     }
@@ -876,6 +886,208 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
   XSEG_FLUSH;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer (3x3, stride 1, 64 input channels, weights resident) with its phases OVERLAPPED.  Stamps of the kernel above:
+// a tile spends 42 % of its time in the MFMA stages, 26 % waiting for halo images, 8 % issuing them and 24 % in the epilogue
+// (store-throughput bound: 64 KB of results per tile) -- one after the other, because all eight waves are in the same phase.
+// Here a 768-thread workgroup holds TWO groups of four multiplying waves (one wave per SIMD each) and four loader waves:
+//   * group g walks its own stream of 8 x 32-pixel tiles in three intervals per tile -- chunk 0, chunk 1, epilogue -- and
+//     group 1 runs one interval behind group 0, so in every interval at least one group feeds the matrix pipe while the other
+//     stores its results:  (C0 | E) (C1 | C0) (E | C1) ...  One workgroup-wide barrier ends each interval.
+//   * the loader waves issue the halo images (10 x 34 pixels x 32 channels, two buffers per group) for tile k + 1 as soon as
+//     the barrier has freed a buffer -- three intervals before it is needed -- and absorb the DMA issue stalls and the waits.
+// LDS: weights 73,728 + 4 x 21,760 + bias <= 163,840 bytes.
+template <bool LEAN>
+__global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
+  constexpr int HALO_W = 34, HALO_H = 10, HALO_PX = HALO_W * HALO_H, R = 4;
+  constexpr int A_BYTES = HALO_PX * R * 16;            // 21,760
+  constexpr int W_BYTES = 2 * 9 * 4 * 64 * 16;         // 73,728
+  constexpr int NA = (HALO_PX * R + 255) / 256;        // 6 slots per loader thread per image
+  constexpr int NW = W_BYTES / 16 / 256;               // 18 slots per loader thread for the weight slab
+  constexpr int MT = 2, NT = 2;
+  extern __shared__ __attribute__((aligned(16))) char xsm[];
+  float* const bias_lds = reinterpret_cast<float*>(xsm + W_BYTES + 4 * A_BYTES);
+  const unsigned xsm_lds = xlds_addr(xsm);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int tn = (int)blockIdx.x % P.tiles_n, sg = (int)blockIdx.x / P.tiles_n;
+  const int n0 = tn * 64;
+  const int gpt = P.gpt, NS = P.ns;
+  const int T_me = (NS - sg + gpt - 1) / gpt;          // 8 x 32 tiles of this workgroup: tile j = 2 k + g goes to group g
+  const int T0 = (T_me + 1) / 2, T1 = T_me / 2;
+  const int NI = (3 * T0 > 3 * T1 + 1) ? 3 * T0 : 3 * T1 + 1;      // intervals (T1 <= T0 <= T1 + 1)
+
+  x_stage_bias(P, bias_lds, P.nbias, 768);
+
+  auto tile_geo = [&](int j) -> XGeo {
+    int t = sg + j * gpt;
+    const int tx = t % P.tiles_x; t /= P.tiles_x;
+    const int ty = t % P.tiles_y; t /= P.tiles_y;
+    XGeo g;
+    g.img = t; g.n0 = n0; g.oy0 = ty * 8; g.ox0 = tx * 32; g.tile_in_img = ty * P.tiles_x + tx;
+    return g;
+  };
+  auto end_interval = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= 8) {
+    // ------------------------------------------------ loader waves ------------------------------------------------
+    const int dtid = tid - 512, dwave = wave - 8;
+    const unsigned lds0 = xuni(xsm_lds + (unsigned)dwave * 1024u);
+    const unsigned pixb = (unsigned)P.ld[0] * 2u;
+    int issued = 0;
+    {   // weight slab: rows n0 .. n0+63 of every (chunk, tap, piece) -- 72 runs of 1 KiB (rows past cout clamped)
+      const unsigned short* wp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.weight));
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int e = dtid + i * 256;
+        int row = n0 + (e & 63);
+        row = row < P.cout ? row : P.cout - 1;
+        xglds16((unsigned)((e >> 6) * P.cout + row) * 16u, wp, lds0 + i * 4096u);
+      }
+      issued += NW;
+    }
+    int a_pix[2][NA];                                  // per group: the tile whose images are being issued
+    int a_img[2] = {0, 0}, a_cnt[2] = {0, 0};
+    bool a_pad[2] = {false, false};
+    int mark[2][2] = {{0, 0}, {0, 0}};
+    auto enter = [&](const int g, int k) {             // g compile-time
+      const XGeo t = tile_geo(2 * k + g);
+      int cnt = 0; bool pad = false;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = dtid + i * 256;
+        int pix = -1;
+        if (e < HALO_PX * R) {
+          const int hp = e / R;
+          const int iy = t.oy0 - 1 + hp / HALO_W, ix = t.ox0 - 1 + hp % HALO_W;
+          if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) pix = iy * P.w + ix;
+          pad = pad || pix < 0;
+        }
+        a_pix[g][i] = pix;
+        cnt += (__ballot(pix >= 0) != 0ull) ? 1 : 0;
+      }
+      a_img[g] = t.img; a_cnt[g] = cnt; a_pad[g] = __ballot(pad) != 0ull;
+    };
+    auto issue = [&](const int g, const int c) {       // image of chunk c of group g's current tile -> buffer (g, c)
+      const unsigned short* sp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.src[0] + (long long)a_img[g] * P.img_stride[0] + c * 32));
+      const unsigned la = xuni(lds0 + (unsigned)(W_BYTES + (2 * g + c) * A_BYTES));
+      if (a_pad[g]) {
+        char* ab = xsm + W_BYTES + (2 * g + c) * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          if (dtid + i * 256 < HALO_PX * R && a_pix[g][i] < 0) *reinterpret_cast<float4*>(ab + (dtid + i * 256) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (a_pix[g][i] >= 0) {
+          const int e = dtid + i * 256, hp = e / R;
+          const unsigned q = (unsigned)((e % R) ^ ((hp >> 2) & 3));
+          xglds16((unsigned)a_pix[g][i] * pixb + 16u * q, sp, la + i * 4096u);
+        }
+      issued += a_cnt[g];
+      mark[g][c] = issued;
+    };
+    // prologue: tile 0 of both groups, in the order of use
+    enter(0, 0); issue(0, 0); issue(0, 1);
+    if (T1 > 0) { enter(1, 0); issue(1, 0); issue(1, 1); }
+    xwait_vmcnt(issued - mark[0][0]);
+    end_interval();
+    for (int i = 0; i < NI; ++i) {
+      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-g) % 3 of its tile (i-1-g) / 3 in interval i-1
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int u = i - 1 - g;
+        if (u >= 0) {
+          const int k = u / 3, c = u - 3 * k;
+          if (c < 2 && k + 1 < (g ? T1 : T0)) {
+            if (c == 0) { enter(g, k + 1); issue(g, 0); } else issue(g, 1);
+          }
+        }
+      }
+      // the images interval i + 1 reads must have landed
+      int need = 0;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int u = i + 1 - g;
+        if (u >= 0) {
+          const int k = u / 3, c = u - 3 * k;
+          if (c < 2 && k < (g ? T1 : T0)) { const int m = c ? mark[g][1] : mark[g][0]; need = m > need ? m : need; }
+        }
+      }
+      xwait_vmcnt(issued - need);
+      end_interval();
+    }
+    return;
+  }
+
+  // ------------------------------------------------ multiplying waves ------------------------------------------------
+  const int g = wave >> 2, w4 = wave & 3;              // group, wave of the group: pixel rows 2 w4, 2 w4 + 1 of the 8 x 32 tile
+  const int T_g = g ? T1 : T0;
+  // fragment byte offsets (tile-invariant): one entry per (halo row, kx); k-step 1 flips bit 5
+  unsigned aoff[MT + 2][3];
+#pragma unroll
+  for (int rr = 0; rr < MT + 2; ++rr)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int hp = (2 * w4 + rr) * HALO_W + li + kx;
+      aoff[rr][kx] = (unsigned)(W_BYTES + 2 * g * A_BYTES + hp * 64 + ((lh ^ ((hp >> 2) & 3)) * 16));   // (all bases are multiples of 64)
+    }
+  const unsigned b_frag = (unsigned)(li * 16 + lh * 1024);
+
+  end_interval();                                      // prologue barrier (weights + first image have landed)
+  for (int s = 0; s < g; ++s) end_interval();          // group 1 runs one interval behind
+  for (int k = 0; k < T_g; ++k) {
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll 1
+    for (int chunk = 0; chunk < 2; ++chunk) {
+      const unsigned A = (unsigned)(chunk * A_BYTES);
+      const unsigned B = b_frag + (unsigned)(chunk * (9 * 4 * 1024));
+      bf16x8 fa[2][MT], fb[2][NT];
+      auto load_step = [&](int set, int st) {
+        const int tap = st >> 1, ks = st & 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned o = aoff[mt + tap / 3][tap % 3];
+          fa[set][mt] = xlds_read16(xsm_lds + A + (ks ? (o ^ 32u) : o));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[set][nt] = xlds_read16(xsm_lds + B + (unsigned)((tap * 4 + 2 * ks) * 1024 + nt * 512));
+      };
+      load_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        if (st + 1 < 18) load_step((st + 1) & 1, st + 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st & 1][nt], fa[st & 1][mt], acc[mt][nt], 0, 0, 0);
+      }
+      end_interval();
+    }
+    const XGeo geo = tile_geo(2 * k + g);
+    // opaque per-tile copies of the lane coordinates: everything the epilogue derives from them (8 store addresses, residual
+    // addresses, ...) is tile-invariant, and hoisted above the MFMA loop it costs ~30 registers the 168-register budget does not
+    // have -- the spill reloads then sit behind the epilogue's own stores on the in-order vmcnt (measured: 1.35x slower)
+    int li2 = li, lh2 = lh;
+    asm volatile("" : "+v"(li2), "+v"(lh2));
+    x_epilogue<MT, NT, false, false, LEAN>(P, geo, acc, w4 * 64, 0, geo.tile_in_img * 4 + w4, bias_lds, li2, lh2);
+    end_interval();
+  }
+  for (int s = 3 * T_g + g; s < NI; ++s) end_interval();
+}
+
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0>
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
   auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS>;
@@ -907,7 +1119,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
 using namespace gpemsr;
 
 namespace {
-struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean; size_t lds; };
+struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean; int res_form; size_t lds; };
 
 // geometry + tile choice of one launch (shared by the launcher and by gpemsr_conv2d_bf16_gn_parts)
 int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
@@ -943,7 +1155,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.weight = reinterpret_cast<const unsigned short*>(d->weight); P.w_img_stride = d->weight_image_stride;
   P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.res_f32 = d->res_f32; P.pixmul = d->pixmul;
   P.out = d->out; P.out_ld = d->out_ld; P.out_f32 = d->out_f32; P.out32 = d->out32; P.out32_ld = d->out32_ld;
-  P.gn_ws = d->gn_partials;
+  P.gn_ws = d->gn_partials; P.gn_cpg = d->gn_cpg;
   P.nbias = d->cout;
   const int bias_bytes = ((d->cout + 7) & ~7) * 4;
   int BN, TH, TPS, WM, WN, NL = 0;
@@ -1020,7 +1232,8 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d_bf16: grid too large");
   P.nblocks = (int)nb;
   P.gn_parts = P.tiles_y * P.tiles_x * WM;                   // one row of partial sums per wave row of a tile
-  if (d->gn_partials) GP_REQUIRE(P.store_mode == XS_PLAIN && !tr, "conv2d_bf16: gn partial sums need the plain store");
+  if (d->gn_partials) GP_REQUIRE(P.store_mode == XS_PLAIN && !tr && d->cout % 4 == 0 && (reinterpret_cast<uintptr_t>(d->gn_partials) & 15) == 0,
+                                 "conv2d_bf16: gn partial sums need the plain store, cout %% 4 == 0 and a 16-byte aligned workspace");
   const int R = CK / 8;
   const int nth = (WM * WN + NL) * 64;
   const int dth = NL ? NL * 64 : nth;                       // threads that issue DMA
@@ -1051,13 +1264,17 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   if (!tr && !gemm && d->ksize == 3 && d->stride == 1 && d->nsrc == 1 && d->src[0].c == 64 && d->weight_image_stride == 0 && var != 3 &&
       bias_bytes <= 8 * 1024) {
     L.resident = true;
+    // form 2 (default): two staggered groups of multiplying waves + loader waves on 8 x 32 tiles; form 1 (variant 6, or a bias
+    // array that does not fit beside four halo buffers): eight waves in lockstep on 16 x 32 tiles
+    L.res_form = (var == 6 || bias_bytes > 3072) ? 1 : 2;
+    const int rows = L.res_form == 2 ? 8 : 16;
     P.tiles_n = cdiv(P.cout, 64);
-    P.tiles_x = cdiv(P.ow, 32); P.tiles_y = cdiv(P.oh, 16);
+    P.tiles_x = cdiv(P.ow, 32); P.tiles_y = cdiv(P.oh, rows);
     const long long ns = (long long)d->n * P.tiles_y * P.tiles_x;
     GP_REQUIRE(ns < (1ll << 31), "conv2d_bf16: grid too large");
     P.ns = (int)ns;
-    P.gn_parts = P.tiles_y * P.tiles_x * 8;
-    lds = 73728 + 2 * 39168 + bias_bytes;
+    P.gn_parts = P.tiles_y * P.tiles_x * (L.res_form == 2 ? 4 : 8);
+    lds = L.res_form == 2 ? 73728 + 4 * 21760 + bias_bytes : 73728 + 2 * 39168 + bias_bytes;
   }
   L.lds = lds;
   // the lean epilogue (see x_epilogue) covers this descriptor?
@@ -1095,7 +1312,9 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     static bool attr = false;
     if (!attr) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(GPEMSR_ELAUNCH, "conv2d_bf16: cannot raise the dynamic LDS limit");
       attr = true;
     }
@@ -1105,6 +1324,11 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (gpt < 1) gpt = 1;
     if (gpt > P.ns) gpt = P.ns;
     P.gpt = gpt;
+    if (L.res_form == 2) {
+      if (L.lean) hipLaunchKernelGGL(conv64_resident2_kernel<true>, dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
+      else hipLaunchKernelGGL(conv64_resident2_kernel<false>, dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
+      return check_launch("conv64_resident2_kernel");
+    }
     if (L.lean) hipLaunchKernelGGL(conv64_resident_kernel<true>, dim3(gpt * P.tiles_n), dim3(512), lds, st, P);
     else hipLaunchKernelGGL(conv64_resident_kernel<false>, dim3(gpt * P.tiles_n), dim3(512), lds, st, P);
     return check_launch("conv64_resident_kernel");

@@ -828,6 +828,7 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
             _abi.check(parts, "conv2d_bf16_gn_parts")
         ws = torch.empty(n * parts * pc.cout * 2, dtype=torch.float32, device=dev)
         d.gn_partials = ws.data_ptr()
+        d.gn_cpg = pc.cout // 32 if pc.cout % 32 == 0 else 1       # GroupNorm(32 groups) everywhere in the model (model/blocks.py:5-6)
         out.gn = (ws, parts)
 
     def _go():

@@ -141,6 +141,9 @@ typedef struct {
                                       GroupNorm (model/blocks.py:5-6) -- as [n][parts][cout][2], parts = gpemsr_conv2d_bf16_gn_parts();
                                       feed to gpemsr_groupnorm_finish.  NULL = none */
   int32_t variant;                 /* 0 = default tile choice; other values select alternative tilings (tuning only) */
+  int32_t gn_cpg;                  /* with gn_partials: channels per GroupNorm group (0 / 1: unknown).  When it is a multiple of 2 / 4 the
+                                    * kernel adds 2 / 4 neighbouring channels BEFORE the cross-lane reduction and leaves zeros in the other
+                                    * channel slots of the workspace -- the per-group totals gpemsr_groupnorm_finish forms are unchanged */
 } gpemsr_conv16_desc;
 
 int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream);

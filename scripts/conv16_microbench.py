@@ -15,15 +15,16 @@ from gpemsr_amd.packing import pack_conv, pack_conv_bf16, pack_conv_split, pack_
 
 SHAPES = [
     # name, kind, n, cin, cout, k, stride, h, w, variants
-    ("fe 64->64 3x3 @128^2 x80", "conv", 80, 64, 64, 3, 1, 128, 128, (0, 3)),
-    ("recon 64->64 3x3 @128^2 x16", "conv", 16, 64, 64, 3, 1, 128, 128, (0, 3)),
-    ("mpf 64->64 3x3 @512^2 x8", "conv", 8, 64, 64, 3, 1, 512, 512, (0, 3)),
-    ("vgg/HR 64->64 3x3 @1024^2 x4", "conv", 4, 64, 64, 3, 1, 1024, 1024, (0, 3)),
+    ("fe 64->64 3x3 @128^2 x80", "conv", 80, 64, 64, 3, 1, 128, 128, (0, 6)),
+    ("dec 64->64 3x3 @512^2 x80", "conv", 80, 64, 64, 3, 1, 512, 512, (0, 6)),
+    ("recon 64->64 3x3 @128^2 x16", "conv", 16, 64, 64, 3, 1, 128, 128, (0, 6)),
+    ("mpf 64->64 3x3 @512^2 x8", "conv", 8, 64, 64, 3, 1, 512, 512, (0, 6)),
+    ("vgg/HR 64->64 3x3 @1024^2 x4", "conv", 4, 64, 64, 3, 1, 1024, 1024, (0, 6)),
     ("dec 128->128 3x3 @256^2 x16", "conv", 16, 128, 128, 3, 1, 256, 256, (0, 5)),
     ("vq 256->256 3x3 @128^2 x80", "conv", 80, 256, 256, 3, 1, 128, 128, (0, 5)),
     ("vq 512->512 3x3 @64^2 x80", "conv", 80, 512, 512, 3, 1, 64, 64, (0, 5)),
     ("mpf 128->64 3x3 @512^2 x8", "conv", 8, 128, 64, 3, 1, 512, 512, (0, 2)),
-    ("up 64->256 3x3+ps @512^2 x4", "ps", 4, 64, 256, 3, 1, 512, 512, (0, 3)),
+    ("up 64->256 3x3+ps @512^2 x4", "ps", 4, 64, 256, 3, 1, 512, 512, (0, 6)),
     ("1x1 512->512 @64^2 x80", "conv", 80, 512, 512, 1, 1, 64, 64, (0, 1)),
     ("1x1 320->64 @128^2 x16", "conv", 16, 320, 64, 1, 1, 128, 128, (0, 1)),
     ("down 256->512 3x3 s2 @128^2 x80", "conv", 80, 256, 512, 3, 2, 128, 128, (0,)),
