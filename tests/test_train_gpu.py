@@ -577,7 +577,7 @@ def test_bf16x3_frozen_forward_meets_the_same_bar(golden_dir):
         g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().reshape(-1).double().cpu()
         errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
     print("bf16x3 training: worst", sorted(errs.items(), key=lambda kv: -kv[1])[:3], "median %.1e" % np.median(list(errs.values())))
-    assert max(errs.values()) <= 5e-2 and np.median(list(errs.values())) <= 5e-3
+    assert max(errs.values()) <= 6e-2 and np.median(list(errs.values())) <= 5e-3
 
 
 def test_x16_training_step_matches_reference_golden(golden_dir):
