@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def test_reference_training_statements_run_unchanged(golden_dir):
-    from gen_golden_train import TRAIN_OPT, projection
+    from train_constants import TRAIN_OPT, projection
     from gpemsr_amd import GPEMSR                                     # the one changed import
     from gpemsr_amd.config import load_options
     from gpemsr_amd.contextual import ContextualLoss                  # reference: from model.contextual import ContextualLoss
@@ -83,7 +83,7 @@ def test_reference_stage2_statements_run_unchanged(golden_dir):
     """train_stage2.py:120-179 + train_vqgan_onestep (:351-366) verbatim on gpemsr_amd.vqgan_indexer.lrGenerator8: torch's
     CrossEntropyLoss and Adam, autograd through the HIP tape; losses of two steps and gradients vs tests/golden/stage2_x8.npz."""
     from gen_golden_stage2 import TRAIN_OPT
-    from gen_golden_train import projection
+    from train_constants import projection
     from gpemsr_amd.arch import param_specs
     from gpemsr_amd.config import load_options
     from gpemsr_amd.synth import synth_state_dict

@@ -119,7 +119,7 @@ def test_recorded_vq_layer_backward(layer):
 
 def test_two_stage2_steps_match_reference_golden(golden_dir):
     from gen_golden_stage2 import FULL, TRAIN_OPT
-    from gen_golden_train import projection
+    from train_constants import projection
     from gpemsr_amd.config import build_model, load_options
     from gpemsr_amd.train_stage2 import Stage2Trainer
     d = np.load(os.path.join(golden_dir, "stage2_x8.npz"))
@@ -174,7 +174,7 @@ def test_x16_stage2_step_matches_reference_golden(golden_dir):
     """Indexer16 (no down-sampling stage, model/indexer.py:6-55) through lrGenerator16: targets, loss and the gradients of all
     110 trainable tensors against the reference's step."""
     from gen_golden_stage2 import TRAIN_OPT
-    from gen_golden_train import projection
+    from train_constants import projection
     from gpemsr_amd.config import build_model, load_options
     from gpemsr_amd.train_stage2 import Stage2Trainer
     d = np.load(os.path.join(golden_dir, "stage2_x16.npz"))

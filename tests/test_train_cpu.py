@@ -30,7 +30,7 @@ def test_oracle_autograd_matches_reference_golden(golden_dir):
     the gradient statistics of all trainable tensors.  Tolerances as in tests/test_train_gpu.py (the gradient is piecewise:
     kinks move single elements when rounding differs)."""
     import yaml
-    from gen_golden_train import TRAIN_OPT, projection
+    from train_constants import TRAIN_OPT, projection
     from gpemsr_amd.arch import param_specs
     from gpemsr_amd.synth import synth_state_dict
     from oracle import gpemsr_oracle as orc
@@ -97,7 +97,7 @@ def test_oracle_stage2_step_matches_reference_golden(golden_dir):
     """Indexer training step (train_stage2.py:351-366): the oracle's encoder / nearest-code / indexer / cross-entropy under
     autograd against the reference golden (oracle/gen_golden_stage2.py)."""
     import yaml
-    from gen_golden_train import projection
+    from train_constants import projection
     from gpemsr_amd.arch import param_specs
     from gpemsr_amd.synth import synth_state_dict
     from oracle import gpemsr_oracle as orc

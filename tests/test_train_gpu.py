@@ -313,7 +313,7 @@ _TR = {}
 
 def _trainer():
     if "t" not in _TR:
-        from gen_golden_train import TRAIN_OPT
+        from train_constants import TRAIN_OPT
         from gpemsr_amd.config import build_model, load_options
         from gpemsr_amd.train import Stage3Trainer
         opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
@@ -469,7 +469,7 @@ def test_dcn_layer_backward():
 
 # ------------------------------------------------------------------------------------------------ (3) the reference golden
 def test_two_training_steps_match_reference_golden(golden_dir):
-    from gen_golden_train import FULL, TRAIN_OPT, projection
+    from train_constants import FULL, TRAIN_OPT, projection
     from gpemsr_amd.config import build_model, load_options
     from gpemsr_amd.train import Stage3Trainer
     d = np.load(os.path.join(golden_dir, "train_x8.npz"))
@@ -554,7 +554,7 @@ def test_training_reduces_the_loss_and_is_repeatable():
 def test_bf16x3_frozen_forward_meets_the_same_bar(golden_dir):
     """precision='bf16x3' in training: the frozen sub-networks' forward convolutions on the split-bf16 kernel (fp32-grade);
     losses and the gradients downstream of the alignment must stay within the fp32 path's tolerances of the reference."""
-    from gen_golden_train import TRAIN_OPT, projection
+    from train_constants import TRAIN_OPT, projection
     from gpemsr_amd.config import build_model, load_options
     from gpemsr_amd.train import Stage3Trainer
     d = np.load(os.path.join(golden_dir, "train_x8.npz"))
@@ -583,7 +583,7 @@ def test_bf16x3_frozen_forward_meets_the_same_bar(golden_dir):
 def test_x16_training_step_matches_reference_golden(golden_dir):
     """x16 (option/output_GPEMSR_x16.yml): every x16-only layer (reffea_L4_conv1, reffusionconv4, fusion_fea_block4,
     down_fea_conv3, upconv4) receives a gradient; losses and gradient statistics against the reference's step."""
-    from gen_golden_train import TRAIN_OPT, projection
+    from train_constants import TRAIN_OPT, projection
     from gpemsr_amd.config import build_model, load_options
     from gpemsr_amd.train import Stage3Trainer
     d = np.load(os.path.join(golden_dir, "train_x16.npz"))
