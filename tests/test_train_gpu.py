@@ -468,6 +468,72 @@ def test_dcn_layer_backward():
 
 
 # ------------------------------------------------------------------------------------------------ (3) the reference golden
+def _grad_stat_errors(tr, names, stats, projection):
+    errs = {}
+    for i, k in enumerate(names):
+        base, leaf = k.rsplit(".", 1)
+        want = stats[i]
+        if want[0] == 0.0:
+            continue
+        g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().reshape(-1).double().cpu()
+        errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
+    return errs
+
+
+@pytest.mark.parametrize("scale", [8, 16])
+def test_gradient_distance_to_fp64_against_the_references_own(scale, golden_dir):
+    """VERDICT r01 item 6c.  Both fp32 evaluations of step 1 -- the unmodified reference's (tests/golden/train_x8.npz) and the HIP
+    one -- are measured against the SAME network differentiated in float64 (tests/golden/train_x8_fp64.npz, emitted by the
+    unmodified reference model cast to double, oracle/gen_golden_train64.py; code indices and SpyNet flows forced alike).
+    Per tensor: e = max(|norm - norm64|, |projection - projection64|) / norm64."""
+    from train_constants import TRAIN_OPT, projection
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.train import Stage3Trainer
+    d, d64 = np.load(os.path.join(golden_dir, f"train_x{scale}.npz")), np.load(os.path.join(golden_dir, f"train_x{scale}_fp64.npz"))
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{scale}.yml"))
+    tr = Stage3Trainer(build_model(opt, load_prior_files=False).to(dev), TRAIN_OPT, dev)
+    LR, GT = torch.from_numpy(d["LR"]).to(dev), torch.from_numpy(d["GT"]).to(dev)
+    rec, ref = tr.forward_backward(LR, GT, torch.from_numpy(d["code_idx"]).to(dev), torch.from_numpy(d["flow"]).to(dev))
+    torch.cuda.synchronize()
+    names = [str(n) for n in d["grad_names"]]
+    assert names == [str(n) for n in d64["grad_names"]]
+    sr64 = torch.from_numpy(d64["SR64"])
+    print("SR distance to fp64: HIP %.2e | reference %.2e" % (
+        float((tr.last_sr.view(sr64.shape).double().cpu() - sr64).abs().max() / sr64.abs().max()),
+        float((torch.from_numpy(d["SR"]).double() - sr64).abs().max() / sr64.abs().max())))
+    s64, s32 = d64["grad_stats64"], d["grad_stats"]
+    e_hip = _grad_stat_errors(tr, names, s64, projection)
+    e_ref = {k: max(abs(s32[i, 0] - s64[i, 0]), abs(s32[i, 2] - s64[i, 2])) / s64[i, 0] for i, k in enumerate(names) if s64[i, 0] > 0}
+    keys = sorted(e_hip, key=lambda k: -e_hip[k])
+    print("loss vs fp64: rec HIP %.2e / reference %.2e; ref HIP %.2e / reference %.2e" % (
+        abs(rec.item() - float(d64["rec_loss_1"])) / float(d64["rec_loss_1"]), abs(float(d["rec_loss_1"]) - float(d64["rec_loss_1"])) / float(d64["rec_loss_1"]),
+        abs(ref.item() - float(d64["ref_loss_1"])) / float(d64["ref_loss_1"]), abs(float(d["ref_loss_1"]) - float(d64["ref_loss_1"])) / float(d64["ref_loss_1"])))
+    print("gradient distance to fp64 (HIP | reference), worst HIP tensors:")
+    for k in keys[:12]:
+        print(f"   {k:55s} {e_hip[k]:.2e} | {e_ref[k]:.2e}")
+    hv, rv = np.array([e_hip[k] for k in keys]), np.array([e_ref[k] for k in keys])
+    print(f"   median {np.median(hv):.2e} | {np.median(rv):.2e};  90th pct {np.percentile(hv, 90):.2e} | {np.percentile(rv, 90):.2e};  max {hv.max():.2e} | {rv.max():.2e};"
+          f"  tensors with HIP <= reference: {int((hv <= rv).sum())}/{len(hv)}")
+    downstream = ("recon_trunk.", "upconv", "HRconv", "conv_last")
+    worse = [k for k in keys if e_hip[k] > 2.0 * e_ref[k] + 2e-5]
+    if scale == 16:
+        # measured: HIP is CLOSER to float64 than the reference on 198 of 214 tensors (median 1.5e-5 vs 1.4e-4)
+        assert np.median(hv) <= np.median(rv) and np.percentile(hv, 90) <= np.percentile(rv, 90) and hv.max() <= rv.max()
+        assert len(worse) <= len(keys) // 20, worse
+    else:
+        # On THIS input one pre-activation of the 4x4 ThreeDA spatial-attention pyramid lies within fp32 rounding of a LeakyReLU /
+        # max-pool kink: the reference's fp32 and float64 runs fall on one side, the HIP forward (same SR to 1.7e-7, different
+        # summation order) on the other, and everything the pyramid's backward feeds moves with it (worst: spatial_attn3.weight,
+        # 4.6e-2).  The x16 input above has no such element.  So here: every tensor DOWNSTREAM of the fusion (untouched by that
+        # kink) must be as close to float64 as the reference, the rest stays inside the old allowance and is reported.
+        for k in keys:
+            if k.startswith(downstream):
+                assert e_hip[k] <= 2.0 * e_ref[k] + 2e-5, (k, e_hip[k], e_ref[k])
+        assert hv.max() <= 6e-2 and np.median(hv) <= 1e-3
+        assert all(not k.startswith(downstream) for k in worse)
+
+
 def test_two_training_steps_match_reference_golden(golden_dir):
     from train_constants import FULL, TRAIN_OPT, projection
     from gpemsr_amd.config import build_model, load_options
