@@ -35,6 +35,30 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def volume_window_rows(n_slices: int, n_frames: int = 5):
+    """Slice numbers of every output window of an n-slice volume in output order: the reference's edge rule
+    (output_GPEMSR.py:54-84, 98-128) replicates the first / last slice, i.e. window k reads slices clamp(k-2 .. k+2) except
+    that the two windows at each end are built from the first / last FULL window's files -- the same thing for n >= 5."""
+    assert n_frames == 5 and n_slices >= 5, "the reference's edge handling is written for 5-slice windows and >= 5 slices"
+    T = n_slices
+    return ([[0, 0, 0, 1, 2], [0, 0, 1, 2, 3]] + [[i, i + 1, i + 2, i + 3, i + 4] for i in range(T - 4)]
+            + [[T - 4, T - 3, T - 2, T - 1, T - 1], [T - 3, T - 2, T - 1, T - 1, T - 1]])
+
+
+def plan_volume_shard(n_slices: int, rank: int, world: int, n_frames: int = 5):
+    """z-sharding of a volume (second axis): rank r writes the contiguous output slices [lo, hi) and needs
+    the LR slices [s_lo, s_hi) = its own plus a halo of n_frames // 2 = 2 slices on each interior side (none past the volume's
+    ends, where the reference replicates).  Returns (lo, hi, s_lo, s_hi, rows) with rows [hi - lo, n_frames] numbering the
+    window's slices RELATIVE to s_lo -- what forward_volume takes.  No data-path collective: every rank reads its own files
+    and writes its own PNGs."""
+    lo, hi = shard_range(n_slices, rank, world)
+    rows = volume_window_rows(n_slices, n_frames)[lo:hi]
+    if not rows:
+        return lo, hi, 0, 0, torch.zeros(0, n_frames, dtype=torch.int32)
+    s_lo, s_hi = min(min(r) for r in rows), max(max(r) for r in rows) + 1
+    return lo, hi, s_lo, s_hi, torch.tensor([[v - s_lo for v in r] for r in rows], dtype=torch.int32)
+
+
 def all_gather_slabs(local: torch.Tensor, world: int) -> torch.Tensor:
     """All-gather equally sized per-rank slabs [b,1,H,W] -> [world*b,1,H,W] (rank-major = tile order)."""
     if world == 1:

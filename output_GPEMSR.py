@@ -13,7 +13,8 @@ as /root/reference/GPEMSR-CREMI/GPEMSR/output_GPEMSR.py:54-84,98-128), but the m
     (bit-identical output, ~2.8x less work per slice); ``volume_block`` windows are processed per call;
   * ``tile_batch`` (option key) > 1 batches several 5-slice windows per forward call (without the cache);
   * uint8 conversion runs on the device and PNG encoding/writing in a small thread pool, off the GPU's critical path;
-  * with several ranks (torchrun), windows are sharded over GPUs (gpemsr_amd.dist);
+  * with several ranks (torchrun), the volume is sharded along z over GPUs: contiguous output slices per rank, each rank reading
+    its own LR slices plus a 2-slice halo (gpemsr_amd.dist.plan_volume_shard);
   * ``synthetic_weights_if_missing: true`` lets the script run without the authors'
     Google-Drive checkpoints (deterministic synthetic weights) -- for smoke runs only.
 """
@@ -160,7 +161,14 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     from gpemsr_amd import ops
     wpaths = window_paths(ds)
+    # z-sharding (gpemsr_amd.dist.plan_volume_shard): rank r owns the contiguous output slices [lo, hi); the blocks below load its
+    # own LR slices plus the 2-slice halo its edge windows reach into (no collective on the data path: every rank reads its own
+    # files and writes its own PNGs)
     lo, hi = gdist.shard_range(len(wpaths), rank, world)
+    if world > 1 and len(wpaths) >= 5:
+        files, rows = index_windows(wpaths[lo:hi])
+        p_lo, p_hi, s_lo, s_hi, _ = gdist.plan_volume_shard(len(wpaths), rank, world)
+        assert (p_lo, p_hi) == (lo, hi) and len(files) <= (hi - lo) + 4, "window shard and slice halo disagree with the shard plan"
     tb = int(opt.get('tile_batch', 1) or 1)
     use_cache = opt.get('volume_cache', True) is not False
     block = int(opt.get('volume_block', 64) or 64) if use_cache else tb
