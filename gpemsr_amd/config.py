@@ -33,6 +33,10 @@ def build_model(opt: dict, load_prior_files: bool = True, **extra):
     """GPEMSR(...) exactly as output_GPEMSR.py:36-43 constructs it."""
     from .model import GPEMSR
     net = opt["network"]
+    # additive option key (not in the reference's YAMLs): `precision: fp32 | bf16x3 | bf16` under `network:` or at the top level
+    prec = net.get("precision") or opt.get("precision")
+    if prec and "precision" not in extra:
+        extra["precision"] = str(prec)
     return GPEMSR(ref_path_G=net["ref_path_G"] if load_prior_files else None,
                   ref_path_Indexer=net["ref_path_Indexer"] if load_prior_files else None,
                   argref=net["argref"], nf=net["nf"], nframes=net["nframes"], groups=net["groups"],
