@@ -520,6 +520,64 @@ class _TrainerState:
         self.eng.refresh_weights()
 
 
+    # ---- exchange with the reference's checkpoints (train_stage3.py:183-184 saves optimizer.state_dict() / scheduler.state_dict()) ----
+    def _flat_params(self):
+        """(name, offset, shape) of every trainable parameter inside the flat buffers, in optimizer order."""
+        base, out = self.flat_p.data_ptr(), []
+        for k, p in self.model.named_parameters():
+            off = (p.data_ptr() - base) // 4
+            if 0 <= off < self.flat_p.numel() and p.requires_grad:
+                out.append((k, int(off), tuple(p.shape)))
+        return out
+
+    def torch_optimizer_state_dict(self) -> dict:
+        """The Adam state in ``torch.optim.Adam.state_dict()`` layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``, one param
+        group over the trainable parameters in ``named_parameters()`` order, which is how train_stage3.py:153-158 builds it), so a run
+        can be resumed by the reference and vice versa."""
+        state, params = {}, self._flat_params()
+        for i, (k, off, shape) in enumerate(params):
+            n = 1
+            for d in shape:
+                n *= d
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.flat_m[off:off + n].detach().clone().view(shape),
+                        "exp_avg_sq": self.flat_v[off:off + n].detach().clone().view(shape)}
+        group = {"lr": float(self.lr), "betas": (float(self.opt.get("beta1", 0.9)), float(self.opt.get("beta2", 0.99))), "eps": 1e-8,
+                 "weight_decay": float(self.opt.get("weight_decay_G", 0) or 0), "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "initial_lr": float(self.opt.get("lr_G", self.lr)),
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_torch_optimizer_state_dict(self, sd: dict, scheduler_state: dict = None):
+        """Inverse of ``torch_optimizer_state_dict``: accepts what ``torch.optim.Adam.state_dict()`` returns for the same parameter
+        list (and optionally the reference scheduler's ``state_dict()``, of which ``last_epoch`` positions this scheduler)."""
+        params = self._flat_params()
+        assert len(sd["param_groups"]) == 1 and len(sd["param_groups"][0]["params"]) == len(params), "optimizer state for another parameter list"
+        steps = set()
+        for i, (k, off, shape) in enumerate(params):
+            st = sd["state"].get(i)
+            if st is None:                   # a parameter torch never stepped (no gradient): moments stay zero
+                continue
+            assert tuple(st["exp_avg"].shape) == shape, (k, tuple(st["exp_avg"].shape), shape)
+            n = st["exp_avg"].numel()
+            self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(self.flat_m.device, torch.float32))
+            self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.flat_v.device, torch.float32))
+            steps.add(int(float(st["step"])))
+        assert len(steps) <= 1, f"per-parameter step counters differ: {sorted(steps)}"
+        if steps:
+            self.step_count = steps.pop()
+        self.lr = float(sd["param_groups"][0]["lr"])
+        if scheduler_state is not None and "last_epoch" in scheduler_state:
+            e = int(scheduler_state["last_epoch"])
+            sc = self.sched
+            sc.last_epoch, sc.lr = e, self.lr           # the optimizer's lr IS the scheduler's last value (its recurrence continues from it)
+            if hasattr(sc, "last_restart"):             # cosine: which period we are in (the reference's state dict carries these)
+                past = [r for r in sc.restarts if r <= e]
+                sc.last_restart = int(scheduler_state.get("last_restart", past[-1] if past else 0))
+                sc.T_max = int(scheduler_state.get("T_max", sc.T_period[len(past)] if past else sc.T_period[0]))
+        self.eng.refresh_weights()
+
+
 class Stage3Trainer(_TrainerState):
     """``train_EMSR_onestep`` (train_stage3.py:343-366).  ``opt_train`` is the ``train:`` block of
     option/train_stage3_x{8,16}.yml (lr_G, beta1, beta2, lr_scheme, T_period, restarts, restart_weights, eta_min,

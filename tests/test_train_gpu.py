@@ -739,3 +739,70 @@ def test_trainer_resume_continues_bit_for_bit_on_the_optimizer_side():
     assert a.lr == b.lr and a.step_count == b.step_count == 2
     _close(b.flat_p, a.flat_p, 1e-6, "parameters after resume")
     _close(b.flat_m, a.flat_m, 1e-4, "exp_avg after resume")
+
+
+def test_optimizer_state_round_trips_through_torch_adam_format():
+    """the flat Adam moments export as / import from ``torch.optim.Adam.state_dict()`` (what train_stage3.py:183
+    saves), so a run can move between the reference loop and this trainer.  Cross-check with a real torch Adam over the same
+    parameter list: it must accept the exported dict, and a trainer loaded from torch's own state dict continues identically."""
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    topt = dict(lr_G=2e-4, beta1=0.9, beta2=0.99, T_period=[4, 6], restarts=[4], restart_weights=[0.5], eta_min=1e-7,
+                rec_loss_factor=1, ref_loss_factor=0.001)
+    LR = synth_lr_tiles(1, 5, 16, 16, seed=41, kind="smooth").to(dev)
+    GT = torch.rand(1, 1, 128, 128, generator=torch.Generator().manual_seed(42)).to(dev)
+    a = Stage3Trainer(build_model(opt, load_prior_files=False).to(dev), topt, dev)
+    a.step(LR, GT)
+    sd = a.torch_optimizer_state_dict()
+    params = [p for _, p in a.model.named_parameters() if p.requires_grad]
+    tadam = torch.optim.Adam(params, lr=topt["lr_G"], betas=(0.9, 0.99))
+    tadam.load_state_dict(sd)                                             # torch accepts the layout
+    back = tadam.state_dict()
+    assert len(back["state"]) == len(params) and float(back["state"][0]["step"]) == 1.0
+    weights = {k: v.clone() for k, v in a.model.state_dict().items()}
+    a.step(LR, GT)
+    m2 = build_model(opt, load_prior_files=False)
+    m2.load_state_dict(weights, strict=True)
+    b = Stage3Trainer(m2.to(dev), topt, dev)
+    b.load_torch_optimizer_state_dict(back, scheduler_state={"last_epoch": 1})
+    assert b.step_count == 1
+    b.step(LR, GT)
+    assert b.step_count == a.step_count == 2 and abs(a.lr - b.lr) < 1e-12
+    _close(b.flat_p, a.flat_p, 1e-6, "parameters after a resume through the torch-Adam layout")
+
+
+def test_validation_between_training_steps_uses_the_current_weights():
+    """step, validate, step, validate -- the inference engine's packed weights must follow the optimizer
+    (R:train_stage3.py:197-312 validates every val_freq steps).  The second validation equals a freshly built model that loaded
+    the current state dict, and differs from the first."""
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
+    dev = _dev()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    topt = dict(lr_G=4e-4, beta1=0.9, beta2=0.99, T_period=[1 << 20], restarts=None, restart_weights=None, eta_min=1e-7,
+                rec_loss_factor=1, ref_loss_factor=0.001)
+    LR = synth_lr_tiles(1, 5, 16, 16, seed=51, kind="smooth").to(dev)
+    GT = torch.rand(1, 1, 128, 128, generator=torch.Generator().manual_seed(52)).to(dev)
+    model = build_model(opt, load_prior_files=False).to(dev)
+    tr = Stage3Trainer(model, topt, dev)
+    tr.step(LR, GT)
+    model.eval()
+    with torch.no_grad():
+        v1, _ = model(LR)
+    model.train()
+    tr.step(LR, GT)
+    model.eval()
+    with torch.no_grad():
+        v2, _ = model(LR)
+    fresh = build_model(opt, load_prior_files=False)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    fresh = fresh.eval().to(dev)
+    with torch.no_grad():
+        vf, _ = fresh(LR)
+    torch.cuda.synchronize()
+    assert torch.equal(v2, vf), float((v2 - vf).abs().max())
+    assert float((v2 - v1).abs().max()) > 0.0
