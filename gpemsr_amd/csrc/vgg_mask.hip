@@ -18,6 +18,7 @@
 //      order -> deterministic.
 // No HBM traffic besides the two 1-channel images and 4 bytes per patch.
 #include "bf16_common.h"
+#include <stdlib.h>
 
 namespace gpemsr {
 
@@ -29,6 +30,7 @@ struct VggParams {
   const unsigned short* w2; const float* b2; // conv1_2: staged bf16 [2][9][4][64][8], [64]
   float* out;                                // [n][H/16][W/16]
   int tiles_x, tiles_y, ns;
+  int dbg;                                   // timing experiments only (GPEMSR_VGG_DBG): 1 = producers idle, 2 = no conv1_2
 };
 
 __device__ __forceinline__ void vsrc_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
@@ -246,6 +248,256 @@ __global__ __launch_bounds__(512, 2) void vgg_mask_kernel(VggParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same computation with its phases OVERLAPPED (the kernel above runs window load -> conv1_1 -> conv1_2 -> reduction one after
+// the other on all 8 waves: the matrix pipe is busy 31 % of the time).  768 threads = 8 multiplying waves + 4 producer waves, a
+// stream of work items (8 x 32-pixel half-tile, image) and two A-image buffers:
+//   interval i:  multiplying waves: conv1_2 of item i from buffer i & 1 (wave w = pixel row w, 32 pixels x 64 couts, 72 MFMAs);
+//                producer waves: conv1_1 of item i + 1 into buffer (i + 1) & 1 -- each lane fetches the 3x3 window of its halo
+//                pixel straight from the 1-channel image (the LR image is resampled on the fly), no window staging in LDS;
+//   one workgroup-wide barrier per interval.  A 16 x 32 super-tile = 4 items (upper half: prior image, up-sampled LR; lower half:
+//   the same); the per-lane patch sums live in registers across its two halves, the cross-wave reduction of super-tile k is
+//   finished in the interval after its last item.
+// LDS: W2 73,728 + 4 x 21,760 (two buffers x two 32-channel chunks of a 10 x 34 halo) + 704 bytes of constants / partial sums.
+__global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
+  constexpr int HALO_W = 34, HALO_H = 10, HALO_PX = HALO_W * HALO_H;      // conv1_2 input window of an 8 x 32 half-tile
+  constexpr int A_BYTES = HALO_PX * 64;                                   // 21,760
+  constexpr int W_BYTES = 2 * 9 * 4 * 64 * 16;
+  constexpr int NW = W_BYTES / 16 / 768;                                  // 6
+  constexpr int NGRP = (HALO_PX + 31) / 32;                               // 11 groups of 32 halo pixels
+  extern __shared__ __attribute__((aligned(16))) char vsm[];
+  float* const cst = reinterpret_cast<float*>(vsm + W_BYTES + 4 * A_BYTES);   // b1[64], b2[64]
+  float* const red = cst + 128;                                               // [8 waves][2 patches][3]
+  const unsigned vsm_lds = xlds_addr(vsm);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  {
+    const unsigned lds0 = xuni(vsm_lds + (unsigned)wave * 1024u);
+    const unsigned short* wp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.w2));
+#pragma unroll
+    for (int i = 0; i < NW; ++i) xglds16((unsigned)(tid + i * 768) * 16u, wp, lds0 + i * 12288u);
+  }
+  if (tid < 64) { cst[tid] = P.b1[tid]; cst[64 + tid] = P.b2[tid]; }
+  const int T_me = (P.ns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // 16 x 32 super-tiles of this workgroup
+  const int NWI = 4 * T_me;
+  auto item_geo = [&](int wi, int& img, int& oy0, int& ox0, int& tx, int& ty) {
+    int q = (int)blockIdx.x + (wi >> 2) * (int)gridDim.x;
+    tx = q % P.tiles_x; q /= P.tiles_x;
+    ty = q % P.tiles_y; q /= P.tiles_y;
+    img = q; oy0 = ty * 16 + ((wi >> 1) & 1) * 8; ox0 = tx * 32;
+  };
+  auto end_interval = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= 8) {
+    // ------------------------------------------------ producer waves: conv1_1 ------------------------------------------------
+    const int pw = wave - 8;
+    // W1 fragments: row operand of D^T = W1 . im2col^T.  k slots: 0..8 = taps (hi half of the pixel), 9..17 = the same taps (lo
+    // half), 18..31 = 0.  Lane (li = cout within the 32-row tile ct, lh) holds k = 16 s + 8 lh + j.
+    bf16x8 w1f[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 16 * s + 8 * lh + j;
+          const int tap = k < 9 ? k : k - 9;
+          const float v = k < 18 ? P.w1[(ct * 32 + li) * 9 + tap] : 0.f;
+          w1f[ct][s][j] = (short)(xcvt_pk_bf16(v, 0.f) & 0xFFFFu);
+        }
+    float b1r[2][16];                     // conv1_1 bias of this lane's couts: 32 ct + 8 g + 4 lh + j  (register 4 g + j)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) b1r[ct][r] = P.b1[ct * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
+    auto produce = [&](int wi) {
+      int img, oy0, ox0, tx, ty;
+      item_geo(wi, img, oy0, ox0, tx, ty);
+      const int which = wi & 1;
+      char* const dst = vsm + W_BYTES + (2 * (wi & 1)) * A_BYTES;          // buffer = item parity
+      const float* rimg = P.ref + (long long)img * P.H * P.W;
+      const float* limg = P.lr + (long long)img * P.h * P.w;
+#pragma unroll 1
+      for (int grp = pw; grp < NGRP; grp += 4) {
+        const int hp = grp * 32 + li;
+        const bool exists = hp < HALO_PX;
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int Y = oy0 - 1 + hy, X = ox0 - 1 + hx;                     // this halo pixel; its 3x3 window is centred on it
+        // the 3x3 window of this halo pixel, branch-free (clamped addresses, masked values) so that all loads of a group are in
+        // flight together: with a branch per tap the producer waves were the bottleneck (36 dependent L2 round trips per group)
+        float pv[9];
+        bool rin[3], cin[3];
+        int yc[3], xc[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int yy = Y - 1 + d, xx = X - 1 + d;
+          rin[d] = yy >= 0 && yy < P.H; cin[d] = xx >= 0 && xx < P.W;
+          yc[d] = yy < 0 ? 0 : (yy > P.H - 1 ? P.H - 1 : yy);
+          xc[d] = xx < 0 ? 0 : (xx > P.W - 1 ? P.W - 1 : xx);
+        }
+        if (which == 0) {
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const float v = rimg[(long long)yc[tp / 3] * P.W + xc[tp % 3]];
+            pv[tp] = (exists && rin[tp / 3] && cin[tp % 3]) ? v : 0.f;          // zero outside the image = conv1_1's padding
+          }
+        } else {
+          int y0[3], y1[3], x0[3], x1[3]; float ly[3], lx[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { vsrc_index(yc[d], P.sh, P.h, y0[d], y1[d], ly[d]); vsrc_index(xc[d], P.sw, P.w, x0[d], x1[d], lx[d]); }
+          float q[6][6];                  // LR pixels at rows (y0, y1) x cols (x0, x1) of the three window rows / columns
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+              q[a][b] = limg[((a & 1) ? y1[a >> 1] : y0[a >> 1]) * P.w + ((b & 1) ? x1[b >> 1] : x0[b >> 1])];
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const int r = tp / 3, c = tp % 3;
+            const float hy2 = 1.f - ly[r], hx2 = 1.f - lx[c];
+            const float v = hy2 * (hx2 * q[2 * r][2 * c] + lx[c] * q[2 * r][2 * c + 1]) + ly[r] * (hx2 * q[2 * r + 1][2 * c] + lx[c] * q[2 * r + 1][2 * c + 1]);
+            pv[tp] = (exists && rin[r] && cin[c]) ? v : 0.f;
+          }
+        }
+        unsigned hi[9], lo[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          hi[tp] = xcvt_pk_bf16(pv[tp], 0.f) & 0xFFFFu;
+          lo[tp] = xcvt_pk_bf16(pv[tp] - xbf_lo(hi[tp]), 0.f) & 0xFFFFu;
+        }
+        bf16x8 f0, f1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned v0 = lh == 0 ? hi[j] : (j == 0 ? hi[8] : lo[j - 1]);
+          const unsigned v1 = lh == 0 ? (j == 0 ? lo[7] : (j == 1 ? lo[8] : 0u)) : 0u;
+          f0[j] = (short)v0; f1[j] = (short)v1;
+        }
+        const bool inside = exists && Y >= 0 && Y < P.H && X >= 0 && X < P.W;        // else: conv1_2's zero padding
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ct][0], f0, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[ct][1], f1, d, 0, 0, 0);
+          if (exists) {
+            char* arow = dst + ct * A_BYTES + hp * 64;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = inside ? fmaxf(d[4 * g + j] + b1r[ct][4 * g + j], 0.f) : 0.f;
+              *reinterpret_cast<uint2*>(arow + ((g ^ ((hp >> 2) & 3)) * 16) + lh * 8) = make_uint2(xcvt_pk_bf16(v[0], v[1]), xcvt_pk_bf16(v[2], v[3]));
+            }
+          }
+        }
+      }
+    };
+    if (NWI > 0) produce(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    end_interval();                                                       // weights, constants and item 0 are in LDS
+    for (int i = 0; i <= NWI; ++i) {
+      if (i + 1 < NWI && !(P.dbg == 1 && i >= 2)) produce(i + 1);
+      end_interval();
+    }
+    return;
+  }
+
+  // ------------------------------------------------ multiplying waves: conv1_2 + patch sums ------------------------------------------------
+  unsigned aoff[3][3];
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int hp = (wave + rr) * HALO_W + li + kx;
+      aoff[rr][kx] = (unsigned)(W_BYTES + hp * 64 + ((lh ^ ((hp >> 2) & 3)) * 16));
+    }
+  const unsigned b_frag = (unsigned)(li * 16 + lh * 1024);
+  float b2r[2][16];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  end_interval();
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b2r[nt][r] = cst[64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+  unsigned pa[2][8];                      // relu1_2 features of the prior image at this lane's pixel, packed bf16 pairs
+  float dot = 0.f, na = 0.f, nb = 0.f;
+  for (int i = 0; i <= NWI; ++i) {
+    if (i < NWI) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+      const unsigned bufo = (unsigned)((i & 1) * 2 * A_BYTES);
+#pragma unroll 1
+      for (int chunk = 0; chunk < (P.dbg == 2 ? 0 : 2); ++chunk) {
+        const unsigned A = vsm_lds + bufo + (unsigned)(chunk * A_BYTES);
+        const unsigned B = vsm_lds + b_frag + (unsigned)(chunk * (9 * 4 * 1024));
+        bf16x8 fa[2], fb[2][2];
+        auto load_step = [&](int set, int st) {
+          const int tap = st >> 1, ks = st & 1;
+          const unsigned o = aoff[tap / 3][tap % 3];
+          fa[set] = xlds_read16(A + (ks ? (o ^ 32u) : o));
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) fb[set][nt] = xlds_read16(B + (unsigned)((tap * 4 + 2 * ks) * 1024 + nt * 512));
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+          if (st + 1 < 18) load_step((st + 1) & 1, st + 1);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st & 1][nt], fa[st & 1], acc[nt], 0, 0, 0);
+        }
+      }
+      if ((i & 1) == 0) {                 // prior image: keep a = relu(conv1_2 + bias) as bf16 (what the layered path stores in HBM)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            pa[nt][k] = xcvt_pk_bf16(fmaxf(acc[nt][2 * k] + b2r[nt][2 * k], 0.f), fmaxf(acc[nt][2 * k + 1] + b2r[nt][2 * k + 1], 0.f));
+      } else {                            // up-sampled LR: products with the prior image's features, summed over the 64 couts
+        int img, oy0, ox0, tx, ty;
+        item_geo(i, img, oy0, ox0, tx, ty);
+        const float okf = (ox0 + li < P.W && oy0 + wave < P.H) ? 1.f : 0.f;        // (pixels beyond a ragged last tile: masked out)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a = okf * ((r & 1) ? xbf_hi(pa[nt][r >> 1]) : xbf_lo(pa[nt][r >> 1]));
+            const float b = okf * fmaxf(acc[nt][r] + b2r[nt][r], 0.f);
+            dot = fmaf(a, b, dot); na = fmaf(a, a, na); nb = fmaf(b, b, nb);
+          }
+        if ((i & 3) == 3) {               // both halves of the super-tile are in: per-wave patch sums -> LDS
+#pragma unroll
+          for (int o = 1; o <= 8; o <<= 1) { dot += __shfl_xor(dot, o); na += __shfl_xor(na, o); nb += __shfl_xor(nb, o); }
+          dot += __shfl_xor(dot, 32); na += __shfl_xor(na, 32); nb += __shfl_xor(nb, 32);
+          if (lane == 0 || lane == 16) {
+            float* rp = red + (wave * 2 + (lane >> 4)) * 3;
+            rp[0] = dot; rp[1] = na; rp[2] = nb;
+          }
+          dot = 0.f; na = 0.f; nb = 0.f;
+        }
+      }
+    }
+    if (i >= 4 && (i & 3) == 0 && tid < 2) {          // finish the super-tile whose last item ran in the previous interval
+      int img, oy0, ox0, tx, ty;
+      item_geo(i - 4, img, oy0, ox0, tx, ty);
+      float d = 0.f, x = 0.f, y = 0.f;
+      for (int wv = 0; wv < 8; ++wv) { d += red[(wv * 2 + tid) * 3]; x += red[(wv * 2 + tid) * 3 + 1]; y += red[(wv * 2 + tid) * 3 + 2]; }
+      const int pxx = tx * 2 + tid;
+      if (pxx < P.W / 16)
+        P.out[((long long)img * (P.H / 16) + ty) * (P.W / 16) + pxx] = d / (fmaxf(sqrtf(x), 1e-12f) * fmaxf(sqrtf(y), 1e-12f));   // F.normalize eps
+    }
+    end_interval();
+  }
+}
+
 }  // namespace gpemsr
 
 using namespace gpemsr;
@@ -266,18 +518,27 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
   GP_REQUIRE(ns < (1ll << 31), "vgg_mask_bf16: grid too large");
   P.ns = (int)ns;
   const size_t lds = 73728 + 2 * (18 * 34 * 64) + (20 * 36 + 128 + 48) * 4;
+  const size_t lds2 = 73728 + 4 * (10 * 34 * 64) + (128 + 48) * 4;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(GPEMSR_ELAUNCH, "vgg_mask_bf16: cannot raise the dynamic LDS limit");
     attr = true;
   }
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_VGG_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
+  static int form = -1;                 // GPEMSR_VGG_FORM=1 selects the lockstep kernel (A/B measurements)
+  if (form < 0) { const char* e = getenv("GPEMSR_VGG_FORM"); form = (e && e[0] == '1') ? 1 : 2; }
   static int cus = 0;
   if (cus == 0) {
     int dev = 0; hipDeviceProp_t prop;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
   const int grid = P.ns < cus ? P.ns : cus;
+  if (form == 2) {
+    hipLaunchKernelGGL(vgg_mask2_kernel, dim3(grid), dim3(768), lds2, reinterpret_cast<hipStream_t>(stream), P);
+    return check_launch("vgg_mask2_kernel");
+  }
   hipLaunchKernelGGL(vgg_mask_kernel, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), P);
   return check_launch("vgg_mask_kernel");
 }
