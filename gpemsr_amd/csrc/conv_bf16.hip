@@ -105,7 +105,7 @@ __device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, 
   XParams P = Pfull;          // (a by-value view whose fixed fields fold at compile time)
   if (CONVT) P.store_mode = XS_CONVT;
   else if (GEMM && P.store_mode != XS_KPACK) P.store_mode = XS_PLAIN;
-  if (LEAN) { P.store_mode = XS_PLAIN; P.pixmul = nullptr; P.out32 = nullptr; P.out_f32 = 0; P.res_f32 = 0; }
+  if (LEAN) { P.store_mode = XS_PLAIN; P.out32 = nullptr; P.out_f32 = 0; P.res_f32 = 0; }       // (the per-pixel multiplier stays: one load + 8 multiplies)
   const long long img_pix0 = (long long)g.img * P.OH * P.OW;
   const bool up = P.store_mode == XS_PIXSHUF || P.store_mode == XS_CONVT;
 #pragma unroll
@@ -1278,7 +1278,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   }
   L.lds = lds;
   // the lean epilogue (see x_epilogue) covers this descriptor?
-  L.lean = P.store_mode == XS_PLAIN && !d->out_f32 && !d->out32 && !d->pixmul && (!d->residual || !d->res_f32) && d->cout % 8 == 0 &&
+  L.lean = P.store_mode == XS_PLAIN && !d->out_f32 && !d->out32 && (!d->residual || !d->res_f32) && d->cout % 8 == 0 &&
            (d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU);
   return GPEMSR_OK;
 }

@@ -191,6 +191,90 @@ __global__ __launch_bounds__(256, 2) void tap_sum_kernel(TapParams P) {
   }
 }
 
+// Conv2d(16 -> 2, 7x7, pad 3) + fp32 residual: the last layer of every SpyNet level (basicsr SpyNet BasicModule, conv index 8:
+// flow update = conv(...) + up-sampled coarser flow).  On the implicit-GEMM kernel two output channels fill 2 of 32 MFMA rows
+// (42 TFLOP/s, 1.6 ms at the finest level).  Here the matrix pipe forms ROW SUMS
+//     R[ky][co][row][x] = sum_{kx, c} W[co][c][ky][kx] * in[row][x + kx - 3][c]          rows = (ky, co): 14 of 32, K = 7 k-steps (one per kx)
+// for every halo row of a 16 x 32 tile, with the input fragments loaded straight from global memory (a k-step's operand is the
+// same 1 KiB of pixels shifted by one, so the seven loads of a row hit L1), and the output is the vertical 7-sum
+//     out[co][y][x] = bias[co] + sum_ky R[ky][co][y + ky][x]   (+ residual)
+// from LDS.  Weights as bf16 hi halves in rows 0..13 and lo halves in rows 16..29 of the same MFMA (fp32-accurate weights for free).
+struct Row7Params {
+  const tbf16_t* x;
+  int n, h, w, ld;
+  const bf16x8* wfrag;     // [7 kx][64 lanes]
+  const float* bias;       // [2] or null
+  const float* residual;
+  int res_ld;
+  float* out;
+  int out_ld;
+  int tiles_x, tiles_y;
+  long long total;
+};
+
+__global__ __launch_bounds__(256, 2) void rowsum7_kernel(Row7Params P) {
+  constexpr int TR = 16, TC = 32, HR = TR + 6;
+  __shared__ float rs[14 * HR * TC];                   // 39,424 B
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lp = lane & 31, hf = lane >> 5;
+  long long tile;
+  {
+    const long long q = P.total / 8, r = P.total % 8, bid = blockIdx.x;
+    const long long xcd = bid % 8, idx = bid / 8;
+    tile = xcd * q + (xcd < r ? xcd : r) + idx;
+  }
+  const int tx = (int)(tile % P.tiles_x), ty = (int)((tile / P.tiles_x) % P.tiles_y), img = (int)(tile / ((long long)P.tiles_x * P.tiles_y));
+  const int h = P.h, w = P.w;
+  const int y0 = ty * TR - 3, x0 = tx * TC;
+  bf16x8 wa[7];
+#pragma unroll
+  for (int kx = 0; kx < 7; ++kx) wa[kx] = P.wfrag[kx * 64 + lane];
+  for (int hr = wave; hr < HR; hr += 4) {
+    const int gy = y0 + hr;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool rowok = gy >= 0 && gy < h;               // wave-uniform
+    if (rowok) {
+      bf16x8 xb[7];
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int gx = x0 + lp + kx - 3;
+        const bool ok = gx >= 0 && gx < w;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) v = *reinterpret_cast<const bf16x8*>(P.x + (((long long)img * h + gy) * w + gx) * P.ld + hf * 8);
+        xb[kx] = v;
+      }
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kx], xb[kx], acc, 0, 0, 0);
+    }
+    // rows (ky, co) = 2 ky + co: lanes hf = 0 hold rows 0-3 (registers 0-3) and 8-11 (4-7), hf = 1 rows 4-7 and 12-13; lo halves 8 registers on
+    float* rp = rs + hr * TC + lp;
+#pragma unroll
+    for (int z = 0; z < 4; ++z) rp[(4 * hf + z) * HR * TC] = acc[z] + acc[z + 8];
+#pragma unroll
+    for (int z = 0; z < 4; ++z) {
+      const int row = 8 + 4 * hf + z;
+      if (row < 14) rp[row * HR * TC] = acc[4 + z] + acc[12 + z];
+    }
+  }
+  __syncthreads();
+  const float b0 = P.bias ? P.bias[0] : 0.f, b1 = P.bias ? P.bias[1] : 0.f;
+  for (int e = threadIdx.x; e < TR * TC; e += 256) {
+    const int ly = e / TC, lx = e - ly * TC;
+    const int oy = ty * TR + ly, ox = x0 + lx;
+    if (oy >= h || ox >= w) continue;
+    float s0 = b0, s1 = b1;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      s0 += rs[((2 * ky) * HR + ly + ky) * TC + lx];
+      s1 += rs[((2 * ky + 1) * HR + ly + ky) * TC + lx];
+    }
+    const long long pix = ((long long)img * h + oy) * w + ox;
+    if (P.residual) { s0 += P.residual[pix * P.res_ld]; s1 += P.residual[pix * P.res_ld + 1]; }
+    P.out[pix * P.out_ld] = s0; P.out[pix * P.out_ld + 1] = s1;
+  }
+}
+
 template <bool UP>
 static int launch_tap(TapParams& P, hipStream_t st) {
   constexpr int TR = UP ? 8 : 16;
@@ -230,4 +314,19 @@ extern "C" int gpemsr_upconv_out_c64_bf16(const void* x, int n, int h, int w, in
   P.cst = consts;
   P.out = out; P.out_ld = out_ld;
   return launch_tap<true>(P, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int gpemsr_conv7_c16_cout2_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, const float* residual,
+                                           int res_ld, float* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && wfrag && out, "conv7_c16_cout2_bf16: null pointer");
+  GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 16 && ld % 8 == 0 && A16(x) && A16(wfrag) && out_ld >= 2 && (!residual || res_ld >= 2),
+             "conv7_c16_cout2_bf16: bad geometry / alignment");
+  Row7Params P{};
+  P.x = reinterpret_cast<const tbf16_t*>(x); P.n = n; P.h = h; P.w = w; P.ld = ld;
+  P.wfrag = reinterpret_cast<const bf16x8*>(wfrag); P.bias = bias; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
+  P.tiles_x = (w + 31) / 32; P.tiles_y = (h + 15) / 16;
+  P.total = (long long)n * P.tiles_x * P.tiles_y;
+  if (P.total >= (1ll << 31)) return fail(GPEMSR_EINVAL, "conv7_c16_cout2_bf16: too many tiles");
+  hipLaunchKernelGGL(rowsum7_kernel, dim3((unsigned)P.total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
+  return check_launch("rowsum7_kernel");
 }

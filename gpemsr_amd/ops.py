@@ -176,6 +176,7 @@ class PackedConv:
     w16: Optional[torch.Tensor] = None     # split-bf16 weights [2][tap][cout][cin] (packing.pack_conv_split), optional
     wb: Optional[torch.Tensor] = None      # bf16 data path: staged-order weights (packing.pack_conv_bf16 / pack_convT_bf16)
     wtap: Optional[torch.Tensor] = None    # bf16 data path, 64 -> 1 3x3: tap fragments (packing.pack_cout1_taps)
+    wrow7: Optional[torch.Tensor] = None   # bf16 data path, 16 -> 2 7x7 (SpyNet flow update): row-sum fragments (packing.pack_rowsum7)
 
     @property
     def cin(self) -> int:
@@ -755,6 +756,22 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
         return out
     taps = 9.0 / 4.0 if pc.transposed else float(k * k)
     flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps
+    # SpyNet's flow update: 16 -> 2, 7x7, fp32 result + fp32 residual (csrc/tap_sum.hip, rowsum7_kernel)
+    if (pc.wrow7 is not None and plain and not force_mfma and s0.bf16 and s0.c == 16 and pc.cout == 2 and k == 7 and stride == 1 and act == ACT_NONE
+            and (residual is None or (not residual.bf16 and residual.c == 2))):
+        if out is None:
+            out = new_act(n, OH, OW, 2, device=dev)
+        assert not out.bf16 and (out.n, out.h, out.w, out.c) == (n, OH, OW, 2)
+
+        def _go_row7():
+            _abi.check(lib.gpemsr_conv7_c16_cout2_bf16(s0.ptr, n, h, w, s0.ld, pc.wrow7.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
+                                                       residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
+                                                       out.ptr, out.ld, _stream()), "conv7_c16_cout2_bf16")
+        if PROFILER is not None:
+            PROFILER.run("tap_sum", tag, flops, _go_row7)
+        else:
+            _go_row7()
+        return out
     # tiny channel counts: VALU kernel with fp32 packed weights (1-channel results are fp32 images)
     use_direct = (plain and not force_mfma and pc.cout <= 16 and (pc.cout <= 2 or pc.cin <= 16) and k >= 3 and pc.ck == 8
                   and (residual is None or (pc.cin == 64 and pc.cout == 1 and k == 3 and stride == 1 and not residual.bf16)))

@@ -231,3 +231,19 @@ def pack_upconv_out(w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tens
     frag = torch.stack([_tap_fragments(hi), _tap_fragments(lo)]).contiguous().to(device)
     consts = torch.cat([s, torch.tensor([bb], dtype=torch.float64), wy0.reshape(-1), wx0.reshape(-1), wc]).to(torch.float32).contiguous().to(device)
     return frag, consts
+
+
+def pack_rowsum7(w: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d(16 -> 2, 7x7) weight [2][16][7][7] -> per-kx A-operand fragments [7][64 lanes][8] bf16 for gpemsr_conv7_c16_cout2_bf16:
+    MFMA row 2 ky + co carries W[co][:, ky, kx] (bf16 hi half), row 16 + 2 ky + co its lo half; lane l holds row l % 32, channels
+    8 (l // 32) .. + 8."""
+    assert tuple(w.shape) == (2, 16, 7, 7)
+    wf = w.detach().to(torch.float32).cpu()
+    frags = []
+    for kx in range(7):
+        rows = wf[:, :, :, kx].permute(2, 0, 1).reshape(14, 16)                 # [(ky, co)][c]
+        hi, lo = _hi_lo(rows)
+        full = torch.zeros(32, 16)
+        full[0:14], full[16:30] = hi, lo
+        frags.append(full.reshape(32, 2, 8).permute(1, 0, 2).reshape(64, 8))      # lane = half * 32 + row
+    return torch.stack(frags).to(torch.bfloat16).contiguous().to(device)

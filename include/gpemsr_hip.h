@@ -213,6 +213,11 @@ int gpemsr_conv_c64_cout1_bf16(const void* x, int n, int h, int w, int ld, const
                                const float* residual, int res_ld, float* out, int out_ld, void* stream);
 int gpemsr_upconv_out_c64_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* consts, float* out,
                                int out_ld, void* stream);
+/* Conv2d(16 -> 2, 7x7, pad 3) + fp32 residual [n][h][w][res_ld >= 2] -> fp32 out [n][h][w][out_ld >= 2]: SpyNet's flow-update
+ * convolution (basicsr SpyNet BasicModule, last conv) as row sums on the matrix cores + a vertical 7-sum (csrc/tap_sum.hip);
+ * wfrag from packing.pack_rowsum7. */
+int gpemsr_conv7_c16_cout2_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, const float* residual,
+                                int res_ld, float* out, int out_ld, void* stream);
 
 /* Direct (VALU) convolution for tiny channel counts: cout <= 16, any k<=7, stride 1/2/4.
  * replaces: POD.flowdsconv* (model/GPEMSR.py:70-75,101-106), SpyNet's last 16->2 conv,

@@ -455,3 +455,24 @@ def test_upconv_out_composed_operator(n, h, w, ld, off):
         err = (g[sl] - wv[sl]).abs().max().item()
         assert err <= 1e-5 * wv.abs().max().item() + 1e-6, f"{name}: {err:.3e}"
     _close(got.nchw(), want, 1e-5, "composed up-block + output layer")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 16, 32), (1, 37, 70), (3, 5, 9), (1, 64, 33)])
+def test_spynet_flow_update_row_sums(n, h, w):
+    """gpemsr_conv7_c16_cout2_bf16 (rowsum7_kernel): Conv2d(16 -> 2, 7x7) + fp32 residual == the fp64 convolution of the
+    bf16-rounded input with the fp32 weights (hi + lo halves) to 1e-5; 16 x 32 tiles, ragged edges, images smaller than a tile."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_rowsum7
+    dev = _dev()
+    x = _r(_rand(n, 16, h, w, seed=400 + h))
+    wt = _rand(2, 16, 7, 7, seed=401, scale=1.0 / 28); b = _rand(2, seed=402)
+    up = _rand(n, 2, h, w, seed=403, scale=3.0)
+    pc = pack_conv(wt, b, dev)
+    pc.wrow7 = pack_rowsum7(wt, dev)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 3) + up.double()
+    got = ops.conv2d([_act16(x, dev)], pc, 0, residual=_act32(up, dev), precision="bf16", out_f32=True)
+    assert not got.bf16 and got.c == 2
+    _close(got.nchw(), want, 1e-5, "flow update with residual")
+    pc.b = None
+    got = ops.conv2d([_act16(x, dev)], pc, 0, precision="bf16", out_f32=True)
+    _close(got.nchw(), want - up.double() - b.double().view(1, 2, 1, 1), 1e-5, "flow update, no bias, no residual")
