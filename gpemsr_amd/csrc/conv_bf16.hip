@@ -99,13 +99,20 @@ struct XGeo { int img, oy0, ox0, n0, tile_in_img; };
 // of the network uses (plain NHWC bf16 store, cout % 8 == 0, optional bf16 residual, none / ReLU / LeakyReLU, optional GroupNorm
 // partial sums) is compiled without the other paths; the host picks it whenever the descriptor allows (plan_x).  The transposed
 // kernels know their store map at compile time as well.
-template <int MT, int NT, bool GEMM, bool CONVT = false, bool LEAN = false>
-__device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, f32x16 (&acc)[MT][NT], int pix_base, int cout_base, int gn_part,
-                                           const float* bias_lds, int li, int lh) {
+// PRE (lean form only): the layer has a residual and / or a per-pixel multiplier -- they are fetched branch-free before the stores;
+// layers without either take the PRE = false copy, which has no load at all (a dummy load would put its latency, and a run-time
+// `if` around the loads a vmcnt(0), in front of the stores of every tile).
+// PRE: 0 = residual / multiplier loaded where they are used (under a run-time `if`); 1 = prefetched branch-free; 2 = the layer has
+// neither (compiled out).  The two-copy form (1 / 2 behind one uniform branch) is used by the weights-resident kernel only: on the
+// ring kernel's 168-register budget the second copy spills (measured: slower overall).
+template <int MT, int NT, bool GEMM, bool CONVT, bool LEAN, int PRE>
+__device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XGeo& g, f32x16 (&acc)[MT][NT], int pix_base, int cout_base,
+                                                  const float* bias_lds, int li, int lh) {
   XParams P = Pfull;          // (a by-value view whose fixed fields fold at compile time)
   if (CONVT) P.store_mode = XS_CONVT;
   else if (GEMM && P.store_mode != XS_KPACK) P.store_mode = XS_PLAIN;
-  if (LEAN) { P.store_mode = XS_PLAIN; P.out32 = nullptr; P.out_f32 = 0; P.res_f32 = 0; }       // (the per-pixel multiplier stays: one load + 8 multiplies)
+  if (LEAN) { P.store_mode = XS_PLAIN; P.out32 = nullptr; P.out_f32 = 0; P.res_f32 = 0; }
+  if (LEAN && PRE == 2) { P.residual = nullptr; P.pixmul = nullptr; }
   const long long img_pix0 = (long long)g.img * P.OH * P.OW;
   const bool up = P.store_mode == XS_PIXSHUF || P.store_mode == XS_CONVT;
 #pragma unroll
@@ -114,6 +121,30 @@ __device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, 
     int oy, ox; bool pok;
     if (GEMM) { oy = 0; ox = g.ox0 + p; pok = ox < P.oh * P.ow; }
     else { oy = g.oy0 + (p >> 5); ox = g.ox0 + (p & 31); pok = oy < P.oh && ox < P.ow; }
+    // LEAN: the residual pieces and the per-pixel multiplier of this pixel are fetched BEFORE its first store -- a load issued after
+    // a store waits for that store on the in-order vmcnt, which made every conv2 of a residual block pay the store latency 4 times
+    // BRANCH-FREE on purpose: loads under a run-time `if` make the compiler wait with vmcnt(0) at every later use -- i.e. behind the
+    // stores again.  Lanes / layers without a residual read 16 bytes of the weight array instead (one cached address) and select 0.
+    uint4 rpre[NT][2];
+    float mpre = 1.f;
+    if (LEAN && PRE == 1) {
+      const long long opl = img_pix0 + (GEMM ? (long long)ox : (long long)oy * P.OW + ox);
+      const unsigned short* rbase = reinterpret_cast<const unsigned short*>(P.residual);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int nidx = g.n0 + cout_base + nt * 32 + 8 * (2 * h2 + lh);
+          const bool use = rbase != nullptr && pok && nidx < P.cout;
+          const unsigned short* ap = use ? rbase + opl * P.res_ld + nidx : P.weight;
+          uint4 u = *reinterpret_cast<const uint4*>(ap);
+          if (!use) u = make_uint4(0u, 0u, 0u, 0u);
+          rpre[nt][h2] = u;
+        }
+      const bool usem = P.pixmul != nullptr && pok;
+      const float mv = *(usem ? P.pixmul + opl : reinterpret_cast<const float*>(P.weight));
+      mpre = usem ? mv : 1.f;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int cb0 = g.n0 + cout_base + nt * 32;            // first cout (GEMM column) of this 32-row accumulator tile
@@ -159,7 +190,13 @@ __device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, 
         else if (P.store_mode == XS_CONVT) { const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); sy = q >> 1; sx = q & 1; }
         const int opix = GEMM ? ox : (up ? (2 * oy + sy) * P.OW + 2 * ox + sx : oy * P.OW + ox);
         const bool full = nvalid == 8;
-        if (P.residual) {
+        if (LEAN && PRE == 1) {
+          const uint4 u = rpre[nt][gp >> 1];
+          w8[0] += xbf_lo(u.x); w8[1] += xbf_hi(u.x); w8[2] += xbf_lo(u.y); w8[3] += xbf_hi(u.y);
+          w8[4] += xbf_lo(u.z); w8[5] += xbf_hi(u.z); w8[6] += xbf_lo(u.w); w8[7] += xbf_hi(u.w);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w8[k] *= mpre;
+        } else if (P.residual) {
           if (P.res_f32) {
             const float* rp = reinterpret_cast<const float*>(P.residual) + (img_pix0 + opix) * P.res_ld + ch;
             if (full) {
@@ -179,7 +216,7 @@ __device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, 
             }
           }
         }
-        if (P.pixmul) {
+        if (!(LEAN && PRE == 1) && P.pixmul) {
           const float m = P.pixmul[img_pix0 + opix];
 #pragma unroll
           for (int k = 0; k < 8; ++k) w8[k] *= m;
@@ -218,6 +255,17 @@ __device__ __forceinline__ void x_epilogue(const XParams& Pfull, const XGeo& g, 
       // with 128 accumulator registers has (the stores are fire-and-forget, the loads are few)
       asm volatile("" ::: "memory");
     }
+  }
+}
+
+template <int MT, int NT, bool GEMM, bool CONVT = false, bool LEAN = false, bool TWO_COPIES = false>
+__device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x16 (&acc)[MT][NT], int pix_base, int cout_base, int gn_part,
+                                           const float* bias_lds, int li, int lh) {
+  if (LEAN && TWO_COPIES) {
+    if (P.residual || P.pixmul) x_epilogue_stores<MT, NT, GEMM, CONVT, LEAN, 1>(P, g, acc, pix_base, cout_base, bias_lds, li, lh);
+    else x_epilogue_stores<MT, NT, GEMM, CONVT, LEAN, 2>(P, g, acc, pix_base, cout_base, bias_lds, li, lh);
+  } else {
+    x_epilogue_stores<MT, NT, GEMM, CONVT, LEAN, 0>(P, g, acc, pix_base, cout_base, bias_lds, li, lh);
   }
   if (P.gn_ws) {
     // Partial sums of (conv + bias) and its square over the tile's valid pixels, per channel -- or per 2 / 4 neighbouring channels
@@ -528,13 +576,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
   // one entry per (halo row, kx) -- (MT - 1) S + KW rows instead of MT * KW.
   constexpr bool TABLE = KK <= 9;
   constexpr int AR = !TABLE || GEMM ? MT : (MT - 1) * S + KW, AC = !TABLE ? TPS : (GEMM ? 1 : KW);
-  int a_off[AR][AC];
-  if (TABLE) {
-#pragma unroll
-    for (int rr = 0; rr < AR; ++rr)
-#pragma unroll
-      for (int kx = 0; kx < AC; ++kx) a_off[rr][kx] = GEMM ? a_offset2(rr, 0, 0) : a_offset2(0, rr, kx);
-  }
+  int a_off[AR][AC];                 // TABLE: (re)built at the top of every tile, so it is not live across the epilogue
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
   const unsigned xsm_lds = xlds_addr(xsm);
 
@@ -614,6 +656,18 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    if (TABLE) {
+      int li3 = li, lh3 = lh;           // opaque: the table is tile-invariant, but kept across the epilogue it costs 12 registers of the 168
+      asm volatile("" : "+v"(li3), "+v"(lh3));
+      const int p0 = wm * PM + li3;
+#pragma unroll
+      for (int rr = 0; rr < AR; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < AC; ++kx) {
+          const int hp = GEMM ? p0 + rr * 32 : ((p0 >> 5) * S + rr) * HALO_W + (p0 & 31) * S + kx;
+          a_off[rr][kx] = hp * ROWB + ((lh3 ^ ((hp >> SWZ_SH) & SWZ_MK)) * 16) + a_slot * A_BYTES;
+        }
+    }
 
     auto stage = [&](const int grp) {                  // grp is a compile-time constant in the unrolled (TABLE) form
       // TABLE: a_off already points into the current halo image (moved once per chunk, below) -- adding the image base per
@@ -690,7 +744,11 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) vo
     if (ti + 2 < T_me) nxt = tile_geo(ti + 2);
 
     // ---- epilogue, straight from the accumulators (D^T: lane = pixel, registers = couts) ----
-    x_epilogue<MT, NT, GEMM, CONVT, LEAN>(P, g, acc, wm * PM, wn * WNT, g.tile_in_img * WM + wm, bias_lds, li, lh);
+    {
+      int li2 = li, lh2 = lh;           // opaque per-tile copies: keeps the epilogue's tile-invariant addressing out of the MFMA loop's live set
+      asm volatile("" : "+v"(li2), "+v"(lh2));
+      x_epilogue<MT, NT, GEMM, CONVT, LEAN>(P, g, acc, wm * PM, wn * WNT, g.tile_in_img * WM + wm, bias_lds, li2, lh2);
+    }
     XSEG(5);
   }
   XSEG_FLUSH;
@@ -1082,7 +1140,7 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     // have -- the spill reloads then sit behind the epilogue's own stores on the in-order vmcnt (measured: 1.35x slower)
     int li2 = li, lh2 = lh;
     asm volatile("" : "+v"(li2), "+v"(lh2));
-    x_epilogue<MT, NT, false, false, LEAN>(P, geo, acc, w4 * 64, 0, geo.tile_in_img * 4 + w4, bias_lds, li2, lh2);
+    x_epilogue<MT, NT, false, false, LEAN, true>(P, geo, acc, w4 * 64, 0, geo.tile_in_img * 4 + w4, bias_lds, li2, lh2);
     end_interval();
   }
   for (int s = 3 * T_g + g; s < NI; ++s) end_interval();
