@@ -130,18 +130,21 @@ def spawn_ranks(args, argv) -> int:
     out0.seek(0)
     text = out0.read()
     out0.close()
-    if rc == 0:
-        line = None
-        for ln in text.splitlines():
-            if ln.startswith("{"):
-                try:
-                    line = json.loads(ln)
-                except Exception:
-                    pass
-        if line is None or line.get("n_gpus") != n:
-            print("[bench launcher] rank 0 printed no JSON line for n_gpus=%d" % n, file=sys.stderr, flush=True)
-            rc = 1
-    sys.stdout.write(text)
+    json_line = None
+    for ln in text.splitlines():
+        if ln.startswith("{"):
+            try:
+                if json.loads(ln).get("n_gpus") == n:
+                    json_line = ln
+            except Exception:
+                pass
+        elif ln.strip():
+            print(ln, file=sys.stderr)          # library chatter on rank 0's stdout (e.g. gloo's connection notice): not part of the ONE line
+    if rc == 0 and json_line is None:
+        print("[bench launcher] rank 0 printed no JSON line for n_gpus=%d" % n, file=sys.stderr, flush=True)
+        rc = 1
+    if json_line is not None:
+        sys.stdout.write(json_line + "\n")
     sys.stdout.flush()
     return rc
 
@@ -364,6 +367,8 @@ def run_forward(args) -> int:
         from gpemsr_amd.config import build_model, load_options
         from gpemsr_amd.synth import synth_lr_tiles
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+        if os.environ.get("GPEMSR_BENCH_SHARE_GPU") == "1":       # rehearsal on a box with fewer GPUs than ranks (use with --backend gloo)
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         sync = torch.cuda.synchronize
