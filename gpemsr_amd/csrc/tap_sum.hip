@@ -23,9 +23,10 @@ namespace gpemsr {
 typedef unsigned short tbf16_t;
 
 struct TapParams {
-  const tbf16_t* x;
+  const void* xv;          // bf16 or fp32 NHWC input, 64 channels
   int n, h, w, ld;
-  const bf16x8* wfrag;     // [sets][4 k-steps][64 lanes] A-operand fragments (rows = taps)
+  const void* wfrag;       // bf16 input: [sets][4 k-steps][64 lanes] bf16x8 A-operand fragments (rows = taps, hi / lo halves);
+                           // fp32 input: [32 k-steps][64 lanes] floats (v_mfma_f32_32x32x2_f32: lane l = row l % 32, k = l / 32)
   const float* cst;        // 3x3: [0] = bias (or null).  up+out: [dy*3+dx] = sum_co b1[co] w2[co][dy][dx], [9] = b2, then
                            //      [10 + ...] = Wy0 5x64 | Wx0 5x64 | Wc 64 fp32 (border routes, see above)
   int act;
@@ -37,6 +38,15 @@ struct TapParams {
   long long total;         // tiles
 };
 
+__device__ __forceinline__ float tdot64(const float* xp, const float* wp) {
+  float s = 0.f;
+#pragma unroll 4
+  for (int c4 = 0; c4 < 16; ++c4) {
+    const float4 v = *reinterpret_cast<const float4*>(xp + 4 * c4), w4 = *reinterpret_cast<const float4*>(wp + 4 * c4);
+    s = fmaf(v.x, w4.x, s); s = fmaf(v.y, w4.y, s); s = fmaf(v.z, w4.z, s); s = fmaf(v.w, w4.w, s);
+  }
+  return s;
+}
 __device__ __forceinline__ float tdot64(const tbf16_t* xp, const float* wp) {
   float s = 0.f;
 #pragma unroll 2
@@ -49,8 +59,12 @@ __device__ __forceinline__ float tdot64(const tbf16_t* xp, const float* wp) {
   return s;
 }
 
-template <bool UP>
+// TI = tbf16_t: v_mfma_f32_32x32x16_bf16 with hi + lo weight halves.  TI = float (the exact-fp32 path): v_mfma_f32_32x32x2_f32, a lane's
+// operand values are channels 2 ks + (lane / 32) of its pixel, picked out of the pixel's sixteen float4 loads.
+template <bool UP, typename TI>
 __global__ __launch_bounds__(256, 2) void tap_sum_kernel(TapParams P) {
+  constexpr bool F32 = sizeof(TI) == 4;
+  const TI* const Px = reinterpret_cast<const TI*>(P.xv);
   constexpr int TAPS = UP ? 25 : 9;
   constexpr int HR = UP ? 10 : 18;          // halo rows per tile; 64 halo columns; the tile owns (HR - 2) x 62 pixels
   constexpr int TR = HR - 2, TC = 62;
@@ -69,38 +83,9 @@ __global__ __launch_bounds__(256, 2) void tap_sum_kernel(TapParams P) {
   const int h = P.h, w = P.w;
   const int y0 = ty * TR - 1, x0 = tx * TC - 1;
 
-  bf16x8 wa[SETS][4];
-#pragma unroll
-  for (int s = 0; s < SETS; ++s)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wa[s][ks] = P.wfrag[(s * 4 + ks) * 64 + lane];
-
-  bf16x8 xb[PER][4];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int mt = wave + 4 * i, gy = y0 + (mt >> 1), gx = x0 + (mt & 1) * 32 + lp;
-    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
-    const tbf16_t* p = P.x + (((long long)img * h + (ok ? gy : 0)) * w + (ok ? gx : 0)) * P.ld + hf * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) v = *reinterpret_cast<const bf16x8*>(p + ks * 16);
-      xb[i][ks] = v;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][ks], xb[i][ks], acc, 0, 0, 0);
-      if (SETS == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[SETS - 1][ks], xb[i][ks], acc, 0, 0, 0);
-    }
-    const int mt = wave + 4 * i;
+  auto store_rows = [&](const f32x16& acc, int mt) {
     float* pp = ps + (mt >> 1) * 64 + (mt & 1) * 32 + lp;
-    if (!UP) {        // rows 0..8 = hi halves, rows 16..24 = lo halves of the same 9 taps
+    if (!UP && !F32) {        // rows 0..8 = hi halves, rows 16..24 = lo halves of the same 9 taps
 #pragma unroll
       for (int z = 0; z < 4; ++z) pp[(4 * hf + z) * HR * 64] = acc[z] + acc[z + 8];
       if (hf == 0) pp[8 * HR * 64] = acc[4] + acc[12];
@@ -110,6 +95,67 @@ __global__ __launch_bounds__(256, 2) void tap_sum_kernel(TapParams P) {
         const int row = (r >> 2) * 8 + hf * 4 + (r & 3);
         if (row < TAPS) pp[row * HR * 64] = acc[r];
       }
+    }
+  };
+  if (!F32) {
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(P.wfrag);
+    bf16x8 wa[SETS][4];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) wa[s][ks] = wf[(s * 4 + ks) * 64 + lane];
+
+    bf16x8 xb[PER][4];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int mt = wave + 4 * i, gy = y0 + (mt >> 1), gx = x0 + (mt & 1) * 32 + lp;
+      const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const tbf16_t* p = reinterpret_cast<const tbf16_t*>(P.xv) + (((long long)img * h + (ok ? gy : 0)) * w + (ok ? gx : 0)) * P.ld + hf * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) v = *reinterpret_cast<const bf16x8*>(p + ks * 16);
+        xb[i][ks] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][ks], xb[i][ks], acc, 0, 0, 0);
+        if (SETS == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[SETS - 1][ks], xb[i][ks], acc, 0, 0, 0);
+      }
+      store_rows(acc, wave + 4 * i);
+    }
+  } else {
+    const float* wf = reinterpret_cast<const float*>(P.wfrag);
+    float wa[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) wa[ks] = wf[ks * 64 + lane];
+#pragma unroll 1
+    for (int i = 0; i < PER; ++i) {
+      const int mt = wave + 4 * i, gy = y0 + (mt >> 1), gx = x0 + (mt & 1) * 32 + lp;
+      const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const float* p = reinterpret_cast<const float*>(P.xv) + (((long long)img * h + (ok ? gy : 0)) * w + (ok ? gx : 0)) * P.ld;
+      float4 xv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(p + 4 * j);
+        xv[j] = v;
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {       // k-steps 2 j (channels 4 j + hf) and 2 j + 1 (channels 4 j + 2 + hf)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * j], hf ? xv[j].y : xv[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * j + 1], hf ? xv[j].w : xv[j].z, acc, 0, 0, 0);
+      }
+      store_rows(acc, mt);
     }
   }
   __syncthreads();
@@ -169,16 +215,16 @@ __global__ __launch_bounds__(256, 2) void tap_sum_kernel(TapParams P) {
           if (oy == 0) {          // routes through intermediate row -1: input row 0, k_y = 0, d_y = 0
             for (int t = ox & 1; t < 5; t += 2) {
               const int jj = (ox + 2 - t) >> 1;
-              if (jj >= 0 && jj < w) s -= tdot64(P.x + (((long long)img * h) * w + jj) * P.ld, fix + t * 64);
+              if (jj >= 0 && jj < w) s -= tdot64(Px + (((long long)img * h) * w + jj) * P.ld, fix + t * 64);
             }
           }
           if (ox == 0) {
             for (int t = oy & 1; t < 5; t += 2) {
               const int ii = (oy + 2 - t) >> 1;
-              if (ii >= 0 && ii < h) s -= tdot64(P.x + (((long long)img * h + ii) * w) * P.ld, fix + 320 + t * 64);
+              if (ii >= 0 && ii < h) s -= tdot64(Px + (((long long)img * h + ii) * w) * P.ld, fix + 320 + t * 64);
             }
           }
-          if (oy == 0 && ox == 0) s += tdot64(P.x + ((long long)img * h) * w * P.ld, fix + 640);
+          if (oy == 0 && ox == 0) s += tdot64(Px + ((long long)img * h) * w * P.ld, fix + 640);
           o[py][px] = s;
         }
 #pragma unroll
@@ -275,14 +321,14 @@ __global__ __launch_bounds__(256, 2) void rowsum7_kernel(Row7Params P) {
   }
 }
 
-template <bool UP>
+template <bool UP, typename TI>
 static int launch_tap(TapParams& P, hipStream_t st) {
   constexpr int TR = UP ? 8 : 16;
   P.tiles_x = (P.w + 61) / 62;
   P.tiles_y = (P.h + TR - 1) / TR;
   P.total = (long long)P.n * P.tiles_x * P.tiles_y;
   if (P.total >= (1ll << 31)) return fail(GPEMSR_EINVAL, "tap_sum: too many tiles");
-  hipLaunchKernelGGL(tap_sum_kernel<UP>, dim3((unsigned)P.total), dim3(256), 0, st, P);
+  hipLaunchKernelGGL((tap_sum_kernel<UP, TI>), dim3((unsigned)P.total), dim3(256), 0, st, P);
   return check_launch(UP ? "tap_sum_kernel<up>" : "tap_sum_kernel<3x3>");
 }
 
@@ -296,11 +342,21 @@ extern "C" int gpemsr_conv_c64_cout1_bf16(const void* x, int n, int h, int w, in
   GP_REQUIRE(x && wfrag && out, "conv_c64_cout1_bf16: null pointer");
   GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 64 && ld % 8 == 0 && A16(x) && A16(wfrag) && out_ld >= 1, "conv_c64_cout1_bf16: bad geometry / alignment");
   TapParams P{};
-  P.x = reinterpret_cast<const tbf16_t*>(x); P.n = n; P.h = h; P.w = w; P.ld = ld;
-  P.wfrag = reinterpret_cast<const bf16x8*>(wfrag);
+  P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld;
+  P.wfrag = wfrag;
   P.cst = bias;
   P.act = act; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
-  return launch_tap<false>(P, reinterpret_cast<hipStream_t>(stream));
+  return launch_tap<false, tbf16_t>(P, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int gpemsr_conv_c64_cout1_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, int act,
+                                         const float* residual, int res_ld, float* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && wfrag && out, "conv_c64_cout1_f32: null pointer");
+  GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 64 && ld % 4 == 0 && A16(x) && A16(wfrag) && out_ld >= 1, "conv_c64_cout1_f32: bad geometry / alignment");
+  TapParams P{};
+  P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld; P.wfrag = wfrag; P.cst = bias;
+  P.act = act; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
+  return launch_tap<false, float>(P, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int gpemsr_upconv_out_c64_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* consts, float* out,
@@ -309,11 +365,21 @@ extern "C" int gpemsr_upconv_out_c64_bf16(const void* x, int n, int h, int w, in
   GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 64 && ld % 8 == 0 && A16(x) && A16(wfrag) && out_ld >= 1 && (out_ld > 1 || (reinterpret_cast<uintptr_t>(out) & 7) == 0)
              && (reinterpret_cast<uintptr_t>(consts) & 7) == 0, "upconv_out_c64_bf16: bad geometry / alignment");
   TapParams P{};
-  P.x = reinterpret_cast<const tbf16_t*>(x); P.n = n; P.h = h; P.w = w; P.ld = ld;
-  P.wfrag = reinterpret_cast<const bf16x8*>(wfrag);
+  P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld;
+  P.wfrag = wfrag;
   P.cst = consts;
   P.out = out; P.out_ld = out_ld;
-  return launch_tap<true>(P, reinterpret_cast<hipStream_t>(stream));
+  return launch_tap<true, tbf16_t>(P, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int gpemsr_upconv_out_c64_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* consts, float* out,
+                                         int out_ld, void* stream) {
+  GP_REQUIRE(x && wfrag && consts && out, "upconv_out_c64_f32: null pointer");
+  GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 64 && ld % 4 == 0 && A16(x) && A16(wfrag) && out_ld >= 1 && (out_ld > 1 || (reinterpret_cast<uintptr_t>(out) & 7) == 0)
+             && (reinterpret_cast<uintptr_t>(consts) & 7) == 0, "upconv_out_c64_f32: bad geometry / alignment");
+  TapParams P{};
+  P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld; P.wfrag = wfrag; P.cst = consts; P.out = out; P.out_ld = out_ld;
+  return launch_tap<true, float>(P, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int gpemsr_conv7_c16_cout2_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, const float* residual,

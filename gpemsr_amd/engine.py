@@ -28,7 +28,7 @@ import torch
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
 from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear,
-                      pack_vgg_first, pack_cout1_taps, pack_upconv_out, pack_rowsum7)
+                      pack_vgg_first, pack_cout1_taps, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -178,6 +178,8 @@ class Engine:
                 self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
             if self.bf16 and tuple(w.shape) == (1, 64, 3, 3):
                 self.pc[name].wtap = pack_cout1_taps(w, dev)            # 64 -> 1 on the matrix cores (csrc/tap_sum.hip)
+            if not self.bf16 and tuple(w.shape) == (1, 64, 3, 3) and getattr(self, "fuse_tail_f32", True):
+                self.pc[name].wtap32 = pack_cout1_taps_f32(w, dev)      # the same on the fp32 matrix pipe
             if self.bf16 and tuple(w.shape) == (2, 16, 7, 7):
                 self.pc[name].wrow7 = pack_rowsum7(w, dev)              # SpyNet flow update as row sums (csrc/tap_sum.hip)
         elif w.dim() == 2 and name.endswith("indexer.embedding"):
@@ -364,7 +366,7 @@ class Engine:
         # bf16: the last up-block (64 -> 64) and the output layer (64 -> 1) have nothing in between and the 64-channel tensor at
         # the full resolution has no other reader: they run as one composed operator (csrc/tap_sum.hip)
         last = f"{p}.feat_extract.{n_fe - 1}.upblock"
-        fuse_tail = (self.bf16 and n_fe >= 2 and last in self.pc and tuple(self.sd[last + ".weight"].shape) == (64, 64, 3, 3)
+        fuse_tail = (getattr(self, "fuse_tail_f32", True) or self.bf16) and (n_fe >= 2 and last in self.pc and tuple(self.sd[last + ".weight"].shape) == (64, 64, 3, 3)
                      and tuple(self.sd[p + ".output_layer.weight"].shape) == (1, 64, 3, 3) and (n_fe - 2 - nrb + 1) % (nrb + 1) != 0)
         for i in range(n_fe - 1 - int(fuse_tail)):
             x = self.vq_layer(x, f"{p}.feat_extract.{i + 1}")
@@ -372,10 +374,12 @@ class Engine:
                 feats.append(x)
         if fuse_tail:
             if "@upout.frag" not in self.par:
-                self.par["@upout.frag"], self.par["@upout.consts"] = pack_upconv_out(
+                packer = pack_upconv_out if self.bf16 else pack_upconv_out_f32
+                self.par["@upout.frag"], self.par["@upout.consts"] = packer(
                     self.sd[last + ".weight"], self.sd.get(last + ".bias"), self.sd[p + ".output_layer.weight"],
                     self.sd.get(p + ".output_layer.bias"), self.dev)
-            feats.append(self.o.upconv_out_bf16(x, self.par["@upout.frag"], self.par["@upout.consts"], tag=last + "+output_layer"))
+            tail = self.o.upconv_out_bf16 if self.bf16 else self.o.upconv_out_f32
+            feats.append(tail(x, self.par["@upout.frag"], self.par["@upout.consts"], tag=last + "+output_layer"))
         else:
             feats.append(self.conv(x, p + ".output_layer"))
         return feats

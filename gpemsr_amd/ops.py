@@ -177,6 +177,7 @@ class PackedConv:
     wb: Optional[torch.Tensor] = None      # bf16 data path: staged-order weights (packing.pack_conv_bf16 / pack_convT_bf16)
     wtap: Optional[torch.Tensor] = None    # bf16 data path, 64 -> 1 3x3: tap fragments (packing.pack_cout1_taps)
     wrow7: Optional[torch.Tensor] = None   # bf16 data path, 16 -> 2 7x7 (SpyNet flow update): row-sum fragments (packing.pack_rowsum7)
+    wtap32: Optional[torch.Tensor] = None  # fp32 activations, 64 -> 1 3x3: fp32 tap fragments (packing.pack_cout1_taps_f32)
 
     @property
     def cin(self) -> int:
@@ -229,6 +230,16 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
     # algorithmic FLOPs of this launch (2*MAC, un-padded channel counts)
     taps = 9.0 / 4.0 if pc.transposed else float(k * k)
     flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps
+    if use_direct and pc.wtap32 is not None and pc.cin == 64 and pc.cout == 1 and k == 3 and stride == 1 and s0.ld % 4 == 0 and not s0.bf16:
+        def _go_taps32():       # 64 -> 1 as tap partial products on the fp32 matrix pipe (csrc/tap_sum.hip): the tensor is read once
+            _abi.check(lib.gpemsr_conv_c64_cout1_f32(s0.ptr, n, h, w, s0.ld, pc.wtap32.data_ptr(), pc.b.data_ptr() if pc.b is not None else None, act,
+                                                     residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
+                                                     out.ptr, out.ld, _stream()), "conv_c64_cout1_f32")
+        if PROFILER is not None:
+            PROFILER.run("tap_sum", tag, flops, _go_taps32)
+        else:
+            _go_taps32()
+        return out
     if use_direct:
         def _go():
             _abi.check(lib.gpemsr_conv2d_direct(s0.ptr, n, h, w, s0.ld, s0.c, pc.w.data_ptr(),
@@ -871,6 +882,24 @@ def upconv_out_bf16(x: Act, frag: torch.Tensor, consts: torch.Tensor, out: Optio
                                                           _stream()), "upconv_out_c64_bf16")
     if PROFILER is not None:
         # the arithmetic of the layered form it replaces: 2.25 taps x 64 x 64 for the up-block + 9 x 64 for the output conv
+        PROFILER.run("tap_sum", tag, 2.0 * x.n * 4 * x.h * x.w * (64 * 64 * 2.25 + 64 * 9), _go)
+    else:
+        _go()
+    return out
+
+
+def upconv_out_f32(x: Act, frag: torch.Tensor, consts: torch.Tensor, out: Optional[Act] = None, tag: str = "") -> Act:
+    """upconv_out_bf16 for fp32 activations (the exact-fp32 path): v_mfma_f32_32x32x2_f32, fp32 composed weights."""
+    _require_gpu(x)
+    assert not x.bf16 and x.c == 64 and x.ld % 4 == 0
+    if out is None:
+        out = new_act(x.n, 2 * x.h, 2 * x.w, 1, device=x.buf.device)
+    assert (out.n, out.h, out.w, out.c) == (x.n, 2 * x.h, 2 * x.w, 1)
+
+    def _go():
+        _abi.check(_abi.load().gpemsr_upconv_out_c64_f32(x.ptr, x.n, x.h, x.w, x.ld, frag.data_ptr(), consts.data_ptr(), out.ptr, out.ld,
+                                                         _stream()), "upconv_out_c64_f32")
+    if PROFILER is not None:
         PROFILER.run("tap_sum", tag, 2.0 * x.n * 4 * x.h * x.w * (64 * 64 * 2.25 + 64 * 9), _go)
     else:
         _go()

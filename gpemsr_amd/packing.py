@@ -247,3 +247,26 @@ def pack_rowsum7(w: torch.Tensor, device) -> torch.Tensor:
         full[0:14], full[16:30] = hi, lo
         frags.append(full.reshape(32, 2, 8).permute(1, 0, 2).reshape(64, 8))      # lane = half * 32 + row
     return torch.stack(frags).to(torch.bfloat16).contiguous().to(device)
+
+
+def _tap_fragments_f32(rows: torch.Tensor) -> torch.Tensor:
+    """rows [R <= 32][64] fp32 -> A-operand fragments [32 k-steps][64 lanes] of v_mfma_f32_32x32x2_f32: lane l holds row l % 32,
+    channel 2 ks + l // 32."""
+    full = torch.zeros(32, 64, dtype=torch.float32)
+    full[:rows.shape[0]] = rows
+    return full.reshape(32, 32, 2).permute(1, 2, 0).reshape(32, 64).contiguous()          # [ks][half][row] -> [ks][lane]
+
+
+def pack_cout1_taps_f32(w: torch.Tensor, device) -> torch.Tensor:
+    assert tuple(w.shape) == (1, 64, 3, 3)
+    rows = w.detach().to(torch.float32).cpu()[0].permute(1, 2, 0).reshape(9, 64)
+    return _tap_fragments_f32(rows).to(device)
+
+
+def pack_upconv_out_f32(w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor], device):
+    """-> (fragments [32][64] fp32, consts [10 + 5*64 + 5*64 + 64] fp32) for gpemsr_upconv_out_c64_f32 (composition in fp64)."""
+    assert tuple(w1.shape) == (64, 64, 3, 3) and tuple(w2.shape) == (1, 64, 3, 3)
+    taps, s, bb, wy0, wx0, wc = compose_upconv_out(w1, b1, w2, b2)
+    frag = _tap_fragments_f32(taps.to(torch.float32)).to(device)
+    consts = torch.cat([s, torch.tensor([bb], dtype=torch.float64), wy0.reshape(-1), wx0.reshape(-1), wc]).to(torch.float32).contiguous().to(device)
+    return frag, consts

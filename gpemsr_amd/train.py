@@ -209,6 +209,8 @@ class TrainEngine(Engine):
     def __init__(self, sd, device, scale, nframes, groups, nf, dec_nrb, trainable, gw: Dict[str, torch.Tensor],
                  gb: Dict[str, torch.Tensor], precision: str = "fp32"):
         self.trainable = set(trainable)                        # before the base constructor packs the weights
+        self.fuse_tail_f32 = False                             # training keeps the layered decoder tail / VALU 64 -> 1 convs: the tape's
+        #                                                        backward kernels were validated against exactly that forward
         super().__init__(sd, device, scale, nframes, groups, nf, dec_nrb, frame_chunk=1 << 20, tile_chunk=1 << 20, precision=precision)
         self.gw, self.gb = gw, gb
         self.tape: Optional[list] = None

@@ -213,6 +213,12 @@ int gpemsr_conv_c64_cout1_bf16(const void* x, int n, int h, int w, int ld, const
                                const float* residual, int res_ld, float* out, int out_ld, void* stream);
 int gpemsr_upconv_out_c64_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* consts, float* out,
                                int out_ld, void* stream);
+/* The same two operators for the exact-fp32 path: fp32 NHWC input (ld % 4 == 0), v_mfma_f32_32x32x2_f32, fp32 weights
+ * (wfrag: [32 k-steps][64 lanes] floats, packing.pack_cout1_taps_f32 / pack_upconv_out_f32). */
+int gpemsr_conv_c64_cout1_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, int act,
+                              const float* residual, int res_ld, float* out, int out_ld, void* stream);
+int gpemsr_upconv_out_c64_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* consts, float* out,
+                              int out_ld, void* stream);
 /* Conv2d(16 -> 2, 7x7, pad 3) + fp32 residual [n][h][w][res_ld >= 2] -> fp32 out [n][h][w][out_ld >= 2]: SpyNet's flow-update
  * convolution (basicsr SpyNet BasicModule, last conv) as row sums on the matrix cores + a vertical 7-sum (csrc/tap_sum.hip);
  * wfrag from packing.pack_rowsum7. */

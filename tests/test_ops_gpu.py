@@ -528,3 +528,38 @@ def test_split_batched_matmul_with_device_split_operand():
     Sf = ops.conv2d([qa], ops.PackedConv(ka.buf, None, 1, T, (c,), 32), ops.ACT_NONE, weight_image_stride=T * c)
     torch.cuda.synchronize()
     assert float((Sf.buf.view(n, T, T) - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("n,h,w,ld,off", [(2, 16, 24, 64, 0), (1, 37, 131, 96, 16), (1, 70, 63, 64, 0)])
+def test_tap_sum_fp32_conv_64_to_1(n, h, w, ld, off):
+    """gpemsr_conv_c64_cout1_f32: Conv2d(64 -> 1, 3x3) of the exact-fp32 path as tap partial products on v_mfma_f32_32x32x2_f32."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_cout1_taps_f32
+    dev = _dev()
+    x = _rand(n, 64, h, w, seed=500 + h)
+    wt = _rand(1, 64, 3, 3, seed=501, scale=1.0 / 24); b = _rand(1, seed=502)
+    base = _rand(n, 1, h, w, seed=503)
+    pc = pack_conv(wt, b, dev)
+    pc.wtap32 = pack_cout1_taps_f32(wt, dev)
+    xa = _to_act(x, dev, ld, off)
+    want = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    got = ops.conv2d([xa], pc, 0, residual=_to_act(base, dev))
+    _close(got.nchw(), (want + base.double()).float(), tol=3e-6, what="fp32 tap-sum 64 -> 1 with residual")
+    got = ops.conv2d([xa], pc, 4)
+    _close(got.nchw(), torch.sigmoid(torch.nn.functional.leaky_relu(want, 0.1)).float(), tol=3e-6, what="fp32 tap-sum mask head")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 8, 12), (1, 19, 67), (1, 33, 125), (1, 1, 1)])
+def test_upconv_out_composed_operator_fp32(n, h, w):
+    """gpemsr_upconv_out_c64_f32: the decoder tail as one composed operator on the fp32 matrix pipe == the layered fp64 evaluation."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_upconv_out_f32
+    dev = _dev()
+    x = _rand(n, 64, h, w, seed=510 + h)
+    w1 = _rand(64, 64, 3, 3, seed=511, scale=1.0 / 12); b1 = _rand(64, seed=512, scale=0.5)
+    w2 = _rand(1, 64, 3, 3, seed=513, scale=1.0 / 24); b2 = _rand(1, seed=514)
+    want = torch.nn.functional.conv2d(torch.nn.functional.conv_transpose2d(x.double(), w1.double(), b1.double(), stride=2, padding=1, output_padding=1),
+                                      w2.double(), b2.double(), padding=1)
+    frag, consts = pack_upconv_out_f32(w1, b1, w2, b2, dev)
+    got = ops.upconv_out_f32(_to_act(x, dev), frag, consts)
+    _close(got.nchw(), want.float(), tol=5e-6, what="composed up-block + output layer, fp32")
