@@ -26,6 +26,8 @@ def run(args, root: str, effective_cores):
     rank, world, local = gdist.init_from_env(backend=getattr(args, "backend", "") or None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    if os.environ.get("GPEMSR_BENCH_SHARE_GPU") == "1":       # rehearsal on a box with fewer GPUs than ranks (--backend gloo)
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     s = args.scale
@@ -165,6 +167,8 @@ def run_stage2(args, root: str, effective_cores):
     rank, world, local = gdist.init_from_env(backend=getattr(args, "backend", "") or None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    if os.environ.get("GPEMSR_BENCH_SHARE_GPU") == "1":       # rehearsal on a box with fewer GPUs than ranks (--backend gloo)
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     s = args.scale
