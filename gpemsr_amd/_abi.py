@@ -180,10 +180,10 @@ def load():
     lib.gpemsr_conv2d_stem1_bf16.argtypes = [p, i32, i32, i32, p, p, i32, i32, p, i32, p]
     lib.gpemsr_vgg_mask_bf16.argtypes = [p, p, i32, i32, i32, i32, p, p, p, p, p, p]
     lib.gpemsr_conv2d_direct_bf16.argtypes = [p, i32, i32, i32, i32, i32, i32, p, p, i32, i32, i32, i32, p, i32, p, i32, i32, p]
-    lib.gpemsr_conv_c64_cout1_bf16.argtypes = [p, i32, i32, i32, i32, p, p, i32, p, i32, p, i32, p]
+    lib.gpemsr_conv_c64_cout1_bf16.argtypes = [p, i32, i32, i32, i32, p, p, i32, p, i32, p, i32, p, p]
     lib.gpemsr_upconv_out_c64_bf16.argtypes = [p, i32, i32, i32, i32, p, p, p, i32, p]
     lib.gpemsr_conv7_c16_cout2_bf16.argtypes = [p, i32, i32, i32, i32, p, p, p, i32, p, i32, p]
-    lib.gpemsr_conv_c64_cout1_f32.argtypes = [p, i32, i32, i32, i32, p, p, i32, p, i32, p, i32, p]
+    lib.gpemsr_conv_c64_cout1_f32.argtypes = [p, i32, i32, i32, i32, p, p, i32, p, i32, p, i32, p, p]
     lib.gpemsr_upconv_out_c64_f32.argtypes = [p, i32, i32, i32, i32, p, p, p, i32, p]
     _lib = lib
     return lib

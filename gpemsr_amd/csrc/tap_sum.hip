@@ -34,6 +34,8 @@ struct TapParams {
   int res_ld;
   float* out;
   int out_ld;
+  unsigned char* out_u8;   // 3x3 form, optional: the reference's tensor2img (util/util.py:145-163: clamp to [0,1], x255, round half even)
+                           // of the same value, [n][h][w] -- the uint8 image leaves the LAST kernel of the network, no extra pass
   int tiles_x, tiles_y;
   long long total;         // tiles
 };
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void tap_sum_kernel(TapParams P) {
       const long long pix = ((long long)img * h + oy) * w + ox;
       if (P.residual) s += P.residual[pix * P.res_ld];
       P.out[pix * P.out_ld] = s;
+      if (P.out_u8) P.out_u8[pix] = (unsigned char)rintf(fminf(fmaxf(s, 0.f), 1.f) * 255.0f);
     }
   } else {
     const int OH = 2 * h, OW = 2 * w;
@@ -338,24 +341,24 @@ using namespace gpemsr;
 #define A16(p) ((reinterpret_cast<uintptr_t>(p) & 15) == 0)
 
 extern "C" int gpemsr_conv_c64_cout1_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, int act,
-                                          const float* residual, int res_ld, float* out, int out_ld, void* stream) {
+                                          const float* residual, int res_ld, float* out, int out_ld, uint8_t* out_u8, void* stream) {
   GP_REQUIRE(x && wfrag && out, "conv_c64_cout1_bf16: null pointer");
   GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 64 && ld % 8 == 0 && A16(x) && A16(wfrag) && out_ld >= 1, "conv_c64_cout1_bf16: bad geometry / alignment");
   TapParams P{};
   P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld;
   P.wfrag = wfrag;
   P.cst = bias;
-  P.act = act; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
+  P.act = act; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld; P.out_u8 = out_u8;
   return launch_tap<false, tbf16_t>(P, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int gpemsr_conv_c64_cout1_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, int act,
-                                         const float* residual, int res_ld, float* out, int out_ld, void* stream) {
+                                         const float* residual, int res_ld, float* out, int out_ld, uint8_t* out_u8, void* stream) {
   GP_REQUIRE(x && wfrag && out, "conv_c64_cout1_f32: null pointer");
   GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 64 && ld % 4 == 0 && A16(x) && A16(wfrag) && out_ld >= 1, "conv_c64_cout1_f32: bad geometry / alignment");
   TapParams P{};
   P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld; P.wfrag = wfrag; P.cst = bias;
-  P.act = act; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
+  P.act = act; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld; P.out_u8 = out_u8;
   return launch_tap<false, float>(P, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -642,8 +642,19 @@ class Engine:
             if trace is not None:
                 trace.setdefault("hr", []).append(o.nchw())
             base = self.o.bilinear(self.o.gather_images(xa, cen_idx), H * s, W * s)
-            self.conv(o, "conv_last", ACT_NONE, residual=base, out=out_act.images(b0, bm))
+            u8 = getattr(self, "_u8_out", None)          # uint8 image straight from the last kernel (conv_last + base + tensor2img)
+            self.conv(o, "conv_last", ACT_NONE, residual=base, out=out_act.images(b0, bm), out_u8=None if u8 is None else u8[b0:b0 + bm])
         return out
+
+    def with_u8(self, fn, n_out: int, H: int, W: int):
+        """Run ``fn`` (a forward) with the uint8 image of the SR output produced by the network's last kernel; returns fn's results
+        plus that image [n_out, sH, sW] (R:util/util.py:145-163 semantics; what output_GPEMSR.py writes)."""
+        self._u8_out = torch.empty(n_out, H * self.scale, W * self.scale, dtype=torch.uint8, device=self.dev)
+        try:
+            res = fn()
+            return tuple(res) + (self._u8_out,)
+        finally:
+            self._u8_out = None
 
     def forward(self, x: torch.Tensor, forced_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):
         """GPEMSR.forward (model/GPEMSR.py:323-456): independent windows x[B, N, 1, H, W] -> (out, ref_img)."""

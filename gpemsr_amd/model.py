@@ -155,7 +155,9 @@ class GPEMSR(nn.Module):
             self._train_state = TrainState(self, device)
         return self._train_state
 
-    def forward(self, x, forced_code_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None):
+    def forward(self, x, forced_code_idx: Optional[torch.Tensor] = None, trace: Optional[dict] = None, want_u8: bool = False):
+        """The reference's ``SR, ref_img = model(LQ)``.  Additive keyword: ``want_u8=True`` (inference) returns a third value, the 8-bit
+        image [B, sH, sW] that util.tensor2img would make of SR, written by the network's last kernel."""
         if not x.is_cuda:
             raise RuntimeError("gpemsr_amd.GPEMSR.forward: input must live on a cuda/HIP device "
                                "(the MI355X kernel path is the only path)")
@@ -166,9 +168,12 @@ class GPEMSR(nn.Module):
             st = self._get_train_state(x.device)
             return SRForward.apply(st, x, *st.params())
         with torch.no_grad():
-            return self._get_engine(x.device).forward(x, forced_code_idx, trace)
+            eng = self._get_engine(x.device)
+            if want_u8 and x.shape[0] > 0:
+                return eng.with_u8(lambda: eng.forward(x, forced_code_idx, trace), x.shape[0], x.shape[3], x.shape[4])
+            return eng.forward(x, forced_code_idx, trace)
 
-    def forward_volume(self, frames, windows, forced_code_idx: Optional[torch.Tensor] = None):
+    def forward_volume(self, frames, windows, forced_code_idx: Optional[torch.Tensor] = None, want_u8: bool = False):
         """Volume mode: ``frames`` [T,1,H,W] are the distinct LR slices, ``windows`` [Wn,nframes] the slice numbers of
         every sliding window (edge windows repeat slices, output_GPEMSR.py:54-84,98-128).  The per-slice half of the
         network (VQGAN prior, VGG mask, prior fusion, pyramid) runs once per slice instead of once per window; results
@@ -176,7 +181,10 @@ class GPEMSR(nn.Module):
         if not frames.is_cuda:
             raise RuntimeError("gpemsr_amd.GPEMSR.forward_volume: input must live on a cuda/HIP device")
         with torch.no_grad():
-            return self._get_engine(frames.device).forward_volume(frames, windows, forced_code_idx)
+            eng = self._get_engine(frames.device)
+            if want_u8:
+                return eng.with_u8(lambda: eng.forward_volume(frames, windows, forced_code_idx), len(windows), frames.shape[2], frames.shape[3])
+            return eng.forward_volume(frames, windows, forced_code_idx)
 
     @property
     def vgg_features(self):

@@ -184,10 +184,23 @@ class PackedConv:
         return sum(self.splits)
 
 
-def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
+def conv2d(srcs, pc: "PackedConv", *args, out_u8: Optional[torch.Tensor] = None, **kw) -> "Act":
+    """gpemsr_conv2d and its specialisations (see _conv2d).  out_u8 (1-channel fp32 results only): also store the reference's
+    tensor2img of the result there ([n, h, w] uint8) -- fused into the 64 -> 1 tap kernel when that runs, a separate pass otherwise."""
+    if out_u8 is None:
+        return _conv2d(srcs, pc, *args, **kw)
+    assert pc.cout == 1 and out_u8.dtype == torch.uint8 and out_u8.is_contiguous()
+    fused = [False]
+    r = _conv2d(srcs, pc, *args, out_u8=out_u8, _u8_fused=fused, **kw)
+    if not fused[0]:
+        _u8_pass(r, out_u8)
+    return r
+
+
+def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
            pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
            src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
-           precision: str = "fp32", **kw16) -> Act:
+           precision: str = "fp32", out_u8: Optional[torch.Tensor] = None, _u8_fused: Optional[list] = None, **kw16) -> Act:
     lib = _abi.load()
     if isinstance(srcs, Act):
         srcs = [srcs]
@@ -195,7 +208,8 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
     assert len(srcs) == len(pc.splits) and all(s.c == c for s, c in zip(srcs, pc.splits)), \
         f"source channels {[s.c for s in srcs]} != packed splits {pc.splits}"
     if precision == "bf16":
-        return conv2d_bf16(srcs, pc, act, stride, residual, pixmul, out, weight_image_stride, src_image_stride, force_mfma, tag, **kw16)
+        return conv2d_bf16(srcs, pc, act, stride, residual, pixmul, out, weight_image_stride, src_image_stride, force_mfma, tag, out_u8=out_u8,
+                           _u8_fused=_u8_fused, **kw16)
     assert not kw16 or not any(kw16.values()), f"{sorted(kw16)} are options of the bf16 data path"
     s0 = srcs[0]
     n, h, w = s0.n, s0.h, s0.w
@@ -234,7 +248,10 @@ def conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual:
         def _go_taps32():       # 64 -> 1 as tap partial products on the fp32 matrix pipe (csrc/tap_sum.hip): the tensor is read once
             _abi.check(lib.gpemsr_conv_c64_cout1_f32(s0.ptr, n, h, w, s0.ld, pc.wtap32.data_ptr(), pc.b.data_ptr() if pc.b is not None else None, act,
                                                      residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
-                                                     out.ptr, out.ld, _stream()), "conv_c64_cout1_f32")
+                                                     out.ptr, out.ld, out_u8.data_ptr() if (out_u8 is not None and out.ld == 1) else None, _stream()),
+                       "conv_c64_cout1_f32")
+        if out_u8 is not None and out.ld == 1:
+            _u8_fused[0] = True
         if PROFILER is not None:
             PROFILER.run("tap_sum", tag, flops, _go_taps32)
         else:
@@ -466,6 +483,12 @@ def threeda_combine(feat: Act, attn: Act, attn_add: Act, f2: Act, f3: Act) -> Ac
     _abi.check(_abi.load().gpemsr_threeda_combine(feat.ptr, attn.ptr, attn_add.ptr, f2.ptr, f3.ptr, feat.pixels * feat.c,
                                                   out.ptr, _stream()), "threeda_combine")
     return out
+
+
+def _u8_pass(out: "Act", out_u8: torch.Tensor):
+    """tensor2img of a 1-channel fp32 result as its own pass (paths that do not end in the tap kernel)."""
+    assert not out.bf16 and out.c == 1 and out.ld == 1 and out_u8.numel() == out.pixels
+    _abi.check(_abi.load().gpemsr_tensor2img_u8(out.ptr, out.pixels, out_u8.data_ptr(), _stream()), "tensor2img")
 
 
 def tensor2img_u8(x: torch.Tensor) -> torch.Tensor:
@@ -734,7 +757,7 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
                 pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
                 src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
                 out_f32: bool = False, out32: Optional[Act] = None, gn_stats: bool = False, kpack: bool = False,
-                variant: int = 0) -> Act:
+                variant: int = 0, out_u8: Optional[torch.Tensor] = None, _u8_fused: Optional[list] = None) -> Act:
     """Convolution of the bf16 path.  out_f32: fp32 result (logits input, deformable offsets, flows, 1-channel images);
     out32: additionally store the un-rounded fp32 result there; gn_stats: leave GroupNorm partial sums on the result
     (``out.gn``); kpack: store as the B operand [n][cout/8][pixels][8] of a later 1x1 product (returns the raw tensor)."""
@@ -795,9 +818,12 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
         def _go_taps():
             _abi.check(lib.gpemsr_conv_c64_cout1_bf16(s0.ptr, n, h, w, s0.ld, pc.wtap.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
                                                       act, residual.ptr if residual is not None else None,
-                                                      residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()),
+                                                      residual.ld if residual is not None else 0, out.ptr, out.ld,
+                                                      out_u8.data_ptr() if (out_u8 is not None and out.ld == 1) else None, _stream()),
                        "conv_c64_cout1_bf16")
         if pc.wtap is not None and s0.bf16 and pc.cin == 64 and pc.cout == 1 and k == 3 and stride == 1:
+            if out_u8 is not None and out.ld == 1:
+                _u8_fused[0] = True
             if PROFILER is not None:
                 PROFILER.run("tap_sum", tag, flops, _go_taps)
             else:

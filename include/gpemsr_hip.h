@@ -205,18 +205,20 @@ int gpemsr_conv2d_direct_bf16(const void* x, int x_f32, int n, int h, int w, int
 /* One-output-channel convolutions over 64 bf16 channels as tap partial products on the matrix cores (csrc/tap_sum.hip): the input
  * is read from HBM once, fp32 result [n][h][w] with pixel stride out_ld.  wfrag: MFMA A-operand fragments of the taps as bf16
  * hi + lo halves (packing.pack_cout1_taps / pack_upconv_out).
- *   conv_c64_cout1: Conv2d(64 -> 1, 3x3, pad 1) + act + fp32 residual -- conv_last (model/GPEMSR.py:318,455).
+ *   conv_c64_cout1: Conv2d(64 -> 1, 3x3, pad 1) + act + fp32 residual -- conv_last (model/GPEMSR.py:318,455); out_u8 (optional,
+ *                   [n][h][w]): additionally the reference's tensor2img of the result (util/util.py:145-163), so the 8-bit image
+ *                   leaves the network's last kernel (conv_last + base + uint8 in one pass).
  *   upconv_out_c64: ConvTranspose2d(64 -> 64, k3 s2 p1 op1) then Conv2d(64 -> 1, 3x3, pad 1) with nothing in between, composed
  *                   into one 5x5 stride-2 operator 64 -> 1 (the VQGAN decoder's last up-block + output_layer, model/vqgan.py):
  *                   x [n][h][w] -> out [n][2h][2w]; consts = [9 bias-through-tap sums, b2, Wy0 5x64, Wx0 5x64, Wc 64] fp32. */
 int gpemsr_conv_c64_cout1_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, int act,
-                               const float* residual, int res_ld, float* out, int out_ld, void* stream);
+                               const float* residual, int res_ld, float* out, int out_ld, uint8_t* out_u8, void* stream);
 int gpemsr_upconv_out_c64_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* consts, float* out,
                                int out_ld, void* stream);
 /* The same two operators for the exact-fp32 path: fp32 NHWC input (ld % 4 == 0), v_mfma_f32_32x32x2_f32, fp32 weights
  * (wfrag: [32 k-steps][64 lanes] floats, packing.pack_cout1_taps_f32 / pack_upconv_out_f32). */
 int gpemsr_conv_c64_cout1_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, int act,
-                              const float* residual, int res_ld, float* out, int out_ld, void* stream);
+                              const float* residual, int res_ld, float* out, int out_ld, uint8_t* out_u8, void* stream);
 int gpemsr_upconv_out_c64_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* consts, float* out,
                               int out_ld, void* stream);
 /* Conv2d(16 -> 2, 7x7, pad 3) + fp32 residual [n][h][w][res_ld >= 2] -> fp32 out [n][h][w][out_ld >= 2]: SpyNet's flow-update

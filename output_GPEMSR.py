@@ -189,11 +189,12 @@ def main():
             b1 = min(hi, b0 + block)
             host, win = nxt.result()
             nxt = loaders.submit(load_block, b1) if b1 < hi else None       # decode the next block while the GPU works
+            # the 8-bit image is written by the network's last kernel (conv_last + bilinear base + tensor2img): 1 B/pixel D2H
             if use_cache:
-                SR, _ = model.forward_volume(host.to(device, non_blocking=True), win)
+                _, _, u8 = model.forward_volume(host.to(device, non_blocking=True), win, want_u8=True)
             else:
-                SR, _ = model(host.to(device, non_blocking=True))
-            u8 = ops.tensor2img_u8(SR[:, 0]).cpu().numpy()                   # device-side clamp/scale/round, 1 B/pixel D2H
+                _, _, u8 = model(host.to(device, non_blocking=True), want_u8=True)
+            u8 = u8.cpu().numpy()
             for j in range(b1 - b0):
                 pending.append(writers.submit(save_img, u8[j], osp.join(im_path_SR, '{}.png'.format(b0 + j))))
     for f in pending:

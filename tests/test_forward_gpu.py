@@ -484,3 +484,22 @@ def test_edge_shapes_empty_minimal_and_large_tile():
     # seconds, so check a size-independent property instead: the output is the bilinear base plus a bounded residual
     base = torch.nn.functional.interpolate(x[:, 2], scale_factor=8, mode="bilinear", align_corners=False)
     assert float((out - base).abs().max()) < 10.0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_uint8_image_from_the_last_kernel(precision):
+    """want_u8: conv_last + bilinear base + tensor2img in ONE kernel must give exactly the bytes of the separate tensor2img pass."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.synth import synth_lr_tiles
+    model = _model(8) if precision == "fp32" else _pmodel(8, precision)
+    x = synth_lr_tiles(3, 5, 16, 24, seed=61, kind="smooth").cuda()
+    out, ref, u8 = model(x, want_u8=True)
+    torch.cuda.synchronize()
+    assert u8.shape == (3, 128, 192) and u8.dtype == torch.uint8
+    assert torch.equal(u8, ops.tensor2img_u8(out[:, 0]))
+    out2, _ = model(x)
+    assert torch.equal(out, out2)
+    frames = synth_lr_tiles(1, 6, 16, 16, seed=62, kind="smooth")[0].cuda()
+    win = torch.tensor([[0, 0, 0, 1, 2], [0, 1, 2, 3, 4], [1, 2, 3, 4, 5]], dtype=torch.int32)
+    o, _, u = model.forward_volume(frames, win, want_u8=True)
+    assert torch.equal(u, ops.tensor2img_u8(o[:, 0]))
