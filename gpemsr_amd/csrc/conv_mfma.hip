@@ -658,6 +658,13 @@ static int launch(const ConvParams& P, size_t lds_bytes, hipStream_t st) {
 }  // namespace gpemsr
 
 using namespace gpemsr;
+// tuning switches are read from the environment ONCE per process (this entry point runs 225 times per forward)
+template <int SLOT>
+static bool env_flag_once(const char* name) {
+  static const bool set = getenv(name) != nullptr;
+  return set;
+}
+
 
 extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   GP_REQUIRE(d != nullptr, "conv2d: null descriptor");
@@ -712,13 +719,13 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   // small launches (training crops): 8-row blocks would leave CUs idle, the 4x32 flavour doubles the block count
   if (!tr && TH == 8 && (long long)d->n * cdiv(P.oh, 8) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 1024) TH = 4;
   // still fewer blocks than the chip has slots (3 per CU): split the output channels over narrower blocks (128 -> 64 -> 32)
-  if (!tr && BN == 128 && d->ksize != 7 && getenv("GPEMSR_CONV_NO_BNSPLIT") == nullptr &&
+  if (!tr && BN == 128 && d->ksize != 7 && !env_flag_once<0>("GPEMSR_CONV_NO_BNSPLIT") &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 64;
-  if (!tr && BN == 64 && getenv("GPEMSR_CONV_NO_BN32") == nullptr &&
+  if (!tr && BN == 64 && !env_flag_once<1>("GPEMSR_CONV_NO_BN32") &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 32;
   // narrow maps (training crops: 16x16 latents): 2*TH x 16-pixel tiles waste no columns; a 32-pixel MFMA tile is then two rows
   const int pad32 = cdiv(P.ow, 32) * 32, pad16 = cdiv(P.ow, 16) * 16;
-  const int TW = (!tr && (pad32 - pad16) * 4 >= pad32 && getenv("GPEMSR_CONV_NO_TW16") == nullptr) ? 16 : TILE_W;   // >= 25 % fewer dead columns
+  const int TW = (!tr && (pad32 - pad16) * 4 >= pad32 && !env_flag_once<2>("GPEMSR_CONV_NO_TW16")) ? 16 : TILE_W;   // >= 25 % fewer dead columns
   P.tw_lg = TW == 16 ? 4 : 5;
   const int TROWS = TH * TILE_W / TW;
   P.halo_h = (TROWS - 1) * P.stride + P.kh; P.halo_w = (TW - 1) * P.stride + P.kw;

@@ -489,7 +489,8 @@ extern "C" int gpemsr_conv2d_split(const gpemsr_conv_desc* d, const void* weight
   // 7x7: 32-cout blocks of 4x32 pixels keep the (larger) halo + 7-tap weight images at two workgroups per CU
   // 7x7: 32-cout blocks; plain bf16 (one plane) has room for 64-cout blocks at two workgroups per CU (the fp32 halo tile is then
   // staged and converted once per 64 couts instead of twice) -- GPEMSR_SPLIT_NO_7x7_BN64 restores 32
-  const bool bn64_7 = (nsplit == 1 && d->cout >= 64 && getenv("GPEMSR_SPLIT_NO_7x7_BN64") == nullptr);
+  static const bool no_bn64_7 = getenv("GPEMSR_SPLIT_NO_7x7_BN64") != nullptr;     // read once per process
+  const bool bn64_7 = (nsplit == 1 && d->cout >= 64 && !no_bn64_7);
   const int BN = tr ? 128 : (gemm ? (d->cout <= 64 ? 64 : 128) : (KW == 7 ? (bn64_7 ? 64 : 32) : (d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128))));
   const int TH = (BN == 128 || KW == 7 || gemm) ? 4 : 8;
   P.pad = (tr || gemm) ? 0 : KW / 2;

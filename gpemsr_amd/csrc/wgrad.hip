@@ -335,11 +335,12 @@ extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const floa
   P.dz_vec = (dz_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
   P.part = ws;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  static const bool wgrad_no_dma = getenv("GPEMSR_WGRAD_NO_DMA") != nullptr;       // read once per process
   // LDS-DMA flavour: full 64x64 channel blocks, 16-B aligned rows, 32-bit byte offsets inside one image
   const bool dma = (cout % 64 == 0) && (cin % 64 == 0) && P.x_vec && P.dz_vec && stride <= 2 &&
                    ((long long)h * w * x_ld * 4 < (1ll << 32)) && ((long long)oh * ow * dz_ld * 4 < (1ll << 32)) &&
                    ((((stride == 1 ? 2 : 1) * (31 * stride + ksize) + 3) / 4 + 3) / 4 <= 5) &&   // <= 5 X pieces per wave
-                   getenv("GPEMSR_WGRAD_NO_DMA") == nullptr;
+                   !wgrad_no_dma;
   if (dma) {
     P.th = stride == 1 ? 2 : 1;
     P.hr = P.th;
