@@ -383,7 +383,7 @@ def test_spynet_prep_bf16_matches_fp32_kernel():
     _close(in16.nchw(), in32.nchw(), BF, "level input")
 
 
-@pytest.mark.parametrize("n,h,w,scale", [(2, 16, 24, 8), (1, 32, 32, 8), (3, 8, 12, 16), (1, 10, 6, 8)])
+@pytest.mark.parametrize("n,h,w,scale", [(2, 16, 24, 8), (1, 32, 32, 8), (3, 8, 12, 16), (1, 10, 6, 8), (4, 32, 48, 8)])      # the last: 768 super-tiles, 3 per workgroup
 def test_vgg_mask_fused_matches_the_layered_form(n, h, w, scale):
     """gpemsr_vgg_mask_bf16 (conv1_1 -> conv1_2 -> 16x16 patch cosine in one kernel, R:model/GPEMSR.py:385-395) against torch:
     relu1_2 of the image expanded to 3 identical channels, F.interpolate for the LR slice, unfold + normalize + sum."""
