@@ -259,7 +259,8 @@ __global__ __launch_bounds__(512, 2) void vgg_mask_kernel(VggParams P) {
 //   the same); the per-lane patch sums live in registers across its two halves, the cross-wave reduction of super-tile k is
 //   finished in the interval after its last item.
 // LDS: W2 73,728 + 4 x 21,760 (two buffers x two 32-channel chunks of a 10 x 34 halo) + 704 bytes of constants / partial sums.
-__global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
+template <int NPROD>
+__global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask2_kernel(VggParams P) {
   constexpr int HALO_W = 34, HALO_H = 10, HALO_PX = HALO_W * HALO_H;      // conv1_2 input window of an 8 x 32 half-tile
   constexpr int A_BYTES = HALO_PX * 64;                                   // 21,760
   constexpr int W_BYTES = 2 * 9 * 4 * 64 * 16;
@@ -275,10 +276,15 @@ __global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
   {
     const unsigned lds0 = xuni(vsm_lds + (unsigned)wave * 1024u);
     const unsigned short* wp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.w2));
+    if (tid < 768) {
 #pragma unroll
-    for (int i = 0; i < NW; ++i) xglds16((unsigned)(tid + i * 768) * 16u, wp, lds0 + i * 12288u);
+      for (int i = 0; i < NW; ++i) xglds16((unsigned)(tid + i * 768) * 16u, wp, lds0 + i * 12288u);
+    }
   }
   if (tid < 64) { cst[tid] = P.b1[tid]; cst[64 + tid] = P.b2[tid]; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();           // the biases are read from LDS by both roles (registers are scarce in the 16-wave form)
+  asm volatile("" ::: "memory");
   const int T_me = (P.ns - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // 16 x 32 super-tiles of this workgroup
   const int NWI = 4 * T_me;
   auto item_geo = [&](int wi, int& img, int& oy0, int& ox0, int& tx, int& ty) {
@@ -310,11 +316,6 @@ __global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
           const float v = k < 18 ? P.w1[(ct * 32 + li) * 9 + tap] : 0.f;
           w1f[ct][s][j] = (short)(xcvt_pk_bf16(v, 0.f) & 0xFFFFu);
         }
-    float b1r[2][16];                     // conv1_1 bias of this lane's couts: 32 ct + 8 g + 4 lh + j  (register 4 g + j)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) b1r[ct][r] = P.b1[ct * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
     auto produce = [&](int wi) {
       int img, oy0, ox0, tx, ty;
       item_geo(wi, img, oy0, ox0, tx, ty);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
       const float* rimg = P.ref + (long long)img * P.H * P.W;
       const float* limg = P.lr + (long long)img * P.h * P.w;
 #pragma unroll 1
-      for (int grp = pw; grp < NGRP; grp += 4) {
+      for (int grp = pw; grp < NGRP; grp += NPROD) {
         const int hp = grp * 32 + li;
         const bool exists = hp < HALO_PX;
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
@@ -390,8 +391,10 @@ __global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               float v[4];
+              const float4 bb = *reinterpret_cast<const float4*>(cst + ct * 32 + 8 * g + 4 * lh);       // conv1_1 bias (LDS)
+              const float bj[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = inside ? fmaxf(d[4 * g + j] + b1r[ct][4 * g + j], 0.f) : 0.f;
+              for (int j = 0; j < 4; ++j) v[j] = inside ? fmaxf(d[4 * g + j] + bj[j], 0.f) : 0.f;
               *reinterpret_cast<uint2*>(arow + ((g ^ ((hp >> 2) & 3)) * 16) + lh * 8) = make_uint2(xcvt_pk_bf16(v[0], v[1]), xcvt_pk_bf16(v[2], v[3]));
             }
           }
@@ -418,13 +421,9 @@ __global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
       aoff[rr][kx] = (unsigned)(W_BYTES + hp * 64 + ((lh ^ ((hp >> 2) & 3)) * 16));
     }
   const unsigned b_frag = (unsigned)(li * 16 + lh * 1024);
-  float b2r[2][16];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   end_interval();
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) b2r[nt][r] = cst[64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+  auto b2 = [&](int nt, int r) -> float { return cst[64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]; };       // conv1_2 bias (LDS)
   unsigned pa[2][8];                      // relu1_2 features of the prior image at this lane's pixel, packed bf16 pairs
   float dot = 0.f, na = 0.f, nb = 0.f;
   for (int i = 0; i <= NWI; ++i) {
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            pa[nt][k] = xcvt_pk_bf16(fmaxf(acc[nt][2 * k] + b2r[nt][2 * k], 0.f), fmaxf(acc[nt][2 * k + 1] + b2r[nt][2 * k + 1], 0.f));
+            pa[nt][k] = xcvt_pk_bf16(fmaxf(acc[nt][2 * k] + b2(nt, 2 * k), 0.f), fmaxf(acc[nt][2 * k + 1] + b2(nt, 2 * k + 1), 0.f));
       } else {                            // up-sampled LR: products with the prior image's features, summed over the 64 couts
         int img, oy0, ox0, tx, ty;
         item_geo(i, img, oy0, ox0, tx, ty);
@@ -470,7 +469,7 @@ __global__ __launch_bounds__(768, 3) void vgg_mask2_kernel(VggParams P) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float a = okf * ((r & 1) ? xbf_hi(pa[nt][r >> 1]) : xbf_lo(pa[nt][r >> 1]));
-            const float b = okf * fmaxf(acc[nt][r] + b2r[nt][r], 0.f);
+            const float b = okf * fmaxf(acc[nt][r] + b2(nt, r), 0.f);
             dot = fmaf(a, b, dot); na = fmaf(a, a, na); nb = fmaf(b, b, nb);
           }
         if ((i & 3) == 3) {               // both halves of the super-tile are in: per-wave patch sums -> LDS
@@ -522,13 +521,14 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(GPEMSR_ELAUNCH, "vgg_mask_bf16: cannot raise the dynamic LDS limit");
     attr = true;
   }
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_VGG_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
   static int form = -1;                 // GPEMSR_VGG_FORM=1 selects the lockstep kernel (A/B measurements)
-  if (form < 0) { const char* e = getenv("GPEMSR_VGG_FORM"); form = (e && e[0] == '1') ? 1 : 2; }
+  if (form < 0) { const char* e = getenv("GPEMSR_VGG_FORM"); form = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 3); }      // 3: 8 producer waves
   static int cus = 0;
   if (cus == 0) {
     int dev = 0; hipDeviceProp_t prop;
@@ -536,7 +536,11 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
   }
   const int grid = P.ns < cus ? P.ns : cus;
   if (form == 2) {
-    hipLaunchKernelGGL(vgg_mask2_kernel, dim3(grid), dim3(768), lds2, reinterpret_cast<hipStream_t>(stream), P);
+    hipLaunchKernelGGL(vgg_mask2_kernel<4>, dim3(grid), dim3(768), lds2, reinterpret_cast<hipStream_t>(stream), P);
+    return check_launch("vgg_mask2_kernel");
+  }
+  if (form == 3) {
+    hipLaunchKernelGGL(vgg_mask2_kernel<8>, dim3(grid), dim3(1024), lds2, reinterpret_cast<hipStream_t>(stream), P);
     return check_launch("vgg_mask2_kernel");
   }
   hipLaunchKernelGGL(vgg_mask_kernel, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), P);
