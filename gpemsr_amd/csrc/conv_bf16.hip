@@ -344,7 +344,7 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
 // that have nothing else to do: per stage the multiplying waves run  MFMAs -> barrier , the loader waves  wait for stage
 // s + 1 -> barrier -> refill the slot the barrier freed , and both meet at the one barrier per stage.
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false, int SS = 0>
-__global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 8 ? 3 : 2) void conv_bf16_kernel(XParams P) {
+__global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM * WN + NL) > 8 ? 3 : 2)) void conv_bf16_kernel(XParams P) {
   constexpr int NC = WM * WN;          // multiplying waves
   constexpr bool SPEC = NL > 0;
   constexpr int NTH = (NC + NL) * 64;  // 256 threads: two workgroups per CU; 512 threads ("big tile" forms): one
@@ -1248,6 +1248,9 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
         // loader waves only for 16-channel chunks: with 32-channel chunks a loader thread owns 14 halo slots, the slot loops stop
         // being unrolled and the whole cursor state goes to scratch (1.1 KB per lane; measured 4x slower)
         if (var != 4 && CK == 16) NL = 4;
+        // 32-channel chunks, couts <= 32 (SpyNet 64 -> 32 and 32 -> 16): EIGHT loader waves (7 halo slots per loader thread, 16 waves per
+        // CU = 128 registers, which the 32-accumulator multiplying waves fit)
+        if (var != 4 && CK == 32 && BN == 32) NL = 8;
       }
     }
     else if (d->stride == 2) {
@@ -1396,6 +1399,11 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
 #define GP_IS(BNv, WMv, WNv, THv, TPSv) (L.BN == BNv && L.WM == WMv && L.WN == WNv && L.TH == THv && L.TPS == TPSv)
 #define GP_XL(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
   (L.CK == 32 ? launch_x<32, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st) : launch_x<16, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st))
+  if (L.NL == 8) {
+    if (!L.tr && !L.gemm && GP_IS(32, 8, 1, 16, 7) && L.CK == 32)
+      return L.lean ? launch_x<32, 32, 8, 1, 16, 7, false, false, 8, true>(P, lds, st) : launch_x<32, 32, 8, 1, 16, 7, false, false, 8, false>(P, lds, st);
+    return fail(GPEMSR_EUNSUPPORTED, "conv2d_bf16: no 8-loader kernel for this tile");
+  }
   if (L.lean) {               // lean-epilogue instantiations of the hottest tiles (anything else falls through to the general ones)
     if (L.NL == 4 && !L.tr && !L.gemm && GP_IS(64, 8, 1, 16, 9))
       return L.CK == 32 ? launch_x<32, 64, 8, 1, 16, 9, false, false, 4, true>(P, lds, st) : launch_x<16, 64, 8, 1, 16, 9, false, false, 4, true>(P, lds, st);
