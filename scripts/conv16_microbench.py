@@ -31,7 +31,7 @@ SHAPES = [
     ("down 64->64 3x3 s2 @512^2 x16", "conv", 16, 64, 64, 3, 2, 512, 512, (0,)),
     ("convT 64->64 @512^2 x8", "convT", 8, 64, 64, 3, 1, 512, 512, (0, 1)),
     ("convT 512->256 @64^2 x80", "convT", 80, 512, 256, 3, 1, 64, 64, (0, 1)),
-    ("spy 32->64 7x7 @512^2 x16", "conv", 16, 32, 64, 7, 1, 512, 512, (0, 1, 4)),
+    ("spy 32->64 7x7 @512^2 x16", "conv", 16, 32, 64, 7, 1, 512, 512, (0, 6)),
     ("spy 64->32 7x7 @512^2 x16", "conv", 16, 64, 32, 7, 1, 512, 512, (0, 1, 4)),
     ("spy 16->32 7x7 @512^2 x16", "conv", 16, 16, 32, 7, 1, 512, 512, (0, 1, 4)),
     ("spy 32->16 7x7 @512^2 x16", "conv", 16, 32, 16, 7, 1, 512, 512, (0, 1, 4)),
