@@ -520,6 +520,31 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* sr, const 
   __syncthreads();
   if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// Codebook.forward's loss and gradients (model/codebook.py:20-31), zq = E[idx]:
+//   loss = mean((zq.detach() - z)^2) + beta * mean((zq - z.detach())^2)            (one value: (1 + beta) * mean((zq - z)^2))
+//   dz += cz * (z - zq),  dE[idx] += ce * (zq - z)  (several tokens share a code: float atomics),  zq_out = zq
+// (the decoder input z + (zq - z).detach() has the VALUE zq; its gradient is added to dz by the caller)
+__global__ __launch_bounds__(256) void vq_loss_partial_kernel(const float* z, int z_ld, const float* E, const int* idx, long long rows, int C,
+                                                              float cz, float ce, float* dz, int dz_ld, float* dE, float* zq, int zq_ld, float* ws) {
+  float s = 0.f;
+  const long long count = rows * C;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) {
+    const long long row = e / C; const int c = (int)(e - row * C);
+    const int k = idx[row];
+    const float q = E[(long long)k * C + c];
+    const float d = q - z[row * z_ld + c];
+    s = fmaf(d, d, s);
+    if (dz) dz[row * dz_ld + c] -= cz * d;
+    if (dE) atomicAdd(dE + (long long)k * C + c, ce * d);
+    zq[row * zq_ld + c] = q;
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ void sum_scale_kernel(const float* ws, int blocks, float scale, float* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double s = 0.0;
@@ -697,6 +722,21 @@ extern "C" int gpemsr_l1_loss(const float* sr, const float* gt, int64_t count, f
                      grad_scale / (float)count, dsr, ws);
   hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(64), 0, ST(stream), ws, (int)blocks, 1.f / (float)count, loss);
   return check_launch("l1_loss");
+}
+
+extern "C" int gpemsr_vq_codebook_loss(const float* z, int z_ld, const float* embedding, const int32_t* idx, int64_t rows, int dim, float beta,
+                                       float grad_scale, float* dz, int dz_ld, float* dembedding, float* zq, int zq_ld, float* ws,
+                                       int64_t ws_floats, float* loss, void* stream) {
+  GP_REQUIRE(z && embedding && idx && zq && ws && loss && rows > 0 && dim > 0 && ws_floats >= 1, "vq_codebook_loss: bad args");
+  const long long count = (long long)rows * dim;
+  long long blocks = (count + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks > ws_floats) blocks = ws_floats;
+  const float inv = 1.f / (float)count;
+  hipLaunchKernelGGL(vq_loss_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), z, z_ld, embedding, idx, (long long)rows, dim,
+                     2.f * grad_scale * inv, 2.f * grad_scale * beta * inv, dz, dz_ld, dembedding, zq, zq_ld, ws);
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(64), 0, ST(stream), ws, (int)blocks, (1.f + beta) * inv, loss);
+  return check_launch("vq_codebook_loss");
 }
 
 extern "C" int gpemsr_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,

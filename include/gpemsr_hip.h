@@ -388,6 +388,13 @@ int gpemsr_maxpool2_bwd(const float* x, int n, int h, int w, int c, int ld, cons
 /* backward of gpemsr_gather_images / gpemsr_copy_images: dtarget[i] += sum_{j: idx[j]==i} dsrc[j] (fixed order) */
 int gpemsr_scatter_add_images(const float* dsrc, const int* idx, float* dtarget, int n_src, int n_dst, int64_t elems_per_image,
                               void* stream);
+/* Codebook.forward (R:model/codebook.py:20-31) past the arg-min: zq = embedding[idx] -> zq [rows][zq_ld]; loss[0] =
+ * mean((zq.detach() - z)^2) + beta * mean((zq - z.detach())^2); dz -= ... i.e. dz += grad_scale * 2 (z - zq) / (rows*dim),
+ * dembedding[idx] += grad_scale * beta * 2 (zq - z) / (rows*dim) (float atomics; either may be NULL).  The straight-through decoder
+ * input z + (zq - z).detach() has the value zq; the caller adds its gradient to dz.  ws >= 1024 floats.  (Stage-1 generator phase.) */
+int gpemsr_vq_codebook_loss(const float* z, int z_ld, const float* embedding, const int32_t* idx, int64_t rows, int dim, float beta,
+                            float grad_scale, float* dz, int dz_ld, float* dembedding, float* zq, int zq_ld, float* ws,
+                            int64_t ws_floats, float* loss, void* stream);
 /* torch.nn.L1Loss()(GT, SR) (mean) -> loss[0]; dsr += grad_scale * sign(sr - gt) / count (dsr may be NULL); ws >= 1024 */
 int gpemsr_l1_loss(const float* sr, const float* gt, int64_t count, float grad_scale, float* dsr, float* ws, int64_t ws_floats,
                    float* loss, void* stream);
