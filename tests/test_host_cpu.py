@@ -289,3 +289,85 @@ def test_packed_weights_follow_in_place_parameter_updates():
     m.HRconv.bias.data.view(-1)[0] = 123.0                              # .data writes do not bump _version
     m.mark_weights_written(["HRconv.bias"])
     assert float(m._get_engine(dev).pc["HRconv"].b[0]) == 123.0
+
+
+def test_composed_decoder_tail_is_exact_in_float64():
+    """packing.compose_upconv_out: ConvTranspose2d(k3 s2 p1 op1) followed by Conv2d(3x3, pad 1, one output channel) as ONE 5x5 stride-2
+    operator + border routes + bias-through-taps table == the layered evaluation (float64, every border class, odd sizes).  This is the
+    algebra csrc/tap_sum.hip (tap_sum_kernel<true, .>) implements; the GPU tests check the kernel, this checks the composition."""
+    import torch.nn.functional as F
+    from gpemsr_amd.packing import compose_upconv_out
+    torch.manual_seed(0)
+    C, M = 8, 6
+    w1 = torch.randn(C, M, 3, 3, dtype=torch.float64); b1 = torch.randn(M, dtype=torch.float64)
+    w2 = torch.randn(1, M, 3, 3, dtype=torch.float64); b2 = torch.randn(1, dtype=torch.float64)
+    for (h, w) in ((5, 7), (1, 1), (2, 3)):
+        x = torch.randn(2, C, h, w, dtype=torch.float64)
+        ref = F.conv2d(F.conv_transpose2d(x, w1, b1, stride=2, padding=1, output_padding=1), w2, b2, padding=1)
+        taps, s, bb, wy0, wx0, wc = compose_upconv_out(w1, b1, w2, b2)
+        W5 = taps.reshape(5, 5, C).permute(2, 0, 1).unsqueeze(1)                      # [C][1][5][5]: o = 2 i + t - 2
+        out = F.conv_transpose2d(x, W5, None, stride=2, padding=2, output_padding=1) + bb
+        OH, OW = 2 * h, 2 * w
+        S = s.reshape(3, 3)
+        for oy in range(OH):
+            for ox in range(OW):
+                for dy in range(3):
+                    for dx in range(3):
+                        if 0 <= oy + dy - 1 < OH and 0 <= ox + dx - 1 < OW:
+                            out[:, 0, oy, ox] += S[dy, dx]
+        for ox in range(OW):                        # routes through intermediate row -1
+            for t in range(ox & 1, 5, 2):
+                jj = (ox + 2 - t) >> 1
+                if 0 <= jj < w:
+                    out[:, 0, 0, ox] -= x[:, :, 0, jj] @ wy0[t]
+        for oy in range(OH):                        # ... column -1
+            for t in range(oy & 1, 5, 2):
+                ii = (oy + 2 - t) >> 1
+                if 0 <= ii < h:
+                    out[:, 0, oy, 0] -= x[:, :, ii, 0] @ wx0[t]
+        out[:, 0, 0, 0] += x[:, :, 0, 0] @ wc       # subtracted twice
+        assert float((out - ref).abs().max()) <= 1e-12 * max(1.0, float(ref.abs().max())), (h, w)
+
+
+def test_mfma_fragment_packers_place_every_weight_where_the_kernel_reads_it():
+    """packing._tap_fragments / _tap_fragments_f32 / pack_rowsum7: rebuild the weight rows from the lane layout the kernels document
+    (bf16 32x32x16: lane l = row l % 32, channels 16 ks + 8 (l // 32) .. + 8; fp32 32x32x2: lane l = row l % 32, channel 2 ks + l // 32)."""
+    from gpemsr_amd.packing import _tap_fragments, _tap_fragments_f32, pack_cout1_taps, pack_rowsum7
+    g = torch.Generator().manual_seed(3)
+    rows = (torch.rand(25, 64, generator=g) - 0.5).to(torch.bfloat16).to(torch.float32)
+    f = _tap_fragments(rows).to(torch.float32)                                         # [4][64][8]
+    back = torch.zeros(32, 64)
+    for ks in range(4):
+        for l in range(64):
+            back[l % 32, 16 * ks + 8 * (l // 32): 16 * ks + 8 * (l // 32) + 8] = f[ks, l]
+    assert torch.equal(back[:25], rows) and float(back[25:].abs().max()) == 0.0
+    r32 = torch.rand(9, 64, generator=g) - 0.5
+    f32 = _tap_fragments_f32(r32)                                                        # [32][64]
+    back = torch.zeros(32, 64)
+    for ks in range(32):
+        for l in range(64):
+            back[l % 32, 2 * ks + l // 32] = f32[ks, l]
+    assert torch.equal(back[:9], r32)
+    w = torch.rand(1, 64, 3, 3, generator=g) - 0.5
+    ft = pack_cout1_taps(w, "cpu").to(torch.float32)                                      # hi rows 0..8, lo rows 16..24
+    back = torch.zeros(32, 64)
+    for ks in range(4):
+        for l in range(64):
+            back[l % 32, 16 * ks + 8 * (l // 32): 16 * ks + 8 * (l // 32) + 8] = ft[ks, l]
+    want = w[0].permute(1, 2, 0).reshape(9, 64)
+    assert float((back[0:9] + back[16:25] - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max())
+    w7 = torch.rand(2, 16, 7, 7, generator=g) - 0.5
+    f7 = pack_rowsum7(w7, "cpu").to(torch.float32)                                        # [7 kx][64 lanes][8]
+    for kx in range(7):
+        back = torch.zeros(32, 16)
+        for l in range(64):
+            back[l % 32, 8 * (l // 32): 8 * (l // 32) + 8] = f7[kx, l]
+        want = w7[:, :, :, kx].permute(2, 0, 1).reshape(14, 16)                            # row 2 ky + co
+        assert float((back[0:14] + back[16:30] - want).abs().max()) <= 2.0 ** -16 * float(want.abs().max()), kx
+
+
+def test_volume_window_table_matches_the_reference_script():
+    """dist.volume_window_rows == the index arithmetic of R:output_GPEMSR.py:54-128 (first / last two outputs replicate edge slices)."""
+    from gpemsr_amd.dist import volume_window_rows
+    rows = volume_window_rows(7)
+    assert rows == [[0, 0, 0, 1, 2], [0, 0, 1, 2, 3], [0, 1, 2, 3, 4], [1, 2, 3, 4, 5], [2, 3, 4, 5, 6], [3, 4, 5, 6, 6], [4, 5, 6, 6, 6]]
