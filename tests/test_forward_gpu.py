@@ -503,3 +503,18 @@ def test_uint8_image_from_the_last_kernel(precision):
     win = torch.tensor([[0, 0, 0, 1, 2], [0, 1, 2, 3, 4], [1, 2, 3, 4, 5]], dtype=torch.int32)
     o, _, u = model.forward_volume(frames, win, want_u8=True)
     assert torch.equal(u, ops.tensor2img_u8(o[:, 0]))
+
+
+def test_bf16_forward_is_bit_stable_run_to_run():
+    """Race screen for the bf16 data path (loader / producer waves, staggered groups, counted waits): two forwards of the same
+    batch, and the same windows inside a larger batch, must agree bit for bit (no float atomics, fixed reduction orders)."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    model = _pmodel(8, "bf16")
+    x = synth_lr_tiles(3, 5, 32, 48, seed=71, kind="smooth").cuda()
+    a, ra = model(x)
+    b, rb = model(x)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(ra, rb)
+    c, rc = model(torch.cat([x, x[:1]], dim=0))
+    torch.cuda.synchronize()
+    assert torch.equal(c[:3], a) and torch.equal(c[3], a[0]) and torch.equal(rc[:3], ra)
