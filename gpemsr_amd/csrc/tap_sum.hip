@@ -249,9 +249,9 @@ __global__ __launch_bounds__(256, 2) void tap_sum_kernel(TapParams P) {
 //     out[co][y][x] = bias[co] + sum_ky R[ky][co][y + ky][x]   (+ residual)
 // from LDS.  Weights as bf16 hi halves in rows 0..13 and lo halves in rows 16..29 of the same MFMA (fp32-accurate weights for free).
 struct Row7Params {
-  const tbf16_t* x;
+  const void* xv;          // bf16 or fp32 NHWC input, 16 channels
   int n, h, w, ld;
-  const bf16x8* wfrag;     // [7 kx][64 lanes]
+  const void* wfrag;       // bf16: [7 kx][64 lanes] bf16x8 (hi rows 0..13, lo rows 16..29); fp32: [7 kx][8 k-steps][64 lanes] floats
   const float* bias;       // [2] or null
   const float* residual;
   int res_ld;
@@ -261,7 +261,9 @@ struct Row7Params {
   long long total;
 };
 
+template <typename TI>
 __global__ __launch_bounds__(256, 2) void rowsum7_kernel(Row7Params P) {
+  constexpr bool F32 = sizeof(TI) == 4;
   constexpr int TR = 16, TC = 32, HR = TR + 6;
   __shared__ float rs[14 * HR * TC];                   // 39,424 B
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lp = lane & 31, hf = lane >> 5;
@@ -274,36 +276,71 @@ __global__ __launch_bounds__(256, 2) void rowsum7_kernel(Row7Params P) {
   const int tx = (int)(tile % P.tiles_x), ty = (int)((tile / P.tiles_x) % P.tiles_y), img = (int)(tile / ((long long)P.tiles_x * P.tiles_y));
   const int h = P.h, w = P.w;
   const int y0 = ty * TR - 3, x0 = tx * TC;
-  bf16x8 wa[7];
+  if (!F32) {
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(P.wfrag);
+    bf16x8 wa[7];
 #pragma unroll
-  for (int kx = 0; kx < 7; ++kx) wa[kx] = P.wfrag[kx * 64 + lane];
-  for (int hr = wave; hr < HR; hr += 4) {
-    const int gy = y0 + hr;
-    f32x16 acc;
+    for (int kx = 0; kx < 7; ++kx) wa[kx] = wf[kx * 64 + lane];
+    for (int hr = wave; hr < HR; hr += 4) {
+      const int gy = y0 + hr;
+      f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool rowok = gy >= 0 && gy < h;               // wave-uniform
-    if (rowok) {
-      bf16x8 xb[7];
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const bool rowok = gy >= 0 && gy < h;               // wave-uniform
+      if (rowok) {
+        bf16x8 xb[7];
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
-        const int gx = x0 + lp + kx - 3;
-        const bool ok = gx >= 0 && gx < w;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) v = *reinterpret_cast<const bf16x8*>(P.x + (((long long)img * h + gy) * w + gx) * P.ld + hf * 8);
-        xb[kx] = v;
+        for (int kx = 0; kx < 7; ++kx) {
+          const int gx = x0 + lp + kx - 3;
+          const bool ok = gx >= 0 && gx < w;
+          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (ok) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const tbf16_t*>(P.xv) + (((long long)img * h + gy) * w + gx) * P.ld + hf * 8);
+          xb[kx] = v;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kx], xb[kx], acc, 0, 0, 0);
       }
+      // rows (ky, co) = 2 ky + co: lanes hf = 0 hold rows 0-3 (registers 0-3) and 8-11 (4-7), hf = 1 rows 4-7 and 12-13; lo halves 8 registers on
+      float* rp = rs + hr * TC + lp;
 #pragma unroll
-      for (int kx = 0; kx < 7; ++kx) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[kx], xb[kx], acc, 0, 0, 0);
+      for (int z = 0; z < 4; ++z) rp[(4 * hf + z) * HR * TC] = acc[z] + acc[z + 8];
+#pragma unroll
+      for (int z = 0; z < 4; ++z) {
+        const int row = 8 + 4 * hf + z;
+        if (row < 14) rp[row * HR * TC] = acc[4 + z] + acc[12 + z];
+      }
     }
-    // rows (ky, co) = 2 ky + co: lanes hf = 0 hold rows 0-3 (registers 0-3) and 8-11 (4-7), hf = 1 rows 4-7 and 12-13; lo halves 8 registers on
-    float* rp = rs + hr * TC + lp;
+  } else {
+    // exact-fp32 path: v_mfma_f32_32x32x2_f32, 8 k-steps per kx (lane's operand = channel 2 ks + hf of its pixel), fp32 weights
+    const float* wf = reinterpret_cast<const float*>(P.wfrag);
+    for (int hr = wave; hr < HR; hr += 4) {
+      const int gy = y0 + hr;
+      f32x16 acc;
 #pragma unroll
-    for (int z = 0; z < 4; ++z) rp[(4 * hf + z) * HR * TC] = acc[z] + acc[z + 8];
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const bool rowok = gy >= 0 && gy < h;
+      if (rowok) {
 #pragma unroll
-    for (int z = 0; z < 4; ++z) {
-      const int row = 8 + 4 * hf + z;
-      if (row < 14) rp[row * HR * TC] = acc[4 + z] + acc[12 + z];
+        for (int kx = 0; kx < 7; ++kx) {
+          const int gx = x0 + lp + kx - 3;
+          const bool ok = gx >= 0 && gx < w;
+          const float* p = reinterpret_cast<const float*>(P.xv) + (((long long)img * h + gy) * w + (ok ? gx : 0)) * P.ld;
+          float4 xv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { float4 v = make_float4(0.f, 0.f, 0.f, 0.f); if (ok) v = *reinterpret_cast<const float4*>(p + 4 * j); xv[j] = v; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(kx * 8 + 2 * j) * 64 + lane], hf ? xv[j].y : xv[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[(kx * 8 + 2 * j + 1) * 64 + lane], hf ? xv[j].w : xv[j].z, acc, 0, 0, 0);
+          }
+        }
+      }
+      float* rp = rs + hr * TC + lp;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = (r >> 2) * 8 + hf * 4 + (r & 3);
+        if (row < 14) rp[row * HR * TC] = acc[r];
+      }
     }
   }
   __syncthreads();
@@ -391,11 +428,25 @@ extern "C" int gpemsr_conv7_c16_cout2_bf16(const void* x, int n, int h, int w, i
   GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 16 && ld % 8 == 0 && A16(x) && A16(wfrag) && out_ld >= 2 && (!residual || res_ld >= 2),
              "conv7_c16_cout2_bf16: bad geometry / alignment");
   Row7Params P{};
-  P.x = reinterpret_cast<const tbf16_t*>(x); P.n = n; P.h = h; P.w = w; P.ld = ld;
-  P.wfrag = reinterpret_cast<const bf16x8*>(wfrag); P.bias = bias; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
+  P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld;
+  P.wfrag = wfrag; P.bias = bias; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
   P.tiles_x = (w + 31) / 32; P.tiles_y = (h + 15) / 16;
   P.total = (long long)n * P.tiles_x * P.tiles_y;
   if (P.total >= (1ll << 31)) return fail(GPEMSR_EINVAL, "conv7_c16_cout2_bf16: too many tiles");
-  hipLaunchKernelGGL(rowsum7_kernel, dim3((unsigned)P.total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
+  hipLaunchKernelGGL(rowsum7_kernel<tbf16_t>, dim3((unsigned)P.total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
+  return check_launch("rowsum7_kernel");
+}
+
+extern "C" int gpemsr_conv7_c16_cout2_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, const float* residual,
+                                          int res_ld, float* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && wfrag && out, "conv7_c16_cout2_f32: null pointer");
+  GP_REQUIRE(n > 0 && h > 0 && w > 0 && ld >= 16 && ld % 4 == 0 && A16(x) && out_ld >= 2 && (!residual || res_ld >= 2), "conv7_c16_cout2_f32: bad geometry / alignment");
+  Row7Params P{};
+  P.xv = x; P.n = n; P.h = h; P.w = w; P.ld = ld;
+  P.wfrag = wfrag; P.bias = bias; P.residual = residual; P.res_ld = res_ld; P.out = out; P.out_ld = out_ld;
+  P.tiles_x = (w + 31) / 32; P.tiles_y = (h + 15) / 16;
+  P.total = (long long)n * P.tiles_x * P.tiles_y;
+  if (P.total >= (1ll << 31)) return fail(GPEMSR_EINVAL, "conv7_c16_cout2_f32: too many tiles");
+  hipLaunchKernelGGL(rowsum7_kernel<float>, dim3((unsigned)P.total), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P);
   return check_launch("rowsum7_kernel");
 }

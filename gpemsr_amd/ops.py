@@ -178,6 +178,7 @@ class PackedConv:
     wtap: Optional[torch.Tensor] = None    # bf16 data path, 64 -> 1 3x3: tap fragments (packing.pack_cout1_taps)
     wrow7: Optional[torch.Tensor] = None   # bf16 data path, 16 -> 2 7x7 (SpyNet flow update): row-sum fragments (packing.pack_rowsum7)
     wtap32: Optional[torch.Tensor] = None  # fp32 activations, 64 -> 1 3x3: fp32 tap fragments (packing.pack_cout1_taps_f32)
+    wrow7_32: Optional[torch.Tensor] = None  # fp32 activations, 16 -> 2 7x7: row-sum fragments (packing.pack_rowsum7_f32)
 
     @property
     def cin(self) -> int:
@@ -244,6 +245,17 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     # algorithmic FLOPs of this launch (2*MAC, un-padded channel counts)
     taps = 9.0 / 4.0 if pc.transposed else float(k * k)
     flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps
+    if (use_direct and pc.wrow7_32 is not None and pc.cin == 16 and s0.c == 16 and pc.cout == 2 and k == 7 and stride == 1 and act == ACT_NONE and s0.ld % 4 == 0
+            and not s0.bf16 and (residual is None or residual.c == 2)):
+        def _go_row7_32():      # SpyNet's flow update as row sums on the fp32 matrix pipe (csrc/tap_sum.hip)
+            _abi.check(lib.gpemsr_conv7_c16_cout2_f32(s0.ptr, n, h, w, s0.ld, pc.wrow7_32.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
+                                                      residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
+                                                      out.ptr, out.ld, _stream()), "conv7_c16_cout2_f32")
+        if PROFILER is not None:
+            PROFILER.run("tap_sum", tag, flops, _go_row7_32)
+        else:
+            _go_row7_32()
+        return out
     if use_direct and pc.wtap32 is not None and pc.cin == 64 and pc.cout == 1 and k == 3 and stride == 1 and s0.ld % 4 == 0 and not s0.bf16:
         def _go_taps32():       # 64 -> 1 as tap partial products on the fp32 matrix pipe (csrc/tap_sum.hip): the tensor is read once
             _abi.check(lib.gpemsr_conv_c64_cout1_f32(s0.ptr, n, h, w, s0.ld, pc.wtap32.data_ptr(), pc.b.data_ptr() if pc.b is not None else None, act,

@@ -270,3 +270,15 @@ def pack_upconv_out_f32(w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.
     frag = _tap_fragments_f32(taps.to(torch.float32)).to(device)
     consts = torch.cat([s, torch.tensor([bb], dtype=torch.float64), wy0.reshape(-1), wx0.reshape(-1), wc]).to(torch.float32).contiguous().to(device)
     return frag, consts
+
+
+def pack_rowsum7_f32(w: torch.Tensor, device) -> torch.Tensor:
+    """pack_rowsum7 for fp32 activations: [7 kx][8 k-steps][64 lanes] floats -- lane l holds row l % 32 (= 2 ky + co), channel 2 ks + l // 32."""
+    assert tuple(w.shape) == (2, 16, 7, 7)
+    wf = w.detach().to(torch.float32).cpu()
+    frags = []
+    for kx in range(7):
+        rows = torch.zeros(32, 16)
+        rows[0:14] = wf[:, :, :, kx].permute(2, 0, 1).reshape(14, 16)
+        frags.append(rows.reshape(32, 8, 2).permute(1, 2, 0).reshape(8, 64))                 # [ks][half][row] -> [ks][lane]
+    return torch.stack(frags).contiguous().to(device)

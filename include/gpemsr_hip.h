@@ -226,6 +226,9 @@ int gpemsr_upconv_out_c64_f32(const float* x, int n, int h, int w, int ld, const
  * wfrag from packing.pack_rowsum7. */
 int gpemsr_conv7_c16_cout2_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, const float* residual,
                                 int res_ld, float* out, int out_ld, void* stream);
+/* the same for fp32 activations (exact-fp32 path): v_mfma_f32_32x32x2_f32, wfrag [7 kx][8 k-steps][64 lanes] floats (packing.pack_rowsum7_f32) */
+int gpemsr_conv7_c16_cout2_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, const float* residual,
+                               int res_ld, float* out, int out_ld, void* stream);
 
 /* Direct (VALU) convolution for tiny channel counts: cout <= 16, any k<=7, stride 1/2/4.
  * replaces: POD.flowdsconv* (model/GPEMSR.py:70-75,101-106), SpyNet's last 16->2 conv,

@@ -563,3 +563,19 @@ def test_upconv_out_composed_operator_fp32(n, h, w):
     frag, consts = pack_upconv_out_f32(w1, b1, w2, b2, dev)
     got = ops.upconv_out_f32(_to_act(x, dev), frag, consts)
     _close(got.nchw(), want.float(), tol=5e-6, what="composed up-block + output layer, fp32")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 16, 32), (1, 37, 70), (3, 5, 9)])
+def test_spynet_flow_update_row_sums_fp32(n, h, w):
+    """gpemsr_conv7_c16_cout2_f32: Conv2d(16 -> 2, 7x7) + residual of the exact-fp32 path as MFMA row sums + vertical 7-sum."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_rowsum7_f32
+    dev = _dev()
+    x = _rand(n, 16, h, w, seed=600 + h)
+    wt = _rand(2, 16, 7, 7, seed=601, scale=1.0 / 28); b = _rand(2, seed=602)
+    up = _rand(n, 2, h, w, seed=603, scale=3.0)
+    pc = pack_conv(wt, b, dev)
+    pc.wrow7_32 = pack_rowsum7_f32(wt, dev)
+    want = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), 1, 3) + up.double()
+    got = ops.conv2d([_to_act(x, dev)], pc, 0, residual=_to_act(up, dev))
+    _close(got.nchw(), want.float(), tol=3e-6, what="fp32 flow update with residual")
