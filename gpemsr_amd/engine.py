@@ -225,7 +225,11 @@ class Engine:
         if c % 32 != 0 or T % 4 != 0:
             raise RuntimeError(f"gpemsr_amd: non-local block needs channels ({c}) % 32 == 0 and latent tokens ({T}) % 4 == 0")
         if self.bf16:
-            return self._nonlocal_bf16(x, p)
+            if T % 16 == 0:
+                return self._nonlocal_bf16(x, p)
+            # token counts the bf16 matrix-product tiles cannot take (e.g. CREMI's 156 x 156 LR slices -> 78 x 78 = 6084 tokens): this
+            # one block runs on the exact-fp32 kernels (zero-padded score rows), the rest of the path stays bf16
+            return self.o.cast_bf16(self._nonlocal_ragged(self.o.cast_f32(x), p, precision="fp32"))
         if T % 32 != 0:
             return self._nonlocal_ragged(x, p)
         hn = self.o.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
@@ -285,7 +289,7 @@ class Engine:
             del S, P
         return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
 
-    def _nonlocal_ragged(self, x: Act, p: str) -> Act:
+    def _nonlocal_ragged(self, x: Act, p: str, precision: Optional[str] = None) -> Act:
         """The same block when the token count is not a multiple of 32 (e.g. 24x40 LR tiles -> 12x20 latents): the score rows
         and v^T rows are padded with zeros to the GEMM's 32-column granule (row stride Tp), the row softmax runs over the T
         real columns; the products stay on the exact f32 kernel in every precision mode."""
@@ -293,8 +297,9 @@ class Engine:
         T = h * w
         Tp = (T + 31) // 32 * 32
         hn = self.o.groupnorm_relu(x, self.par[p + ".gn.weight"], self.par[p + ".gn.bias"], relu=False)
-        q = self.conv(hn, p + ".q")
-        k = self.conv(hn, p + ".k")
+        kw = {} if precision is None else {"precision": precision}
+        q = self.conv(hn, p + ".q", **kw)
+        k = self.conv(hn, p + ".k", **kw)
         wv = self.pc[p + ".v"]
         vT = Act(torch.zeros(n * c * Tp, dtype=torch.float32, device=self.dev), n, c // 32, 32, T, Tp, 0)
         a = Act(wv.w, n, c // 32, 32, c, c, 0)
@@ -311,7 +316,7 @@ class Engine:
             Sp = Act(S.buf, m, h, w, Tp, Tp, 0)               # padded columns are zeros and meet zero rows of v^T
             self.o.conv2d([Sp], self.o.PackedConv(vT.images(f0, m).buf, wv.b, 1, c, (Tp,), 32), ACT_NONE,
                           weight_image_stride=c * Tp, out=out.images(f0, m), tag=p + ".pv")
-        return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
+        return self.conv(out, p + ".proj_out", ACT_NONE, residual=x, **kw)
 
     def _vt(self, wv_packed: torch.Tensor, hn: Act, n: int, c: int, T: int) -> Act:
         vT = self.o.new_act(n, c // 32, 32, T, device=self.dev)
@@ -579,10 +584,10 @@ class Engine:
 
     # ------------------------------------------------------------------ whole forward
     def _check_lr(self, H: int, W: int):
-        if self.scale == 8:
-            assert H % 8 == 0 and W % 8 == 0, "x8: LR height/width must be multiples of 8"
-        else:
-            assert H % 4 == 0 and W % 4 == 0, "x16: LR height/width must be multiples of 4"
+        # the L2 / L3 pyramid and the x8 latent grid (H/2 x W/2) halve twice (model/GPEMSR.py:395,424-426); CREMI's 156 x 156 x8 LR
+        # slices are a multiple of 4 but not of 8
+        if H % 4 != 0 or W % 4 != 0 or H < 4 or W < 4:
+            raise RuntimeError(f"gpemsr_amd: LR height/width must be multiples of 4 (got {H} x {W})")
 
     def _front_all(self, xa: Act, forced_idx, trace):
         """Per-frame half (everything up to the L1/L2/L3 pyramid, model/GPEMSR.py:325-426) for all frames of ``xa``."""

@@ -140,6 +140,32 @@ def test_full_size_properties():
     assert float((out.cpu() - base).abs().max()) < 5.0
 
 
+@pytest.mark.parametrize("scale,lr", [(8, 156), (16, 76)])
+def test_cremi_sized_slices_run_whole_in_both_precisions(scale, lr):
+    """Whole CREMI-sized slices instead of tiles (1250 x 1250 HR sections cropped to a multiple of 4 x scale: 1248 -> 156 x 156 LR at
+    x8, 1216 -> 76 x 76 at x16): 78 x 78 = 6084 / 76 x 76 = 5776 latent tokens, counts the fp32 attention tiles (x8 and x16) and
+    the bf16 ones (x8) do not divide -> the zero-padded ragged path, to which bf16 mode falls back for that block; LR sizes that
+    are multiples of 4 but not of 8 / 32 (SpyNet resizes).  No CPU oracle at this size (minutes): shapes, finiteness,
+    determinism, and the bf16 path against the fp32 one with the fp32 run's code indices teacher-forced, at the bf16 bars."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    x = synth_lr_tiles(1, 5, lr, lr, seed=90 + scale, kind="smooth").cuda()
+    m32, m16 = _model(scale), _pmodel(scale, "bf16")
+    tr = {}
+    out, ref = m32(x, trace=tr)
+    torch.cuda.synchronize()
+    hr, lat = lr * scale, lr * scale // 16
+    assert out.shape == (1, 1, hr, hr) and ref.shape == (1, 5, 1, hr, hr)
+    assert torch.isfinite(out).all() and torch.isfinite(ref).all()
+    idx = torch.cat(tr["code_idx"])
+    assert idx.numel() == 5 * lat * lat
+    out_b, _ = m32(x, forced_code_idx=idx)
+    assert torch.equal(out, out_b)
+    o16, r16 = m16(x, forced_code_idx=idx)
+    torch.cuda.synchronize()
+    assert float((o16 - out).abs().max() / out.abs().max()) <= 1e-3
+    assert float((r16 - ref).abs().max() / ref.abs().max()) <= 2e-2
+
+
 def test_x16_ragged_size_exercises_spynet_resize():
     """x16 on a 20x24 tile: 4H = 80 is not a multiple of 32, so basicsr SpyNet resizes its input to 96x96, the pyramid
     has odd levels (3x3 coarsest, replicate-padded flow upsampling) and the flow is rescaled per axis."""
@@ -159,7 +185,7 @@ def test_x16_ragged_size_exercises_spynet_resize():
         assert err <= REL_TOL, f"{name}: rel err {err:.3e}"
 
 
-@pytest.mark.parametrize("scale,h,w", [(8, 24, 40), (16, 20, 20)])
+@pytest.mark.parametrize("scale,h,w", [(8, 24, 40), (16, 20, 20), (8, 20, 20), (8, 12, 28)])
 def test_latent_token_count_not_multiple_of_32(scale, h, w):
     """x8 24x40 -> 12x20 = 240 latent tokens, x16 20x20 -> 400: the attention products run on score rows padded to the
     GEMM's 32-column granule (engine._nonlocal_ragged); results must match the CPU oracle like any other size."""
@@ -197,8 +223,8 @@ def test_batch_crossing_chunk_boundaries():
         o1, r1 = model(x[b:b + 1], forced_code_idx=idx[b])
         assert float((o1 - out[b:b + 1]).abs().max()) <= 1e-5 * float(out.abs().max()), b
         assert float((r1 - ref[b:b + 1]).abs().max()) <= 1e-5 * float(ref.abs().max()), b
-    with pytest.raises(AssertionError):
-        model(torch.rand(1, 5, 1, 12, 16).cuda())          # x8 needs LR sizes that are multiples of 8
+    with pytest.raises(RuntimeError):
+        model(torch.rand(1, 5, 1, 14, 16).cuda())          # LR sizes must be multiples of 4 (the pyramid halves twice)
     with pytest.raises(AssertionError):
         model(torch.rand(1, 3, 1, 16, 16).cuda())          # N must equal nframes
 
@@ -301,6 +327,29 @@ def test_bf16_data_path_against_the_reference_golden(tag, golden_dir):
     print(f"bf16 path {tag}: rel err " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()) +
           f"; code agreement {agree:.4f} ({int(safe.sum())}/{safe.size} cells have a margin > 4 x the logit error {abs_err:.1e})")
     assert (idx[safe] == d["code_idx"][safe]).all() and agree > 0.9
+
+
+@pytest.mark.parametrize("scale,h,w", [(8, 24, 40), (16, 20, 20), (8, 20, 20), (8, 12, 28)])
+def test_bf16_path_with_latent_tokens_not_multiple_of_16(scale, h, w):
+    """precision='bf16' on tile sizes whose latent token count the bf16 attention tiles cannot take (x8 24x40 -> 240 tokens is
+    fine, x16 20x20 -> 400 is fine, x8 20x20 -> 10x10 = 100 tokens is not: CREMI's 156x156 LR slices give 78x78 = 6084): the
+    non-local block alone falls back to the exact-fp32 ragged kernels (engine.nonlocal_block), everything else stays bf16.
+    Against the CPU oracle, the same bars as the bf16 golden test."""
+    from gpemsr_amd.synth import synth_lr_tiles
+    from oracle import gpemsr_oracle as orc
+    model = _pmodel(scale, "bf16")
+    x = synth_lr_tiles(1, 5, h, w, seed=80 + scale, kind="smooth")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    otr, tr = {}, {}
+    with torch.no_grad():
+        want, want_ref = orc.gpemsr_forward(sd, x, scale=scale, trace=otr)
+    out, ref_img = model(x.cuda(), forced_code_idx=otr["code_idx"].cuda(), trace=tr)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 1, h * scale, w * scale)
+    for got, wnt, name, tol in ((out, want, "out", 1e-3), (ref_img, want_ref, "ref_img", 2e-2),
+                                (torch.cat(tr["logits"]), otr["logits"], "logits", 5e-2)):
+        err = float((got.float().cpu().reshape(wnt.shape) - wnt).abs().max() / wnt.abs().max())
+        assert err <= tol, f"{name}: rel err {err:.3e}"
 
 
 @pytest.mark.parametrize("tag,precision", [("full_x8_lr128", "fp32"), ("full_x16_lr64", "fp32"), ("full_x8_lr128", "bf16"), ("full_x16_lr64", "bf16")])
