@@ -409,7 +409,7 @@ def run_forward(args) -> int:
     if rank == 0:
         cfg_name = {8: "BASELINE.json configs[1]" if args.precision == "fp32" else "BASELINE.json configs[2], one GPU's share",
                     16: "BASELINE.json configs[3], one GPU's share"}[s]
-        dtype = {"fp32": "f32", "bf16": "bf16 (bf16 activations in HBM, bf16 MFMA, fp32 accumulate; indexer logits + argmax fp32)",
+        dtype = {"fp32": "f32", "bf16": "bf16 (bf16 activations in HBM, bf16 MFMA, fp32 accumulate; indexer logits at fp32 precision = 3 bf16 products of hi+lo operands, argmax on fp32 logits)",
                  "bf16x3": "bf16x3 (fp32 activations; convs as 3 split hi+lo bf16 MFMA products, fp32 accumulate)",
                  "bf16op": "bf16 operands rounded in the kernel (fp32 activations in HBM), fp32 accumulate"}[args.precision]
         line = {

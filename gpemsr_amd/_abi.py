@@ -39,7 +39,7 @@ SYMBOLS = [
     "gpemsr_bilinear_bf16", "gpemsr_pool3s2_maxavg_bf16", "gpemsr_spynet_prep_bf16", "gpemsr_dcn_columns_bf16", "gpemsr_patch_cosine_bf16",
     "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
     "gpemsr_copy_channels_f32_bf16", "gpemsr_conv2d_stem1_bf16", "gpemsr_conv2d_direct_bf16", "gpemsr_vgg_mask_bf16",
-    "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32",
+    "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32", "gpemsr_split_f32_bf16x2",
 ]
 
 
@@ -167,6 +167,7 @@ def load():
     lib.gpemsr_pack_rows_bf16.argtypes = [p, i32, i32, i32, i32, i64, p, p]
     lib.gpemsr_cast_f32_bf16.argtypes = [p, i64, i32, i32, p, i32, p]
     lib.gpemsr_cast_bf16_f32.argtypes = [p, i64, i32, i32, p, i32, p]
+    lib.gpemsr_split_f32_bf16x2.argtypes = [p, i64, i32, i32, p, i32, p, i32, p]
     lib.gpemsr_bilinear_bf16.argtypes = [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, i32, p]
     lib.gpemsr_pool3s2_maxavg_bf16.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
     lib.gpemsr_spynet_prep_bf16.argtypes = [p, p, p, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), p, p, p]

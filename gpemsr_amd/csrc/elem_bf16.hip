@@ -53,6 +53,22 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* x, lon
   }
 }
 
+// x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-17 |x|: the A operands of a "three bf16 products" GEMM
+// (hi*Whi + lo*Whi + hi*Wlo) that keeps an fp32 tensor's precision on the bf16 matrix pipe (the indexer's logits, engine.py).
+__global__ __launch_bounds__(256) void split_f32_bf16x2_kernel(const float* x, long long pixels, int c4, int x_ld, bf16_t* hi, int hi_ld, bf16_t* lo, int lo_ld) {
+  const long long total = pixels * c4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long p = e / c4; const int ch = 4 * (int)(e % c4);
+    const float4 v = *reinterpret_cast<const float4*>(x + p * x_ld + ch);
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { h[k] = to_bf16(f[k]); l[k] = to_bf16(f[k] - from_bf16(h[k])); }
+    *reinterpret_cast<uint2*>(hi + p * hi_ld + ch) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(lo + p * lo_ld + ch) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  }
+}
+
 // ---- GroupNorm: statistics pass for tensors no convolution just produced, and the apply pass ----
 // grid (parts, n); thread t owns 8 channels (t % c8) of pixel rows t / c8 + k*(256/c8)
 __global__ __launch_bounds__(256) void gn_partial16_kernel(const bf16_t* x, int hw, int c, int ld, int parts, float* ws) {
@@ -757,6 +773,14 @@ extern "C" int gpemsr_cast_bf16_f32(const void* x, int64_t pixels, int c, int x_
   GP_REQUIRE(x && out && pixels > 0 && c > 0, "cast_bf16_f32: bad args");
   hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid16(pixels * c)), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), (long long)pixels, c, x_ld, out, out_ld);
   return check_launch("cast_bf16_f32");
+}
+
+extern "C" int gpemsr_split_f32_bf16x2(const float* x, int64_t pixels, int c, int x_ld, void* hi, int hi_ld, void* lo, int lo_ld, void* stream) {
+  GP_REQUIRE(x && hi && lo && pixels > 0 && c > 0, "split_f32_bf16x2: bad args");
+  GP_REQUIRE(c % 4 == 0 && x_ld % 4 == 0 && hi_ld % 4 == 0 && lo_ld % 4 == 0 && A16(x) && A16(hi) && A16(lo), "split_f32_bf16x2: channels and row strides must be multiples of 4, bases 16-byte aligned");
+  hipLaunchKernelGGL(split_f32_bf16x2_kernel, dim3(grid16(pixels * (c / 4))), dim3(256), 0, ST(stream), x, (long long)pixels, c / 4, x_ld,
+                     reinterpret_cast<bf16_t*>(hi), hi_ld, reinterpret_cast<bf16_t*>(lo), lo_ld);
+  return check_launch("split_f32_bf16x2");
 }
 
 extern "C" int gpemsr_groupnorm_stats_bf16(const void* x, int n, int hw, int c, int ld, float* ws, int parts, void* stream) {

@@ -21,13 +21,15 @@ torch is used for allocation and stream plumbing only; there is no CPU path.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional
 
 import torch
 
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
-from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear,
+from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3,
                       pack_vgg_first, pack_cout1_taps, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
@@ -59,7 +61,8 @@ class Engine:
         assert precision in ("fp32", "bf16x3", "bf16", "bf16op"), precision
         # fp32: exact fp32 MFMA everywhere (default).
         # bf16: bf16 NHWC activations in HBM + bf16 MFMA (BASELINE configs[2]); 1-channel images, flows, deformable offsets
-        #       and the indexer's logits GEMM + argmax stay fp32.
+        #       and the indexer's logits + argmax stay at fp32 precision: the logits GEMM takes the fp32 output of
+        #       the last convolution and runs as three bf16 products of hi + lo operands (GPEMSR_LOGITS_X3=0: the fp32 MFMA kernel).
         # bf16x3 / bf16op: fp32 activations; convolutions whose sources are multiples of 16 channels run on the bf16 matrix
         #       pipe with operands converted in LDS (split hi+lo = fp32-grade, or plain bf16 operands).
         self.precision = precision
@@ -186,6 +189,8 @@ class Engine:
                 self.pc[name].wrow7 = pack_rowsum7(w, dev)              # SpyNet flow update as row sums (csrc/tap_sum.hip)
         elif w.dim() == 2 and name.endswith("indexer.embedding"):
             self.pc[name] = pack_linear(w, b, dev)
+            if self.bf16 and w.shape[1] % 16 == 0 and os.environ.get("GPEMSR_LOGITS_X3", "1") != "0":
+                self.pc[name + "@x3"] = pack_linear_bf16x3(w, b, dev)
         elif w.dim() == 2 and name.endswith("codebook.embedding"):
             self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
         elif w.dim() == 5:                             # ThreeDA.conv3D_{1,2}: [t,t,1,1,1]
@@ -350,6 +355,12 @@ class Engine:
                 h = self.conv(h, name, out_f32=True)       # the logits GEMM + argmax stay fp32
             else:
                 h = self.vq_layer(h, name)
+        if (p + ".embedding@x3") in self.pc and not h.bf16:
+            # nn.Linear (indexer.py:100) at fp32 precision on the bf16 matrix pipe: operands split hi + lo, three products, fp32
+            # accumulation (packing.pack_linear_bf16x3; ~2^-16 of the logit scale, the bf16 activations upstream move logits by ~1e-2)
+            hi, lo = self.o.split_hi_lo_bf16(h)
+            del h
+            return self.o.conv2d([hi, lo, hi], self.pc[p + ".embedding@x3"], ACT_NONE, tag=p + ".embedding", precision="bf16", out_f32=True)
         if h.bf16:
             h = self.o.cast_f32(h)
         return self.conv(h, p + ".embedding", precision="fp32")    # nn.Linear on NHWC == 1x1 conv (indexer.py:100)

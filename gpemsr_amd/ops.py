@@ -956,6 +956,15 @@ def cast_f32(x: Act) -> Act:
     return out
 
 
+def split_hi_lo_bf16(x: Act):
+    """fp32 activation -> (hi, lo) bf16 activations with x = hi + lo to 2^-17 relative (gpemsr_split_f32_bf16x2)."""
+    assert not x.bf16
+    hi = new_act(x.n, x.h, x.w, x.c, device=x.buf.device, bf16=True)
+    lo = new_act(x.n, x.h, x.w, x.c, device=x.buf.device, bf16=True)
+    _abi.check(_abi.load().gpemsr_split_f32_bf16x2(x.ptr, x.pixels, x.c, x.ld, hi.ptr, hi.ld, lo.ptr, lo.ld, _stream()), "split_f32_bf16x2")
+    return hi, lo
+
+
 def pack_rows_bf16(a: Act) -> torch.Tensor:
     """bf16 rows [n][h*w][c] -> [n][c/8][h*w][8]: the per-image B operand of a 1x1 product (attention)."""
     assert a.bf16 and a.c % 8 == 0

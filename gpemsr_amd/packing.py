@@ -157,6 +157,21 @@ def pack_conv_bf16(w: torch.Tensor, device, splits: Optional[Sequence[int]] = No
     return _stage_order_bf16(wt, bf16_chunk(splits)).to(torch.bfloat16).to(device)
 
 
+def pack_linear_bf16x3(w: torch.Tensor, b: Optional[torch.Tensor], device) -> PackedConv:
+    """nn.Linear [out, in] fp32 -> the weight of its three-bf16-product form: with W = Whi + Wlo (+ 2^-17) and the activation split
+    the same way (ops.split_hi_lo_bf16), x W^T = hi Whi^T + lo Whi^T + hi Wlo^T to ~2^-16 relative -- a 1x1 bf16 convolution over the
+    sources [hi, lo, hi] with the input-channel blocks [Whi | Whi | Wlo] and fp32 accumulation (the lo*Wlo term, 2^-18, is dropped)."""
+    wf = w.detach().to(torch.float32).cpu()
+    whi = wf.to(torch.bfloat16).to(torch.float32)
+    wlo = (wf - whi).to(torch.bfloat16).to(torch.float32)
+    cout, cin = wf.shape
+    w3 = torch.cat([whi, whi, wlo], dim=1).reshape(cout, 3 * cin, 1, 1)
+    pc = PackedConv(torch.empty(0, device=device), None if b is None else b.detach().to(torch.float32).contiguous().to(device),
+                    1, cout, (cin, cin, cin), 32)
+    pc.wb = pack_conv_bf16(w3, device, (cin, cin, cin))
+    return pc
+
+
 def pack_convT_bf16(w: torch.Tensor, device) -> torch.Tensor:
     """ConvTranspose2d(k3,s2,p1,op1) [Cin,Cout,3,3] -> phase-stacked 2x2-tap rows (pack_convT) in staged bf16 order."""
     cin, cout, kh, kw = w.shape

@@ -168,6 +168,9 @@ int gpemsr_pack_rows_bf16(const void* src, int n, int rows, int c, int ld, int64
 /* format changes at the module boundary / between the fp32 and bf16 parts of the path */
 int gpemsr_cast_f32_bf16(const float* x, int64_t pixels, int c, int x_ld, void* out, int out_ld, void* stream);
 int gpemsr_cast_bf16_f32(const void* x, int64_t pixels, int c, int x_ld, float* out, int out_ld, void* stream);
+/* fp32 -> two bf16 tensors, hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to 2^-17): the A operands of the three-product form of the
+ * indexer's nn.Linear (indexer.py:100; logits keep fp32 precision on the bf16 matrix pipe).  c, row strides % 4 == 0 */
+int gpemsr_split_f32_bf16x2(const float* x, int64_t pixels, int c, int x_ld, void* hi, int hi_ld, void* lo, int lo_ld, void* stream);
 /* bf16 counterparts of gpemsr_bilinear / _pool3s2_maxavg / _spynet_prep (16-channel bf16 level input, channels 8..15 zero; flows
  * stay fp32) / _dcn_columns (x and columns bf16, offsets + mask logits fp32) / _patch_cosine / _temporal_gate /
  * _frame_mix_lrelu / _threeda_combine / _copy_channels (c % 8 == 0) */

@@ -476,3 +476,26 @@ def test_spynet_flow_update_row_sums(n, h, w):
     pc.b = None
     got = ops.conv2d([_act16(x, dev)], pc, 0, precision="bf16", out_f32=True)
     _close(got.nchw(), want - up.double() - b.double().view(1, 2, 1, 1), 1e-5, "flow update, no bias, no residual")
+
+
+@pytest.mark.parametrize("rows_hw,cin,cout", [((2, 16, 32), 512, 1024), ((1, 5, 12), 64, 96)])
+def test_linear_as_three_bf16_products_keeps_fp32_precision(rows_hw, cin, cout):
+    """The indexer's nn.Linear in bf16 mode (engine.indexer_logits): ops.split_hi_lo_bf16 + packing.pack_linear_bf16x3 + the 1x1 bf16
+    kernel over [hi, lo, hi].  hi + lo reproduces the fp32 input to 2^-16; the logits match the fp64 product of the UNROUNDED fp32
+    operands to 2e-5 of the logit scale (fp32 kernel: ~1e-6; one bf16 rounding of either operand alone would be ~2e-3)."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_linear_bf16x3
+    dev = _dev()
+    n, h, w = rows_hw
+    x = _rand(n, cin, h, w, seed=500 + cin, scale=3.0)
+    wt = _rand(cout, cin, seed=501, scale=1.0 / cin ** 0.5); b = _rand(cout, seed=502)
+    hi, lo = ops.split_hi_lo_bf16(_act32(x, dev))
+    assert hi.bf16 and lo.bf16
+    rec = hi.nchw().double() + lo.nchw().double()
+    assert float((rec.cpu() - x.double()).abs().max()) <= 2.0 ** -16 * float(x.abs().max())
+    assert torch.equal(hi.nchw().cpu().float(), _r(x))
+    pc = pack_linear_bf16x3(wt, b, dev)
+    got = ops.conv2d([hi, lo, hi], pc, 0, precision="bf16", out_f32=True)
+    assert not got.bf16 and got.c == cout
+    want = torch.einsum("nchw,oc->nohw", x.double(), wt.double()) + b.double().view(1, -1, 1, 1)
+    _close(got.nchw(), want, 2e-5, "three-product linear")
