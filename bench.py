@@ -213,9 +213,9 @@ def pmc_traffic(tag: str, launches_per_step: int):
 
 FAMILIES = {
     "fp32": (("conv_mfma",), "conv_mfma_kernel (implicit-GEMM conv/GEMM family, v_mfma_f32_32x32x2_f32)", PEAK_F32_MATRIX_TFLOPS),
-    "bf16": (("conv_bf16", "vgg_mask", "attn_bf16"),
-             "bf16 MFMA family (v_mfma_f32_32x32x16_bf16): conv_bf16_kernel (implicit-GEMM conv / 1x1 / transposed / attention "
-             "products), vgg_mask_kernel (fused VGG relu1_2 + 16x16 patch cosine), attn_bf16 (fused attention)", PEAK_BF16_MATRIX_TFLOPS),
+    "bf16": (("conv_bf16", "vgg_mask"),
+             "bf16 MFMA family (v_mfma_f32_32x32x16_bf16): conv_bf16_kernel / conv64_resident2_kernel (implicit-GEMM conv / 1x1 / transposed / "
+             "attention products), vgg_mask2_kernel (fused VGG relu1_2 + 16x16 patch cosine)", PEAK_BF16_MATRIX_TFLOPS),
     "bf16x3": (("conv_split",), "conv_split_kernel (v_mfma_f32_32x32x16_bf16, 3 split products per algorithmic product)", PEAK_BF16_MATRIX_TFLOPS),
     "bf16op": (("conv_split",), "conv_split_kernel (v_mfma_f32_32x32x16_bf16, bf16 operands rounded in LDS)", PEAK_BF16_MATRIX_TFLOPS),
 }

@@ -393,24 +393,29 @@ __global__ __launch_bounds__(256) void dcn_columns16_kernel(const bf16_t* x, int
     const float ml = o[2 * groups * K + g * K + k];
     const float m = 1.f / (1.f + expf(-ml));
     const float py = (float)(yq - 1 + k / 3) + dy, px = (float)(xq - 1 + k % 3) + dx;
+    // BRANCH-FREE: the four corner rows are always fetched (clamped addresses, all four loads in flight together); corners outside the
+    // image and sampling points outside (-1, h) x (-1, w) get weight 0 -- the same sums in the same order as the branchy form
+    const bool inside = py > -1.f && py < (float)h && px > -1.f && px < (float)w;
+    const float fy = floorf(py), fx = floorf(px);
+    const float ly = py - fy, lx = px - fx;
+    const int y0 = (int)fmaxf(fminf(fy, (float)h), -2.f), x0 = (int)fmaxf(fminf(fx, (float)w), -2.f);
+    const float wts[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+    const int ys[4] = {y0, y0, y0 + 1, y0 + 1}, xs[4] = {x0, x0 + 1, x0, x0 + 1};
+    float v[4][8], wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = inside && ys[q] >= 0 && ys[q] <= h - 1 && xs[q] >= 0 && xs[q] <= w - 1;
+      const int yc = min(max(ys[q], 0), h - 1), xc = min(max(xs[q], 0), w - 1);
+      ld8(x + (((long long)img * h + yc) * w + xc) * ld + g * cg, v[q]);
+      wq[q] = ok ? wts[q] : 0.f;
+    }
     float acc[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    if (py > -1.f && py < (float)h && px > -1.f && px < (float)w) {
-      const int y0 = (int)floorf(py), x0 = (int)floorf(px);
-      const float ly = py - y0, lx = px - x0;
-      const float wts[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
-      const int ys[4] = {y0, y0, y0 + 1, y0 + 1}, xs[4] = {x0, x0 + 1, x0, x0 + 1};
+    for (int z = 0; z < 8; ++z) acc[z] = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (ys[q] >= 0 && ys[q] <= h - 1 && xs[q] >= 0 && xs[q] <= w - 1) {
-          float v[8];
-          ld8(x + (((long long)img * h + ys[q]) * w + xs[q]) * ld + g * cg, v);
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int z = 0; z < 8; ++z) acc[z] += wts[q] * v[z];
-        }
-      }
-    }
+      for (int z = 0; z < 8; ++z) acc[z] += wq[q] * v[q][z];
 #pragma unroll
     for (int z = 0; z < 8; ++z) acc[z] *= m;
     st8(col + pix * (long long)(K * c) + k * c + g * cg, acc);

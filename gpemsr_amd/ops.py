@@ -179,6 +179,8 @@ class PackedConv:
     wrow7: Optional[torch.Tensor] = None   # bf16 data path, 16 -> 2 7x7 (SpyNet flow update): row-sum fragments (packing.pack_rowsum7)
     wtap32: Optional[torch.Tensor] = None  # fp32 activations, 64 -> 1 3x3: fp32 tap fragments (packing.pack_cout1_taps_f32)
     wrow7_32: Optional[torch.Tensor] = None  # fp32 activations, 16 -> 2 7x7: row-sum fragments (packing.pack_rowsum7_f32)
+    algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
+                                           # the profiler's flop count uses this, so split products are not credited as extra work
 
     @property
     def cin(self) -> int:
@@ -244,7 +246,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         return out
     # algorithmic FLOPs of this launch (2*MAC, un-padded channel counts)
     taps = 9.0 / 4.0 if pc.transposed else float(k * k)
-    flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps
+    flops = 2.0 * n * oh * ow * pc.cout * (pc.algo_cin or pc.cin) * taps
     if (use_direct and pc.wrow7_32 is not None and pc.cin == 16 and s0.c == 16 and pc.cout == 2 and k == 7 and stride == 1 and act == ACT_NONE and s0.ld % 4 == 0
             and not s0.bf16 and (residual is None or residual.c == 2)):
         def _go_row7_32():      # SpyNet's flow update as row sums on the fp32 matrix pipe (csrc/tap_sum.hip)
@@ -801,7 +803,7 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
             _go_stem()
         return out
     taps = 9.0 / 4.0 if pc.transposed else float(k * k)
-    flops = 2.0 * n * oh * ow * pc.cout * pc.cin * taps
+    flops = 2.0 * n * oh * ow * pc.cout * (pc.algo_cin or pc.cin) * taps
     # SpyNet's flow update: 16 -> 2, 7x7, fp32 result + fp32 residual (csrc/tap_sum.hip, rowsum7_kernel)
     if (pc.wrow7 is not None and plain and not force_mfma and s0.bf16 and s0.c == 16 and pc.cout == 2 and k == 7 and stride == 1 and act == ACT_NONE
             and (residual is None or (not residual.bf16 and residual.c == 2))):

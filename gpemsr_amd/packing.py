@@ -169,6 +169,7 @@ def pack_linear_bf16x3(w: torch.Tensor, b: Optional[torch.Tensor], device) -> Pa
     pc = PackedConv(torch.empty(0, device=device), None if b is None else b.detach().to(torch.float32).contiguous().to(device),
                     1, cout, (cin, cin, cin), 32)
     pc.wb = pack_conv_bf16(w3, device, (cin, cin, cin))
+    pc.algo_cin = cin
     return pc
 
 
