@@ -52,7 +52,7 @@ __device__ unsigned long long g_stamps[8 * 65536];
 constexpr int TILE_W = 32;                // a 32-pixel MFMA tile is one contiguous tile row: conflict-free A fragment reads
 constexpr int A_LOADS = 5;   // float4 per thread per A stage (17*33 halo px * 2 / 256 -> 5)
 
-enum { STORE_PLAIN = 0, STORE_PIXSHUF = 1, STORE_CONVT = 2 };
+enum { STORE_PLAIN = 0, STORE_PIXSHUF = 1, STORE_CONVT = 2, STORE_ROWPAIR = 3 };
 
 struct ConvParams {
   const float* src[GPEMSR_MAX_SRC];
@@ -66,6 +66,7 @@ struct ConvParams {
   int OH, OW;             // stored output geometry
   int cin_pad, cout;      // cout = GEMM N (4*Cout for the transposed form)
   int kh, kw, stride, pad;
+  int stride_x;           // horizontal stride (= stride except in the row-pair form: rows step 2, columns 1)
   const float* weight; long long w_img_stride;
   const float* bias; int act;
   const float* residual; int res_ld;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
   const int img = t;
   const int tw_lg = P.tw_lg, tw_mask = (1 << tw_lg) - 1;
   const int oy0 = ty * (NPIX >> tw_lg), ox0 = tx << tw_lg, n0 = tn * BN;
-  const int S = P.stride;
-  const int iy0 = oy0 * S - P.pad, ix0 = ox0 * S - P.pad;
+  const int S = P.stride, SX = P.stride_x;
+  const int iy0 = oy0 * S - P.pad, ix0 = ox0 * SX - P.pad;
   const int halo_px = P.halo_h * P.halo_w;
   const int tpg = P.tpg_h * P.tpg_w;
 
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = wm * PM + mt * 32 + li;
-    a_frag[mt] = (((p >> tw_lg) * S) * P.halo_w + (p & tw_mask) * S) * APIX + (SWZ ? 0 : 4 * lh);
+    a_frag[mt] = (((p >> tw_lg) * S) * P.halo_w + (p & tw_mask) * SX) * APIX + (SWZ ? 0 : 4 * lh);
   }
   const int b_frag = (wn * WNT + li) * BPIX + (SWZ ? 0 : 4 * lh);
   const int swz_x = li & 7;            // SWZ: row & 7 of this lane's A and B rows (tile bases are multiples of 8)
@@ -498,9 +499,12 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
         const int q = nidx / P.cq; ch = nidx - q * P.cq; sy = q >> 1; sx = q & 1;
       } else if (P.store_mode == STORE_CONVT) {
         const int blk = nidx >> 7, q = (nidx & 127) >> 5; ch = blk * 32 + (nidx & 31); bidx = ch; sy = q >> 1; sx = q & 1;
+      } else if (P.store_mode == STORE_ROWPAIR) {        // GEMM rows cq .. 2cq-1 are the same couts of the output row below
+        sy = nidx >= P.cq ? 1 : 0; ch = nidx - sy * P.cq; bidx = ch;
       }
       const bool colok = nidx < P.cout;
       const bool up = P.store_mode != STORE_PLAIN;
+      const bool upx = up && P.store_mode != STORE_ROWPAIR;
       float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (P.bias && colok) b4 = *reinterpret_cast<const float4*>(P.bias + bidx);
       const unsigned chb = (unsigned)ch * 4u;
@@ -511,8 +515,8 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
       for (int it = 0; it < ITER; ++it) {
         const int p = ppass * 128 + ep0 + it * PSTEP;
         const int oy = oy0 + (p >> tw_lg), ox = ox0 + (p & tw_mask);
-        const bool ok = colok && oy < P.oh && ox < P.ow;
-        const int Y = up ? 2 * oy + sy : oy, X = up ? 2 * ox + sx : ox;
+        const int Y = up ? 2 * oy + sy : oy, X = upx ? 2 * ox + sx : ox;
+        const bool ok = colok && oy < P.oh && ox < P.ow && Y < P.OH;
         opx[it] = ok ? (unsigned)(Y * P.OW + X) : 0xFFFFFFFFu;
         if (has_res && ok) rres[it] = *reinterpret_cast<const float4*>(res_b + opx[it] * res_ldb + chb);
         if (has_mul && ok) rmul[it] = mul_img[opx[it]];
@@ -673,7 +677,11 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   GP_REQUIRE(d->ksize == 1 || d->ksize == 3 || d->ksize == 7, "conv2d: ksize=%d unsupported", d->ksize);
   GP_REQUIRE(d->weight && d->out, "conv2d: null weight/out");
   ConvParams P{};
-  const bool tr = d->transposed != 0;
+  const bool tr = d->transposed == 1;
+  const bool rowpair = d->transposed == 2;
+  GP_REQUIRE(d->transposed >= 0 && d->transposed <= 2, "conv2d: transposed=%d", d->transposed);
+  if (rowpair) GP_REQUIRE(d->ksize == 7 && d->stride == 1 && d->cout == 16 && !d->pixel_shuffle,
+                          "conv2d: the row-pair form is a 7x7 stride-1 convolution with 16 output channels");
   if (tr) GP_REQUIRE(d->ksize == 3 && !d->pixel_shuffle && d->cout % 32 == 0 && !d->pixmul,
                      "conv2d: transposed needs k=3, cout%%32==0, no pixel_shuffle/pixmul");
   else GP_REQUIRE(d->stride == 1 || d->stride == 2, "conv2d: stride=%d unsupported (use conv2d_direct)", d->stride);
@@ -698,12 +706,20 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   int BN;
   if (tr) {
     // phase-stacked 2x2-tap form; weight = [4 taps (dy,dx)][4*Cout][cin_pad] (gpemsr_amd/packing.py::pack_convT)
-    P.kh = P.kw = 2; P.stride = 1; P.pad = 0; P.cout = 4 * d->cout;
+    P.kh = P.kw = 2; P.stride = 1; P.stride_x = 1; P.pad = 0; P.cout = 4 * d->cout;
     P.oh = d->h; P.ow = d->w; P.OH = 2 * d->h; P.OW = 2 * d->w;
     P.store_mode = STORE_CONVT; P.cq = d->cout;
     P.tpg_h = 2; P.tpg_w = 2; P.ngroups = 1; BN = 128;
+  } else if (rowpair) {
+    // 16 couts fill half of a 32-row MFMA tile: rows 16..31 compute the SAME couts for the output row below -- an 8 x 7-tap
+    // filter on every second row (weights shifted down one tap row for the second half: packing.pack_rowpair7), 56 / 49 of the
+    // taps for half the pixel tiles
+    P.kh = 8; P.kw = 7; P.stride = 2; P.stride_x = 1; P.pad = 3; P.cout = 32;
+    P.oh = (d->h + 1) / 2; P.ow = d->w; P.OH = d->h; P.OW = d->w;
+    P.store_mode = STORE_ROWPAIR; P.cq = 16;
+    P.tpg_h = 1; P.tpg_w = 7; P.ngroups = 8; BN = 32;
   } else {
-    P.kh = P.kw = d->ksize; P.stride = d->stride; P.pad = d->ksize / 2; P.cout = d->cout;
+    P.kh = P.kw = d->ksize; P.stride = d->stride; P.stride_x = d->stride; P.pad = d->ksize / 2; P.cout = d->cout;
     P.oh = (d->h + 2 * P.pad - d->ksize) / P.stride + 1;
     P.ow = (d->w + 2 * P.pad - d->ksize) / P.stride + 1;
     P.store_mode = d->pixel_shuffle ? STORE_PIXSHUF : STORE_PLAIN; P.cq = d->cout / 4;
@@ -728,7 +744,7 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   const int TW = (!tr && (pad32 - pad16) * 4 >= pad32 && !env_flag_once<2>("GPEMSR_CONV_NO_TW16")) ? 16 : TILE_W;   // >= 25 % fewer dead columns
   P.tw_lg = TW == 16 ? 4 : 5;
   const int TROWS = TH * TILE_W / TW;
-  P.halo_h = (TROWS - 1) * P.stride + P.kh; P.halo_w = (TW - 1) * P.stride + P.kw;
+  P.halo_h = (TROWS - 1) * P.stride + P.kh; P.halo_w = (TW - 1) * P.stride_x + P.kw;
   P.tiles_x = cdiv(P.ow, TW); P.tiles_y = cdiv(P.oh, TROWS); P.tiles_n = cdiv(P.cout, BN);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d: grid too large");
@@ -737,6 +753,7 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
                ((long long)P.OH * P.OW * d->out_ld * 4 < (1ll << 32)) && (!d->residual || (long long)P.OH * P.OW * d->res_ld * 4 < (1ll << 32)) &&
                (P.store_mode != STORE_PIXSHUF || P.cq % 4 == 0);
   GP_REQUIRE(P.halo_h * P.halo_w * (CK / 4) <= A_LOADS * 256, "conv2d: halo too large");
+  if (rowpair) GP_REQUIRE(P.epi_fast, "conv2d: the row-pair form needs 16-byte aligned out / bias / residual rows");
   // DMA staging needs: every source 16-B aligned rows with c % CK == 0 (no partial chunks), 32-bit byte offsets
   bool dma = true;
   for (int s = 0; s < d->nsrc; ++s)

@@ -29,7 +29,7 @@ import torch
 
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
-from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3,
+from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3, pack_rowpair7,
                       pack_vgg_first, pack_cout1_taps, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
@@ -185,6 +185,9 @@ class Engine:
                 self.pc[name].wtap32 = pack_cout1_taps_f32(w, dev)      # the same on the fp32 matrix pipe
             if self.precision == "fp32" and tuple(w.shape) == (2, 16, 7, 7) and getattr(self, "fuse_tail_f32", True):
                 self.pc[name].wrow7_32 = pack_rowsum7_f32(w, dev)       # SpyNet flow update as row sums, fp32 matrix pipe
+            if self.precision == "fp32" and w.shape[0] == 16 and tuple(w.shape[2:]) == (7, 7) and getattr(self, "fuse_tail_f32", True) \
+                    and os.environ.get("GPEMSR_ROWPAIR7", "1") != "0":
+                self.pc[name].wpair7 = pack_rowpair7(w, dev)            # SpyNet 32 -> 16: row-pair form (16 couts fill half a matrix tile)
             if self.bf16 and tuple(w.shape) == (2, 16, 7, 7):
                 self.pc[name].wrow7 = pack_rowsum7(w, dev)              # SpyNet flow update as row sums (csrc/tap_sum.hip)
         elif w.dim() == 2 and name.endswith("indexer.embedding"):

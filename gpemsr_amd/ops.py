@@ -179,6 +179,7 @@ class PackedConv:
     wrow7: Optional[torch.Tensor] = None   # bf16 data path, 16 -> 2 7x7 (SpyNet flow update): row-sum fragments (packing.pack_rowsum7)
     wtap32: Optional[torch.Tensor] = None  # fp32 activations, 64 -> 1 3x3: fp32 tap fragments (packing.pack_cout1_taps_f32)
     wrow7_32: Optional[torch.Tensor] = None  # fp32 activations, 16 -> 2 7x7: row-sum fragments (packing.pack_rowsum7_f32)
+    wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
                                            # the profiler's flop count uses this, so split products are not credited as extra work
 
@@ -320,6 +321,10 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         else:
             _go_split()
         return out
+    if (pc.wpair7 is not None and precision == "fp32" and k == 7 and stride == 1 and pc.cout == 16 and not pc.transposed and not pc.pixel_shuffle
+            and pixmul is None and weight_image_stride == 0 and src_image_stride is None and out.ld % 4 == 0 and out.ptr % 16 == 0
+            and (residual is None or (residual.ld % 4 == 0 and residual.ptr % 16 == 0))):
+        d.transposed, d.weight = 2, pc.wpair7.data_ptr()       # row-pair form: both halves of the 32-row matrix tile do useful work
     if PROFILER is not None:
         PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"))
     else:

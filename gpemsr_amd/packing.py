@@ -49,6 +49,20 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, splits: Option
                       transposed=False, pixel_shuffle=pixel_shuffle)
 
 
+def pack_rowpair7(w: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d(cin -> 16, 7x7, stride 1, pad 3) fp32 weight -> the ROW-PAIR form of gpemsr_conv2d (descriptor.transposed = 2):
+    out(2i, x) = sum_{ky'=0..6} in(2i-3+ky') W[ky'] and out(2i+1, x) = sum_{ky'=1..7} in(2i-3+ky') W[ky'-1] share the 8-row window of
+    input rows 2i-3 .. 2i+4, so one 32-row matrix tile holds the 16 couts of both rows: [tap = ky'*7+kx][32][cin_pad]."""
+    cout, cin, kh, kw = w.shape
+    assert cout == 16 and kh == 7 and kw == 7
+    wf = w.detach().to(torch.float32).cpu()
+    w8 = torch.zeros(32, cin, 8, 7, dtype=torch.float32)
+    w8[:16, :, 0:7] = wf
+    w8[16:, :, 1:8] = wf
+    wt = w8.permute(2, 3, 0, 1).reshape(56, 32, cin)
+    return _pad_split(wt, (cin,), 8).to(device)
+
+
 def pack_convT(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
     """ConvTranspose2d(k3,s2,p1,op1) [Cin,Cout,3,3] -> the kernel's phase-stacked 2x2-tap form
     [tap = 2*dy+dx][n' = (co//32)*128 + q*32 + co%32][cin_pad], q = 2*py+px:

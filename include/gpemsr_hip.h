@@ -71,7 +71,12 @@ typedef struct {
   int32_t cout;
   int32_t ksize;                   /* 1, 3 or 7 */
   int32_t stride;                  /* 1 or 2 (ignored when transposed) */
-  int32_t transposed;              /* 1 = ConvTranspose2d(k=3,s=2,p=1,op=1): out is 2h x 2w */
+  int32_t transposed;              /* 1 = ConvTranspose2d(k=3,s=2,p=1,op=1): out is 2h x 2w.
+                                      2 = ROW-PAIR form of a 7x7 stride-1 convolution with 16 output channels (SpyNet's 32 -> 16 layers,
+                                      basicsr spynet_arch.BasicModule via R:model/GPEMSR.py:67): same result, but the 32-row matrix tile
+                                      computes the 16 couts of output rows 2i AND 2i+1 from an 8 x 7-tap window; weight =
+                                      [tap = ky'*7+kx, ky' < 8][32][cin_pad], rows 0..15 = W[ky'] (0 for ky' = 7), rows 16..31 = W[ky'-1]
+                                      (0 for ky' = 0) (gpemsr_amd/packing.py::pack_rowpair7); cout stays 16, out is h x w */
   const float* weight;             /* packed [tap][cout][cin_pad], tap = ky*k+kx, cin fastest, cin padded per source to 8
                                       (k>=3) or 32 (k=1).  transposed: [tap = 2*dy+dx][n' = (co/32)*128 + q*32 + co%32][cin_pad],
                                       q = 2*py+px, the phase-stacked 2x2-tap form (gpemsr_amd/packing.py::pack_convT) */

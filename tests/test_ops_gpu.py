@@ -579,3 +579,25 @@ def test_spynet_flow_update_row_sums_fp32(n, h, w):
     want = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), 1, 3) + up.double()
     got = ops.conv2d([_to_act(x, dev)], pc, 0, residual=_to_act(up, dev))
     _close(got.nchw(), want.float(), tol=3e-6, what="fp32 flow update with residual")
+
+
+@pytest.mark.parametrize("n,cin,h,w,res", [(2, 32, 37, 70, False), (1, 32, 16, 16, True), (1, 32, 5, 9, False), (3, 32, 64, 64, True), (1, 64, 33, 40, False)])
+def test_conv7_cout16_row_pair_form(n, cin, h, w, res):
+    """gpemsr_conv2d with descriptor.transposed = 2 (packing.pack_rowpair7): Conv2d(cin -> 16, 7x7, pad 3) + bias + ReLU (+ residual)
+    with output rows 2i and 2i+1 sharing one 32-row matrix tile == the plain kernel's result to rounding and the fp64 convolution to
+    3e-6; odd heights (the last pair has no second row), maps narrower than a tile, several images."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_rowpair7
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=700 + h)
+    wt = _rand(16, cin, 7, 7, seed=701, scale=1.0 / (7 * cin ** 0.5)); b = _rand(16, seed=702)
+    r = _rand(n, 16, h, w, seed=703) if res else None
+    pc = pack_conv(wt, b, dev)
+    plain = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_RELU, residual=_to_act(r, dev) if res else None).nchw().clone()
+    pc.wpair7 = pack_rowpair7(wt, dev)
+    got = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_RELU, residual=_to_act(r, dev) if res else None)
+    want = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), 1, 3))
+    if res:
+        want = want + r.double()
+    _close(got.nchw(), want.float(), tol=3e-6, what="row-pair 7x7 vs fp64")
+    _close(got.nchw(), plain, tol=2e-6, what="row-pair 7x7 vs the plain kernel")
