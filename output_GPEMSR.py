@@ -183,8 +183,18 @@ def main():
         return torch.stack([load_frames(p) for p in wpaths[b0:b1]], dim=0).pin_memory(), None
 
     pending = []
+
+    def flush(item):
+        # the block's 8-bit images have landed in pinned host memory once its event has passed: hand them to the PNG writers
+        hostbuf, ev, c0, c1 = item
+        ev.synchronize()
+        u8 = hostbuf.numpy()
+        for j in range(c1 - c0):
+            pending.append(writers.submit(save_img, u8[j], osp.join(im_path_SR, '{}.png'.format(c0 + j))))
+
     with torch.no_grad():
         nxt = loaders.submit(load_block, lo) if lo < hi else None
+        inflight = None
         for b0 in range(lo, hi, block):
             b1 = min(hi, b0 + block)
             host, win = nxt.result()
@@ -194,9 +204,17 @@ def main():
                 _, _, u8 = model.forward_volume(host.to(device, non_blocking=True), win, want_u8=True)
             else:
                 _, _, u8 = model(host.to(device, non_blocking=True), want_u8=True)
-            u8 = u8.cpu().numpy()
-            for j in range(b1 - b0):
-                pending.append(writers.submit(save_img, u8[j], osp.join(im_path_SR, '{}.png'.format(b0 + j))))
+            # asynchronous D2H into pinned memory; the host only waits for block k-1 AFTER block k has been enqueued, so the
+            # device never idles between blocks (R:output_GPEMSR.py:88-95 moves every slice synchronously)
+            hostbuf = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+            hostbuf.copy_(u8, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            if inflight is not None:
+                flush(inflight)
+            inflight = (hostbuf, ev, b0, b1)
+        if inflight is not None:
+            flush(inflight)
     for f in pending:
         f.result()
     writers.shutdown(); loaders.shutdown()
