@@ -83,6 +83,7 @@ struct ConvParams {
   int nblocks;
   int tw_lg;                      // log2 of the tile width in pixels: 5 (TH x 32 tiles) or 4 (2*TH x 16 tiles, for maps <= 16 wide)
   int epi_fast;                   // lean epilogue: float4 rows, cout % 4 == 0, 32-bit byte offsets, 16-B aligned bias
+  float* gn_ws; int gn_parts;     // optional GroupNorm partial sums of (conv + bias): [n][gn_parts][cout][2] (fast epilogue only)
 };
 
 // One LDS-DMA piece: lane l's 16 bytes at (base + voff) land at LDS byte (lds_addr + 16*l); base and lds_addr are
@@ -539,11 +540,16 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
       }
       __syncthreads();
       const float* erow = E + ep0 * EPIX + 4 * ej;
+      float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};       // GroupNorm partial sums of this thread's 4 channels
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         if (opx[it] == 0xFFFFFFFFu) continue;
         float4 v = *reinterpret_cast<const float4*>(erow + it * PSTEP * EPIX);
         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (P.gn_ws) {
+          gs[0] += v.x; gs[1] += v.y; gs[2] += v.z; gs[3] += v.w;
+          gq[0] = fmaf(v.x, v.x, gq[0]); gq[1] = fmaf(v.y, v.y, gq[1]); gq[2] = fmaf(v.z, v.z, gq[2]); gq[3] = fmaf(v.w, v.w, gq[3]);
+        }
         if (act == GPEMSR_ACT_RELU) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         } else if (act == GPEMSR_ACT_LRELU) {          // max(v, 0.1 v) == (v > 0 ? v : 0.1 v)
@@ -554,6 +560,38 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
         if (has_res) { v.x += rres[it].x; v.y += rres[it].y; v.z += rres[it].z; v.w += rres[it].w; }
         if (has_mul) { v.x *= rmul[it]; v.y *= rmul[it]; v.z *= rmul[it]; v.w *= rmul[it]; }
         *reinterpret_cast<float4*>(out_b + opx[it] * out_ldb + chb) = v;
+      }
+      if (P.gn_ws) {
+        // first pass of GroupNorm (model/blocks.py:5-6) from the accumulators: per (tile, pixel pass, channel) sum and sum of squares of
+        // conv + bias.  Lanes with the same float4 column (lane % NV) are added by shuffles, the 4 waves through LDS behind the E tile;
+        // fixed order -> bit-stable.  Readers of pass p and writers of pass p + 1 are separated by the barriers at the top of p + 1.
+        float* red = E + 128 * EPIX;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          for (int o = NV; o < 64; o <<= 1) { gs[k] += __shfl_xor(gs[k], o); gq[k] += __shfl_xor(gq[k], o); }
+        if (lane < NV) {
+          float* r = red + (wave * NV + lane) * 8;
+          *reinterpret_cast<float4*>(r) = make_float4(gs[0], gq[0], gs[1], gq[1]);
+          *reinterpret_cast<float4*>(r + 4) = make_float4(gs[2], gq[2], gs[3], gq[3]);
+        }
+        __syncthreads();
+        if (tid < NV) {
+          float4 a = *reinterpret_cast<const float4*>(red + tid * 8), b = *reinterpret_cast<const float4*>(red + tid * 8 + 4);
+#pragma unroll
+          for (int wv = 1; wv < 4; ++wv) {
+            const float4 a2 = *reinterpret_cast<const float4*>(red + (wv * NV + tid) * 8), b2 = *reinterpret_cast<const float4*>(red + (wv * NV + tid) * 8 + 4);
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+          }
+          const int c0 = n0 + cpass * EW + 4 * tid;
+          if (c0 < P.cout) {
+            // canonical numbering by 128-pixel strip (4 tile rows), whatever the tile height: the records and the order gpemsr_groupnorm_finish
+            // adds them in do not depend on the batch-size-dependent tile choice -> results are bit-identical across batch sizes
+            const int part = (ty * NPP + ppass) * P.tiles_x + tx;
+            float* wsp = P.gn_ws + (((long long)img * P.gn_parts + part) * P.cout + c0) * 2;
+            *reinterpret_cast<float4*>(wsp) = a;
+            *reinterpret_cast<float4*>(wsp + 4) = b;
+          }
+        }
       }
     }
     GP_ST(3);
@@ -670,7 +708,18 @@ static bool env_flag_once(const char* name) {
 }
 
 
-extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
+static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only);
+
+extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) { return conv2d_impl(d, stream, nullptr); }
+
+// number of partial-sum records per image (`parts`) a launch of this descriptor leaves in d->gn_partials: [n][parts][cout][2]
+extern "C" int gpemsr_conv2d_gn_parts(const gpemsr_conv_desc* d) {
+  int parts = 0;
+  const int rc = conv2d_impl(d, nullptr, &parts);
+  return rc < 0 ? rc : parts;
+}
+
+static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only) {
   GP_REQUIRE(d != nullptr, "conv2d: null descriptor");
   GP_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "conv2d: bad geometry n=%d h=%d w=%d cout=%d", d->n, d->h, d->w, d->cout);
   GP_REQUIRE(d->nsrc >= 1 && d->nsrc <= GPEMSR_MAX_SRC, "conv2d: nsrc=%d", d->nsrc);
@@ -737,7 +786,8 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   // still fewer blocks than the chip has slots (3 per CU): split the output channels over narrower blocks (128 -> 64 -> 32)
   if (!tr && BN == 128 && d->ksize != 7 && !env_flag_once<0>("GPEMSR_CONV_NO_BNSPLIT") &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 64;
-  if (!tr && BN == 64 && !env_flag_once<1>("GPEMSR_CONV_NO_BN32") &&
+  const bool want_gn = d->gn_partials != nullptr || parts_only != nullptr;     // (64-column epilogue passes keep the summation order fixed)
+  if (!tr && BN == 64 && !want_gn && !env_flag_once<1>("GPEMSR_CONV_NO_BN32") &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 32;
   // narrow maps (training crops: 16x16 latents): 2*TH x 16-pixel tiles waste no columns; a 32-pixel MFMA tile is then two rows
   const int pad32 = cdiv(P.ow, 32) * 32, pad16 = cdiv(P.ow, 16) * 16;
@@ -753,6 +803,14 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
                ((long long)P.OH * P.OW * d->out_ld * 4 < (1ll << 32)) && (!d->residual || (long long)P.OH * P.OW * d->res_ld * 4 < (1ll << 32)) &&
                (P.store_mode != STORE_PIXSHUF || P.cq % 4 == 0);
   GP_REQUIRE(P.halo_h * P.halo_w * (CK / 4) <= A_LOADS * 256, "conv2d: halo too large");
+  if (d->gn_partials || parts_only) {
+    GP_REQUIRE(P.epi_fast && P.store_mode == STORE_PLAIN && d->act == GPEMSR_ACT_NONE && !d->residual && !d->pixmul && P.cout % 4 == 0,
+               "conv2d: GroupNorm partial sums need the plain store, no activation / residual / multiplier, cout %% 4 == 0, aligned rows");
+    P.gn_parts = P.tiles_y * P.tiles_x * (TH / 4);
+    if (parts_only) { *parts_only = P.gn_parts; return 0; }
+    GP_REQUIRE((reinterpret_cast<uintptr_t>(d->gn_partials) & 15) == 0, "conv2d: gn_partials must be 16-byte aligned");
+    P.gn_ws = d->gn_partials;
+  }
   if (rowpair) GP_REQUIRE(P.epi_fast, "conv2d: the row-pair form needs 16-byte aligned out / bias / residual rows");
   // DMA staging needs: every source 16-B aligned rows with c % CK == 0 (no partial chunks), 32-bit byte offsets
   bool dma = true;
@@ -772,7 +830,7 @@ extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) {
   }
   P.ring = dma ? 1 : 0;
   size_t lds_floats = 2 * (size_t)P.a_buf_floats + (size_t)(P.ring ? 3 : 2) * P.b_buf_floats;
-  const size_t epi_floats = 128 * (size_t)((BN < 64 ? BN : 64) + 4);
+  const size_t epi_floats = 128 * (size_t)((BN < 64 ? BN : 64) + 4) + (P.gn_ws ? 512 : 0);   // + the partial sums' 4-wave exchange
   if (epi_floats > lds_floats) lds_floats = epi_floats;
   const size_t lds = lds_floats * sizeof(float);
   GP_REQUIRE(lds <= 160 * 1024, "conv2d: LDS %zu too large", lds);
@@ -798,4 +856,4 @@ extern "C" int gpemsr_debug_read_stamps(unsigned long long* host, int nblocks) {
 #endif
 
 // The Python binding (gpemsr_amd/_abi.py) mirrors this struct field by field.
-static_assert(sizeof(gpemsr_conv_desc) == 208, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");
+static_assert(sizeof(gpemsr_conv_desc) == 216, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");

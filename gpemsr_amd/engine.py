@@ -59,6 +59,7 @@ class Engine:
         self.dec_nrb = dec_num_res_blocks
         self.frame_chunk, self.tile_chunk = frame_chunk, tile_chunk
         assert precision in ("fp32", "bf16x3", "bf16", "bf16op"), precision
+        self.gn_epi = precision == "bf16" or (precision == "fp32" and os.environ.get("GPEMSR_GN_EPI32", "1") != "0")
         # fp32: exact fp32 MFMA everywhere (default).
         # bf16: bf16 NHWC activations in HBM + bf16 MFMA (BASELINE configs[2]); 1-channel images, flows, deformable offsets
         #       and the indexer's logits + argmax stay at fp32 precision: the logits GEMM takes the fp32 output of
@@ -219,10 +220,10 @@ class Engine:
 
     # ------------------------------------------------------------------ VQGAN prior
     def vq_resblock(self, x: Act, p: str) -> Act:
-        # bf16 path: the conv epilogue leaves the GroupNorm partial sums (no statistics pass over the tensor)
-        t = self.conv(x, p + ".block.0", gn_stats=self.bf16)
+        # the conv epilogue leaves the GroupNorm partial sums (no statistics pass over the tensor): bf16 path and exact-fp32 path
+        t = self.conv(x, p + ".block.0", gn_stats=self.gn_epi)
         self.o.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
-        u = self.conv(t, p + ".block.3", gn_stats=self.bf16)
+        u = self.conv(t, p + ".block.3", gn_stats=self.gn_epi)
         skip = self.conv(x, p + ".channel_up") if (p + ".channel_up") in self.pc else x
         return self.o.groupnorm_relu(u, self.par[p + ".block.4.weight"], self.par[p + ".block.4.bias"], True, residual=skip, out=u)
 

@@ -214,6 +214,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     if precision == "bf16":
         return conv2d_bf16(srcs, pc, act, stride, residual, pixmul, out, weight_image_stride, src_image_stride, force_mfma, tag, out_u8=out_u8,
                            _u8_fused=_u8_fused, **kw16)
+    gn_stats = bool(kw16.pop("gn_stats", False))          # fp32 too: GroupNorm partial sums from the epilogue (gpemsr_conv_desc.gn_partials)
     assert not kw16 or not any(kw16.values()), f"{sorted(kw16)} are options of the bf16 data path"
     s0 = srcs[0]
     n, h, w = s0.n, s0.h, s0.w
@@ -321,6 +322,13 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         else:
             _go_split()
         return out
+    if (gn_stats and precision == "fp32" and act == ACT_NONE and residual is None and pixmul is None and not pc.transposed and not pc.pixel_shuffle
+            and pc.cout % 4 == 0 and out.ld % 4 == 0 and out.ptr % 16 == 0 and (pc.b is None or pc.b.data_ptr() % 16 == 0)):
+        parts = lib.gpemsr_conv2d_gn_parts(C.byref(d))
+        if parts > 0:                                   # (< 0: this shape takes the general epilogue -- the statistics pass runs instead)
+            gws = torch.empty(n * parts * pc.cout * 2, dtype=torch.float32, device=s0.buf.device)
+            d.gn_partials = gws.data_ptr()
+            out.gn = (gws, parts)
     if (pc.wpair7 is not None and precision == "fp32" and k == 7 and stride == 1 and pc.cout == 16 and not pc.transposed and not pc.pixel_shuffle
             and pixmul is None and weight_image_stride == 0 and src_image_stride is None and out.ld % 4 == 0 and out.ptr % 16 == 0
             and (residual is None or (residual.ld % 4 == 0 and residual.ptr % 16 == 0))):
@@ -359,8 +367,13 @@ def groupnorm_relu(x: Act, gamma: torch.Tensor, beta: torch.Tensor, relu: bool =
     parts = max(1, min(64, hw // 64))
     ws = torch.empty(x.n * parts * x.c * 2 + x.n * groups * 2, dtype=torch.float32, device=x.buf.device)
     mr = ws[x.n * parts * x.c * 2:]
-    _abi.check(lib.gpemsr_groupnorm_stats(x.ptr, x.n, hw, x.c, x.ld, groups, eps, ws.data_ptr(), parts, mr.data_ptr(),
-                                          _stream()), "groupnorm_stats")
+    if x.gn is not None:        # the producing convolution left the partial sums (gpemsr_conv_desc.gn_partials): no statistics pass
+        gws, gparts = x.gn
+        _abi.check(lib.gpemsr_groupnorm_finish(gws.data_ptr(), x.n, hw, x.c, groups, gparts, eps, mr.data_ptr(), _stream()), "groupnorm_finish")
+        x.gn = None
+    else:
+        _abi.check(lib.gpemsr_groupnorm_stats(x.ptr, x.n, hw, x.c, x.ld, groups, eps, ws.data_ptr(), parts, mr.data_ptr(),
+                                              _stream()), "groupnorm_stats")
     if out is None:
         out = new_act(x.n, x.h, x.w, x.c, device=x.buf.device)
     _abi.check(lib.gpemsr_groupnorm_apply(x.ptr, x.n, hw, x.c, x.ld, groups, mr.data_ptr(), gamma.data_ptr(),

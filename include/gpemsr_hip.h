@@ -90,9 +90,15 @@ typedef struct {
                                       cout index = (2*i+j)*(cout/4)+c ; out is [n][2oh][2ow][cout/4] */
   float* out;
   int32_t out_ld;
+  float* gn_partials;              /* optional: per (tile, channel) sum / sum of squares of (conv + bias) -- the first pass of the GroupNorm
+                                      that follows (R:model/blocks.py:5-6,16-21) -- as [n][parts][cout][2], parts = gpemsr_conv2d_gn_parts(d);
+                                      feed to gpemsr_groupnorm_finish + gpemsr_groupnorm_apply.  Needs act NONE, no residual / pixmul /
+                                      pixel_shuffle / transposed, cout % 4 == 0.  NULL = none */
 } gpemsr_conv_desc;
 
 int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream);
+/* records per image a launch of `d` writes to d->gn_partials (the tiling is chosen by the library); < 0: error */
+int gpemsr_conv2d_gn_parts(const gpemsr_conv_desc* d);
 
 /* The same 3x3 stride-1 convolution on the bf16 matrix pipe.  nsplit = 2: every fp32 operand is split into hi + lo bf16 and the
  * product evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation (relative error ~2^-16 per product: fp32-grade for the 1e-3

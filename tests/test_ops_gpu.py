@@ -601,3 +601,28 @@ def test_conv7_cout16_row_pair_form(n, cin, h, w, res):
         want = want + r.double()
     _close(got.nchw(), want.float(), tol=3e-6, what="row-pair 7x7 vs fp64")
     _close(got.nchw(), plain, tol=2e-6, what="row-pair 7x7 vs the plain kernel")
+
+
+@pytest.mark.parametrize("n,cin,cout,k,h,w", [(2, 64, 64, 3, 37, 70), (1, 128, 256, 3, 20, 36), (3, 64, 512, 1, 16, 16), (1, 32, 128, 3, 64, 64), (2, 64, 32, 3, 9, 50)])
+def test_groupnorm_statistics_from_the_fp32_conv_epilogue(n, cin, cout, k, h, w):
+    """gpemsr_conv_desc.gn_partials: the conv output is unchanged (bit for bit) and groupnorm_relu on it -- now finish + apply, no
+    statistics pass -- equals GroupNorm(32, eps 1e-6)(conv) + ReLU in fp64 to 1e-5 and the statistics-pass result to 2e-6."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=800 + h)
+    wt = _rand(cout, cin, k, k, seed=801, scale=1.0 / (k * cin ** 0.5)); b = _rand(cout, seed=802)
+    g = (1.0 + 0.2 * _rand(cout, seed=803)).to(dev); be = (0.2 * _rand(cout, seed=804)).to(dev)
+    pc = pack_conv(wt, b, dev)
+    plain = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_NONE)
+    assert plain.gn is None
+    y0 = ops.groupnorm_relu(plain, g, be, True).nchw().clone()
+    got = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_NONE, gn_stats=True)
+    assert got.gn is not None, "this shape should take the lean epilogue"
+    assert torch.equal(got.nchw(), plain.nchw())
+    y1 = ops.groupnorm_relu(got, g, be, True)
+    assert got.gn is None
+    conv = F.conv2d(x.double(), wt.double(), b.double(), 1, k // 2)
+    want = torch.relu(F.group_norm(conv, 32, g.double().cpu(), be.double().cpu(), 1e-6))
+    _close(y1.nchw(), want.float(), tol=1e-5, what="GN from epilogue sums vs fp64")
+    _close(y1.nchw(), y0, tol=2e-6, what="GN from epilogue sums vs the statistics pass")
