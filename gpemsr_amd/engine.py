@@ -59,7 +59,7 @@ class Engine:
         self.dec_nrb = dec_num_res_blocks
         self.frame_chunk, self.tile_chunk = frame_chunk, tile_chunk
         assert precision in ("fp32", "bf16x3", "bf16", "bf16op"), precision
-        self.gn_epi = precision == "bf16" or (precision == "fp32" and os.environ.get("GPEMSR_GN_EPI32", "1") != "0")
+        self.gn_epi = precision == "bf16" or (precision == "fp32" and getattr(self, "fuse_tail_f32", True) and os.environ.get("GPEMSR_GN_EPI32", "1") != "0")
         # fp32: exact fp32 MFMA everywhere (default).
         # bf16: bf16 NHWC activations in HBM + bf16 MFMA (BASELINE configs[2]); 1-channel images, flows, deformable offsets
         #       and the indexer's logits + argmax stay at fp32 precision: the logits GEMM takes the fp32 output of
