@@ -39,7 +39,7 @@ SYMBOLS = [
     "gpemsr_bilinear_bf16", "gpemsr_pool3s2_maxavg_bf16", "gpemsr_spynet_prep_bf16", "gpemsr_dcn_columns_bf16", "gpemsr_patch_cosine_bf16",
     "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
     "gpemsr_copy_channels_f32_bf16", "gpemsr_conv2d_stem1_bf16", "gpemsr_conv2d_direct_bf16", "gpemsr_vgg_mask_bf16",
-    "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32", "gpemsr_split_f32_bf16x2", "gpemsr_conv2d_gn_parts",
+    "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32", "gpemsr_split_f32_bf16x2", "gpemsr_conv2d_gn_parts", "gpemsr_patch_cosine_finish",
 ]
 
 
@@ -58,7 +58,7 @@ class ConvDesc(C.Structure):
         ("residual", C.c_void_p), ("res_ld", C.c_int32),
         ("pixmul", C.c_void_p), ("pixel_shuffle", C.c_int32),
         ("out", C.c_void_p), ("out_ld", C.c_int32),
-        ("gn_partials", C.c_void_p),
+        ("gn_partials", C.c_void_p), ("cos_partials", C.c_void_p),
     ]
 
 
@@ -102,6 +102,7 @@ def load():
     p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     lib.gpemsr_conv2d.argtypes = [C.POINTER(ConvDesc), p]
     lib.gpemsr_conv2d_gn_parts.argtypes = [C.POINTER(ConvDesc)]
+    lib.gpemsr_patch_cosine_finish.argtypes = [p, i32, i32, i32, p, p]
     lib.gpemsr_conv2d_split.argtypes = [C.POINTER(ConvDesc), p, i64, i32, p]
     lib.gpemsr_conv2d_direct.argtypes = [p, i32, i32, i32, i32, i32, p, p, i32, i32, i32, i32, p, i32, p, i32, p]
     lib.gpemsr_conv2d_stem1.argtypes = [p, i32, i32, i32, p, p, i32, i32, p, i32, p]

@@ -84,6 +84,7 @@ struct ConvParams {
   int tw_lg;                      // log2 of the tile width in pixels: 5 (TH x 32 tiles) or 4 (2*TH x 16 tiles, for maps <= 16 wide)
   int epi_fast;                   // lean epilogue: float4 rows, cout % 4 == 0, 32-bit byte offsets, 16-B aligned bias
   float* gn_ws; int gn_parts;     // optional GroupNorm partial sums of (conv + bias): [n][gn_parts][cout][2] (fast epilogue only)
+  float* cos_ws;                  // optional: patch-cosine partial sums against the `residual` operand INSTEAD of storing the result
 };
 
 // One LDS-DMA piece: lane l's 16 bytes at (base + voff) land at LDS byte (lds_addr + 16*l); base and lds_addr are
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
       __syncthreads();
       const float* erow = E + ep0 * EPIX + 4 * ej;
       float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};       // GroupNorm partial sums of this thread's 4 channels
+      float cab[2] = {0.f, 0.f}, caa[2] = {0.f, 0.f}, cbb[2] = {0.f, 0.f};    // patch-cosine partial sums, two patch columns
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         if (opx[it] == 0xFFFFFFFFu) continue;
@@ -557,9 +559,37 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
         } else if (act != GPEMSR_ACT_NONE) {
           v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
         }
+        if (P.cos_ws) {          // 64-column passes: this thread's pixel of item `it` lies in patch column it & 1 of the 32-pixel tile row
+          const float4 r = rres[it];
+          const int pc = it & 1;
+          cab[pc] += (v.x * r.x + v.y * r.y) + (v.z * r.z + v.w * r.w);
+          caa[pc] += (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
+          cbb[pc] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          continue;              // the feature map itself is not stored
+        }
         if (has_res) { v.x += rres[it].x; v.y += rres[it].y; v.z += rres[it].z; v.w += rres[it].w; }
         if (has_mul) { v.x *= rmul[it]; v.y *= rmul[it]; v.z *= rmul[it]; v.w *= rmul[it]; }
         *reinterpret_cast<float4*>(out_b + opx[it] * out_ldb + chb) = v;
+      }
+      if (P.cos_ws) {
+        // model/GPEMSR.py:387-395 without the second feature map in memory: sums of a.b, a.a, b.b over this 4-row strip of the two 16-pixel
+        // patch columns the tile row crosses (b = this convolution's result, a = the `residual` operand); four strips make a patch
+        // (gpemsr_patch_cosine_finish).  Fixed reduction tree; records numbered by strip and patch column, independent of the tile height.
+        float* red = E + 128 * EPIX;
+        float c6[6] = {cab[0], caa[0], cbb[0], cab[1], caa[1], cbb[1]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          for (int o = 1; o < 64; o <<= 1) c6[k] += __shfl_xor(c6[k], o);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) red[wave * 8 + k] = c6[k];
+        }
+        __syncthreads();
+        if (tid < 6) {
+          const float tot = (red[tid] + red[8 + tid]) + (red[16 + tid] + red[24 + tid]);
+          const int strip = ty * NPP + ppass, pcol = tx * 2 + tid / 3;
+          P.cos_ws[(((long long)img * (P.tiles_y * NPP) + strip) * (P.tiles_x * 2) + pcol) * 4 + tid % 3] = tot;
+        }
       }
       if (P.gn_ws) {
         // first pass of GroupNorm (model/blocks.py:5-6) from the accumulators: per (tile, pixel pass, channel) sum and sum of squares of
@@ -786,7 +816,7 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
   // still fewer blocks than the chip has slots (3 per CU): split the output channels over narrower blocks (128 -> 64 -> 32)
   if (!tr && BN == 128 && d->ksize != 7 && !env_flag_once<0>("GPEMSR_CONV_NO_BNSPLIT") &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 64;
-  const bool want_gn = d->gn_partials != nullptr || parts_only != nullptr;     // (64-column epilogue passes keep the summation order fixed)
+  const bool want_gn = d->gn_partials != nullptr || parts_only != nullptr || d->cos_partials != nullptr;     // (64-column epilogue passes keep the summation order fixed)
   if (!tr && BN == 64 && !want_gn && !env_flag_once<1>("GPEMSR_CONV_NO_BN32") &&
       (long long)d->n * cdiv(P.oh, TH) * cdiv(P.ow, TILE_W) * cdiv(P.cout, BN) < 512) BN = 32;
   // narrow maps (training crops: 16x16 latents): 2*TH x 16-pixel tiles waste no columns; a 32-pixel MFMA tile is then two rows
@@ -803,6 +833,12 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
                ((long long)P.OH * P.OW * d->out_ld * 4 < (1ll << 32)) && (!d->residual || (long long)P.OH * P.OW * d->res_ld * 4 < (1ll << 32)) &&
                (P.store_mode != STORE_PIXSHUF || P.cq % 4 == 0);
   GP_REQUIRE(P.halo_h * P.halo_w * (CK / 4) <= A_LOADS * 256, "conv2d: halo too large");
+  if (d->cos_partials) {
+    GP_REQUIRE(!parts_only && !d->gn_partials && P.epi_fast && P.store_mode == STORE_PLAIN && !d->pixmul && d->residual && BN == 64 && P.tiles_n == 1 &&
+               P.tw_lg == 5 && P.oh % 16 == 0 && P.ow % 32 == 0 && (reinterpret_cast<uintptr_t>(d->cos_partials) & 15) == 0,
+               "conv2d: patch-cosine sums need 33..64 output channels, the operand in `residual`, height %% 16 == 0, width %% 32 == 0");
+    P.cos_ws = d->cos_partials;
+  }
   if (d->gn_partials || parts_only) {
     GP_REQUIRE(P.epi_fast && P.store_mode == STORE_PLAIN && d->act == GPEMSR_ACT_NONE && !d->residual && !d->pixmul && P.cout % 4 == 0,
                "conv2d: GroupNorm partial sums need the plain store, no activation / residual / multiplier, cout %% 4 == 0, aligned rows");
@@ -830,7 +866,7 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
   }
   P.ring = dma ? 1 : 0;
   size_t lds_floats = 2 * (size_t)P.a_buf_floats + (size_t)(P.ring ? 3 : 2) * P.b_buf_floats;
-  const size_t epi_floats = 128 * (size_t)((BN < 64 ? BN : 64) + 4) + (P.gn_ws ? 512 : 0);   // + the partial sums' 4-wave exchange
+  const size_t epi_floats = 128 * (size_t)((BN < 64 ? BN : 64) + 4) + ((P.gn_ws || P.cos_ws) ? 512 : 0);   // + the partial sums' 4-wave exchange
   if (epi_floats > lds_floats) lds_floats = epi_floats;
   const size_t lds = lds_floats * sizeof(float);
   GP_REQUIRE(lds <= 160 * 1024, "conv2d: LDS %zu too large", lds);
@@ -849,6 +885,30 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
 #undef GP_LAUNCH
 }
 
+namespace gpemsr {
+// four 4-row strips of partial sums -> cosine of one 16x16 patch (model/GPEMSR.py:392-395: F.normalize's eps 1e-12 on each norm)
+__global__ __launch_bounds__(256) void patch_cosine_finish_kernel(const float* ws, int n, int ph, int pw, float* out) {
+  const int total = n * ph * pw;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int px = e % pw, py = (e / pw) % ph, img = e / (pw * ph);
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (((long long)img * (ph * 4) + py * 4 + s) * pw + px) * 4);
+      ab += v.x; aa += v.y; bb += v.z;
+    }
+    out[e] = ab / (fmaxf(sqrtf(aa), 1e-12f) * fmaxf(sqrtf(bb), 1e-12f));
+  }
+}
+}  // namespace gpemsr
+
+extern "C" int gpemsr_patch_cosine_finish(const float* ws, int n, int ph, int pw, float* out, void* stream) {
+  GP_REQUIRE(ws && out && n > 0 && ph > 0 && pw > 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "patch_cosine_finish: bad args");
+  const int total = n * ph * pw;
+  hipLaunchKernelGGL(gpemsr::patch_cosine_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws, n, ph, pw, out);
+  return check_launch("patch_cosine_finish");
+}
+
 #ifdef GP_STAMP
 extern "C" int gpemsr_debug_read_stamps(unsigned long long* host, int nblocks) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gpemsr::g_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks);
@@ -856,4 +916,4 @@ extern "C" int gpemsr_debug_read_stamps(unsigned long long* host, int nblocks) {
 #endif
 
 // The Python binding (gpemsr_amd/_abi.py) mirrors this struct field by field.
-static_assert(sizeof(gpemsr_conv_desc) == 216, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");
+static_assert(sizeof(gpemsr_conv_desc) == 224, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");

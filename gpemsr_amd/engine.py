@@ -59,6 +59,7 @@ class Engine:
         self.dec_nrb = dec_num_res_blocks
         self.frame_chunk, self.tile_chunk = frame_chunk, tile_chunk
         assert precision in ("fp32", "bf16x3", "bf16", "bf16op"), precision
+        self.vgg_cos_epi = precision == "fp32" and getattr(self, "fuse_tail_f32", True) and os.environ.get("GPEMSR_VGG_COS32", "1") != "0"
         self.gn_epi = precision == "bf16" or (precision == "fp32" and getattr(self, "fuse_tail_f32", True) and os.environ.get("GPEMSR_GN_EPI32", "1") != "0")
         # fp32: exact fp32 MFMA everywhere (default).
         # bf16: bf16 NHWC activations in HBM + bf16 MFMA (BASELINE configs[2]); 1-channel images, flows, deformable offsets
@@ -415,8 +416,15 @@ class Engine:
         for i0 in range(0, n, per):
             m = min(per, n - i0)
             fa = self.conv(self.conv(ref_img.images(i0, m), "vgg.slice1.0", ACT_RELU), "vgg.slice1.2", ACT_RELU)
-            fb = self.conv(self.conv(up_lr.images(i0, m), "vgg.slice1.0", ACT_RELU), "vgg.slice1.2", ACT_RELU)
-            o = self.o.patch_cosine(fa, fb)
+            tb = self.conv(up_lr.images(i0, m), "vgg.slice1.0", ACT_RELU)
+            if self.vgg_cos_epi and self.o.conv_cosine_ok(tb, self.pc["vgg.slice1.2"]) and fa.ld % 4 == 0:
+                # the second relu1_2 map never reaches memory: its patch sums against the first come from the convolution's epilogue
+                o = self.conv(tb, "vgg.slice1.2", ACT_RELU, cos_with=fa)
+            else:
+                fb = self.conv(tb, "vgg.slice1.2", ACT_RELU)
+                o = self.o.patch_cosine(fa, fb)
+                del fb
+            del tb
             self.o.copy_channels(o, out.images(i0, m))
         return out
 

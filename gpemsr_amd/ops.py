@@ -201,6 +201,41 @@ def conv2d(srcs, pc: "PackedConv", *args, out_u8: Optional[torch.Tensor] = None,
     return r
 
 
+def conv_cosine_ok(src: "Act", pc: "PackedConv") -> bool:
+    """Shapes gpemsr_conv_desc.cos_partials takes: 3x3 stride 1, 33..64 output channels, height % 16 == 0, width % 32 == 0, aligned rows."""
+    return (not src.bf16 and pc.ksize == 3 and 32 < pc.cout <= 64 and pc.cout % 4 == 0 and not pc.transposed and not pc.pixel_shuffle
+            and src.h % 16 == 0 and src.w % 32 == 0 and src.ld % 4 == 0 and src.ptr % 16 == 0 and len(pc.splits) == 1 and src.c % 8 == 0)
+
+
+def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str) -> "Act":
+    """act(conv(src)) is NOT stored: its 16x16-patch cosine against `a` (R:model/GPEMSR.py:387-395) comes from partial sums formed in the
+    convolution's epilogue (gpemsr_conv_desc.cos_partials) + gpemsr_patch_cosine_finish -> [n, h/16, w/16, 1]."""
+    lib = _abi.load()
+    s0 = srcs[0]
+    n, h, w = s0.n, s0.h, s0.w
+    assert conv_cosine_ok(s0, pc) and (a.n, a.h, a.w, a.c) == (n, h, w, pc.cout) and a.ld % 4 == 0 and a.ptr % 16 == 0 and not a.bf16
+    ws = torch.empty(n * (h // 4) * (w // 16) * 4, dtype=torch.float32, device=s0.buf.device)
+    d = _abi.ConvDesc()
+    d.n, d.h, d.w, d.nsrc = n, h, w, 1
+    d.src[0].ptr, d.src[0].ld, d.src[0].c = s0.ptr, s0.ld, s0.c
+    d.src_image_stride[0] = -1
+    d.cout, d.ksize, d.stride, d.transposed = pc.cout, 3, 1, 0
+    d.weight, d.weight_image_stride = pc.w.data_ptr(), 0
+    d.bias = pc.b.data_ptr() if pc.b is not None else None
+    d.act = act
+    d.residual, d.res_ld = a.ptr, a.ld
+    d.out, d.out_ld = a.ptr, a.ld                  # (never written in this mode; the descriptor wants a valid aligned row layout)
+    d.cos_partials = ws.data_ptr()
+    flops = 2.0 * n * h * w * pc.cout * pc.cin * 9.0
+    if PROFILER is not None:
+        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"))
+    else:
+        _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
+    out = new_act(n, h // 16, w // 16, 1, device=s0.buf.device)
+    _abi.check(lib.gpemsr_patch_cosine_finish(ws.data_ptr(), n, h // 16, w // 16, out.ptr, _stream()), "patch_cosine_finish")
+    return out
+
+
 def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual: Optional[Act] = None,
            pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
            src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
@@ -215,6 +250,9 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         return conv2d_bf16(srcs, pc, act, stride, residual, pixmul, out, weight_image_stride, src_image_stride, force_mfma, tag, out_u8=out_u8,
                            _u8_fused=_u8_fused, **kw16)
     gn_stats = bool(kw16.pop("gn_stats", False))          # fp32 too: GroupNorm partial sums from the epilogue (gpemsr_conv_desc.gn_partials)
+    cos_with = kw16.pop("cos_with", None)                  # fp32: patch cosine of the result against this tensor, result not stored
+    if cos_with is not None:
+        return _conv2d_cosine(srcs, pc, act, cos_with, tag)
     assert not kw16 or not any(kw16.values()), f"{sorted(kw16)} are options of the bf16 data path"
     s0 = srcs[0]
     n, h, w = s0.n, s0.h, s0.w

@@ -94,9 +94,16 @@ typedef struct {
                                       that follows (R:model/blocks.py:5-6,16-21) -- as [n][parts][cout][2], parts = gpemsr_conv2d_gn_parts(d);
                                       feed to gpemsr_groupnorm_finish + gpemsr_groupnorm_apply.  Needs act NONE, no residual / pixmul /
                                       pixel_shuffle / transposed, cout % 4 == 0.  NULL = none */
+  float* cos_partials;             /* optional: do NOT store the result; accumulate, per 4-row strip and 16-pixel patch column, the sums
+                                      (b.a, a.a, b.b) of the result b against the tensor a given in `residual` (same geometry) -- the
+                                      16x16-patch cosine of two VGG relu1_2 maps (R:model/GPEMSR.py:387-395) without the second map in
+                                      memory: [n][h/4][w/16][4] floats, then gpemsr_patch_cosine_finish.  33..64 output channels, h % 16 == 0,
+                                      w % 32 == 0.  NULL = none */
 } gpemsr_conv_desc;
 
 int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream);
+/* cos_partials workspace -> the cosine map [n][ph][pw] of R:model/GPEMSR.py:387-395 (ph = h/16, pw = w/16) */
+int gpemsr_patch_cosine_finish(const float* ws, int n, int ph, int pw, float* out, void* stream);
 /* records per image a launch of `d` writes to d->gn_partials (the tiling is chosen by the library); < 0: error */
 int gpemsr_conv2d_gn_parts(const gpemsr_conv_desc* d);
 

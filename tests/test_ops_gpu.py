@@ -626,3 +626,32 @@ def test_groupnorm_statistics_from_the_fp32_conv_epilogue(n, cin, cout, k, h, w)
     want = torch.relu(F.group_norm(conv, 32, g.double().cpu(), be.double().cpu(), 1e-6))
     _close(y1.nchw(), want.float(), tol=1e-5, what="GN from epilogue sums vs fp64")
     _close(y1.nchw(), y0, tol=2e-6, what="GN from epilogue sums vs the statistics pass")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 128, 96), (3, 16, 32), (1, 48, 160)])
+def test_patch_cosine_from_the_conv_epilogue(n, h, w):
+    """gpemsr_conv_desc.cos_partials + gpemsr_patch_cosine_finish (R:model/GPEMSR.py:387-395): the cosine of relu(conv(t)) against a second
+    64-channel map over 16x16 patches, without storing relu(conv(t)) -- equal to patch_cosine of the stored maps to 2e-6 and to the fp64
+    value to 1e-5; the operand tensor is left untouched."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv
+    dev = _dev()
+    t = torch.relu(_rand(n, 64, h, w, seed=900 + h))
+    a = torch.relu(_rand(n, 64, h, w, seed=901 + w) + 0.3)
+    wt = _rand(64, 64, 3, 3, seed=902, scale=1.0 / 24); b = _rand(64, seed=903, scale=0.1)
+    pc = pack_conv(wt, b, dev)
+    ta, aa = _to_act(t, dev), _to_act(a, dev)
+    assert ops.conv_cosine_ok(ta, pc)
+    fb = ops.conv2d([ta], pc, ops.ACT_RELU)
+    want32 = ops.patch_cosine(aa, fb).nchw().clone()
+    a_before = aa.nchw().clone()
+    got = ops.conv2d([ta], pc, ops.ACT_RELU, cos_with=aa)
+    assert (got.n, got.h, got.w, got.c) == (n, h // 16, w // 16, 1)
+    assert torch.equal(aa.nchw(), a_before)
+    f64 = torch.relu(F.conv2d(t.double(), wt.double(), b.double(), 1, 1))
+    def patches(z):
+        return z.reshape(n, 64, h // 16, 16, w // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(n, h // 16, w // 16, -1)
+    pa, pb = patches(a.double()), patches(f64)
+    want = ((pa * pb).sum(-1) / (pa.norm(dim=-1).clamp_min(1e-12) * pb.norm(dim=-1).clamp_min(1e-12))).unsqueeze(1)
+    _close(got.nchw(), want.float(), tol=1e-5, what="epilogue patch cosine vs fp64")
+    _close(got.nchw(), want32, tol=2e-6, what="epilogue patch cosine vs the stored-map kernel")
