@@ -117,7 +117,11 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   }
 }
 
-template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA>
+// XEPI = 1 / 2: the instantiations whose lean epilogue also forms GroupNorm (1) / patch-cosine (2) partial sums (1: no residual or
+// multiplier operands exist; 2: nothing is stored).  A separate instantiation ON PURPOSE: with
+// that code in the common kernels the 168-register budget overflowed (164-232 bytes of scratch per lane in EVERY launch, +150 GB of
+// HBM traffic per step); the common kernels compile exactly as before and only the launches that ask for the sums pay for them.
+template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA, int XEPI = 0>
 __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_kernel(ConvParams P) {
   constexpr int NPIX = TH * TILE_W;   // output pixels per workgroup (TH x 32)
   constexpr int PM = NPIX / WM;       // pixels per wave
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
     const unsigned out_ldb = (unsigned)P.out_ld * 4u, res_ldb = (unsigned)P.res_ld * 4u;
     const char* res_b = reinterpret_cast<const char*>(res_img);
     char* out_b = reinterpret_cast<char*>(out_img);
-    const bool has_res = P.residual != nullptr, has_mul = P.pixmul != nullptr;
+    const bool has_res = XEPI == 1 ? false : (XEPI == 2 ? true : P.residual != nullptr), has_mul = XEPI ? false : P.pixmul != nullptr;
     const int act = P.act;
 #pragma unroll 1
     for (int pass = 0; pass < NCP * NPP; ++pass) {
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
         if (opx[it] == 0xFFFFFFFFu) continue;
         float4 v = *reinterpret_cast<const float4*>(erow + it * PSTEP * EPIX);
         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        if (P.gn_ws) {
+        if (XEPI == 1) {
           gs[0] += v.x; gs[1] += v.y; gs[2] += v.z; gs[3] += v.w;
           gq[0] = fmaf(v.x, v.x, gq[0]); gq[1] = fmaf(v.y, v.y, gq[1]); gq[2] = fmaf(v.z, v.z, gq[2]); gq[3] = fmaf(v.w, v.w, gq[3]);
         }
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
         } else if (act != GPEMSR_ACT_NONE) {
           v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
         }
-        if (P.cos_ws) {          // 64-column passes: this thread's pixel of item `it` lies in patch column it & 1 of the 32-pixel tile row
+        if (XEPI == 2) {          // 64-column passes: this thread's pixel of item `it` lies in patch column it & 1 of the 32-pixel tile row
           const float4 r = rres[it];
           const int pc = it & 1;
           cab[pc] += (v.x * r.x + v.y * r.y) + (v.z * r.z + v.w * r.w);
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
         if (has_mul) { v.x *= rmul[it]; v.y *= rmul[it]; v.z *= rmul[it]; v.w *= rmul[it]; }
         *reinterpret_cast<float4*>(out_b + opx[it] * out_ldb + chb) = v;
       }
-      if (P.cos_ws) {
+      if (XEPI == 2) {
         // model/GPEMSR.py:387-395 without the second feature map in memory: sums of a.b, a.a, b.b over this 4-row strip of the two 16-pixel
         // patch columns the tile row crosses (b = this convolution's result, a = the `residual` operand); four strips make a patch
         // (gpemsr_patch_cosine_finish).  Fixed reduction tree; records numbered by strip and patch column, independent of the tile height.
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
           P.cos_ws[(((long long)img * (P.tiles_y * NPP) + strip) * (P.tiles_x * 2) + pcol) * 4 + tid % 3] = tot;
         }
       }
-      if (P.gn_ws) {
+      if (XEPI == 1) {
         // first pass of GroupNorm (model/blocks.py:5-6) from the accumulators: per (tile, pixel pass, channel) sum and sum of squares of
         // conv + bias.  Lanes with the same float4 column (lane % NV) are added by shuffles, the 4 waves through LDS behind the E tile;
         // fixed order -> bit-stable.  Readers of pass p and writers of pass p + 1 are separated by the barriers at the top of p + 1.
@@ -712,9 +716,9 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
   GP_ST(3);
 }
 
-template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA>
+template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA, int XEPI = 0>
 static int launch(const ConvParams& P, size_t lds_bytes, hipStream_t st) {
-  auto kfn = conv_mfma_kernel<CK, BN, WM, WN, TH, MASKED, DMA>;
+  auto kfn = conv_mfma_kernel<CK, BN, WM, WN, TH, MASKED, DMA, XEPI>;
   if (lds_bytes > 64 * 1024) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -873,6 +877,22 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define GP_LAUNCH(CKv, BNv, WMv, WNv, THv, MK) \
   (dma ? launch<CKv, BNv, WMv, WNv, THv, MK, true>(P, lds, st) : launch<CKv, BNv, WMv, WNv, THv, MK, false>(P, lds, st))
+#define GP_LAUNCH_X(CKv, BNv, WMv, WNv, THv) launch<CKv, BNv, WMv, WNv, THv, false, true, 1>(P, lds, st)
+  if (P.gn_ws || P.cos_ws) {        // the partial-sum epilogue lives in its own instantiations (DMA staging only)
+    GP_REQUIRE(dma && BN >= 32, "conv2d: partial sums need 16-byte aligned sources with channel counts that are multiples of the chunk");
+    if (P.cos_ws) {                 // (3x3, 64-column blocks: checked above)
+      GP_REQUIRE(CK == 8 && BN == 64, "conv2d: patch-cosine sums are a 3x3 form");
+      return TH == 8 ? launch<8, 64, 4, 1, 8, false, true, 2>(P, lds, st) : launch<8, 64, 2, 2, 4, false, true, 2>(P, lds, st);
+    }
+    if (CK == 8) {
+      if (BN == 32) return TH == 8 ? GP_LAUNCH_X(8, 32, 4, 1, 8) : GP_LAUNCH_X(8, 32, 4, 1, 4);
+      if (BN == 64) return TH == 8 ? GP_LAUNCH_X(8, 64, 4, 1, 8) : GP_LAUNCH_X(8, 64, 2, 2, 4);
+      return GP_LAUNCH_X(8, 128, 2, 2, 4);
+    }
+    if (BN == 32) return GP_LAUNCH_X(32, 32, 4, 1, 4);
+    if (BN == 64) return GP_LAUNCH_X(32, 64, 2, 2, 4);
+    return GP_LAUNCH_X(32, 128, 2, 2, 4);
+  }
   if (tr) return GP_LAUNCH(8, 128, 4, 1, 8, true);
   if (CK == 8) {
     if (BN == 32) return TH == 8 ? GP_LAUNCH(8, 32, 4, 1, 8, false) : GP_LAUNCH(8, 32, 4, 1, 4, false);
@@ -883,6 +903,7 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
   if (BN == 64) return GP_LAUNCH(32, 64, 2, 2, 4, false);
   return GP_LAUNCH(32, 128, 2, 2, 4, false);
 #undef GP_LAUNCH
+#undef GP_LAUNCH_X
 }
 
 namespace gpemsr {
