@@ -484,20 +484,27 @@ __global__ __launch_bounds__(256) void temporal_gate16_kernel(const bf16_t* alig
   }
 }
 
-__global__ __launch_bounds__(256) void frame_mix16_kernel(const bf16_t* af, long long pixels, int t, int c, const float* m,
+// TT > 0: the frame count at compile time (the network's 5): loops unroll and in[][] stays in registers -- with run-time bounds the
+// array is indexed dynamically and lives in scratch (272 bytes per lane)
+template <int TT>
+__global__ __launch_bounds__(256) void frame_mix16_kernel(const bf16_t* af, long long pixels, int t_rt, int c, const float* m,
                                                           const float* bias, bf16_t* out) {
+  const int t = TT > 0 ? TT : t_rt;
   const int c8 = c >> 3;
   const long long total = pixels * c8;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int j = (int)(e % c8);
     const long long p = e / c8;
     const bf16_t* ip = af + p * ((long long)t * c) + 8 * j;
-    float in[8][8];
+    float in[TT > 0 ? TT : 8][8];
+#pragma unroll
     for (int k = 0; k < t; ++k) ld8(ip + k * c, in[k]);
+#pragma unroll
     for (int i = 0; i < t; ++i) {
       float s[8];
 #pragma unroll
       for (int z = 0; z < 8; ++z) s[z] = bias[i];
+#pragma unroll
       for (int k = 0; k < t; ++k) {
         const float wv = m[i * t + k];
 #pragma unroll
@@ -907,8 +914,12 @@ extern "C" int gpemsr_temporal_gate_bf16(const void* aligned, const void* emb, c
 
 extern "C" int gpemsr_frame_mix_lrelu_bf16(const void* af, int64_t pixels, int t, int c, const float* m, const float* bias, void* out, void* stream) {
   GP_REQUIRE(af && m && bias && out && t <= 8 && c % 8 == 0 && A16(af) && A16(out), "frame_mix_bf16: bad args");
-  hipLaunchKernelGGL(frame_mix16_kernel, dim3(grid16(pixels * (c / 8))), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(af), (long long)pixels, t, c, m, bias,
-                     reinterpret_cast<bf16_t*>(out));
+  if (t == 5)
+    hipLaunchKernelGGL(frame_mix16_kernel<5>, dim3(grid16(pixels * (c / 8))), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(af), (long long)pixels, t, c, m, bias,
+                       reinterpret_cast<bf16_t*>(out));
+  else
+    hipLaunchKernelGGL(frame_mix16_kernel<0>, dim3(grid16(pixels * (c / 8))), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(af), (long long)pixels, t, c, m, bias,
+                       reinterpret_cast<bf16_t*>(out));
   return check_launch("frame_mix_bf16");
 }
 
