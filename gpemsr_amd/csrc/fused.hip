@@ -66,18 +66,24 @@ __global__ __launch_bounds__(256) void temporal_gate_kernel(const float* aligned
   }
 }
 
-__global__ __launch_bounds__(256) void frame_mix_kernel(const float* af, long long pixels, int t, int c, const float* m,
+// TT > 0: the frame count at compile time (the network's 5) -- with run-time loop bounds in[] is indexed dynamically and lives in scratch
+template <int TT>
+__global__ __launch_bounds__(256) void frame_mix_kernel(const float* af, long long pixels, int t_rt, int c, const float* m,
                                                         const float* bias, float* out) {
+  const int t = TT > 0 ? TT : t_rt;
   const int c4 = c >> 2;
   const long long total = pixels * c4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int j = (int)(e % c4);
     const long long p = e / c4;
     const float* ip = af + p * ((long long)t * c) + 4 * j;
-    float4 in[8];
+    float4 in[TT > 0 ? TT : 8];
+#pragma unroll
     for (int k = 0; k < t; ++k) in[k] = *reinterpret_cast<const float4*>(ip + k * c);
+#pragma unroll
     for (int i = 0; i < t; ++i) {
       float4 s = make_float4(bias[i], bias[i], bias[i], bias[i]);
+#pragma unroll
       for (int k = 0; k < t; ++k) {
         const float wv = m[i * t + k];
         s.x = fmaf(wv, in[k].x, s.x); s.y = fmaf(wv, in[k].y, s.y); s.z = fmaf(wv, in[k].z, s.z); s.w = fmaf(wv, in[k].w, s.w);
@@ -172,8 +178,12 @@ extern "C" int gpemsr_temporal_gate(const float* aligned, const float* emb, cons
 extern "C" int gpemsr_frame_mix_lrelu(const float* af, int64_t pixels, int t, int c, const float* m, const float* bias,
                                       float* out, void* stream) {
   GP_REQUIRE(af && m && bias && out && t <= 8 && c % 4 == 0, "frame_mix: bad args");
-  hipLaunchKernelGGL(frame_mix_kernel, dim3(grid_for(pixels * (c / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     af, (long long)pixels, t, c, m, bias, out);
+  if (t == 5)
+    hipLaunchKernelGGL(frame_mix_kernel<5>, dim3(grid_for(pixels * (c / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       af, (long long)pixels, t, c, m, bias, out);
+  else
+    hipLaunchKernelGGL(frame_mix_kernel<0>, dim3(grid_for(pixels * (c / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       af, (long long)pixels, t, c, m, bias, out);
   return check_launch("frame_mix");
 }
 
