@@ -717,11 +717,11 @@ __global__ __launch_bounds__(256) void conv_small16_kernel(const TI* x, int n, i
     float acc[16];
 #pragma unroll
     for (int co = 0; co < 16; ++co) acc[co] = bs[co];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {              // (fully unrolled, the nine taps' inputs were all kept live: 356 bytes of scratch per lane)
       const int iy = oy * stride - 1 + ky;
       if (iy < 0 || iy >= h) continue;
-#pragma unroll
+#pragma unroll 1
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * stride - 1 + kx;
         if (ix < 0 || ix >= w) continue;
