@@ -368,18 +368,23 @@ __global__ __launch_bounds__(256) void temporal_gate_bwd_kernel(const float* ali
 
 // Conv3d(t,t,1)+LeakyReLU backward.  out = lrelu(bias_i + sum_k M[i][k] af[k]).  d_af += M^T dz; per-block partial sums of
 // dM (t*t) and dbias (t) go to ws[block][t*t + t]; frame_mix_bwd_final adds them up in block order.
+// TT > 0: frame count at compile time (5): pm[], in[], dz[] stay in registers (dynamic indexing put them in scratch, 176 B/lane)
+template <int TT>
 __global__ __launch_bounds__(256) void frame_mix_bwd_kernel(const float* af, const float* out, const float* dout, long long pixels,
-                                                            int t, int c, const float* m, float* d_af, float* ws) {
+                                                            int t_rt, int c, const float* m, float* d_af, float* ws) {
+  const int t = TT > 0 ? TT : t_rt;
   const int c4 = c >> 2;
   const long long total = pixels * c4;
   float pm[30];                          // t <= 5: 25 + 5
   const int nred = t * t + t;
-  for (int i = 0; i < nred; ++i) pm[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 30; ++i) pm[i] = 0.f;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int j = (int)(e % c4);
     const long long p = e / c4;
     const long long base = p * ((long long)t * c) + 4 * j;
     float4 in[5], dz[5];
+#pragma unroll
     for (int k = 0; k < t; ++k) {
       in[k] = *reinterpret_cast<const float4*>(af + base + k * c);
       const float4 o = *reinterpret_cast<const float4*>(out + base + k * c);
@@ -387,8 +392,10 @@ __global__ __launch_bounds__(256) void frame_mix_bwd_kernel(const float* af, con
       g.x *= o.x > 0.f ? 1.f : 0.1f; g.y *= o.y > 0.f ? 1.f : 0.1f; g.z *= o.z > 0.f ? 1.f : 0.1f; g.w *= o.w > 0.f ? 1.f : 0.1f;
       dz[k] = g;
     }
+#pragma unroll
     for (int k = 0; k < t; ++k) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
       for (int i = 0; i < t; ++i) {
         const float wv = m[i * t + k];
         s.x = fmaf(wv, dz[i].x, s.x); s.y = fmaf(wv, dz[i].y, s.y); s.z = fmaf(wv, dz[i].z, s.z); s.w = fmaf(wv, dz[i].w, s.w);
@@ -396,14 +403,18 @@ __global__ __launch_bounds__(256) void frame_mix_bwd_kernel(const float* af, con
       float4* dp = reinterpret_cast<float4*>(d_af + base + k * c);
       float4 q = *dp; q.x += s.x; q.y += s.y; q.z += s.z; q.w += s.w; *dp = q;
     }
+#pragma unroll
     for (int i = 0; i < t; ++i) {
+#pragma unroll
       for (int k = 0; k < t; ++k)
         pm[i * t + k] += dz[i].x * in[k].x + dz[i].y * in[k].y + dz[i].z * in[k].z + dz[i].w * in[k].w;
       pm[t * t + i] += (dz[i].x + dz[i].y) + (dz[i].z + dz[i].w);
     }
   }
   __shared__ float red[4][30];
-  for (int i = 0; i < nred; ++i) {
+#pragma unroll
+  for (int i = 0; i < (TT > 0 ? TT * TT + TT : 30); ++i) {
+    if (i >= nred) break;
     float v = pm[i];
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
@@ -675,7 +686,8 @@ extern "C" int gpemsr_frame_mix_lrelu_bwd(const float* af, const float* out, con
   if (blocks > 1024) blocks = 1024;
   if (blocks * nred > ws_floats) blocks = ws_floats / nred;
   GP_REQUIRE(blocks >= 1, "frame_mix_bwd: workspace too small");
-  hipLaunchKernelGGL(frame_mix_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), af, out, dout, (long long)pixels, t, c, m, d_af, ws);
+  if (t == 5) hipLaunchKernelGGL(frame_mix_bwd_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, ST(stream), af, out, dout, (long long)pixels, t, c, m, d_af, ws);
+  else hipLaunchKernelGGL(frame_mix_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ST(stream), af, out, dout, (long long)pixels, t, c, m, d_af, ws);
   hipLaunchKernelGGL(frame_mix_bwd_final_kernel, dim3(1), dim3(64), 0, ST(stream), ws, (int)blocks, t, dm, dbias);
   return check_launch("frame_mix_bwd");
 }
