@@ -266,15 +266,60 @@ def _volume_bench(model, fr, win, steps):
     return (time.perf_counter() - tv) / steps
 
 
-def run_extras(args, model, opt, x, out, dt, dev):
-    """Measured beside the official number, never replacing it: volume mode (what output_GPEMSR.py runs) and
-    the bf16 configurations (BASELINE configs[2] names "bf16 MFMA"), each with its own roofline object and its error
-    against this run's fp32 outputs (teacher-forced = the fp32 run's code indices, free-running = its own)."""
+def run_precision_leg(args, opt, x, rank, world, dev, mode, sync):
+    """One more precision of the SAME workload, measured the same way as the headline at the same N: every rank runs its
+    16 tiles, the step ends with the all-gather of the HR slabs, barrier + synchronize on both sides, max over ranks
+    (BASELINE configs[2] = "batch=128 tiles sharded over 8 MI355X, bf16 MFMA, RCCL all-gather of HR slabs" is this leg
+    at --gpus 8).  Returns (entry for `extras`, model, last output)."""
     import torch
-    from gpemsr_amd import ops
-    from gpemsr_amd.config import build_model
-    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd import dist as gdist
     B, s, lr = args.tiles, args.scale, args.lr
+    if args.stub:
+        m3, prof = _StubModel(), None
+    else:
+        from gpemsr_amd import ops
+        from gpemsr_amd.config import build_model
+        torch.cuda.empty_cache()
+        m3 = build_model(opt, load_prior_files=False, precision=mode).eval().to(dev)
+
+    def step3():
+        return gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True)[0]
+    for _ in range(max(args.warmup, 2)):          # the allocator re-grows its pools after empty_cache(): keep that out of the timing
+        step3()
+    if not args.stub:
+        prof = ops.LaunchProfiler()
+        ops.PROFILER = prof
+    d3, o3 = timed_steps(step3, args.steps, world, dev, sync)
+    if not args.stub:
+        ops.PROFILER = None
+    assert o3.shape[0] == B * world
+    opix = o3.shape[-1] * o3.shape[-2]
+    entry = {"value": round(world * B * opix / 1e6 * args.steps / d3, 3), "unit": "MP/s", "n_gpus": world,
+             "ms_per_step": round(1e3 * d3 / args.steps, 2), "tiles_per_gpu": B, "scaling": "weak",
+             "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the HR slabs), synchronize + barrier; max over ranks",
+             "roofline": None if args.stub else build_roofline(args, prof, d3, B, s, precision=mode)}
+    return entry, m3, o3
+
+
+def run_extras(args, model, opt, x, out, dt, dev, rank=0, world=1, sync=None):
+    """Measured beside the official number, never replacing it.  At every N: the bf16 configuration (BASELINE configs[2]) as
+    its own leg with the all-gather inside its timed region.  At N = 1 additionally: volume mode (what
+    output_GPEMSR.py runs) and the bf16 leg's error against this run's fp32 outputs (teacher-forced = the fp32 run's code
+    indices, free-running = its own) incl. the free-running PSNR difference."""
+    import torch
+    B, s, lr = args.tiles, args.scale, args.lr
+    modes = [m for m in args.extras.split(",") if m]
+    if world > 1 or args.stub:
+        extras = {}
+        if args.precision == "fp32" or args.stub:
+            del model
+            for mode in modes:
+                extras[mode], m3, o3 = run_precision_leg(args, opt, x, rank, world, dev, mode, sync)
+                del m3, o3
+        return extras
+    from gpemsr_amd import ops
+    from gpemsr_amd.imgutil import calculate_psnr
+    from gpemsr_amd.synth import synth_lr_tiles
     T = B + 4
     fr = synth_lr_tiles(1, T, lr, lr, seed=77, kind="smooth")[0].to(dev)
     rows = [[min(max(c + o, 0), T - 1) for o in (-2, -1, 0, 1, 2)] for c in range(T)]
@@ -292,32 +337,35 @@ def run_extras(args, model, opt, x, out, dt, dev):
     o2_ref, _ = model(x[:2], trace=tr_ref)                  # two windows, for the teacher-forced comparison
     idx_ref = torch.cat(tr_ref["code_idx"])
     del model
-    for mode in [m for m in args.extras.split(",") if m]:
-        torch.cuda.empty_cache()
-        m3 = build_model(opt, load_prior_files=False, precision=mode).eval().to(dev)
 
-        def step3():
-            return m3(x)[0]
-        for _ in range(max(args.warmup, 2)):          # the allocator re-grows its pools after empty_cache(): keep that out of the timing
-            step3()
-        prof = ops.LaunchProfiler()
-        ops.PROFILER = prof
-        d3, o3 = timed_steps(step3, args.steps, 1, dev, torch.cuda.synchronize)
-        ops.PROFILER = None
+    def psnr_vs_base(o, k):                                 # the reference's image metric (R:util/util.py:253-260) against the bilinear base
+        u8 = ops.tensor2img_u8(o[k, 0]).cpu().numpy()
+        base = torch.nn.functional.interpolate(x[k:k + 1, 2], scale_factor=s, mode="bilinear", align_corners=False)
+        b8 = (base.squeeze().clamp(0, 1) * 255.0).round().to(torch.uint8).cpu().numpy()
+        return calculate_psnr(u8, b8), u8
+    for mode in modes:
+        entry, m3, o3 = run_precision_leg(args, opt, x, 0, 1, dev, mode, torch.cuda.synchronize)
         rel = float((o3[:B] - out_ref).abs().max() / out_ref.abs().max())
         tr3 = {}
         o2_tf, _ = m3(x[:2], forced_code_idx=idx_ref)
         m3(x[:2], trace=tr3)
         rel_tf = float((o2_tf - o2_ref).abs().max() / o2_ref.abs().max())
         agree = float((torch.cat(tr3["code_idx"]) == idx_ref).float().mean())
+        dps, du8 = [], 0
+        for k in range(min(B, 4)):                          # free-running image quality, this leg against the fp32 path, first windows
+            p3, u3 = psnr_vs_base(o3, k)
+            p0, u0 = psnr_vs_base(out_ref, k)
+            dps.append(abs(p3 - p0))
+            du8 = max(du8, int(abs(u3.astype("int32") - u0.astype("int32")).max()))
         vol = _volume_bench(m3, fr, win, args.steps)
-        extras[mode] = {"value": round(B * (lr * s) ** 2 / 1e6 * args.steps / d3, 3), "unit": "MP/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
-                        "volume_mode_value": round(T * (lr * s) ** 2 / 1e6 / vol, 3),
-                        "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
-                        "code_index_agreement_free_running_2_windows": agree,
-                        "rel_err_vs_fp32_path_free_running_all_windows": rel,
-                        "speedup_vs_fp32_path": round(dt / d3, 3),
-                        "roofline": build_roofline(args, prof, d3, B, s, precision=mode)}
+        entry.update({"volume_mode_value": round(T * (lr * s) ** 2 / 1e6 / vol, 3),
+                      "rel_err_vs_fp32_path_teacher_forced_2_windows": rel_tf,
+                      "code_index_agreement_free_running_2_windows": agree,
+                      "rel_err_vs_fp32_path_free_running_all_windows": rel,
+                      "free_running_dpsnr": round(max(dps), 5),
+                      "free_running_u8_max_level_diff": du8,
+                      "speedup_vs_fp32_path": round(dt / (entry["ms_per_step"] * 1e-3 * args.steps), 3)})
+        extras[mode] = entry
         del m3, o3
     return extras
 
@@ -391,18 +439,21 @@ def run_forward(args) -> int:
         ops.PROFILER = None
     assert out.shape[0] == B * world
     rccl_world = torch.distributed.get_world_size() if world > 1 else 1           # the group the all-gathers above ran on
+    dist_backend = torch.distributed.get_backend() if world > 1 else None         # "nccl" = RCCL on ROCm; "gloo" in rehearsals / self-tests
 
     opix = out.shape[-1] * out.shape[-2]
     mp_per_step = world * B * opix / 1e6
     value = mp_per_step * args.steps / dt
     roofline, extras, cpu_baseline = None, None, None
+    if args.stub and not args.no_extras:
+        extras = run_extras(args, model, None, x, out, dt, dev, rank, world, sync)
     if not args.stub:
         roofline = build_roofline(args, prof, dt, B, s)
         if args.layer_report and rank == 0:
             write_layer_report(prof, args.layer_report)
         model_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-        if world == 1 and not args.no_extras:
-            extras = run_extras(args, model, opt, x, out, dt, dev)
+        if not args.no_extras:
+            extras = run_extras(args, model, opt, x, out, dt, dev, rank, world, sync)
         if model_sd is not None:
             cpu_baseline = run_cpu_baseline(args, model_sd, x, out)
 
@@ -414,7 +465,7 @@ def run_forward(args) -> int:
                  "bf16op": "bf16 operands rounded in the kernel (fp32 activations in HBM), fp32 accumulate"}[args.precision]
         line = {
             "metric": "output megapixels/sec, 8x EMSR 128->1024 tiles" if s == 8 else "output megapixels/sec, 16x EMSR 64->1024 tiles",
-            "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "rccl_world": rccl_world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "rccl_world": rccl_world, "dist_backend": dist_backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "stub" if args.stub else dtype, "data": "synthetic",
             "config": {"workload": ("launcher self-test (stub model, CPU, gloo)" if args.stub else

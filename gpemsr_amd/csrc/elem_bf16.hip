@@ -829,18 +829,20 @@ extern "C" int gpemsr_groupnorm_apply_bf16(const void* x, int n, int hw, int c, 
 }
 
 extern "C" int gpemsr_softmax_rows_bf16(const void* s, int s_f32, int64_t rows, int cols, int s_ld, void* p, int p_ld, void* stream) {
-  GP_REQUIRE(s && p && rows > 0 && rows < (1ll << 31) && cols % 8 == 0 && cols <= 256 * 8 * 4 && s_ld % 8 == 0 && p_ld % 8 == 0 && A16(s) && A16(p),
-             "softmax_rows_bf16: bad args (cols %% 8 == 0, <= 8192)");
+  GP_REQUIRE(s && p && rows > 0 && rows < (1ll << 31) && cols % 8 == 0 && cols <= 256 * 8 * 8 && s_ld % 8 == 0 && p_ld % 8 == 0 && A16(s) && A16(p),
+             "softmax_rows_bf16: bad args (cols %% 8 == 0, <= 16384)");
   hipStream_t st = ST(stream);
   bf16_t* pp = reinterpret_cast<bf16_t*>(p);
   if (s_f32) {
     if (cols <= 2048) hipLaunchKernelGGL((softmax16_kernel<1, float>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const float*>(s), cols, s_ld, pp, p_ld);
     else if (cols <= 4096) hipLaunchKernelGGL((softmax16_kernel<2, float>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const float*>(s), cols, s_ld, pp, p_ld);
-    else hipLaunchKernelGGL((softmax16_kernel<4, float>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const float*>(s), cols, s_ld, pp, p_ld);
+    else if (cols <= 8192) hipLaunchKernelGGL((softmax16_kernel<4, float>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const float*>(s), cols, s_ld, pp, p_ld);
+    else hipLaunchKernelGGL((softmax16_kernel<8, float>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const float*>(s), cols, s_ld, pp, p_ld);
   } else {
     if (cols <= 2048) hipLaunchKernelGGL((softmax16_kernel<1, bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(s), cols, s_ld, pp, p_ld);
     else if (cols <= 4096) hipLaunchKernelGGL((softmax16_kernel<2, bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(s), cols, s_ld, pp, p_ld);
-    else hipLaunchKernelGGL((softmax16_kernel<4, bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(s), cols, s_ld, pp, p_ld);
+    else if (cols <= 8192) hipLaunchKernelGGL((softmax16_kernel<4, bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(s), cols, s_ld, pp, p_ld);
+    else hipLaunchKernelGGL((softmax16_kernel<8, bf16_t>), dim3((unsigned)rows), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(s), cols, s_ld, pp, p_ld);
   }
   return check_launch("softmax_rows_bf16");
 }

@@ -47,6 +47,8 @@ def _seq_len(sd, prefix: str) -> int:
 
 
 class Engine:
+    BF16_SOFTMAX_MAX_COLS = 16384      # gpemsr_softmax_rows_bf16: 256 threads x 8 x 8 values (= the fp32 row softmax's limit)
+
     def __init__(self, sd: Dict[str, torch.Tensor], device, scale: int, nframes: int = 5, groups: int = 8,
                  nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 80, tile_chunk: int = 16,
                  precision: str = "fp32"):
@@ -235,10 +237,11 @@ class Engine:
         if c % 32 != 0 or T % 4 != 0:
             raise RuntimeError(f"gpemsr_amd: non-local block needs channels ({c}) % 32 == 0 and latent tokens ({T}) % 4 == 0")
         if self.bf16:
-            if T % 16 == 0:
+            if T % 16 == 0 and T <= self.BF16_SOFTMAX_MAX_COLS:
                 return self._nonlocal_bf16(x, p)
-            # token counts the bf16 matrix-product tiles cannot take (e.g. CREMI's 156 x 156 LR slices -> 78 x 78 = 6084 tokens): this
-            # one block runs on the exact-fp32 kernels (zero-padded score rows), the rest of the path stays bf16
+            # token counts the bf16 matrix-product tiles cannot take (e.g. CREMI's 156 x 156 LR slices -> 78 x 78 = 6084 tokens) or
+            # rows longer than the bf16 softmax kernel holds in registers: this one block runs on the exact-fp32 kernels (zero-padded
+            # score rows; they take what the fp32 path takes), the rest of the path stays bf16
             return self.o.cast_bf16(self._nonlocal_ragged(self.o.cast_f32(x), p, precision="fp32"))
         if T % 32 != 0:
             return self._nonlocal_ragged(x, p)

@@ -146,6 +146,17 @@ class GPEMSR(nn.Module):
         """Called by the trainers after a HIP kernel (Adam on the flat buffer) wrote these parameters in place."""
         self._hip_written = set(getattr(self, "_hip_written", ())) | set(names)
 
+    def invalidate_packed_weights(self, names=None):
+        """Tell the module that parameters were written in a way torch's (data_ptr, _version) counters do not show -- ``p.data.copy_()``,
+        ``p.data.mul_()`` (EMA updates, weight clipping), ``torch._foreach_*`` on ``.data`` views, raw-pointer writes: ``.data`` has its
+        own version counter, so ``sync_weights`` cannot see those.  ``names`` = state-dict keys to repack on the next forward; None =
+        all of them (drops the engine; the next forward repacks everything)."""
+        if names is None:
+            self._engine = None
+            self._train_state = None
+        else:
+            self.mark_weights_written(names)
+
     def _get_train_state(self, device):
         """State of the torch.autograd path (gpemsr_amd/autograd.py): built on the first differentiable forward."""
         if getattr(self, "_train_state", None) is None or self._train_state.eng.dev != device:

@@ -361,7 +361,10 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             _go_split()
         return out
     if (gn_stats and precision == "fp32" and act == ACT_NONE and residual is None and pixmul is None and not pc.transposed and not pc.pixel_shuffle
-            and pc.cout % 4 == 0 and out.ld % 4 == 0 and out.ptr % 16 == 0 and (pc.b is None or pc.b.data_ptr() % 16 == 0)):
+            and pc.cout % 4 == 0 and out.ld % 4 == 0 and out.ptr % 16 == 0 and (pc.b is None or pc.b.data_ptr() % 16 == 0)
+            # the partial-sum epilogue exists only in the LDS-DMA instantiations (conv_mfma.hip: GP_REQUIRE(dma && BN >= 32)): sources it
+            # cannot stage by DMA take the statistics pass instead of failing the launch
+            and all(s.ld % 4 == 0 and s.ptr % 16 == 0 and s.c % (32 if k == 1 else 8) == 0 for s in srcs)):
         parts = lib.gpemsr_conv2d_gn_parts(C.byref(d))
         if parts > 0:                                   # (< 0: this shape takes the general epilogue -- the statistics pass runs instead)
             gws = torch.empty(n * parts * pc.cout * 2, dtype=torch.float32, device=s0.buf.device)

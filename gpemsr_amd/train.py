@@ -52,8 +52,11 @@ class CosineAnnealingLRRestart:
         self.T_period = list(T_period)
         self.T_max = self.T_period[0]
         self.eta_min = float(eta_min)
-        # no `restarts` = no restarts (the reference's default [0] -> [1] indexes T_period[1] at the first step and
-        # raises for a one-period schedule, model/lr_scheduler.py:42-47,58)
+        # `restarts` absent: the reference defaults to [0] -> [1] with weights [1] (model/lr_scheduler.py:40-42), i.e. at step 1 it
+        # switches T_max to T_period[1] -- kept for a multi-period schedule.  For a ONE-period schedule that default indexes
+        # T_period[1] and raises (:52); there, and only there, "no restarts" is used instead.
+        if not restarts and len(self.T_period) > 1:
+            restarts = [0]
         self.restarts = [v + 1 for v in restarts] if restarts else []
         self.restart_weights = (list(weights) if weights else [1] * len(self.restarts))[:len(self.restarts)] if self.restarts else []
         assert len(self.restarts) == len(self.restart_weights), 'restarts and their weights do not match.'
@@ -504,6 +507,13 @@ class _TrainerState:
     (train_stage3.py:183-184: optimizer and scheduler state dicts) -- Adam moments, step counter, scheduler position.
     The weights themselves travel in ``model.state_dict()`` as usual."""
 
+    def adam_hparams(self):
+        """(beta1, beta2, eps, weight_decay) this trainer's ``step()`` really uses -- ONE place, so that the exported torch state dict
+        (``torch_optimizer_state_dict``) can never disagree with the run (ADVICE r2).  Absent keys take torch.optim.Adam's defaults;
+        the reference reads beta1 / beta2 from the option file without a default (R:train_stage3.py:153-158)."""
+        o = self.opt
+        return float(o.get("beta1", 0.9)), float(o.get("beta2", 0.999)), 1e-8, float(o.get("weight_decay_G") or 0.0)
+
     def state_dict(self) -> dict:
         names = [k for k, p in self.model.named_parameters() if p.data_ptr() >= self.flat_p.data_ptr()
                  and p.data_ptr() < self.flat_p.data_ptr() + 4 * self.flat_p.numel()]
@@ -544,8 +554,9 @@ class _TrainerState:
             state[i] = {"step": torch.tensor(float(self.step_count)),
                         "exp_avg": self.flat_m[off:off + n].detach().clone().view(shape),
                         "exp_avg_sq": self.flat_v[off:off + n].detach().clone().view(shape)}
-        group = {"lr": float(self.lr), "betas": (float(self.opt.get("beta1", 0.9)), float(self.opt.get("beta2", 0.99))), "eps": 1e-8,
-                 "weight_decay": float(self.opt.get("weight_decay_G", 0) or 0), "amsgrad": False, "maximize": False, "foreach": None,
+        b1, b2, eps, wd = self.adam_hparams()
+        group = {"lr": float(self.lr), "betas": (b1, b2), "eps": eps,
+                 "weight_decay": wd, "amsgrad": False, "maximize": False, "foreach": None,
                  "capturable": False, "differentiable": False, "fused": None, "initial_lr": float(self.opt.get("lr_G", self.lr)),
                  "params": list(range(len(params)))}
         return {"state": state, "param_groups": [group]}
@@ -682,8 +693,8 @@ class Stage3Trainer(_TrainerState):
         average_gradients(self.flat_g, self.world)                      # DistributedDataParallel: mean over the replicas
         self.step_count += 1
         o = self.opt
-        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, float(o.get("beta1", 0.9)), float(o.get("beta2", 0.999)),
-                      1e-8, float(o.get("weight_decay_G") or 0.0), self.step_count)
+        b1, b2, eps, wd = self.adam_hparams()
+        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, b1, b2, eps, wd, self.step_count)
         self.lr = self.sched.step()
         self.eng.refresh_weights()
         self.model.mark_weights_written(self._param_keys)     # the inference engine's packs are stale now (validation!)

@@ -153,8 +153,8 @@ class Stage1Trainer(_TrainerState):
         average_gradients(self.flat_g, self.world)
         self.step_count += 1
         o = self.opt
-        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, float(o.get("beta1", 0.9)), float(o.get("beta2", 0.999)),
-                      1e-8, float(o.get("weight_decay_G") or 0.0), self.step_count)
+        b1, b2, eps, wd = self.adam_hparams()
+        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, b1, b2, eps, wd, self.step_count)
         self.lr = self.sched.step()
         self.eng.refresh_weights()
         self.model.mark_weights_written(self._param_keys)

@@ -23,14 +23,20 @@ def test_plain_invocation_spawns_two_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_world"] == 2 and d["config"]["global_tiles"] == 6
+    assert d["dist_backend"] == "gloo"                      # `rccl_world` alone cannot tell a rehearsal from an RCCL run
     assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    # BASELINE configs[2] (bf16, tiles sharded over the GPUs, all-gather of the slabs) rides along at EVERY N as its own leg
+    leg = d["extras"]["bf16"]
+    assert leg["n_gpus"] == 2 and leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["tiles_per_gpu"] == 3
+    assert "all-gather" in leg["timed_region"]
 
 
 def test_single_rank_runs_in_process():
     r = _run(["--gpus", "1"])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["n_gpus"] == 1 and d["rccl_world"] == 1
+    assert d["n_gpus"] == 1 and d["rccl_world"] == 1 and d["dist_backend"] is None
+    assert d["extras"]["bf16"]["n_gpus"] == 1
 
 
 def test_failing_rank_fails_the_launcher():

@@ -276,6 +276,23 @@ def test_attention_products_bf16():
     _close(out.torch().reshape(n, T, c), torch.bmm(p_dev, v_ref) + bv, 1e-4, "P.v")
 
 
+@pytest.mark.parametrize("cols", [9216, 16384])
+def test_softmax_rows_bf16_long_rows(cols):
+    """x8 at LR 192x192 gives 9216 latent tokens, x16 at LR 128x128 gives 16384 -- beyond the 8192 columns the bf16 row
+    softmax used to hold in registers.  It now takes what the fp32 path takes (16384); longer rows are routed to the fp32 block by
+    the engine (Engine.BF16_SOFTMAX_MAX_COLS)."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.engine import Engine
+    dev = _dev()
+    assert cols <= Engine.BF16_SOFTMAX_MAX_COLS
+    s = _r(_rand(3, cols, seed=71, scale=4.0))
+    a = ops.Act(s.to(torch.bfloat16).to(dev).contiguous().view(-1), 1, 1, 3, cols, cols, 0)
+    P = ops.softmax_rows_bf16(a)
+    _close(P.torch().float().reshape(3, cols).cpu(), torch.softmax(s, dim=1), 2 * BF, "long-row softmax")
+    with pytest.raises(RuntimeError):
+        ops.softmax_rows_bf16(ops.Act(torch.zeros(2 * 16392, dtype=torch.bfloat16, device=dev), 1, 1, 2, 16392, 16392, 0))
+
+
 def test_elementwise_bf16_kernels():
     from gpemsr_amd import ops
     dev = _dev()

@@ -3,6 +3,7 @@ drop-in module behaviour, weight packing, option files, sharding helpers, C-ABI 
 import ctypes
 import hashlib
 import json
+import math
 import os
 import re
 
@@ -262,6 +263,12 @@ def test_scheduler_defaults_do_not_index_past_t_period():
     c = CosineAnnealingLRRestart(1.0, [4, 4], [4], [0.5], eta_min=0.0)
     seq = [c.step() for _ in range(6)]
     assert seq[4] == pytest.approx(0.5)              # e = 5 = restarts[0] + 1 -> base_lr * weight
+    # `restarts` absent on a MULTI-period schedule: the reference's own default ([0] -> [1], weight 1) switches T_max to
+    # T_period[1] at step 1 (R:model/lr_scheduler.py:40-42,50-53) -- ADVICE r2
+    d = CosineAnnealingLRRestart(1.0, [4, 8], None, None, eta_min=0.0)
+    seq = [d.step() for _ in range(3)]
+    assert d.T_max == 8 and seq[0] == pytest.approx(1.0)
+    assert seq[1] == pytest.approx((1 + math.cos(math.pi * 1 / 8)) / 2)     # cosine over T_period[1] counted from the restart at step 1
 
 
 def test_packed_weights_follow_in_place_parameter_updates():
