@@ -82,6 +82,8 @@ struct XParams {
   int nblocks;
   int nbias;                                 // true output channels (bias entries)
   int gpt, ns;                               // resident kernel: workgroups per cout slab, spatial tiles
+  const float* axs; const float* axh;        // AXF kernels: per (image, input channel) scale / shift applied to the source while it is staged
+  int ax_relu;                               // ... followed by ReLU
 };
 
 struct XGeo { int img, oy0, ox0, n0, tile_in_img; };
@@ -343,7 +345,15 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
 // phase.  With NL loader waves beside the WM x WN multiplying waves the DMA issue stalls and the counted waits sit on waves
 // that have nothing else to do: per stage the multiplying waves run  MFMAs -> barrier , the loader waves  wait for stage
 // s + 1 -> barrier -> refill the slot the barrier freed , and both meet at the one barrier per stage.
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false, int SS = 0>
+//
+// AXF: the source gets a per-(image, channel) affine map + ReLU on its way into LDS -- GroupNorm's apply pass (R:model/blocks.py:5-29)
+// folded into the convolution that consumes it, so the normalised tensor never exists in HBM (it cost one read + one write of every
+// VQGAN block's first intermediate).  LDS-DMA cannot transform, so in this form the loader waves stage the halo image through
+// REGISTERS: 16-byte global loads one chunk ahead (a whole stage of latency cover), 8 FMAs + max + 4 packs per piece, ds_write_b128
+// into the same swizzled image the DMA form builds.  A loader thread keeps ONE logical 8-channel piece (dtid % R), so its 8 scales and
+// shifts are loaded once per chunk; padding pixels are written as zeros (zero padding applies to the NORMALISED tensor).  Weights
+// still arrive by LDS-DMA; the in-order vmcnt sees the register loads and the DMA instructions in one queue (all counted below).
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false>
 __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM * WN + NL) > 8 ? 3 : 2)) void conv_bf16_kernel(XParams P) {
   constexpr int NC = WM * WN;          // multiplying waves
   constexpr bool SPEC = NL > 0;
@@ -580,6 +590,86 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
   const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
   const unsigned xsm_lds = xlds_addr(xsm);
 
+  if constexpr (AXF) {
+    static_assert(SPEC && !GEMM && !CONVT && SPC == 1 && DTH % R == 0 && R == 4, "AXF: loader-wave 3x3 form with whole-chunk stages");
+    if (!is_mul) {
+      // ---- loader waves, register-staged + transformed halo images (see AXF above); host: one source, n_abuf == 2, RING <= stages ----
+      const int q = dtid % R;                            // this thread's logical 16-byte piece (8 channels) of every halo pixel
+      uint4 raw[NA];
+      float sc[8], sh[8];
+      unsigned padmask = 0u;                              // bit i: slot i of the image held in `raw` is padding (or does not exist)
+      const float lo = P.ax_relu ? 0.f : -3.0e38f;
+      auto axf_load = [&]() {                             // halo image of the A cursor's chunk -> registers; NA + 4 vector-memory operations
+        if (a_cross) { a_enter_tile(nxt); a_cross = false; }
+        const unsigned short* sp = srcp[0] + (long long)a_img * src_istride[0] + a_c0 + 8 * q;
+        const float* scp = P.axs + (long long)a_img * src_c[0] + a_c0 + 8 * q;
+        const float* shp = P.axh + (long long)a_img * src_c[0] + a_c0 + 8 * q;
+        unsigned pm = 0u;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int pix = a_pix[i];
+          pm |= (pix < 0 ? 1u : 0u) << i;
+          raw[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sp) + (size_t)(unsigned)(pix < 0 ? 0 : pix) * src_pixb[0]);
+        }
+        padmask = pm;
+        const float4 s0 = *reinterpret_cast<const float4*>(scp), s1 = *reinterpret_cast<const float4*>(scp + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(shp), h1 = *reinterpret_cast<const float4*>(shp + 4);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+        issued_total += NA + 4;
+        ++a_next; a_c0 += CK;
+        if (++a_chunk == nchunks) { a_chunk = 0; a_c0 = 0; ++a_ti; a_cross = true; }
+      };
+      auto axf_write = [&](int buf) {                     // registers -> transformed image `buf` (every existing slot is written)
+        char* ab = a_base + buf * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int e = dtid + i * DTH;
+          if (e < HALO_PX * R) {
+            const int hp = e / R;
+            const unsigned in[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float a = fmaxf(fmaf(__uint_as_float(in[k] << 16), sc[2 * k], sh[2 * k]), lo);
+              const float b = fmaxf(fmaf(__uint_as_float(in[k] & 0xFFFF0000u), sc[2 * k + 1], sh[2 * k + 1]), lo);
+              o[k] = xcvt_pk_bf16(a, b);
+            }
+            const bool pad = (padmask >> i) & 1u;
+            *reinterpret_cast<uint4*>(ab + hp * ROWB + ((q ^ ((hp >> SWZ_SH) & SWZ_MK)) * 16)) =
+                pad ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(o[0], o[1], o[2], o[3]);
+          }
+        }
+      };
+      // prologue: A(0) -> image 0, A(1) -> registers, weights of the first RING stages
+      a_enter_tile(cur);
+      axf_load();
+      axf_write(0);
+      if (a_next < TC) axf_load();
+      for (int j = 0; j < RING && b_next < TS; ++j) issue_b();
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int wbuf = 1;                                       // image that receives the chunk held in registers
+      int s_glob = 0;
+      for (int ti = 0; ti < T_me; ++ti) {
+        for (int cc = 0; cc < nchunks; ++cc, ++s_glob) {
+          // concurrent with the multiplying waves' stage s_glob: image (s+1) % 2 and ring slot (s-1) % RING were freed by the last barrier
+          if (s_glob + 1 < TC) axf_write(wbuf);           // A(s+1), loaded a stage ago (the compiler's wait covers exactly those loads:
+          wbuf ^= 1;                                      //  everything older -- the DMA below is issued BEFORE the next loads -- has landed)
+          if (s_glob > 0 && b_next < TS) issue_b();       // B(s-1+RING)
+          if (a_next < TC) axf_load();                    // A(s+2) -> registers
+          if (s_glob + 1 < TS) xwait_vmcnt(issued_total - get4(markB, s_glob + 1));    // B(s+1) has landed
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        cur = nxt;
+        if (ti + 2 < T_me) nxt = tile_geo(ti + 2);
+      }
+      return;
+    }
+  }
   // ---- prologue: tile 0 (and 1) geometry, A(0) [A(1)], B(0 .. RING-1) ----
   if (is_loader) {
     a_enter_tile(cur);
@@ -955,7 +1045,10 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
 //   * the loader waves issue the halo images (10 x 34 pixels x 32 channels, two buffers per group) for tile k + 1 as soon as
 //     the barrier has freed a buffer -- three intervals before it is needed -- and absorb the DMA issue stalls and the waits.
 // LDS: weights 73,728 + 4 x 21,760 + bias <= 163,840 bytes.
-template <bool LEAN>
+// AXF: the halo images are staged through the loader waves' registers and get the per-(image, channel) affine map + ReLU of a folded
+// GroupNorm apply on the way (see conv_bf16_kernel): loads go out one interval before the transformed image is written, two before
+// it is read.
+template <bool LEAN, bool AXF = false>
 __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   constexpr int HALO_W = 34, HALO_H = 10, HALO_PX = HALO_W * HALO_H, R = 4;
   constexpr int A_BYTES = HALO_PX * R * 16;            // 21,760
@@ -992,6 +1085,106 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     asm volatile("" ::: "memory");
   };
 
+  if (AXF && wave >= 8) {
+    // ------------------------------------------------ loader waves, register-staged + transformed images ------------------------------------------------
+    const int dtid = tid - 512, dwave = wave - 8;
+    const unsigned lds0 = xuni(xsm_lds + (unsigned)dwave * 1024u);
+    const unsigned pixb = (unsigned)P.ld[0] * 2u;
+    {   // weight slab (LDS-DMA, as below)
+      const unsigned short* wp = reinterpret_cast<const unsigned short*>(xuni_ptr(P.weight));
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int e = dtid + i * 256;
+        int row = n0 + (e & 63);
+        row = row < P.cout ? row : P.cout - 1;
+        xglds16((unsigned)((e >> 6) * P.cout + row) * 16u, wp, lds0 + i * 4096u);
+      }
+    }
+    const int q = dtid & 3;                              // this thread's logical 16-byte piece (8 channels) of every halo pixel
+    const float lo = P.ax_relu ? 0.f : -3.0e38f;
+    int a_pix[2][NA];
+    int a_img[2] = {0, 0};
+    uint4 raw[2][NA];
+    float sc[2][8], sh[2][8];
+    unsigned padmask[2] = {0u, 0u};
+    int pend[2] = {-1, -1};                              // chunk of the image held in raw[g] (-1: none)
+    auto enter = [&](const int g, int k) {               // g compile-time
+      const XGeo t = tile_geo(2 * k + g);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = dtid + i * 256;
+        int pix = -1;
+        if (e < HALO_PX * R) {
+          const int hp = e / R;
+          const int iy = t.oy0 - 1 + hp / HALO_W, ix = t.ox0 - 1 + hp % HALO_W;
+          if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) pix = iy * P.w + ix;
+        }
+        a_pix[g][i] = pix;
+      }
+      a_img[g] = t.img;
+    };
+    auto load = [&](const int g, const int c) {          // chunk c of group g's current tile -> registers
+      const char* sp = reinterpret_cast<const char*>(P.src[0] + (long long)a_img[g] * P.img_stride[0] + c * 32 + 8 * q);
+      const float* scp = P.axs + (long long)a_img[g] * 64 + c * 32 + 8 * q;
+      const float* shp = P.axh + (long long)a_img[g] * 64 + c * 32 + 8 * q;
+      unsigned pm = 0u;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int pix = a_pix[g][i];
+        pm |= (pix < 0 ? 1u : 0u) << i;
+        raw[g][i] = *reinterpret_cast<const uint4*>(sp + (size_t)(unsigned)(pix < 0 ? 0 : pix) * pixb);
+      }
+      padmask[g] = pm;
+      const float4 s0 = *reinterpret_cast<const float4*>(scp), s1 = *reinterpret_cast<const float4*>(scp + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(shp), h1 = *reinterpret_cast<const float4*>(shp + 4);
+      sc[g][0] = s0.x; sc[g][1] = s0.y; sc[g][2] = s0.z; sc[g][3] = s0.w; sc[g][4] = s1.x; sc[g][5] = s1.y; sc[g][6] = s1.z; sc[g][7] = s1.w;
+      sh[g][0] = h0.x; sh[g][1] = h0.y; sh[g][2] = h0.z; sh[g][3] = h0.w; sh[g][4] = h1.x; sh[g][5] = h1.y; sh[g][6] = h1.z; sh[g][7] = h1.w;
+      pend[g] = c;
+    };
+    auto write = [&](const int g) {                      // registers -> transformed image (g, pend[g])
+      if (pend[g] < 0) return;
+      char* ab = xsm + W_BYTES + (2 * g + pend[g]) * A_BYTES;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = dtid + i * 256;
+        if (e < HALO_PX * R) {
+          const int hp = e / R;
+          const unsigned in[4] = {raw[g][i].x, raw[g][i].y, raw[g][i].z, raw[g][i].w};
+          unsigned o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float a = fmaxf(fmaf(__uint_as_float(in[k] << 16), sc[g][2 * k], sh[g][2 * k]), lo);
+            const float b = fmaxf(fmaf(__uint_as_float(in[k] & 0xFFFF0000u), sc[g][2 * k + 1], sh[g][2 * k + 1]), lo);
+            o[k] = xcvt_pk_bf16(a, b);
+          }
+          const bool pad = (padmask[g] >> i) & 1u;
+          *reinterpret_cast<uint4*>(ab + hp * 64 + ((q ^ ((hp >> 2) & 3)) * 16)) = pad ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      pend[g] = -1;
+    };
+    // prologue: tile 0 of both groups
+    enter(0, 0); load(0, 0); write(0); load(0, 1); write(0);
+    if (T1 > 0) { enter(1, 0); load(1, 0); write(1); load(1, 1); write(1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight slab
+    end_interval();
+    for (int i = 0; i < NI; ++i) {
+      write(0); write(1);                                // images loaded during the previous interval; read from the next one on
+      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-g) % 3 of its tile (i-1-g) / 3 in interval i-1
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int u = i - 1 - g;
+        if (u >= 0) {
+          const int k = u / 3, c = u - 3 * k;
+          if (c < 2 && k + 1 < (g ? T1 : T0)) {
+            if (c == 0) { enter(g, k + 1); load(g, 0); } else load(g, 1);
+          }
+        }
+      }
+      end_interval();
+    }
+    return;
+  }
   if (wave >= 8) {
     // ------------------------------------------------ loader waves ------------------------------------------------
     const int dtid = tid - 512, dwave = wave - 8;
@@ -1146,9 +1339,9 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   for (int s = 3 * T_g + g; s < NI; ++s) end_interval();
 }
 
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0>
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false>
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS>;
+  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS, AXF>;
   if (lds > 64 * 1024) {
     static bool done = false;
     if (!done) {
@@ -1177,7 +1370,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
 using namespace gpemsr;
 
 namespace {
-struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean; int res_form; size_t lds; };
+struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean, axf, axf_ok; int res_form; size_t lds; };
 
 // geometry + tile choice of one launch (shared by the launcher and by gpemsr_conv2d_bf16_gn_parts)
 int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
@@ -1214,6 +1407,8 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.res_f32 = d->res_f32; P.pixmul = d->pixmul;
   P.out = d->out; P.out_ld = d->out_ld; P.out_f32 = d->out_f32; P.out32 = d->out32; P.out32_ld = d->out32_ld;
   P.gn_ws = d->gn_partials; P.gn_cpg = d->gn_cpg;
+  P.axs = d->a_scale; P.axh = d->a_shift; P.ax_relu = d->a_relu;
+  L.axf = d->a_scale != nullptr || d->a_shift != nullptr;
   P.nbias = d->cout;
   const int bias_bytes = ((d->cout + 7) & ~7) * 4;
   int BN, TH, TPS, WM, WN, NL = 0;
@@ -1342,11 +1537,26 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   // the lean epilogue (see x_epilogue) covers this descriptor?
   L.lean = P.store_mode == XS_PLAIN && !d->out_f32 && !d->out32 && (!d->residual || !d->res_f32) && d->cout % 8 == 0 &&
            (d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU);
+  // source transform (a_scale / a_shift: a folded GroupNorm apply): kernels that stage the halo image through registers exist for the
+  // 64-channel weights-resident form and for the wide 3x3 loader-wave tile -- every second convolution of a VQGAN block
+  L.axf_ok = !tr && !gemm && d->ksize == 3 && d->stride == 1 && d->nsrc == 1 && d->src_image_stride[0] < 0 && d->weight_image_stride == 0 && L.lean &&
+             (L.resident ? L.res_form == 2
+                         : (NL == 4 && BN == 64 && WM == 8 && WN == 1 && TH == 16 && TPS == 9 && CK == 32 && n_abuf == 2 && ring <= stages));
+  if (L.axf) GP_REQUIRE(L.axf_ok && d->a_scale && d->a_shift && (reinterpret_cast<uintptr_t>(d->a_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->a_shift) & 15) == 0,
+                        "conv2d_bf16: no source-transform kernel for this layer (ask gpemsr_conv2d_bf16_axf_ok) or misaligned scale / shift tables");
   return GPEMSR_OK;
 }
 }  // namespace
 
-static_assert(sizeof(gpemsr_conv16_desc) == 240, "gpemsr_conv16_desc layout changed: update gpemsr_amd/_abi.py");
+static_assert(sizeof(gpemsr_conv16_desc) == 264, "gpemsr_conv16_desc layout changed: update gpemsr_amd/_abi.py");
+
+extern "C" int gpemsr_conv2d_bf16_axf_ok(const gpemsr_conv16_desc* d) {
+  XParams P{}; XPlan L{};
+  gpemsr_conv16_desc t = *d;
+  t.a_scale = nullptr; t.a_shift = nullptr;
+  const int rc = plan_x(&t, P, L);
+  return rc == GPEMSR_OK ? (L.axf_ok ? 1 : 0) : rc;
+}
 
 extern "C" int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d) {
   XParams P{}; XPlan L{};
@@ -1376,7 +1586,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(GPEMSR_ELAUNCH, "conv2d_bf16: cannot raise the dynamic LDS limit");
       attr = true;
     }
@@ -1387,7 +1598,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (gpt > P.ns) gpt = P.ns;
     P.gpt = gpt;
     if (L.res_form == 2) {
-      if (L.lean) hipLaunchKernelGGL(conv64_resident2_kernel<true>, dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
+      if (L.axf) hipLaunchKernelGGL((conv64_resident2_kernel<true, true>), dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
+      else if (L.lean) hipLaunchKernelGGL(conv64_resident2_kernel<true>, dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
       else hipLaunchKernelGGL(conv64_resident2_kernel<false>, dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
       return check_launch("conv64_resident2_kernel");
     }
@@ -1400,6 +1612,7 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
 #define GP_IS(BNv, WMv, WNv, THv, TPSv) (L.BN == BNv && L.WM == WMv && L.WN == WNv && L.TH == THv && L.TPS == TPSv)
 #define GP_XL(BNv, WMv, WNv, THv, TPSv, TRv, GEMMv) \
   (L.CK == 32 ? launch_x<32, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st) : launch_x<16, BNv, WMv, WNv, THv, TPSv, TRv, GEMMv, 4>(P, lds, st))
+  if (L.axf) return launch_x<32, 64, 8, 1, 16, 9, false, false, 4, true, 0, true>(P, lds, st);      // (plan_x admitted exactly this tile)
   if (L.NL == 8) {
     if (!L.tr && !L.gemm && GP_IS(32, 8, 1, 16, 7) && L.CK == 32)
       return L.lean ? launch_x<32, 32, 8, 1, 16, 7, false, false, 8, true>(P, lds, st) : launch_x<32, 32, 8, 1, 16, 7, false, false, 8, false>(P, lds, st);

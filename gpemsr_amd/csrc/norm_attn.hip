@@ -194,6 +194,27 @@ extern "C" int gpemsr_groupnorm_stats(const float* x, int n, int hw, int c, int 
   return check_launch("groupnorm_stats");
 }
 
+// scale = rstd * gamma, shift = beta - mean * rstd * gamma per (image, channel): GroupNorm's apply as a per-channel affine map (the
+// form gn_apply16_cols_kernel uses), for convolutions that apply it to their source while staging it (gpemsr_conv16_desc.a_scale)
+__global__ __launch_bounds__(256) void gn_scale_shift_kernel(const float* mr, const float* gamma, const float* beta, int n, int c, int groups,
+                                                             float* scale, float* shift) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * c) return;
+  const int img = e / c, ch = e % c, grp = ch / (c / groups);
+  const float mean = mr[2 * (img * groups + grp)], rstd = mr[2 * (img * groups + grp) + 1];
+  const float g = gamma[ch], b = beta[ch];
+  scale[e] = rstd * g;
+  shift[e] = b - mean * rstd * g;
+}
+
+extern "C" int gpemsr_groupnorm_scale_shift(const float* mean_rstd, const float* gamma, const float* beta, int n, int c, int groups,
+                                            float* scale, float* shift, void* stream) {
+  GP_REQUIRE(mean_rstd && gamma && beta && scale && shift && n > 0 && c > 0 && groups > 0 && c % groups == 0, "groupnorm_scale_shift: bad args");
+  hipLaunchKernelGGL(gn_scale_shift_kernel, dim3(cdiv((long long)n * c, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), mean_rstd, gamma, beta,
+                     n, c, groups, scale, shift);
+  return check_launch("groupnorm_scale_shift");
+}
+
 extern "C" int gpemsr_groupnorm_finish(const float* ws, int n, int hw, int c, int groups, int parts, float eps, float* mean_rstd, void* stream) {
   GP_REQUIRE(ws && mean_rstd && n > 0 && hw > 0 && c % groups == 0 && parts >= 1, "groupnorm_finish: bad args");
   hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(n * groups, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws, n, hw, c, groups, parts, eps, mean_rstd);

@@ -71,6 +71,7 @@ class Engine:
         #       pipe with operands converted in LDS (split hi+lo = fp32-grade, or plain bf16 operands).
         self.precision = precision
         self.bf16 = precision == "bf16"
+        self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.split = precision in ("bf16x3", "bf16op")
         self._forced_flow = None
@@ -225,8 +226,14 @@ class Engine:
     def vq_resblock(self, x: Act, p: str) -> Act:
         # the conv epilogue leaves the GroupNorm partial sums (no statistics pass over the tensor): bf16 path and exact-fp32 path
         t = self.conv(x, p + ".block.0", gn_stats=self.gn_epi)
-        self.o.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
-        u = self.conv(t, p + ".block.3", gn_stats=self.gn_epi)
+        if self.bf16 and self.fold_gn and self.o.conv_affine_source_ok(t, self.pc[p + ".block.3"]):
+            # the first Normalize + ReLU of the block is applied by the second convolution while it stages its source: the normalised
+            # tensor never exists in HBM (one read + one write of the block's intermediate less)
+            sc, sh = self.o.groupnorm_scale_shift(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"])
+            u = self.conv(t, p + ".block.3", gn_stats=self.gn_epi, a_affine=(sc, sh, True))
+        else:
+            self.o.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
+            u = self.conv(t, p + ".block.3", gn_stats=self.gn_epi)
         skip = self.conv(x, p + ".channel_up") if (p + ".channel_up") in self.pc else x
         return self.o.groupnorm_relu(u, self.par[p + ".block.4.weight"], self.par[p + ".block.4.bias"], True, residual=skip, out=u)
 

@@ -830,10 +830,13 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
                 pixmul: Optional[Act] = None, out: Optional[Act] = None, weight_image_stride: int = 0,
                 src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
                 out_f32: bool = False, out32: Optional[Act] = None, gn_stats: bool = False, kpack: bool = False,
-                variant: int = 0, out_u8: Optional[torch.Tensor] = None, _u8_fused: Optional[list] = None) -> Act:
+                variant: int = 0, out_u8: Optional[torch.Tensor] = None, _u8_fused: Optional[list] = None,
+                a_affine: Optional[tuple] = None) -> Act:
     """Convolution of the bf16 path.  out_f32: fp32 result (logits input, deformable offsets, flows, 1-channel images);
     out32: additionally store the un-rounded fp32 result there; gn_stats: leave GroupNorm partial sums on the result
-    (``out.gn``); kpack: store as the B operand [n][cout/8][pixels][8] of a later 1x1 product (returns the raw tensor)."""
+    (``out.gn``); kpack: store as the B operand [n][cout/8][pixels][8] of a later 1x1 product (returns the raw tensor);
+    a_affine = (scale[n][cin], shift[n][cin], relu): the source is read as relu?(scale * x + shift) -- a folded GroupNorm
+    apply (``groupnorm_scale_shift``); only where ``conv_affine_source_ok`` says so."""
     lib = _abi.load()
     s0 = srcs[0]
     n, h, w = s0.n, s0.h, s0.w
@@ -949,6 +952,10 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
     if out32 is not None:
         assert not out32.bf16 and (out32.n, out32.h, out32.w, out32.c) == (n, OH, OW, oc)
         d.out32, d.out32_ld = out32.ptr, out32.ld
+    if a_affine is not None:
+        sc, sh, relu = a_affine
+        assert sc.dtype == torch.float32 and sh.dtype == torch.float32 and sc.numel() == n * srcs[0].c == sh.numel() and len(srcs) == 1
+        d.a_scale, d.a_shift, d.a_relu = sc.data_ptr(), sh.data_ptr(), int(relu)
     if gn_stats:
         parts = lib.gpemsr_conv2d_bf16_gn_parts(C.byref(d))
         if parts < 1:
@@ -965,6 +972,44 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
     else:
         _go()
     return ret
+
+
+def conv_affine_source_ok(x: Act, pc: PackedConv) -> bool:
+    """True when gpemsr_conv2d_bf16 has a kernel that applies a per-(image, channel) affine map + ReLU to its source while
+    staging it (3x3, stride 1, one dense bf16 source of 64 or k*32 channels, plain bf16 store)."""
+    if not (x.bf16 and pc.wb is not None and pc.ksize == 3 and not pc.transposed and not pc.pixel_shuffle and x.c % 32 == 0 and x.c >= 64):
+        return False
+    d = _abi.ConvDesc16()
+    d.n, d.h, d.w, d.nsrc = x.n, x.h, x.w, 1
+    d.src[0].ptr, d.src[0].ld, d.src[0].c = x.ptr, x.ld, x.c
+    d.src_image_stride[0] = -1
+    d.cout, d.ksize, d.stride, d.transposed = pc.cout, 3, 1, 0
+    d.weight = pc.wb.data_ptr()
+    d.bias = pc.b.data_ptr() if pc.b is not None else None
+    d.out, d.out_ld = x.ptr, pc.cout                     # (geometry only: nothing is launched)
+    return _abi.load().gpemsr_conv2d_bf16_axf_ok(C.byref(d)) == 1
+
+
+def groupnorm_scale_shift(x: Act, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6):
+    """GroupNorm(groups, eps, affine) of the bf16 tensor ``x`` as per-(image, channel) scale / shift tables [n][c] (fp32):
+    normalised = scale * x + shift.  Statistics from the producing convolution's epilogue (``x.gn``) or one pass over x."""
+    lib = _abi.load()
+    _require_gpu(x)
+    assert x.bf16
+    hw, dev = x.h * x.w, x.buf.device
+    if x.gn is not None:
+        ws, parts = x.gn
+    else:
+        parts = max(1, min(64, hw // 64))
+        ws = torch.empty(x.n * parts * x.c * 2, dtype=torch.float32, device=dev)
+        _abi.check(lib.gpemsr_groupnorm_stats_bf16(x.ptr, x.n, hw, x.c, x.ld, ws.data_ptr(), parts, _stream()), "groupnorm_stats_bf16")
+    mr = torch.empty(x.n * groups * 2, dtype=torch.float32, device=dev)
+    _abi.check(lib.gpemsr_groupnorm_finish(ws.data_ptr(), x.n, hw, x.c, groups, parts, eps, mr.data_ptr(), _stream()), "groupnorm_finish")
+    ss = torch.empty(2, x.n * x.c, dtype=torch.float32, device=dev)
+    _abi.check(lib.gpemsr_groupnorm_scale_shift(mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.n, x.c, groups, ss[0].data_ptr(), ss[1].data_ptr(),
+                                                _stream()), "groupnorm_scale_shift")
+    x.gn = None
+    return ss[0], ss[1]
 
 
 def upconv_out_bf16(x: Act, frag: torch.Tensor, consts: torch.Tensor, out: Optional[Act] = None, tag: str = "") -> Act:

@@ -162,9 +162,23 @@ typedef struct {
   int32_t gn_cpg;                  /* with gn_partials: channels per GroupNorm group (0 / 1: unknown).  When it is a multiple of 2 / 4 the
                                     * kernel adds 2 / 4 neighbouring channels BEFORE the cross-lane reduction and leaves zeros in the other
                                     * channel slots of the workspace -- the per-group totals gpemsr_groupnorm_finish forms are unchanged */
+  const float* a_scale;            /* optional, with a_shift: fp32 [n][cin].  The SOURCE is read as relu?(a_scale[img][c] * x + a_shift[img][c])
+                                    * (fma in fp32, rounded to bf16; zero padding applies to the transformed tensor) -- the apply pass of
+                                    * Normalize + ReLU (R:model/blocks.py:5-6,13-20: GroupNorm(32, eps 1e-6, affine) between the two convolutions
+                                    * of a ResidualBlock) folded into the convolution that consumes it; tables from gpemsr_groupnorm_scale_shift.
+                                    * Only for layers gpemsr_conv2d_bf16_axf_ok() admits (3x3, stride 1, one dense source of 64 or k*32 channels). */
+  const float* a_shift;
+  int32_t a_relu;                  /* with a_scale: 1 = ReLU after the affine map */
+  int32_t reserved0;
 } gpemsr_conv16_desc;
 
 int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream);
+/* 1: this launch geometry has a kernel that takes a_scale / a_shift; 0: it has not (apply GroupNorm separately); < 0: error code */
+int gpemsr_conv2d_bf16_axf_ok(const gpemsr_conv16_desc* d);
+/* scale[n][c] = rstd * gamma, shift[n][c] = beta - mean * rstd * gamma from mean_rstd[n][groups][2] (gpemsr_groupnorm_finish): the
+ * per-channel affine form of GroupNorm's apply pass, bit-compatible with gpemsr_groupnorm_apply_bf16 (same fma) */
+int gpemsr_groupnorm_scale_shift(const float* mean_rstd, const float* gamma, const float* beta, int n, int c, int groups,
+                                 float* scale, float* shift, void* stream);
 /* rows of the gn_partials workspace per image for this launch geometry (>= 1), or a negative error code */
 int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d);
 

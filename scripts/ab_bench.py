@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GPU box: A/B of environment switches on the forward (batch 16 of 128^2 windows), variants interleaved in ONE process (guide rule 24).
+    python3 scripts/ab_bench.py bf16 GPEMSR_FOLD_GN=0 GPEMSR_FOLD_GN=1 [--rounds 3] [--steps 4]"""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gpemsr_amd.config import build_model, load_options
+from gpemsr_amd.synth import synth_lr_tiles
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 3
+steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 4
+prec, variants = args[0], args[1:]
+dev = torch.device("cuda", 0)
+opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+x = synth_lr_tiles(16, 5, 128, 128, seed=1000, kind="uniform").to(dev)
+models = []
+for v in variants:
+    for kv in v.split(","):
+        k, val = kv.split("=")
+        os.environ[k] = val
+    m = build_model(opt, load_prior_files=False, precision=prec).eval().to(dev)
+    m(x); torch.cuda.synchronize()          # engine construction reads the switches
+    models.append(m)
+outs = []
+for r in range(rounds):
+    for v, m in zip(variants, models):
+        m(x); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = m(x)[0]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print(f"round {r} {v:40s} {1e3 * dt:8.2f} ms/step {16 * 1.048576 / dt:8.2f} MP/s", flush=True)
+        if r == 0:
+            outs.append(o.clone())
+for v, o in zip(variants[1:], outs[1:]):
+    print(f"max |out[{v}] - out[{variants[0]}]| / max|out| = {float((o - outs[0]).abs().max() / outs[0].abs().max()):.3e}")

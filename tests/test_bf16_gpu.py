@@ -203,6 +203,47 @@ def test_conv2d_bf16_dual_output_and_gn_partials():
         _close(z.nchw(), F.group_norm(_r(conv), 32, gamma, beta, eps=1e-6), 2 * BF, "groupnorm standalone")
 
 
+@pytest.mark.parametrize("n,c,cout,h,w", [(3, 64, 64, 24, 40), (2, 64, 64, 37, 70), (2, 128, 128, 20, 36), (1, 256, 256, 35, 33), (5, 512, 512, 16, 16),
+                                          (80, 64, 64, 16, 32)])
+def test_conv_with_folded_groupnorm_apply(n, c, cout, h, w):
+    """Normalize + ReLU between the two convolutions of a VQGAN block (R:model/blocks.py:5-20) applied by the
+    SECOND convolution while it stages its source (gpemsr_conv16_desc.a_scale / a_shift), so the normalised tensor never exists in HBM.
+    Both kernel families that have the register-staged loader (64-channel weights-resident, wide 3x3 loader-wave tile; ragged tile
+    edges, several tiles per workgroup, image changes inside a workgroup's stream) against (a) torch: conv(relu(group_norm(x))) on the
+    bf16-rounded normalised tensor, and (b) the two-kernel path (gpemsr_groupnorm_apply_bf16, then the plain convolution), which
+    it must reproduce to one bf16 rounding of the normalised tensor."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    x = _r(_rand(n, c, h, w, seed=91) * 2.0 + 0.3 * _rand(n, c, 1, 1, seed=92))
+    gamma, beta = 1.0 + 0.5 * _rand(c, seed=93), 0.3 * _rand(c, seed=94)
+    gamma[::7] *= -1.0                                   # negative scales too
+    wt = _r(_rand(cout, c, 3, 3, seed=95, scale=1.0 / (3.0 * c ** 0.5)))
+    b = _rand(cout, seed=96, scale=0.1)
+    pc = _pc(wt, b, dev)
+    xa = _act16(x, dev)
+    assert ops.conv_affine_source_ok(xa, pc)
+    sc, sh = ops.groupnorm_scale_shift(xa, gamma.to(dev), beta.to(dev))
+    res = _r(_rand(n, cout, h, w, seed=97))
+    got = ops.conv2d([xa], pc, 0, precision="bf16", a_affine=(sc, sh, True), gn_stats=True)
+    torch.cuda.synchronize()
+    y = _r(F.relu(F.group_norm(x, 32, gamma, beta, eps=1e-6)))
+    want = F.conv2d(y, wt, b, 1, 1)
+    _close(got.nchw(), want, 3 * BF, f"conv with folded GroupNorm apply {c}->{cout}")
+    # the two-kernel path on the same input
+    t = ops.groupnorm_relu(_act16(x, dev), gamma.to(dev), beta.to(dev), True)
+    two = ops.conv2d([t], pc, 0, precision="bf16", gn_stats=True)
+    _close(got.nchw(), two.nchw(), 2 * BF, "fused vs two kernels")
+    # the statistics its epilogue leaves feed the block's second GroupNorm as before
+    z = ops.groupnorm_relu(got, gamma[:cout].to(dev) if cout <= c else torch.ones(cout, device=dev), (beta[:cout].to(dev) if cout <= c else torch.zeros(cout, device=dev)),
+                           True, residual=_act16(res, dev))
+    g2, b2 = (gamma[:cout], beta[:cout]) if cout <= c else (torch.ones(cout), torch.zeros(cout))
+    _close(z.nchw(), F.relu(F.group_norm(_r(want), 32, g2, b2, eps=1e-6)) + res, 4 * BF, "second GroupNorm from the epilogue sums")
+    # without ReLU (the affine map alone) and with a residual + LeakyReLU epilogue
+    got2 = ops.conv2d([xa], pc, 2, precision="bf16", a_affine=(sc, sh, False), residual=_act16(res, dev))
+    y2 = _r(F.group_norm(x, 32, gamma, beta, eps=1e-6))
+    _close(got2.nchw(), F.leaky_relu(F.conv2d(y2, wt, b, 1, 1), 0.1) + res, 3 * BF, "affine only + residual epilogue")
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 16, 32), (128, 64, 9, 20), (512, 256, 8, 8), (64, 32, 5, 33)])
 def test_conv_transpose_bf16(cin, cout, h, w):
     from gpemsr_amd import ops
