@@ -252,14 +252,19 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const float* table, 
 }
 
 // NHWC rows [n][rows][c] -> the B-operand layout of gpemsr_conv2d_bf16's 1x1 form: [n][c/8][rows][8]
-__global__ __launch_bounds__(256) void pack_rows16_kernel(const bf16_t* src, int rows, int c, int ld, long long img_stride, bf16_t* dst, long long total) {
+// perm16: position p of every 16-row group holds row 8 ((p & 7) >> 2) + 4 (p >> 3) + (p & 3), i.e. the rows in the order 0-3, 8-11, 4-7,
+// 12-15 -- the order in which a 32x32 MFMA accumulator holds them, so that a product whose COLUMNS these rows become (v^T of the
+// attention block) comes out in the k-slot order of gpemsr_flash_attention_bf16's second product (csrc/attn_bf16.hip)
+__global__ __launch_bounds__(256) void pack_rows16_kernel(const bf16_t* src, int rows, int c, int ld, long long img_stride, bf16_t* dst, long long total, int perm16) {
   const int c8 = c >> 3;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int r = (int)(e % rows);
     const long long t = e / rows;
     const int j = (int)(t % c8);
     const long long img = t / c8;
-    *reinterpret_cast<uint4*>(dst + ((img * c8 + j) * rows + r) * 8) = *reinterpret_cast<const uint4*>(src + img * img_stride + (long long)r * ld + 8 * j);
+    const int p = r & 15;
+    const int rs = perm16 ? (r & ~15) + 8 * ((p & 7) >> 2) + 4 * (p >> 3) + (p & 3) : r;
+    *reinterpret_cast<uint4*>(dst + ((img * c8 + j) * rows + r) * 8) = *reinterpret_cast<const uint4*>(src + img * img_stride + (long long)rs * ld + 8 * j);
   }
 }
 
@@ -853,12 +858,16 @@ extern "C" int gpemsr_gather_rows_bf16(const float* table, int dim, const int32_
   return check_launch("gather_rows_bf16");
 }
 
-extern "C" int gpemsr_pack_rows_bf16(const void* src, int n, int rows, int c, int ld, int64_t img_stride, void* dst, void* stream) {
-  GP_REQUIRE(src && dst && n > 0 && rows > 0 && c % 8 == 0 && ld % 8 == 0 && img_stride % 8 == 0 && A16(src) && A16(dst), "pack_rows_bf16: bad args");
+extern "C" int gpemsr_pack_rows_bf16_ex(const void* src, int n, int rows, int c, int ld, int64_t img_stride, void* dst, int perm16, void* stream) {
+  GP_REQUIRE(src && dst && n > 0 && rows > 0 && c % 8 == 0 && ld % 8 == 0 && img_stride % 8 == 0 && A16(src) && A16(dst) && (!perm16 || rows % 16 == 0),
+             "pack_rows_bf16: bad args (perm16 needs rows %% 16 == 0)");
   const long long total = (long long)n * (c / 8) * rows;
   hipLaunchKernelGGL(pack_rows16_kernel, dim3(grid16(total)), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(src), rows, c, ld, (long long)img_stride,
-                     reinterpret_cast<bf16_t*>(dst), total);
+                     reinterpret_cast<bf16_t*>(dst), total, perm16 ? 1 : 0);
   return check_launch("pack_rows_bf16");
+}
+extern "C" int gpemsr_pack_rows_bf16(const void* src, int n, int rows, int c, int ld, int64_t img_stride, void* dst, void* stream) {
+  return gpemsr_pack_rows_bf16_ex(src, n, rows, c, ld, img_stride, dst, 0, stream);
 }
 
 extern "C" int gpemsr_bilinear_bf16(const void* x, int n, int h, int w, int c, int ld, int oh, int ow, int align_corners, float mul,

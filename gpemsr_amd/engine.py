@@ -72,6 +72,7 @@ class Engine:
         self.precision = precision
         self.bf16 = precision == "bf16"
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
+        self.flash_attn = os.environ.get("GPEMSR_FLASH_ATTN", "1") != "0"   # bf16 path: NonLocalBlock products + softmax as one kernel (C = 512, T % 128 == 0)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.split = precision in ("bf16x3", "bf16op")
         self._forced_flow = None
@@ -292,11 +293,17 @@ class Engine:
         wv = self.pc[p + ".v"]
         if not hasattr(wv, "_wa"):                                      # W_v as the A operand of v^T = W_v . hn^T: [C rows][C]
             wv._wa = self.sd[p + ".v.weight"].detach().reshape(c, c).to(torch.bfloat16).contiguous().to(self.dev)
-        hnp = o.pack_rows_bf16(hn)                                      # hn as B operand: [n][C/8][T][8]
+        flash = self.flash_attn and o.flash_attention_ok(T, c)
+        hnp = o.pack_rows_bf16(hn, perm16=flash)                        # hn as B operand: [n][C/8][T][8]
         wa = Act(wv._wa, n, 1, c, c, c, 0)                              # n "images" that alias the one weight matrix
         vtp = o.conv2d([wa], o.PackedConv(None, None, 1, T, (c,), 32, wb=hnp), ACT_NONE, weight_image_stride=T * c,
                        src_image_stride=[0], kpack=True, tag="nonlocal.vT", precision="bf16")     # v^T: [n][T/8][C][8]
         del hnp, hn
+        if flash:
+            # one kernel: q.k^T, online softmax, P.v -- the T x T score matrix stays on chip (csrc/attn_bf16.hip)
+            out = o.flash_attention_bf16(q, kp, vtp, wv.b, tag=p + ".flash")
+            del kp, vtp, q
+            return self.conv(out, p + ".proj_out", ACT_NONE, residual=x)
         out = o.new_act(n, h, w, c, device=self.dev, bf16=True)
         fc = max(1, min(n, (1 << 30) // (T * T)))                        # frames per score-matrix chunk (<= 2 GiB of bf16)
         for f0 in range(0, n, fc):

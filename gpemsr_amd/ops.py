@@ -1071,12 +1071,37 @@ def split_hi_lo_bf16(x: Act):
     return hi, lo
 
 
-def pack_rows_bf16(a: Act) -> torch.Tensor:
-    """bf16 rows [n][h*w][c] -> [n][c/8][h*w][8]: the per-image B operand of a 1x1 product (attention)."""
+def pack_rows_bf16(a: Act, perm16: bool = False) -> torch.Tensor:
+    """bf16 rows [n][h*w][c] -> [n][c/8][h*w][8]: the per-image B operand of a 1x1 product (attention).  perm16: the rows of every
+    16-group in the order 0-3, 8-11, 4-7, 12-15 (what ``flash_attention_bf16`` wants of v^T's columns)."""
     assert a.bf16 and a.c % 8 == 0
     rows = a.h * a.w
     out = torch.empty(a.n, a.c // 8, rows, 8, dtype=torch.bfloat16, device=a.buf.device)
-    _abi.check(_abi.load().gpemsr_pack_rows_bf16(a.ptr, a.n, rows, a.c, a.ld, rows * a.ld, out.data_ptr(), _stream()), "pack_rows_bf16")
+    _abi.check(_abi.load().gpemsr_pack_rows_bf16_ex(a.ptr, a.n, rows, a.c, a.ld, rows * a.ld, out.data_ptr(), int(perm16), _stream()), "pack_rows_bf16")
+    return out
+
+
+def flash_attention_ok(tokens: int, channels: int) -> bool:
+    return channels == 512 and tokens % 128 == 0 and tokens >= 128
+
+
+def flash_attention_bf16(q: Act, kp: torch.Tensor, vtp: torch.Tensor, bias_v: Optional[torch.Tensor], out: Optional[Act] = None, tag: str = "") -> Act:
+    """softmax(q k^T) v without the score matrix in memory (csrc/attn_bf16.hip).  q [n][T][C] bf16 Act (scale folded in), kp [n][C/8][T][8]
+    (a ``kpack`` convolution result), vtp [n][T/8][C][8] with perm16 key order (the v^T product over ``pack_rows_bf16(hn, perm16=True)``)."""
+    _require_gpu(q)
+    n, T, c = q.n, q.h * q.w, q.c
+    assert q.bf16 and flash_attention_ok(T, c) and tuple(kp.shape) == (n, c // 8, T, 8) and tuple(vtp.shape) == (n, T // 8, c, 8)
+    if out is None:
+        out = new_act(n, q.h, q.w, c, device=q.buf.device, bf16=True)
+    assert out.bf16 and (out.n, out.h * out.w, out.c) == (n, T, c)
+
+    def _go():
+        _abi.check(_abi.load().gpemsr_flash_attention_bf16(q.ptr, q.ld, kp.data_ptr(), vtp.data_ptr(), bias_v.data_ptr() if bias_v is not None else None,
+                                                           n, T, c, out.ptr, out.ld, _stream()), "flash_attention_bf16")
+    if PROFILER is not None:
+        PROFILER.run("conv_bf16", tag, 4.0 * n * T * T * c, _go)      # q.k^T and P.v: 2 x (2 T^2 C) FLOPs per image
+    else:
+        _go()
     return out
 
 

@@ -197,6 +197,15 @@ int gpemsr_softmax_rows_bf16(const void* s, int s_f32, int64_t rows, int cols, i
 int gpemsr_gather_rows_bf16(const float* table, int dim, const int32_t* idx, int64_t rows, void* out, int out_ld, void* stream);
 /* bf16 rows [n][rows][c] -> B-operand layout [n][c/8][rows][8] of gpemsr_conv2d_bf16's 1x1 form (attention: k, v^T) */
 int gpemsr_pack_rows_bf16(const void* src, int n, int rows, int c, int ld, int64_t img_stride, void* dst, void* stream);
+/* the same with perm16 != 0: inside every group of 16 rows the rows are stored in the order 0-3, 8-11, 4-7, 12-15 (rows % 16 == 0) */
+int gpemsr_pack_rows_bf16_ex(const void* src, int n, int rows, int c, int ld, int64_t img_stride, void* dst, int perm16, void* stream);
+/* Single-head attention of NonLocalBlock (R:model/blocks.py:75-80: attn = softmax(q k^T) over keys, A = attn v) with the score matrix
+ * kept on chip (flash style): q bf16 [n][tokens][q_ld] (the C^-1/2 of :76 folded into it), kp = k as [n][C/8][tokens][8] (the "kpack"
+ * store of gpemsr_conv2d_bf16), vtp = v^T as [n][tokens/8][C][8] with the keys of every 16-group in the perm16 order above (the v^T
+ * product over a perm16-packed B operand), bias_v [C] or NULL (added after the product: softmax rows sum to 1) ->
+ * out bf16 [n][tokens][out_ld].  channels == 512, tokens % 128 == 0; fp32 accumulation, online softmax in fp32. */
+int gpemsr_flash_attention_bf16(const void* q, int q_ld, const void* kp, const void* vtp, const float* bias_v, int n, int tokens, int channels,
+                                void* out, int out_ld, void* stream);
 /* format changes at the module boundary / between the fp32 and bf16 parts of the path */
 int gpemsr_cast_f32_bf16(const float* x, int64_t pixels, int c, int x_ld, void* out, int out_ld, void* stream);
 int gpemsr_cast_bf16_f32(const void* x, int64_t pixels, int c, int x_ld, float* out, int out_ld, void* stream);

@@ -317,6 +317,47 @@ def test_attention_products_bf16():
     _close(out.torch().reshape(n, T, c), torch.bmm(p_dev, v_ref) + bv, 1e-4, "P.v")
 
 
+@pytest.mark.parametrize("n,h,w,spike", [(3, 16, 16, False), (2, 32, 32, False), (9, 8, 16, False), (2, 16, 24, True), (1, 64, 64, True)])
+def test_flash_attention_bf16(n, h, w, spike):
+    """the NonLocalBlock products + softmax (R:model/blocks.py:75-80) as ONE kernel, score matrix on chip.  Against
+    torch on the bf16-rounded operands (fp32 softmax); operands come from the same kpack / perm16 producers the engine uses.  `spike`
+    forces the cold path of the lazy online softmax (guide rule 26): one key far down the sequence scores ~60 above everything before
+    it for some queries (its tile maximum outgrows the reference by more than 2^24), another EARLY key dominates other queries, so
+    both "rescale O and l" and "later tiles underflow to zero" happen in one launch; every element is checked against the full
+    reference.  n = 9 covers two image groups of the XCD mapping (images 8.. and the early exit of unused slots)."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    c, T = 512, h * w
+    assert ops.flash_attention_ok(T, c)
+    q = _r(_rand(n, T, c, seed=101, scale=0.25))
+    k = _r(_rand(n, T, c, seed=102, scale=0.25))
+    v = _r(_rand(n, T, c, seed=103, scale=2.0))
+    bv = _rand(c, seed=104, scale=0.5)
+    if spike:
+        k[:, T - 37] = _r(12.0 * q[:, 5])            # late key: huge score for query 5 (and whatever correlates with it)
+        k[:, 3] = _r(9.0 * q[:, 77])                 # early key: dominates query 77 from the first tile on
+    def act(t):
+        return ops.Act(t.reshape(n, h, w, c).to(torch.bfloat16).to(dev).contiguous().view(-1), n, h, w, c, c, 0)
+    qa = act(q)
+    kp = ops.pack_rows_bf16(act(k))                                     # [n][C/8][T][8]
+    # v^T [n][T/8][C][8] in the perm16 key order: pack v^T's columns (= tokens) through the same permutation the engine's product applies
+    pos = torch.arange(T)
+    pp = pos & 15
+    src = (pos & ~15) + 8 * ((pp & 7) >> 2) + 4 * (pp >> 3) + (pp & 3)
+    vtp = v[:, src].reshape(n, T // 8, 8, c).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).to(dev)
+    got = ops.flash_attention_bf16(qa, kp, vtp, bv.to(dev))
+    torch.cuda.synchronize()
+    S = torch.bmm(q.double(), k.double().transpose(1, 2))
+    want = torch.bmm(torch.softmax(S, dim=2), v.double()) + bv.double()
+    assert torch.isfinite(got.torch().float()).all()
+    _close(got.torch().float().reshape(n, T, c), want.float(), 2 * BF, "flash attention")
+    if spike:
+        assert float(S[:, 5].max()) - float(S[:, 5, :T - 64].max()) > 30.0          # the cold path really was needed
+    # the engine's producers give the same operand: pack_rows(perm16) as the B operand of the v^T product
+    hnp = ops.pack_rows_bf16(act(v), perm16=True)                        # rows = tokens of "hn" (here v itself), perm16 order
+    assert torch.equal(hnp.cpu().float().permute(0, 2, 1, 3).reshape(n, T, c), _r(v)[:, src])
+
+
 @pytest.mark.parametrize("cols", [9216, 16384])
 def test_softmax_rows_bf16_long_rows(cols):
     """x8 at LR 192x192 gives 9216 latent tokens, x16 at LR 128x128 gives 16384 -- beyond the 8192 columns the bf16 row
