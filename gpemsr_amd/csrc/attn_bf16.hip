@@ -100,56 +100,83 @@ __global__ __launch_bounds__(256, 1) void flash_attn512_kernel(AttnParams P) {
   const unsigned vfrag = lds + (unsigned)(2 * AT_KBYTES + (lh * 512 + li) * 16);   // + (t&1) * 32K + kk * 16384 + dt * 512
 
   const int NT = T / AT_BK;
+  // ---- software pipeline: iteration t runs  [ QK^T of tile t+1  ||  softmax of tile t ]  then  P.V of tile t .  With ONE wave per SIMD
+  // nothing else hides the ~100 VALU operations of the softmax, the wait states behind an MFMA chain, or a DMA round trip (first
+  // version, everything in sequence: 53 % of the tile time in MFMAs), so the softmax of tile t is cut into 32 slices placed between the
+  // MFMAs of the NEXT tile's score product, and the images are issued early: V^T(t+1) during that phase, K(t+2) during the first half
+  // of P.V(t); both are only waited for at the barrier that ends the iteration.
+  if (NT > 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_k(1, i);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  for (int t = 0; t < NT; ++t) {
-    const unsigned kb = kfrag + (unsigned)((t & 1) * AT_KBYTES), vb = vfrag + (unsigned)((t & 1) * AT_KBYTES);
-    const bool more = t + 1 < NT;
-    // ---- S^T = K_tile . Q^T ----
-    f32x16 s;
+  f32x16 sc, sn;                       // scores of the tile whose softmax is due / of the next tile
+  auto qk_step = [&](f32x16& acc, const bf16x8& kfr, int ks) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(kfr), "v"(qf[ks]));      // arch VGPRs: the softmax reads them
+  };
+  {   // S^T(0)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int r = 0; r < 16; ++r) sc[r] = 0.f;
     bf16x8 kf[2];
-    kf[0] = xlds_read16(kb);
+    kf[0] = xlds_read16(kfrag);
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
-      if (ks + 1 < 32) kf[(ks + 1) & 1] = xlds_read16(kb + (unsigned)((ks + 1) * 1024));
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf[ks & 1]), "v"(qf[ks]));
-      if ((ks & 3) == 3 && more) issue_k(t + 1, ks >> 2);          // next tile's K image, one piece per 4 MFMAs
+      if (ks + 1 < 32) kf[(ks + 1) & 1] = xlds_read16(kfrag + (unsigned)((ks + 1) * 1024));
+      qk_step(sc, kf[ks & 1], ks);
     }
-    // ---- online softmax (lane = query; this lane's 16 keys + the partner half's 16) ----
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s));               // inline-asm MFMA -> VALU read of its result: wait states the compiler cannot count
-    float mt = s[0];
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sc));     // inline-asm MFMA -> VALU read of its result: wait states the compiler cannot count
+  }
+
+  for (int t = 0; t < NT; ++t) {
+    const unsigned kb = kfrag + (unsigned)(((t + 1) & 1) * AT_KBYTES), vb = vfrag + (unsigned)((t & 1) * AT_KBYTES);
+    const bool more = t + 1 < NT, more2 = t + 2 < NT;
+    // ---- softmax of tile t in 32 slices (lane = query; this lane's 16 keys + the partner half's 16) ----
+    float pmax[4], mt = 0.f, p[16];
+    unsigned pku[8];
+    auto slice = [&](const int i) {                     // i is a compile-time constant at every call site
+      if (i < 4) pmax[i] = fmaxf(fmaxf(sc[4 * i], sc[4 * i + 1]), fmaxf(sc[4 * i + 2], sc[4 * i + 3]));
+      else if (i == 4) mt = fmaxf(fmaxf(pmax[0], pmax[1]), fmaxf(pmax[2], pmax[3]));
+      else if (i == 5) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+        mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * LOG2E;
+      } else if (i == 6) {
+        if (t == 0) m2 = mt;                            // (O and l are still zero: nothing to rescale)
+        else if (__builtin_amdgcn_ballot_w64(mt > m2 + AT_THR) != 0ull) {
+          // cold path: some query's maximum outgrew its reference; every lane moves its reference to its running maximum
+          const float mn = fmaxf(m2, mt);
+          const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
+          l *= alpha;
+          AT_SCALE_ALL(alpha);
+          m2 = mn;
+        }
+      } else if (i < 23) { const int r = i - 7; p[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], LOG2E, -m2)); l += p[r]; }
+      else if (i < 31) { const int j = i - 23; pku[j] = xcvt_pk_bf16(p[2 * j], p[2 * j + 1]); }
+    };
+    if (more) {
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-      mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    const float mt2 = mt * LOG2E;
-    if (t == 0) m2 = mt2;                                           // (O and l are still zero: nothing to rescale)
-    else if (__builtin_amdgcn_ballot_w64(mt2 > m2 + AT_THR) != 0ull) {
-      // cold path: some query's maximum outgrew its reference; every lane moves its reference to its running maximum
-      const float mn = fmaxf(m2, mt2);
-      const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
-      l *= alpha;
-      AT_SCALE_ALL(alpha);
-      m2 = mn;
+      for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+      bf16x8 kf[2];
+      kf[0] = xlds_read16(kb);
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        if (ks + 1 < 32) kf[(ks + 1) & 1] = xlds_read16(kb + (unsigned)((ks + 1) * 1024));
+        qk_step(sn, kf[ks & 1], ks);
+        slice(ks);
+        if ((ks & 3) == 3) issue_v(t + 1, ks >> 2);     // next tile's V^T image, one piece per 4 MFMAs
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) slice(i);
     }
     bf16x8 pf[2];
     {
-      float p[16];
+      union { unsigned u[4]; bf16x8 v; } pk0, pk1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, -m2)); l += p[r]; }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        union { unsigned u[4]; bf16x8 v; } pk;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pk.u[j] = xcvt_pk_bf16(p[8 * kk + 2 * j], p[8 * kk + 2 * j + 1]);
-        pf[kk] = pk.v;
-      }
+      for (int j = 0; j < 4; ++j) { pk0.u[j] = pku[j]; pk1.u[j] = pku[4 + j]; }
+      pf[0] = pk0.v; pf[1] = pk1.v;
     }
     // ---- O^T += V^T_tile . P^T : per 32-channel tile dt one fragment per 16-key half ----
     bf16x8 va = xlds_read16(vb), vc;
@@ -158,14 +185,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn512_kernel(AttnParams P) {
     AT_PV_##dt(va, pf[0]);                                                                     \
     if ((dt) + 1 < 16) va = xlds_read16(vb + (unsigned)(((dt) + 1) * 512));                    \
     AT_PV_##dt(vc, pf[1]);                                                                     \
-    if (((dt) & 1) == 1 && more) issue_v(t + 1, (dt) >> 1);
+    if ((dt) < 8 && more2) issue_k(t + 2, (dt));
     AT_PV_STEP(0) AT_PV_STEP(1) AT_PV_STEP(2) AT_PV_STEP(3) AT_PV_STEP(4) AT_PV_STEP(5) AT_PV_STEP(6) AT_PV_STEP(7)
     AT_PV_STEP(8) AT_PV_STEP(9) AT_PV_STEP(10) AT_PV_STEP(11) AT_PV_STEP(12) AT_PV_STEP(13) AT_PV_STEP(14) AT_PV_STEP(15)
 #undef AT_PV_STEP
-    // the next tile's images (issued a whole tile ago) must have landed; everybody is done with this tile's
+    // the images issued in this iteration must have landed; everybody is done with the K image of tile t+1's product and with V^T(t)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    sc = sn;
   }
 
   // ---- epilogue: O / l + v bias -> bf16 rows ----
