@@ -133,7 +133,27 @@ def run(args, root: str, effective_cores):
                      "(fp32-grade, DESIGN 3.3); trainable layers, data and weight gradients: f32 MFMA",
             "losses_last_step": {"rec": float(o3["rec_loss"].item()), "ref": float(o3["ref_loss"].item())},
             "speedup_vs_fp32_step": round((dt / args.steps) / (d3 / args.steps), 3)}}
-        model = m3
+        # ... and with the frozen sub-networks that carry no gradient (VQGAN prior, VGG mask, SpyNet) on the bf16 DATA PATH of the
+        # inference engine (BASELINE configs[2]'s kernels: bf16 activations, fused VGG mask, flash attention); the rest as above
+        del t3, m3
+        torch.cuda.empty_cache()
+        m4 = build_model(opt, load_prior_files=False, precision="bf16").to(dev)
+        t4 = Stage3Trainer(m4, TRAIN_OPT, dev, world=world)
+        for _ in range(max(args.warmup, 1)):
+            t4.step(LR, GT)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            o4 = t4.step(LR, GT)
+        torch.cuda.synchronize()
+        d4 = time.perf_counter() - tb
+        extras["bf16_frozen_subnetworks"] = {
+            "value": round(B * args.steps / d4, 3), "unit": "samples/s", "ms_per_step": round(1e3 * d4 / args.steps, 2),
+            "dtype": "VQGAN prior, VGG relu1_2 mask and SpyNet (frozen, no gradient through them): bf16 activations in HBM + bf16 MFMA; trainable "
+                     "layers and the loss network: fp32 activations, forward products bf16x3 (fp32-grade); data and weight gradients: f32 MFMA",
+            "losses_last_step": {"rec": float(o4["rec_loss"].item()), "ref": float(o4["ref_loss"].item())},
+            "speedup_vs_fp32_step": round((dt / args.steps) / (d4 / args.steps), 3)}
+        model = m4
     if rank == 0:
         line = {
             "metric": f"stage-3 training samples/sec, {s}x EMSR (LR {lr}x{lr} -> {lr * s}x{lr * s} crops), batch {B}/GPU",

@@ -113,7 +113,8 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
   XParams P = Pfull;          // (a by-value view whose fixed fields fold at compile time)
   if (CONVT) P.store_mode = XS_CONVT;
   else if (GEMM && P.store_mode != XS_KPACK) P.store_mode = XS_PLAIN;
-  if (LEAN) { P.store_mode = XS_PLAIN; P.out32 = nullptr; P.out_f32 = 0; P.res_f32 = 0; }
+  if (LEAN) { if (!CONVT) P.store_mode = XS_PLAIN; P.out32 = nullptr; P.out_f32 = 0; P.res_f32 = 0; }
+  if (LEAN && CONVT) { P.residual = nullptr; P.pixmul = nullptr; }
   if (LEAN && PRE == 2) { P.residual = nullptr; P.pixmul = nullptr; }
   const long long img_pix0 = (long long)g.img * P.OH * P.OW;
   const bool up = P.store_mode == XS_PIXSHUF || P.store_mode == XS_CONVT;
@@ -1418,7 +1419,8 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     P.kw = 2; P.kk = 4; P.stride = 1; P.pad = 0; P.cout = 4 * d->cout;
     P.oh = d->h; P.ow = d->w; P.OH = 2 * d->h; P.OW = 2 * d->w;
     P.store_mode = XS_CONVT; P.cq = d->cout; BN = 128; TH = 4; TPS = 2; WM = 4; WN = 1;
-    if (var != 1) { TH = 8; WM = 8; NL = 4; }               // 8x32 px x (4 phases x 32 couts), 8 multiplying + 4 loader waves
+    if (var != 1) { TH = 8; WM = 8; NL = 4; TPS = (var == 2) ? 2 : 4; }   // 8x32 px x (4 phases x 32 couts), 8 multiplying + 4 loader waves;
+                                                            // a stage = all four taps of a chunk (variant 2: tap pairs, round 2's form)
   } else {
     P.kw = d->ksize; P.kk = d->ksize * d->ksize; P.stride = d->stride; P.pad = d->ksize / 2; P.cout = d->cout;
     P.oh = (d->h + 2 * P.pad - d->ksize) / P.stride + 1; P.ow = (d->w + 2 * P.pad - d->ksize) / P.stride + 1;
@@ -1452,7 +1454,8 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     else if (d->stride == 2) {
       TH = 2; WM = 2; WN = 2; TPS = (BN == 128) ? 1 : 3;
       // loader-wave form: 4 x 32 output pixels (9 x 65 halo) x 128 / 64 couts on 4 x 2 multiplying waves
-      if (var != 1 && BN >= 64 && CK == 32) { TH = 4; WM = 4; WN = 2; TPS = 3; NL = 4; }
+      // (64 couts: a stage is the whole 32-channel chunk -- 18 instead of 6 MFMAs of a wave between barriers; variant 2: row stages)
+      if (var != 1 && BN >= 64 && CK == 32) { TH = 4; WM = 4; WN = 2; TPS = (BN == 64 && var != 2 && nchunk_total >= 2) ? 9 : 3; NL = 4; }
     }
     else if (BN == 128) {
       if (var == 1) { TH = 8; TPS = 1; WM = 4; WN = 1; }          // 8x32 px, wave = 64 px x 128 couts, tap stages
@@ -1537,6 +1540,8 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   // the lean epilogue (see x_epilogue) covers this descriptor?
   L.lean = P.store_mode == XS_PLAIN && !d->out_f32 && !d->out32 && (!d->residual || !d->res_f32) && d->cout % 8 == 0 &&
            (d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU);
+  if (tr) L.lean = !d->out_f32 && !d->out32 && !d->residual && !d->pixmul && !d->gn_partials &&
+                   (d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU);
   // source transform (a_scale / a_shift: a folded GroupNorm apply): kernels that stage the halo image through registers exist for the
   // 64-channel weights-resident form and for the wide 3x3 loader-wave tile -- every second convolution of a VQGAN block
   L.axf_ok = !tr && !gemm && d->ksize == 3 && d->stride == 1 && d->nsrc == 1 && d->src_image_stride[0] < 0 && d->weight_image_stride == 0 && L.lean &&
@@ -1629,6 +1634,9 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (L.NL == 4 && !L.tr && !L.gemm && GP_IS(32, 8, 1, 16, 7) && L.CK == 16) return launch_x<16, 32, 8, 1, 16, 7, false, false, 4, true>(P, lds, st);
   }
   if (L.NL == 4) {            // loader-wave forms
+    if (L.tr && L.TPS == 4 && L.lean)
+      return L.CK == 32 ? launch_x<32, 128, 8, 1, 8, 4, true, false, 4, true>(P, lds, st) : launch_x<16, 128, 8, 1, 8, 4, true, false, 4, true>(P, lds, st);
+    if (L.tr && L.TPS == 4) return GP_XL(128, 8, 1, 8, 4, true, false);
     if (L.tr) return GP_XL(128, 8, 1, 8, 2, true, false);
     if (L.gemm) {
       if (GP_IS(128, 4, 2, 8, 1) && L.CK == 64) return launch_x<64, 128, 4, 2, 8, 1, false, true, 4>(P, lds, st);
@@ -1637,6 +1645,8 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     }
     else if (GP_IS(128, 4, 2, 4, 3) && L.CK == 32) return launch_x<32, 128, 4, 2, 4, 3, false, false, 4, false, 2>(P, lds, st);
     else if (GP_IS(64, 4, 2, 4, 3) && L.CK == 32) return launch_x<32, 64, 4, 2, 4, 3, false, false, 4, false, 2>(P, lds, st);
+    else if (GP_IS(64, 4, 2, 4, 9) && L.CK == 32)
+      return L.lean ? launch_x<32, 64, 4, 2, 4, 9, false, false, 4, true, 2>(P, lds, st) : launch_x<32, 64, 4, 2, 4, 9, false, false, 4, false, 2>(P, lds, st);
     else if (GP_IS(64, 8, 1, 16, 9)) return GP_XL(64, 8, 1, 16, 9, false, false);
     else if (GP_IS(64, 8, 1, 16, 3)) return GP_XL(64, 8, 1, 16, 3, false, false);
     else if (GP_IS(32, 8, 1, 16, 3)) return GP_XL(32, 8, 1, 16, 3, false, false);

@@ -465,7 +465,7 @@ class Engine:
         Lr3 = self.conv(Lr2, "reffea_L3_conv1", ACT_LRELU)
         Lr4 = self.conv(Lr3, "reffea_L4_conv1", ACT_LRELU) if s == 16 else None
         ref_x16, ref_x8, ref_x4, ref_x2, ref_img = self.ref_extract(xf, forced_idx, trace)
-        if self.bf16 and (s * H) % 16 == 0 and (s * W) % 16 == 0 and self.fuse_vgg:
+        if (self.bf16 or getattr(self, "_frozen16", None) is not None) and (s * H) % 16 == 0 and (s * W) % 16 == 0 and self.fuse_vgg:
             mask = self.vgg_mask_fused(ref_img, xf)
         else:
             up_lr = self.o.bilinear(xf, s * H, s * W)

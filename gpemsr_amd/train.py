@@ -27,6 +27,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -214,6 +216,15 @@ class TrainEngine(Engine):
         self.trainable = set(trainable)                        # before the base constructor packs the weights
         self.fuse_tail_f32 = False                             # training keeps the layered decoder tail / VALU 64 -> 1 convs: the tape's
         #                                                        backward kernels were validated against exactly that forward
+        # precision "bf16": the FROZEN sub-networks whose inputs carry no gradient -- the VQGAN prior (indexer, codebook, decoder), the
+        # VGG relu1_2 mask and SpyNet: about two thirds of the step's convolution time -- run on the bf16 DATA PATH of the inference
+        # engine (bf16 activations in HBM, fused kernels, flash attention); everything that is trained or differentiated through
+        # (trainable layers, their gradients, the loss network) stays as in "bf16x3": fp32 activations, fp32-grade products.
+        self._frozen16 = None
+        if precision == "bf16":
+            frozen = {k: v for k, v in sd.items() if k.startswith(("refmodel.", "vgg.slice1.", "align_module.spynet."))}
+            self._frozen16 = Engine(frozen, device, scale, nframes, groups, nf, dec_nrb, frame_chunk=1 << 20, tile_chunk=1 << 20, precision="bf16")
+            precision = "bf16x3"
         super().__init__(sd, device, scale, nframes, groups, nf, dec_nrb, frame_chunk=1 << 20, tile_chunk=1 << 20, precision=precision)
         self.gw, self.gb = gw, gb
         self.tape: Optional[list] = None
@@ -229,6 +240,21 @@ class TrainEngine(Engine):
                 if precision != "fp32" and sd[key + ".weight"].shape[1] % 16 == 0:
                     self.pc[key + "@rgb"].w16 = pack_conv_split(self.pc[key + "@rgb"], sd[key + ".weight"], device)
 
+    # -- frozen sub-networks on the bf16 data path (precision "bf16") ------------------------------------------------------
+    def ref_extract(self, xf, forced_idx, trace):
+        if self._frozen16 is None:
+            return super().ref_extract(xf, forced_idx, trace)
+        feats = self._frozen16.ref_extract(xf, forced_idx, trace)       # constants of the step: nothing to record
+        return [ops.cast_f32(f) if f.bf16 else f for f in feats]
+
+    def vgg_mask_fused(self, ref_img, xf):
+        return self._frozen16.vgg_mask_fused(ref_img, xf)
+
+    def spynet(self, ref, supp):
+        if self._frozen16 is None:
+            return super().spynet(ref, supp)
+        return self._frozen16.spynet(ref, supp)
+
     def par_name(self, t: torch.Tensor) -> str:
         for k, v in self.par.items():
             if v.data_ptr() == t.data_ptr() and k.endswith(".weight"):
@@ -243,19 +269,77 @@ class TrainEngine(Engine):
             self.pc[name] = pc
             return
         if name in getattr(self, "trainable", ()):             # trainable layers stay on the exact f32 kernel (their packed copy is
-            prec, self.precision = self.precision, "fp32"      # rebuilt every step; the split-bf16 packing is a host-side routine)
-            try:
+            prec, split = self.precision, self.split           # rebuilt every step; the split-bf16 packing is a host-side routine that
+            self.precision, self.split = "fp32", False         # cost 440 ms per step when `split` alone still asked for it: round 2's
+            try:                                               # "bf16x3" training extras ran at 24 instead of 118 samples/s)
                 super()._pack_one(k, w)
             finally:
-                self.precision = prec
+                self.precision, self.split = prec, split
             return
         super()._pack_one(k, w)
 
     def refresh_weights(self):
         """After an optimizer step: the packed copies of the trainable parameters follow the master weights."""
         self._dpc.clear()
+        if getattr(self, "_ridx", None) is not None:           # one gather for all of them (enable_fast_refresh)
+            torch.index_select(self._rflat, 0, self._ridx, out=self._rtmp)
+            torch.mul(self._rtmp, self._rmask, out=self._rpacked)
+            return
         for name in self.trainable:
             self._pack_one(name + ".weight", self.sd[name + ".weight"])
+
+    def enable_fast_refresh(self, flat_p: torch.Tensor):
+        """Every packed form of a trainable layer is a permutation of its master weights plus zero padding, so the per-step repack
+        (93 layers x ~10 small torch launches = 3.7 ms of host time per step, serial with the device) collapses into ONE gather
+        from the flat parameter buffer: the index map is found by packing index-valued tensors through the very same routines, and the
+        packed tensors become views of one flat buffer."""
+        base, n_flat = flat_p.data_ptr(), flat_p.numel()
+        real, names = {}, sorted(self.trainable)
+        for name in names:
+            for leaf in ("weight", "bias"):
+                k = f"{name}.{leaf}"
+                t = self.sd.get(k)
+                if t is None:
+                    continue
+                off = (t.data_ptr() - base) // 4
+                assert 0 <= off and off + t.numel() <= n_flat, f"{k} is not a view of the flat parameter buffer"
+                assert off + t.numel() < (1 << 24), "index packing uses exact fp32 integers"
+                real[k] = t
+                self.sd[k] = (torch.arange(t.numel(), device=t.device, dtype=torch.float32) + float(off + 1)).view(t.shape)
+        try:
+            for name in names:
+                self._pack_one(name + ".weight", self.sd[name + ".weight"])
+            slots = []
+            for name in names:
+                pc = self.pc.get(name)
+                if pc is not None:
+                    for attr in ("w", "b"):
+                        t = getattr(pc, attr, None)
+                        if t is not None:
+                            slots.append((pc, attr, t))
+                for leaf in ("weight", "bias"):
+                    if f"{name}.{leaf}" in self.par:
+                        slots.append((self.par, f"{name}.{leaf}", self.par[f"{name}.{leaf}"]))
+        finally:
+            self.sd.update(real)
+        def _pad4(t):                                        # every view must stay 16-byte aligned (the kernels' vector loads)
+            t = t.reshape(-1)
+            return torch.cat([t, t.new_zeros((-t.numel()) % 4)])
+        idx = torch.cat([_pad4(t) for _, _, t in slots]).round().to(torch.int64)
+        self._rmask = (idx > 0).to(torch.float32)
+        self._ridx = (idx - 1).clamp_(min=0)
+        self._rflat = flat_p
+        self._rtmp = torch.empty_like(self._rmask)
+        self._rpacked = torch.empty_like(self._rmask)
+        off = 0
+        for obj, key, t in slots:
+            view = self._rpacked[off:off + t.numel()].view(t.shape)
+            if isinstance(obj, dict):
+                obj[key] = view
+            else:
+                setattr(obj, key, view)
+            off += (t.numel() + 3) // 4 * 4
+        self.refresh_weights()
 
     # -- recorded convolution ------------------------------------------------------------------------------------------
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
@@ -603,7 +687,7 @@ class Stage3Trainer(_TrainerState):
         assert all(p.is_cuda for p in model.parameters()), "move the model to the device first (model.to(device))"
         # model.precision "fp32" (default, exact) or "bf16x3": the FORWARD convolutions (incl. the frozen prior / VGG, about two
         # thirds of the step) run on the split-bf16 kernel (fp32-grade); data / weight gradients stay on the f32 pipe
-        assert model.precision in ("fp32", "bf16x3"), "training supports precision fp32 or bf16x3"
+        assert model.precision in ("fp32", "bf16x3", "bf16"), "training supports precision fp32, bf16x3 or bf16 (bf16 data path for the frozen sub-networks)"
         self.opt = dict(opt_train)
         self.band_width = band_width
         # one flat buffer for the trainable parameters (and their gradient / Adam moments): the model's Parameters
@@ -618,6 +702,8 @@ class Stage3Trainer(_TrainerState):
         self.eng = TrainEngine(sd, device, model.scale, model.nframes, model.groups, model.nf, model._dec_nrb, names, gw, gb,
                                precision=model.precision)
         self.gw, self.gb = gw, gb
+        if os.environ.get("GPEMSR_FAST_REFRESH", "1") != "0":
+            self.eng.enable_fast_refresh(self.flat_p)
         self.step_count = 0
         o = self.opt
         self.lr = float(o.get("lr_G", 4e-4))

@@ -11,7 +11,7 @@ from gpemsr_amd.train import Stage3Trainer
 from gpemsr_amd import ops
 dev = torch.device("cuda", 0)
 opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
-tr = Stage3Trainer(build_model(opt, load_prior_files=False).to(dev), TRAIN_OPT, dev)
+tr = Stage3Trainer(build_model(opt, load_prior_files=False, precision=(sys.argv[1] if len(sys.argv) > 1 else "fp32")).to(dev), TRAIN_OPT, dev)
 LR = synth_lr_tiles(8, 5, 32, 32, seed=1, kind="smooth").to(dev)
 GT = torch.rand(8, 1, 256, 256).to(dev)
 tr.step(LR, GT); torch.cuda.synchronize()
