@@ -268,6 +268,25 @@ __global__ __launch_bounds__(256) void pack_rows16_kernel(const bf16_t* src, int
   }
 }
 
+// nn.MaxPool2d(2, 2), floor mode (R:model/VGG.py slices 2-3 of the loss network), 8 channels per thread
+__global__ __launch_bounds__(256) void maxpool2_16_kernel(const bf16_t* x, int n, int h, int w, int c, int ld, bf16_t* out, int out_ld) {
+  const int oh = h >> 1, ow = w >> 1, c8 = c >> 3;
+  const long long total = (long long)n * oh * ow * c8;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e % c8);
+    long long t = e / c8;
+    const int ox = (int)(t % ow); t /= ow;
+    const int oy = (int)(t % oh);
+    const long long img = t / oh;
+    const bf16_t* p = x + ((img * h + 2 * oy) * w + 2 * ox) * (long long)ld + 8 * j;
+    float a[8], b[8], cc[8], d[8];
+    ld8(p, a); ld8(p + ld, b); ld8(p + (long long)w * ld, cc); ld8(p + (long long)w * ld + ld, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(cc[k], d[k]));
+    st8(out + ((img * oh + oy) * ow + ox) * (long long)out_ld + 8 * j, a);
+  }
+}
+
 // ---- resampling ----
 __device__ __forceinline__ void src_index16(int dst, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
   float s = align ? scale * dst : fmaxf(scale * (dst + 0.5f) - 0.5f, 0.f);
@@ -868,6 +887,13 @@ extern "C" int gpemsr_pack_rows_bf16_ex(const void* src, int n, int rows, int c,
 }
 extern "C" int gpemsr_pack_rows_bf16(const void* src, int n, int rows, int c, int ld, int64_t img_stride, void* dst, void* stream) {
   return gpemsr_pack_rows_bf16_ex(src, n, rows, c, ld, img_stride, dst, 0, stream);
+}
+
+extern "C" int gpemsr_maxpool2_bf16(const void* x, int n, int h, int w, int c, int ld, void* out, int out_ld, void* stream) {
+  GP_REQUIRE(x && out && n > 0 && h >= 2 && w >= 2 && c % 8 == 0 && ld % 8 == 0 && out_ld % 8 == 0 && A16(x) && A16(out), "maxpool2_bf16: bad args");
+  hipLaunchKernelGGL(maxpool2_16_kernel, dim3(grid16((long long)n * (h / 2) * (w / 2) * (c / 8))), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), n, h, w, c, ld,
+                     reinterpret_cast<bf16_t*>(out), out_ld);
+  return check_launch("maxpool2_bf16");
 }
 
 extern "C" int gpemsr_bilinear_bf16(const void* x, int n, int h, int w, int c, int ld, int oh, int ow, int align_corners, float mul,

@@ -584,6 +584,10 @@ def copy_channels(src: Act, dst: Act):
 
 def maxpool2(x: Act) -> Act:
     """nn.MaxPool2d(2, 2), floor mode."""
+    if x.bf16:
+        out = new_act(x.n, x.h // 2, x.w // 2, x.c, device=x.buf.device, bf16=True)
+        _abi.check(_abi.load().gpemsr_maxpool2_bf16(x.ptr, x.n, x.h, x.w, x.c, x.ld, out.ptr, out.ld, _stream()), "maxpool2_bf16")
+        return out
     out = new_act(x.n, x.h // 2, x.w // 2, x.c, device=x.buf.device)
     _abi.check(_abi.load().gpemsr_maxpool2(x.ptr, x.n, x.h, x.w, x.c, x.ld, out.ptr, out.ld, _stream()), "maxpool2")
     return out

@@ -723,6 +723,28 @@ class Stage3Trainer(_TrainerState):
                 a = eng.conv(a, f"vgg.slice{sl}.{idx}@rgb", ACT_RELU)
         return a
 
+    def _vgg_relu3_4_target16(self, a: Act) -> Act:
+        """VGG relu3_4 of the constant target frames (R:train_stage3.py:358-359) with bf16 activations: conv1_1 (3 input channels) on
+        the fp32 kernel, everything after it on the bf16 kernels of the frozen engine; the features return as fp32."""
+        from .packing import pack_conv_bf16
+        eng, e16 = self.eng, self.eng._frozen16
+        first = True
+        for sl, idx, kind in _VGG_TO_RELU3_4:
+            if kind == "pool":
+                a = ops.maxpool2(a)
+            elif first:
+                a = ops.cast_bf16(eng.conv(a, f"vgg.slice{sl}.{idx}@rgb", ACT_RELU, precision="fp32"))
+                first = False
+            else:
+                key = f"vgg.slice{sl}.{idx}"
+                if (key + "@t16") not in e16.pc:
+                    w, b = eng.sd[key + ".weight"], eng.sd[key + ".bias"]
+                    pc = pack_conv(w, b, self.dev)
+                    pc.wb = pack_conv_bf16(w, self.dev)
+                    e16.pc[key + "@t16"] = pc
+                a = e16.conv(a, key + "@t16", ACT_RELU)
+        return ops.cast_f32(a)
+
     def _gray3(self, x: Act, taped: bool) -> Act:
         x3 = ops.gray_normalize3(x, VGG_MEAN, VGG_STD)
         if taped and x.requires_grad:
@@ -736,7 +758,10 @@ class Stage3Trainer(_TrainerState):
         eng = self.eng
         fx = self._vgg_relu3_4(self._gray3(sr, True))                   # [b, h/4, w/4, 256], recorded
         tape, eng.tape = eng.tape, None
-        fy = self._vgg_relu3_4(self._gray3(ref_frames, False))          # [b*t, ...], constant
+        if eng._frozen16 is not None and os.environ.get("GPEMSR_CX_TARGET16", "1") != "0":
+            fy = self._vgg_relu3_4_target16(self._gray3(ref_frames, False))     # constant TARGET features on the bf16 data path (5/6 of the
+        else:                                                                     # loss network's forward work: t frames per SR image)
+            fy = self._vgg_relu3_4(self._gray3(ref_frames, False))      # [b*t, ...], constant
         eng.tape = tape
         return self.contextual_features(fx, fy, t, scale)
 

@@ -217,6 +217,8 @@ int gpemsr_split_f32_bf16x2(const float* x, int64_t pixels, int c, int x_ld, voi
  * _frame_mix_lrelu / _threeda_combine / _copy_channels (c % 8 == 0) */
 int gpemsr_bilinear_bf16(const void* x, int n, int h, int w, int c, int ld, int oh, int ow, int align_corners, float mul,
                          void* out, int out_ld, void* stream);
+/* nn.MaxPool2d(2, 2) on a bf16 tensor (the loss network's pools, R:model/VGG.py:22,24); c, strides % 8 == 0 */
+int gpemsr_maxpool2_bf16(const void* x, int n, int h, int w, int c, int ld, void* out, int out_ld, void* stream);
 int gpemsr_pool3s2_maxavg_bf16(const void* x, int n, int h, int w, int c, int ld, void* out, int out_ld, void* stream);
 int gpemsr_spynet_prep_bf16(const float* ref, const float* supp, const float* flow_coarse, int n, int h, int w,
                             const float* mean3, const float* std3, float* up_flow, void* inp16, void* stream);
