@@ -503,7 +503,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
   // stamps: a third of a wide layer's time was spent in that burst, with the matrix pipe idle), so it must go between MFMAs.
   const unsigned short* ia_sp = nullptr; unsigned ia_pixb = 0, ia_la = 0; int ia_cs = 0;
   auto issue_a_begin = [&]() {
-    if (a_cross) { a_enter_tile(nxt); a_cross = false; }
+    if (a_cross) { a_enter_tile(tile_geo(a_ti)); a_cross = false; }     // (the cursor may be TWO tiles ahead: single-chunk layers with two images)
     const unsigned short* sp = nullptr; unsigned pixb = 0; int cs = 0;
 #pragma unroll
     for (int s = 0; s < GPEMSR_MAX_SRC; ++s)
@@ -537,7 +537,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
   };
   const unsigned short* ib_wp = nullptr; unsigned ib_lb = 0;
   auto issue_b_begin = [&]() {
-    if (b_cross) { b_img = nxt.img; b_n0 = nxt.n0; b_cross = false; }
+    if (b_cross) { const Geo gb = tile_geo(b_ti); b_img = gb.img; b_n0 = gb.n0; b_cross = false; }
     const unsigned short* wp = P.weight + (long long)b_img * P.w_img_stride + ((long long)b_chunk * KK + b_grp * TPS) * (R * 8) * P.cout;
     ib_wp = reinterpret_cast<const unsigned short*>(xuni_ptr(wp));
     ib_lb = xuni(lds0 + (unsigned)(n_abuf * A_BYTES + b_dst * B_BYTES));
@@ -1509,7 +1509,10 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   const int budget = (nth >= 512 ? 158 : 80) * 1024 - bias_bytes;      // 512 / 768 threads: one workgroup per CU
   const int stages = nchunk_total * P.spc;
   int ring = stages < 4 ? (stages < 2 ? 2 : stages) : 4;
-  int n_abuf = gemm ? (nchunk_total < 4 ? nchunk_total : 4) : (nchunk_total < 2 ? 1 : 2);
+  // conv: two halo images; a single-chunk layer (SpyNet's 16 / 32-channel 7x7 convolutions) used to keep ONE and to wait for the next
+  // tile's image with the matrix pipe idle -- its cursor now runs two tiles ahead (variant 8: the single image)
+  int n_abuf = gemm ? (nchunk_total < 4 ? nchunk_total : 4) : 2;
+  if (!gemm && nchunk_total < 2 && (var == 8 || 2 * P.a_bytes + 2 * P.b_bytes > budget)) n_abuf = 1;
   while (n_abuf * P.a_bytes + ring * P.b_bytes > budget && (ring > 2 || (gemm && n_abuf > 2))) {
     if (gemm && n_abuf > 2 && n_abuf >= ring) --n_abuf;      // matrix products: both rings advance per stage, keep them level
     else if (ring > 2) --ring;
