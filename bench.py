@@ -197,9 +197,9 @@ def _tf(d):
 
 def pmc_traffic(tag: str, launches_per_step: int):
     """HBM bytes per launch of the dominant kernel family from the rocprofv3 --pmc summary committed for THIS tree
-    (profiles/r02_<tag>_pmc_summary.json, scripts/pmc_round.sh; separate passes, FETCH_SIZE x2 gfx950 correction).  The
+    (profiles/r03_<tag>_pmc_summary.json, scripts/pmc_round2.sh; separate passes, FETCH_SIZE x2 gfx950 correction).  The
     summary records the family's launches per step; a mismatch means it was taken on another tree -> null."""
-    path = os.path.join(ROOT, "profiles", f"r02_{tag}_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", f"r03_{tag}_pmc_summary.json")
     try:
         doc = json.load(open(path))
         fam = doc["dominant_family"]
@@ -214,8 +214,9 @@ def pmc_traffic(tag: str, launches_per_step: int):
 FAMILIES = {
     "fp32": (("conv_mfma",), "conv_mfma_kernel (implicit-GEMM conv/GEMM family, v_mfma_f32_32x32x2_f32)", PEAK_F32_MATRIX_TFLOPS),
     "bf16": (("conv_bf16", "vgg_mask"),
-             "bf16 MFMA family (v_mfma_f32_32x32x16_bf16): conv_bf16_kernel / conv64_resident2_kernel (implicit-GEMM conv / 1x1 / transposed / "
-             "attention products), vgg_mask2_kernel (fused VGG relu1_2 + 16x16 patch cosine)", PEAK_BF16_MATRIX_TFLOPS),
+             "bf16 MFMA family (v_mfma_f32_32x32x16_bf16): conv_bf16_kernel / conv64_resident2_kernel (implicit-GEMM conv / 1x1 / transposed), "
+             "flash_attn512_kernel (q.k^T + online softmax + P.v of the NonLocalBlock), vgg_mask2_kernel (fused VGG relu1_2 + 16x16 patch cosine)",
+             PEAK_BF16_MATRIX_TFLOPS),
     "bf16x3": (("conv_split",), "conv_split_kernel (v_mfma_f32_32x32x16_bf16, 3 split products per algorithmic product)", PEAK_BF16_MATRIX_TFLOPS),
     "bf16op": (("conv_split",), "conv_split_kernel (v_mfma_f32_32x32x16_bf16, bf16 operands rounded in LDS)", PEAK_BF16_MATRIX_TFLOPS),
 }

@@ -670,6 +670,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
       }
       return;
     }
+    // the loader waves of this form issue ~400 vector instructions per stage: the multiplying waves that share their SIMDs get the
+    // issue slots first (MI355X_MICROARCH.md, two waves per SIMD, item 2: arbitration by priority, then age)
+    __builtin_amdgcn_s_setprio(2);
   }
   // ---- prologue: tile 0 (and 1) geometry, A(0) [A(1)], B(0 .. RING-1) ----
   if (is_loader) {
@@ -1278,6 +1281,7 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   }
 
   // ------------------------------------------------ multiplying waves ------------------------------------------------
+  if (AXF) __builtin_amdgcn_s_setprio(2);              // (the transforming loader waves must not take their issue slots)
   const int g = wave >> 2, w4 = wave & 3;              // group, wave of the group: pixel rows 2 w4, 2 w4 + 1 of the 8 x 32 tile
   const int T_g = g ? T1 : T0;
   // fragment byte offsets (tile-invariant): one entry per (halo row, kx); k-step 1 flips bit 5

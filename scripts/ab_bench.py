@@ -7,24 +7,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gpemsr_amd.config import build_model, load_options
 from gpemsr_amd.synth import synth_lr_tiles
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
-rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 3
-steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 4
+argv = sys.argv[1:]
+rounds = int(argv[argv.index("--rounds") + 1]) if "--rounds" in argv else 3
+steps = int(argv[argv.index("--steps") + 1]) if "--steps" in argv else 4
+for f in ("--rounds", "--steps"):
+    if f in argv:
+        i = argv.index(f); del argv[i:i + 2]
+args = argv
 prec, variants = args[0], args[1:]
 dev = torch.device("cuda", 0)
 opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
 x = synth_lr_tiles(16, 5, 128, 128, seed=1000, kind="uniform").to(dev)
-models = []
-for v in variants:
+def setenv(v):
     for kv in v.split(","):
         k, val = kv.split("=")
         os.environ[k] = val
+models = []
+for v in variants:
+    setenv(v)
     m = build_model(opt, load_prior_files=False, precision=prec).eval().to(dev)
     m(x); torch.cuda.synchronize()          # engine construction reads the switches
     models.append(m)
 outs = []
 for r in range(rounds):
     for v, m in zip(variants, models):
+        setenv(v)                           # (switches read at call time)
         m(x); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
