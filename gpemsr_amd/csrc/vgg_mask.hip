@@ -22,6 +22,18 @@
 
 namespace gpemsr {
 
+#ifdef GPVGG_STAMP
+// diagnostic build (scripts/vgg_stamp_probe.py): cycles per bucket of every wave of the first 256 workgroups, summed over the workgroup's life
+__device__ unsigned long long g_vstamps[256 * 16 * 8];
+#define VSEG_DECL unsigned long long vs_t = __builtin_amdgcn_s_memtime(), vs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define VSEG(k) do { const unsigned long long vs_n = __builtin_amdgcn_s_memtime(); vs_acc[k] += vs_n - vs_t; vs_t = vs_n; } while (0)
+#define VSEG_FLUSH do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) { for (int k = 0; k < 8; ++k) g_vstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + k] = vs_acc[k]; } } while (0)
+#else
+#define VSEG_DECL
+#define VSEG(k)
+#define VSEG_FLUSH
+#endif
+
 struct VggParams {
   const float* ref; const float* lr;       // [n][H][W] prior image, [n][h][w] LR slice
   int n, H, W, h, w;
@@ -31,6 +43,7 @@ struct VggParams {
   float* out;                                // [n][H/16][W/16]
   int tiles_x, tiles_y, ns;
   int dbg;                                   // timing experiments only (GPEMSR_VGG_DBG): 1 = producers idle, 2 = no conv1_2
+  int hr2;                                   // `lr` is already at the HR size (scale == 1): both images are read the same way
 };
 
 __device__ __forceinline__ void vsrc_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
@@ -302,6 +315,16 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
   if (wave >= 8) {
     // ------------------------------------------------ producer waves: conv1_1 ------------------------------------------------
     const int pw = wave - 8;
+    VSEG_DECL;
+    // Measured and NOT kept (build switches for A/B: -DVGG_PRIO=n, -DVGG_BAL=1; kernel alone, 80 slices of 128^2 x8, ms): the producers'
+    // few MFMAs lose the arbitration for the matrix pipe to the older multiplying waves (in-kernel stamps: every producer wave sat ~5k
+    // cycles in its conversion phase), but raising their priority only moves the wait to the multiplying waves (12.65 vs 12.35), and
+    // dealing the 22 (group, cout tile) units evenly (three instead of four on the longest wave) does not pay either (12.76): the
+    // interval is set by the SIMDs' total issue + LDS load, not by one role.
+#ifndef VGG_PRIO
+#define VGG_PRIO 0
+#endif
+    if (VGG_PRIO) __builtin_amdgcn_s_setprio(VGG_PRIO);
     // W1 fragments: row operand of D^T = W1 . im2col^T.  k slots: 0..8 = taps (hi half of the pixel), 9..17 = the same taps (lo
     // half), 18..31 = 0.  Lane (li = cout within the 32-row tile ct, lh) holds k = 16 s + 8 lh + j.
     bf16x8 w1f[2][2];
@@ -316,22 +339,40 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
           const float v = k < 18 ? P.w1[(ct * 32 + li) * 9 + tap] : 0.f;
           w1f[ct][s][j] = (short)(xcvt_pk_bf16(v, 0.f) & 0xFFFFu);
         }
-    auto produce = [&](int wi) {
+    // One producer wave owns halo-pixel groups pw, pw + NPROD (11 groups of 32 over NPROD waves: one or two per item).  The 3x3 windows of
+    // ALL its groups are fetched before the first is converted: with one group after the other (round 2) the second group's loads were
+    // issued only after the first group's arithmetic, i.e. two dependent memory round trips (~2 us each under load) per item -- the
+    // producers alone took 11.6 ms of the kernel's 13.9.
+    constexpr int MAXG = (NGRP + NPROD - 1) / NPROD;
+    // FETCH of item i + 2 is issued before the barrier that ends interval i, its values are consumed (masked, converted) in interval
+    // i + 1: the memory round trip (3-4k cycles under load, in-kernel stamps) lies under a whole interval instead of in front of the
+    // conversion.  `raw` / `rmask` are live across the barrier (20 registers).
+    float raw[MAXG][9];
+    unsigned rmask[MAXG];
+    // Work split: groups pw, pw + NPROD (VGG_BAL = 1: group pw whole + one cout tile of groups 8-10 on waves 0-5; see above)
+#ifndef VGG_BAL
+#define VGG_BAL 0
+#endif
+    auto slot_group = [&](int gi) -> int {
+      if (NPROD != 8 || !VGG_BAL) return pw + gi * NPROD;
+      return gi == 0 ? pw : (pw < 6 ? NPROD + (pw >> 1) : NGRP);
+    };
+    auto slot_does = [&](int gi, int ct) -> bool { return NPROD != 8 || !VGG_BAL || gi == 0 || ct == (pw & 1); };
+    auto fetch = [&](int wi) {
       int img, oy0, ox0, tx, ty;
       item_geo(wi, img, oy0, ox0, tx, ty);
       const int which = wi & 1;
-      char* const dst = vsm + W_BYTES + (2 * (wi & 1)) * A_BYTES;          // buffer = item parity
       const float* rimg = P.ref + (long long)img * P.H * P.W;
       const float* limg = P.lr + (long long)img * P.h * P.w;
-#pragma unroll 1
-      for (int grp = pw; grp < NGRP; grp += NPROD) {
+      VSEG(3);
+#pragma unroll
+      for (int gi = 0; gi < MAXG; ++gi) {
+        const int grp = slot_group(gi);
         const int hp = grp * 32 + li;
-        const bool exists = hp < HALO_PX;
-        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const bool exists = grp < NGRP && hp < HALO_PX;
+        const int hpc = exists ? hp : 0;
+        const int hy = hpc / HALO_W, hx = hpc - hy * HALO_W;
         const int Y = oy0 - 1 + hy, X = ox0 - 1 + hx;                     // this halo pixel; its 3x3 window is centred on it
-        // the 3x3 window of this halo pixel, branch-free (clamped addresses, masked values) so that all loads of a group are in
-        // flight together: with a branch per tap the producer waves were the bottleneck (36 dependent L2 round trips per group)
-        float pv[9];
         bool rin[3], cin[3];
         int yc[3], xc[3];
 #pragma unroll
@@ -341,35 +382,63 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
           yc[d] = yy < 0 ? 0 : (yy > P.H - 1 ? P.H - 1 : yy);
           xc[d] = xx < 0 ? 0 : (xx > P.W - 1 ? P.W - 1 : xx);
         }
-        if (which == 0) {
+        unsigned m = 0u;
 #pragma unroll
-          for (int tp = 0; tp < 9; ++tp) {
-            const float v = rimg[(long long)yc[tp / 3] * P.W + xc[tp % 3]];
-            pv[tp] = (exists && rin[tp / 3] && cin[tp % 3]) ? v : 0.f;          // zero outside the image = conv1_1's padding
-          }
+        for (int tp = 0; tp < 9; ++tp) m |= ((exists && rin[tp / 3] && cin[tp % 3]) ? 1u : 0u) << tp;      // zero outside the image = conv1_1's padding
+        rmask[gi] = m;
+        if (which == 0 || P.hr2) {
+          // (the second image already up-sampled by gpemsr_bilinear, `scale` == 1: the on-the-fly resampling below -- 36 loads and
+          // ~250 vector operations per halo pixel group -- kept the producer waves busy for 10k cycles per LR item, in-kernel stamps:
+          // scripts/vgg_stamp_probe.py; the up-sampled image costs 0.34 GB of traffic per step)
+          const float* im = which == 0 ? rimg : P.lr + (long long)img * P.H * P.W;
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) raw[gi][tp] = im[(long long)yc[tp / 3] * P.W + xc[tp % 3]];      // clamped address, masked at use
         } else {
           int y0[3], y1[3], x0[3], x1[3]; float ly[3], lx[3];
 #pragma unroll
           for (int d = 0; d < 3; ++d) { vsrc_index(yc[d], P.sh, P.h, y0[d], y1[d], ly[d]); vsrc_index(xc[d], P.sw, P.w, x0[d], x1[d], lx[d]); }
-          float q[6][6];                  // LR pixels at rows (y0, y1) x cols (x0, x1) of the three window rows / columns
+          float q[6][6];                  // LR pixels at rows (y0, y1) x cols (x0, x1) of the three window rows / columns (L1 / L2 resident)
 #pragma unroll
-          for (int a = 0; a < 6; ++a)
+          for (int a2 = 0; a2 < 6; ++a2)
 #pragma unroll
-            for (int b = 0; b < 6; ++b)
-              q[a][b] = limg[((a & 1) ? y1[a >> 1] : y0[a >> 1]) * P.w + ((b & 1) ? x1[b >> 1] : x0[b >> 1])];
+            for (int b2 = 0; b2 < 6; ++b2)
+              q[a2][b2] = limg[((a2 & 1) ? y1[a2 >> 1] : y0[a2 >> 1]) * P.w + ((b2 & 1) ? x1[b2 >> 1] : x0[b2 >> 1])];
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp) {
             const int r = tp / 3, c = tp % 3;
             const float hy2 = 1.f - ly[r], hx2 = 1.f - lx[c];
-            const float v = hy2 * (hx2 * q[2 * r][2 * c] + lx[c] * q[2 * r][2 * c + 1]) + ly[r] * (hx2 * q[2 * r + 1][2 * c] + lx[c] * q[2 * r + 1][2 * c + 1]);
-            pv[tp] = (exists && rin[r] && cin[c]) ? v : 0.f;
+            raw[gi][tp] = hy2 * (hx2 * q[2 * r][2 * c] + lx[c] * q[2 * r][2 * c + 1]) + ly[r] * (hx2 * q[2 * r + 1][2 * c] + lx[c] * q[2 * r + 1][2 * c + 1]);
           }
         }
+      }
+      VSEG(0);
+    };
+    auto convert = [&](int wi) {
+      int img, oy0, ox0, tx, ty;
+      item_geo(wi, img, oy0, ox0, tx, ty);
+      char* const dst = vsm + W_BYTES + (2 * (wi & 1)) * A_BYTES;          // buffer = item parity
+      float pvs[MAXG][9];
+#pragma unroll
+      for (int gi = 0; gi < MAXG; ++gi)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) pvs[gi][tp] = ((rmask[gi] >> tp) & 1u) ? raw[gi][tp] : 0.f;
+#ifdef GPVGG_STAMP
+      VSEG(4);
+#endif
+      // ---- phase 2: conv1_1 on the matrix pipe, + bias, ReLU, -> bf16 rows of conv1_2's A images ----
+#pragma unroll
+      for (int gi = 0; gi < MAXG; ++gi) {
+        const int grp = slot_group(gi);
+        if (grp >= NGRP) break;                                             // (wave-uniform)
+        const int hp = grp * 32 + li;
+        const bool exists = hp < HALO_PX;
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int Y = oy0 - 1 + hy, X = ox0 - 1 + hx;
         unsigned hi[9], lo[9];
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
-          hi[tp] = xcvt_pk_bf16(pv[tp], 0.f) & 0xFFFFu;
-          lo[tp] = xcvt_pk_bf16(pv[tp] - xbf_lo(hi[tp]), 0.f) & 0xFFFFu;
+          hi[tp] = xcvt_pk_bf16(pvs[gi][tp], 0.f) & 0xFFFFu;
+          lo[tp] = xcvt_pk_bf16(pvs[gi][tp] - xbf_lo(hi[tp]), 0.f) & 0xFFFFu;
         }
         bf16x8 f0, f1;
 #pragma unroll
@@ -381,6 +450,7 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         const bool inside = exists && Y >= 0 && Y < P.H && X >= 0 && X < P.W;        // else: conv1_2's zero padding
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
+          if (!slot_does(gi, ct)) continue;                                 // (wave-uniform: the second slot is one cout tile of a shared group)
           f32x16 d;
 #pragma unroll
           for (int r = 0; r < 16; ++r) d[r] = 0.f;
@@ -401,13 +471,21 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         }
       }
     };
-    if (NWI > 0) produce(0);
+    if (NWI > 0) { fetch(0); convert(0); }
+    if (NWI > 1) fetch(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     end_interval();                                                       // weights, constants and item 0 are in LDS
+    VSEG(3);
     for (int i = 0; i <= NWI; ++i) {
-      if (i + 1 < NWI && !(P.dbg == 1 && i >= 2)) produce(i + 1);
+      if (i + 1 < NWI && !(P.dbg == 1 && i >= 2)) {
+        convert(i + 1);                                                   // windows fetched during the previous interval
+        VSEG(1);
+        if (i + 2 < NWI) fetch(i + 2);
+      }
       end_interval();
+      VSEG(2);
     }
+    VSEG_FLUSH;
     return;
   }
 
@@ -426,7 +504,9 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
   auto b2 = [&](int nt, int r) -> float { return cst[64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]; };       // conv1_2 bias (LDS)
   unsigned pa[2][8];                      // relu1_2 features of the prior image at this lane's pixel, packed bf16 pairs
   float dot = 0.f, na = 0.f, nb = 0.f;
+  VSEG_DECL;
   for (int i = 0; i <= NWI; ++i) {
+    VSEG(3);
     if (i < NWI) {
       f32x16 acc[2];
 #pragma unroll
@@ -454,6 +534,7 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
           for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st & 1][nt], fa[st & 1], acc[nt], 0, 0, 0);
         }
       }
+      VSEG(0);
       if ((i & 1) == 0) {                 // prior image: keep a = relu(conv1_2 + bias) as bf16 (what the layered path stores in HBM)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -484,6 +565,7 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         }
       }
     }
+    VSEG(1);
     if (i >= 4 && (i & 3) == 0 && tid < 2) {          // finish the super-tile whose last item ran in the previous interval
       int img, oy0, ox0, tx, ty;
       item_geo(i - 4, img, oy0, ox0, tx, ty);
@@ -494,7 +576,9 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         P.out[((long long)img * (P.H / 16) + ty) * (P.W / 16) + pxx] = d / (fmaxf(sqrtf(x), 1e-12f) * fmaxf(sqrtf(y), 1e-12f));   // F.normalize eps
     }
     end_interval();
+    VSEG(2);
   }
+  VSEG_FLUSH;
 }
 
 }  // namespace gpemsr
@@ -512,6 +596,7 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
   P.ref = ref_img; P.lr = lr; P.n = n; P.H = H; P.W = W; P.h = h; P.w = w;
   P.sh = (float)((double)h / (double)H); P.sw = (float)((double)w / (double)W);
   P.w1 = w1; P.b1 = b1; P.w2 = reinterpret_cast<const unsigned short*>(w2_bf16); P.b2 = b2; P.out = out;
+  P.hr2 = scale == 1 ? 1 : 0;
   P.tiles_x = cdiv(W, 32); P.tiles_y = H / 16;
   const long long ns = (long long)n * P.tiles_x * P.tiles_y;
   GP_REQUIRE(ns < (1ll << 31), "vgg_mask_bf16: grid too large");
@@ -546,3 +631,9 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
   hipLaunchKernelGGL(vgg_mask_kernel, dim3(grid), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), P);
   return check_launch("vgg_mask_kernel");
 }
+
+#ifdef GPVGG_STAMP
+extern "C" int gpemsr_debug_read_vstamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gpemsr::g_vstamps), sizeof(unsigned long long) * 256 * 16 * 8);
+}
+#endif

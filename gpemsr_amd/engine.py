@@ -452,6 +452,11 @@ class Engine:
             self.par["vgg.w1"] = w.sum(dim=1).reshape(w.shape[0], 9).contiguous().to(self.dev)      # 3 identical input channels
             self.par["vgg.b1"] = self.sd["vgg.slice1.0.bias"].detach().to(torch.float32).contiguous().to(self.dev)
         pc2 = self.pc["vgg.slice1.2"]
+        if os.environ.get("GPEMSR_VGG_UPLR", "1") != "0":
+            # the LR slice is up-sampled ONCE (gpemsr_bilinear, fp32 1-channel: 4 MB per slice) and the fused kernel reads both images the
+            # same way; resampling it on the fly inside the kernel's producer waves cost 4 ms per step (round 3, in-kernel stamps)
+            up = self.o.bilinear(xf, self.scale * xf.h, self.scale * xf.w)
+            return self.o.vgg_mask_bf16(ref_img, up, 1, self.par["vgg.w1"], self.par["vgg.b1"], pc2.wb, pc2.b)
         return self.o.vgg_mask_bf16(ref_img, xf, self.scale, self.par["vgg.w1"], self.par["vgg.b1"], pc2.wb, pc2.b)
 
     # ------------------------------------------------------------------ per-frame front half

@@ -238,7 +238,9 @@ int gpemsr_copy_channels_f32_bf16(const float* src, int src_ld, void* dst, int d
  * channels; w1 = conv1_1 weights summed over the input channels, [64][9], tap = 3*ky + kx), and the cosine similarity of their
  * co-located 16x16x64 patches -> out [n][s*h/16][s*w/16].  conv1_1 runs with fp32-accurate inputs (hi + lo bf16 halves), conv1_2
  * with bf16 operands (w2_bf16 = vgg.slice1.2 in the staged order of gpemsr_conv2d_bf16), fp32 accumulation and reduction.
- * Neither feature map nor the up-sampled image touches HBM. */
+ * Neither feature map touches HBM.  scale == 1: `lr` is already at the HR size (up-sampled once by gpemsr_bilinear: 4 MB per slice) and both
+ * images are read the same way -- the form the engine uses; scale > 1 resamples the LR slice on the fly inside the kernel (no up-sampled
+ * image in HBM, but 36 loads + ~250 vector operations per halo-pixel group: 4 ms slower per step at batch 16). */
 int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n, int h, int w, int scale, const float* w1, const float* b1,
                          const void* w2_bf16, const float* b2, float* out, void* stream);
 /* gpemsr_conv2d_stem1 with bf16 output (cout % 8 == 0); gpemsr_conv2d_direct with fp32 or bf16 input / output (fp32 packed

@@ -509,6 +509,11 @@ def test_vgg_mask_fused_matches_the_layered_form(n, h, w, scale):
     _close(got.nchw(), want, 2e-3, "fused vgg mask")
     again = ops.vgg_mask_bf16(A(ref), A(lr), scale, w1.sum(dim=1).reshape(64, 9).contiguous().to(dev), b1.to(dev), pack_conv_bf16(w2, dev), b2.to(dev))
     assert torch.equal(got.buf, again.buf)
+    # the form the engine uses since round 3: the LR slice up-sampled once by gpemsr_bilinear, both images read the same way (scale = 1)
+    up = ops.bilinear(A(lr), H, W)
+    got2 = ops.vgg_mask_bf16(A(ref), up, 1, w1.sum(dim=1).reshape(64, 9).contiguous().to(dev), b1.to(dev), pack_conv_bf16(w2, dev), b2.to(dev))
+    _close(got2.nchw(), want, 2e-3, "fused vgg mask, pre-up-sampled LR")
+    _close(got2.nchw(), got.nchw(), 2e-4, "both forms")
 
 
 @pytest.mark.parametrize("n,h,w,ld,off", [(2, 16, 24, 64, 0), (1, 37, 131, 96, 16), (3, 5, 62, 64, 0), (1, 70, 63, 64, 0)])
