@@ -329,6 +329,30 @@ def test_bf16_data_path_against_the_reference_golden(tag, golden_dir):
     assert (idx[safe] == d["code_idx"][safe]).all() and agree > 0.9
 
 
+@pytest.mark.parametrize("h,w,route", [(96, 96, "flash"), (16, 577, "three launches, 9232-column softmax"), (64, 64, "flash"), (12, 20, "three launches"),
+                                       (10, 10, "fp32 ragged")])
+def test_bf16_nonlocal_block_every_route_incl_more_than_8192_tokens(h, w, route):
+    """the bf16 NonLocalBlock used to fail above 8192 latent tokens (x8 at LR 192x192 -> 96x96 = 9216, x16 at LR
+    128x128 -> 16384).  Every route the engine can take -- the flash kernel (tokens % 128 == 0, any count), the three-launch form
+    (tokens % 16 == 0, rows up to 16384 columns), the zero-padded fp32 fallback -- against the exact-fp32 engine's block on the same
+    weights and input (bf16 intermediates: 2e-2 bar, R:model/blocks.py:61-83)."""
+    from gpemsr_amd import ops
+    m16, m32 = _pmodel(8, "bf16"), _model(8)
+    dev = torch.device("cuda", 0)
+    e16, e32 = m16._get_engine(dev), m32._get_engine(dev)
+    T = h * w
+    taken = "flash" if (T % 128 == 0) else ("three" if (T % 16 == 0 and T <= e16.BF16_SOFTMAX_MAX_COLS) else "fp32")
+    assert route.startswith(taken)
+    g = torch.Generator().manual_seed(31)
+    x = (torch.rand(1, h, w, 512, generator=g) * 2 - 1).to(dev)
+    p = "refmodel.decoder.feat_extract.0"
+    want = e32.nonlocal_block(ops.from_nhwc(x.contiguous()), p).torch().float().reshape(1, h, w, 512)
+    got = e16.nonlocal_block(ops.cast_bf16(ops.from_nhwc(x.contiguous())), p).torch().float().reshape(1, h, w, 512)
+    torch.cuda.synchronize()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert torch.isfinite(got).all() and err <= 2e-2, f"{route}: rel err {err:.3e}"
+
+
 @pytest.mark.parametrize("scale,h,w", [(8, 24, 40), (16, 20, 20), (8, 20, 20), (8, 12, 28)])
 def test_bf16_path_with_latent_tokens_not_multiple_of_16(scale, h, w):
     """precision='bf16' on tile sizes whose latent token count the bf16 attention tiles cannot take (x8 24x40 -> 240 tokens is
