@@ -34,7 +34,7 @@ SYMBOLS = [
     # stage-2 (indexer) training step
     "gpemsr_groupnorm_bwd", "gpemsr_softmax_bwd_rows", "gpemsr_cross_entropy",
     # bf16 data path
-    "gpemsr_conv2d_bf16", "gpemsr_conv2d_bf16_gn_parts", "gpemsr_conv2d_bf16_axf_ok", "gpemsr_groupnorm_scale_shift", "gpemsr_pack_rows_bf16_ex", "gpemsr_flash_attention_bf16", "gpemsr_maxpool2_bf16", "gpemsr_groupnorm_stats_bf16", "gpemsr_groupnorm_finish", "gpemsr_groupnorm_apply_bf16",
+    "gpemsr_conv2d_bf16", "gpemsr_conv2d_bf16_gn_parts", "gpemsr_conv2d_bf16_axf_ok", "gpemsr_groupnorm_scale_shift", "gpemsr_pack_rows_bf16_ex", "gpemsr_flash_attention_bf16", "gpemsr_maxpool2_bf16", "gpemsr_im2col4", "gpemsr_col2im4", "gpemsr_lrelu_slope", "gpemsr_lrelu_slope_bwd", "gpemsr_sum_scaled", "gpemsr_instnorm_bwd_bwd", "gpemsr_groupnorm_stats_bf16", "gpemsr_groupnorm_finish", "gpemsr_groupnorm_apply_bf16",
     "gpemsr_softmax_rows_bf16", "gpemsr_gather_rows_bf16", "gpemsr_pack_rows_bf16", "gpemsr_cast_f32_bf16", "gpemsr_cast_bf16_f32",
     "gpemsr_bilinear_bf16", "gpemsr_pool3s2_maxavg_bf16", "gpemsr_spynet_prep_bf16", "gpemsr_dcn_columns_bf16", "gpemsr_patch_cosine_bf16",
     "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
@@ -171,6 +171,12 @@ def load():
     lib.gpemsr_softmax_rows_bf16.argtypes = [p, i32, i64, i32, i32, p, i32, p]
     lib.gpemsr_gather_rows_bf16.argtypes = [p, i32, p, i64, p, i32, p]
     lib.gpemsr_pack_rows_bf16.argtypes = [p, i32, i32, i32, i32, i64, p, p]
+    lib.gpemsr_im2col4.argtypes = [p, i32, i32, i32, i32, i32, i32, p, i32, p]
+    lib.gpemsr_col2im4.argtypes = [p, i32, i32, i32, i32, i32, i32, p, i32, i32, p]
+    lib.gpemsr_lrelu_slope.argtypes = [p, i64, f32, p, p]
+    lib.gpemsr_lrelu_slope_bwd.argtypes = [p, p, i64, f32, p, i32, p]
+    lib.gpemsr_sum_scaled.argtypes = [p, i64, f32, i32, p, i32, p]
+    lib.gpemsr_instnorm_bwd_bwd.argtypes = [p, p, p, p, i32, i32, i32, p, p, i32, p]
     lib.gpemsr_maxpool2_bf16.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
     lib.gpemsr_pack_rows_bf16_ex.argtypes = [p, i32, i32, i32, i32, i64, p, i32, p]
     lib.gpemsr_flash_attention_bf16.argtypes = [p, i32, p, p, p, i32, i32, i32, p, i32, p]

@@ -1161,3 +1161,91 @@ def vgg_mask_bf16(ref_img: Act, lr: Act, scale: int, w1: torch.Tensor, b1: torch
     else:
         _go()
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# adversarial phase of stage-1 training (csrc/stage1_adv.hip): PatchGAN discriminator pieces, fp32 NHWC
+# ----------------------------------------------------------------------------------------------------------------------
+def im2col4(x: Act, stride: int, kp: int) -> Act:
+    """Conv2d(k4, stride, padding 0) columns: [n][oh][ow][kp], k = (ky*4 + kx)*c + ci, zero padded to kp."""
+    assert not x.bf16
+    oh, ow = (x.h - 4) // stride + 1, (x.w - 4) // stride + 1
+    col = new_act(x.n, oh, ow, kp, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_im2col4(x.ptr, x.n, x.h, x.w, x.c, x.ld, stride, col.ptr, kp, _stream()), "im2col4")
+    return col
+
+
+def col2im4(dcol: Act, h: int, w: int, c: int, stride: int, dx: Act, accumulate: bool):
+    assert (dx.n, dx.h, dx.w, dx.c) == (dcol.n, h, w, c) and dcol.ld == dcol.c
+    _abi.check(_abi.load().gpemsr_col2im4(dcol.ptr, dcol.n, h, w, c, stride, dcol.c, dx.ptr, dx.ld, int(accumulate), _stream()), "col2im4")
+
+
+def lrelu_slope(x: Act, slope: float) -> Act:
+    assert x.ld == x.c
+    y = new_act(x.n, x.h, x.w, x.c, device=x.buf.device)
+    _abi.check(_abi.load().gpemsr_lrelu_slope(x.ptr, x.pixels * x.c, float(slope), y.ptr, _stream()), "lrelu_slope")
+    return y
+
+
+def lrelu_slope_bwd(dy: Act, y: Act, slope: float, dx: Optional[Act] = None, accumulate: bool = False) -> Act:
+    assert dy.ld == dy.c and y.ld == y.c
+    if dx is None:
+        dx = new_act(y.n, y.h, y.w, y.c, device=y.buf.device)
+    _abi.check(_abi.load().gpemsr_lrelu_slope_bwd(dy.ptr, y.ptr, y.pixels * y.c, float(slope), dx.ptr, int(accumulate), _stream()), "lrelu_slope_bwd")
+    return dx
+
+
+def sum_scaled(x: torch.Tensor, scale: float, square: bool = False, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[0] (+)= scale * sum(x) or scale * sum(x^2) (one workgroup, fixed order)."""
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _abi.check(_abi.load().gpemsr_sum_scaled(x.data_ptr(), x.numel(), float(scale), int(square), out.data_ptr(), int(accumulate), _stream()), "sum_scaled")
+    return out
+
+
+def instnorm(x: Act, eps: float = 1e-5):
+    """nn.InstanceNorm2d(c) (no affine): -> (normalised Act, mean_rstd [n][c][2])."""
+    lib = _abi.load()
+    assert not x.bf16 and x.ld == x.c
+    hw, c, dev = x.h * x.w, x.c, x.buf.device
+    parts = max(1, min(64, hw // 64))
+    ws = torch.empty(x.n * parts * c * 2, dtype=torch.float32, device=dev)
+    mr = torch.empty(x.n * c * 2, dtype=torch.float32, device=dev)
+    _abi.check(lib.gpemsr_groupnorm_stats(x.ptr, x.n, hw, c, x.ld, c, float(eps), ws.data_ptr(), parts, mr.data_ptr(), _stream()), "groupnorm_stats")
+    one, zero = _const_vec(c, 1.0, dev), _const_vec(c, 0.0, dev)
+    out = new_act(x.n, x.h, x.w, c, device=dev)
+    _abi.check(lib.gpemsr_groupnorm_apply(x.ptr, x.n, hw, c, x.ld, c, mr.data_ptr(), one.data_ptr(), zero.data_ptr(), 0, None, 0, out.ptr, out.ld, _stream()),
+               "groupnorm_apply")
+    return out, mr
+
+
+def instnorm_bwd(x: Act, mr: torch.Tensor, dy: Act) -> Act:
+    """dx of nn.InstanceNorm2d given its input, forward statistics and dy."""
+    lib = _abi.load()
+    hw, c, dev = x.h * x.w, x.c, x.buf.device
+    parts = max(1, min(64, hw // 64))
+    w2 = _workspace(x.n * parts * c * 2 + x.n * c * 2 + x.n * c * 2, dev)
+    dx = new_act(x.n, x.h, x.w, c, device=dev, zero=True)
+    one, zero = _const_vec(c, 1.0, dev), _const_vec(c, 0.0, dev)
+    _abi.check(lib.gpemsr_groupnorm_bwd(x.ptr, x.ld, dy.ptr, dy.ld, x.n, hw, c, c, mr.data_ptr(), one.data_ptr(), zero.data_ptr(), 0, w2.data_ptr(), w2.numel(),
+                                        dx.ptr, dx.ld, None, None, _stream()), "groupnorm_bwd")
+    return dx
+
+
+def instnorm_bwd_bwd(x: Act, mr: torch.Tensor, dy: Act, g: Act, gx: Act, accumulate_gx: bool) -> Act:
+    """Second-order terms of nn.InstanceNorm2d: returns gdy = dL/d(dy); gx (+)= dL/dx (csrc/stage1_adv.hip)."""
+    gdy = new_act(x.n, x.h, x.w, x.c, device=x.buf.device)
+    assert x.ld == x.c and dy.ld == x.c and g.ld == x.c and gx.ld == x.c
+    _abi.check(_abi.load().gpemsr_instnorm_bwd_bwd(x.ptr, dy.ptr, g.ptr, mr.data_ptr(), x.n, x.h * x.w, x.c, gx.ptr, gdy.ptr, int(accumulate_gx), _stream()),
+               "instnorm_bwd_bwd")
+    return gdy
+
+
+_CONST_VECS = {}
+
+
+def _const_vec(c: int, v: float, dev) -> torch.Tensor:
+    key = (c, v, str(dev))
+    if key not in _CONST_VECS:
+        _CONST_VECS[key] = torch.full((c,), v, dtype=torch.float32, device=dev)
+    return _CONST_VECS[key]

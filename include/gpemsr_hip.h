@@ -478,6 +478,26 @@ int gpemsr_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int cols, v
 int gpemsr_cross_entropy(const float* logits, const int32_t* target, int64_t rows, int cols, float grad_scale, float* row_loss,
                          float* loss, float* dlogits, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Adversarial phase of stage-1 training (R:train_stage1.py:300-345; PatchGAN discriminator R:model/discriminator.py:9-32).  fp32 NHWC.
+ * ------------------------------------------------------------------------- */
+/* nn.Conv2d(k = 4, stride 1 | 2, padding 0) as a GEMM: col[(n*oh + oy)*ow + ox][kp], k = (ky*4 + kx)*c + ci, zero for 16c <= k < kp;
+ * oh = (h - 4)/stride + 1.  The product with W2[cout][k] is gpemsr_conv2d's 1x1 form, the weight gradient gpemsr_conv2d_wgrad's. */
+int gpemsr_im2col4(const float* x, int n, int h, int w, int c, int ld, int stride, float* col, int kp, void* stream);
+/* its adjoint: dx[n][iy][ix][ci] (+)= sum of the column-gradient entries that read that pixel (gather form, deterministic) */
+int gpemsr_col2im4(const float* dcol, int n, int h, int w, int c, int stride, int kp, float* dx, int dx_ld, int accumulate, void* stream);
+/* nn.LeakyReLU(slope) and its backward from the activation's OUTPUT: dx (+)= dy * (y > 0 ? 1 : slope) */
+int gpemsr_lrelu_slope(const float* x, int64_t count, float slope, float* y, void* stream);
+int gpemsr_lrelu_slope_bwd(const float* dy, const float* y, int64_t count, float slope, float* dx, int accumulate, void* stream);
+/* out[0] (+)= scale * sum(x) (square = 0) or scale * sum(x^2) (square = 1): torch.mean / the R1 penalty's sum of squares; one workgroup */
+int gpemsr_sum_scaled(const float* x, int64_t count, float scale, int square, float* out, int accumulate, void* stream);
+/* Second-order terms of nn.InstanceNorm2d (no affine) for the R1 penalty (torch.autograd.grad(..., create_graph=True) through the
+ * discriminator, R:train_stage1.py:360-372): x the layer input [n][hw][c], mean_rstd [n][c][2] its forward statistics
+ * (gpemsr_groupnorm_stats with groups = c), dy the gradient that entered the layer's backward, g = dL/d(dx) the gradient arriving at that
+ * backward's RESULT -> gdy = dL/d(dy), gx (+)= dL/dx.  Formulas in csrc/stage1_adv.hip. */
+int gpemsr_instnorm_bwd_bwd(const float* x, const float* dy, const float* g, const float* mean_rstd, int n, int hw, int c, float* gx, float* gdy,
+                            int accumulate_gx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
