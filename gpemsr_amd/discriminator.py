@@ -181,11 +181,11 @@ class DiscEngine:
             gw[f"model.{idx}.bias"].add_(db[:cout])
 
     # -- R1 penalty ------------------------------------------------------------------------------------------------------
-    def r1_penalty(self, x: Act, scale: float, gw: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def r1_penalty(self, x: Act, scale: float, gw: Dict[str, torch.Tensor], fwd=None) -> torch.Tensor:
         """penalty = mean_b sum_pixels (d sum(D(x)) / dx)^2 (R:train_stage1.py:360-372); gw += d(scale * penalty)/d(weights).  Returns the
-        penalty (device scalar)."""
+        penalty (device scalar).  ``fwd``: (output, saved activations) of a forward pass over the same x, to reuse."""
         B = x.n
-        out, saved = self.forward(x, save=True)
+        out, saved = fwd if fwd is not None else self.forward(x, save=True)
         ones = ops.new_act(out.n, out.h, out.w, out.c, device=self.dev, zero=True)
         ones.torch().view(-1, out.c)[:, 0] = 1.0                             # d sum(D) / d D: channel 0 only (1-3 are padding)
         keep: list = []
@@ -209,8 +209,7 @@ class DiscEngine:
             G = ops.lrelu_slope_bwd(gdn, rec["y"], SLOPE) if lrelu else gdn     # the mask is its own adjoint
         # (b) ordinary backward from the forward-input gradients of the InstanceNorm layers
         if extra:
-            top = max(extra)
-            self.backward(saved[:top + 1], None, False, gw, extra_dz=extra) if False else self._backward_from(saved, extra, gw)
+            self._backward_from(saved, extra, gw)
         return penalty
 
     def _backward_from(self, saved, extra: dict, gw):

@@ -142,3 +142,32 @@ def test_oracle_contextual_loss_matches_reference_golden(golden_dir):
         rec, ref_loss, u = orc.stage3_losses(sd, T("t_sr"), T("t_ref_img"), T("t_gt"))
         assert abs(float(rec) - float(d["t_rec_loss"])) <= 1e-7
         assert abs(float(ref_loss) - float(d["t_ref_loss"])) <= 1e-5 and np.allclose(u.numpy(), d["t_u"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,step", [("15", 15), ("16f", 16)])
+def test_discriminator_oracle_reproduces_the_reference_adversarial_step(tag, step, golden_dir):
+    """oracle/disc_oracle.py against the UNMODIFIED reference's ``train_vqgan_onestep`` (tests/golden/stage1_adv.npz): the losses it logged
+    and the gradient it left in every discriminator tensor (step 16: with the R1 penalty), from the same initial weights."""
+    from oracle import disc_oracle as do
+    from gpemsr_amd.discriminator import Discriminator
+    from train_constants import projection
+    d = _load(golden_dir, "stage1_adv")
+    ic, nf, nl = [int(v) for v in d["disc_args"]]
+    init = Discriminator(dict(im_channel=ic, num_filters_last=nf, n_layers=nl), init_seed=0).state_dict()      # seeded initial weights only
+    disc = do.DiscOracle(init, ic, nf, nl)
+    opt = [float(v) for v in d["train_opt"]]
+    imgs, decoded = torch.from_numpy(d["imgs"]), torch.from_numpy(d[f"decoded_{tag}"])
+    g_loss, _ = do.generator_gan_term(disc, decoded)
+    assert abs(g_loss.item() - float(d[f"g_loss_{tag}"])) <= 2e-5 * abs(float(d[f"g_loss_{tag}"]))
+    out = do.discriminator_losses(disc, imgs, decoded, step, r1_reg_weight=opt[7], net_d_reg_every=int(opt[8]))
+    for k in ("d_loss_real", "d_loss_fake"):
+        assert abs(out[k] - float(d[f"{k}_{tag}"])) <= 2e-5 * abs(float(d[f"{k}_{tag}"])), k
+    if step % int(opt[8]) == 0:
+        assert abs(out["r1_loss"] - float(d[f"r1_{tag}"])) <= 1e-4 * float(d[f"r1_{tag}"])
+    for i, k in enumerate(str(n) for n in d["d_names"]):
+        want, g = d[f"d_grad_stats_{tag}"][i], disc.grad(k).reshape(-1)
+        if want[0] <= 1e-9:
+            assert float(g.abs().max()) <= 1e-9, k
+            continue
+        err = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
+        assert err <= 2e-4, (k, err)

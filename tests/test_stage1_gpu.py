@@ -83,6 +83,6 @@ def test_two_generator_steps_match_the_reference_golden(golden_dir):
         gsd = tr.generator_state_dict()
         for k in [f[len(f"param{step}__"):] for f in d.files if f.startswith(f"param{step}__")]:
             _close(gsd[k].reshape(d[f"param{step}__" + k].shape), torch.from_numpy(d[f"param{step}__" + k]), 1e-3 if step == 1 else 5e-3, f"step {step} {k}")
-    tr.step_count = 40000
-    with pytest.raises(NotImplementedError):
+    tr.current_step = 40000                                             # the adversarial phase needs a discriminator (test_stage1_adv_gpu.py)
+    with pytest.raises(RuntimeError, match="discriminator"):
         tr.forward_backward(imgs)
