@@ -62,12 +62,13 @@ def parse_args(argv=None):
     ap.add_argument("--extras", type=str, default="bf16", help="comma list of precisions measured beside the official fp32 number")
     ap.add_argument("--cpu-lr", type=int, default=128, help="LR size of the CPU-oracle sample tile")
     ap.add_argument("--layer-report", type=str, default="", help="write a per-layer conv timing table to this file")
-    ap.add_argument("--mode", type=str, default="forward", choices=("forward", "train", "train2"),
+    ap.add_argument("--mode", type=str, default="forward", choices=("forward", "train", "train2", "train1"),
                     help="forward = BASELINE configs[1]/[2]/[3] (the headline metric, default); train = configs[4], the stage-3 "
                          "training step; train2 = the stage-2 (indexer) training step")
     ap.add_argument("--no-profile", action="store_true", help="--mode train: no per-launch HIP events (roofline fields become 0)")
     ap.add_argument("--train-batch", type=int, default=8, help="--mode train: samples per GPU per step")
     ap.add_argument("--stage2-lr", type=int, default=128, help="--mode train2: LR size (GT is scale x larger)")
+    ap.add_argument("--stage1-size", type=int, default=512, help="--mode train1: crop size (option/train_stage1.yml GT_size)")
     ap.add_argument("--train-lr", type=int, default=32, help="--mode train: LR crop size (option/train_stage3_x8.yml LQ_size)")
     ap.add_argument("--backend", type=str, default="", help="torch.distributed backend (default: nccl = RCCL on GPUs)")
     ap.add_argument("--stub", action="store_true",
@@ -496,6 +497,10 @@ def main(argv=None) -> int:
     if args.mode == "train2":
         import bench_train
         bench_train.run_stage2(args, ROOT, effective_cores)
+        return 0
+    if args.mode == "train1":
+        import bench_train
+        bench_train.run_stage1(args, ROOT, effective_cores)
         return 0
     return run_forward(args)
 

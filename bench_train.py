@@ -267,3 +267,101 @@ def run_stage2(args, root: str, effective_cores):
             "cpu_baseline": cpu_baseline}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def run_stage1(args, root: str, effective_cores):
+    """`bench.py --mode train1`: the stage-1 (VQGAN) training step, train_stage1.py:291-357, at the reference's geometry
+    (option/train_stage1.yml: batch 8, 512x512 crops), same timing protocol.  `value` = the ADVERSARIAL phase (current_step > gan_start:
+    generator step with the GAN term + discriminator step, R1 penalty every net_d_reg_every = 16 steps; the timed steps are whole
+    16-step cycles so that exactly 1/16 of them carry the penalty); the generator phase (the first 40,000 steps) is in `extras`."""
+    from gpemsr_amd import dist as gdist, ops
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.discriminator import Discriminator
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train_stage1 import Stage1Trainer
+
+    rank, world, local = gdist.init_from_env(backend=getattr(args, "backend", "") or None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
+    if os.environ.get("GPEMSR_BENCH_SHARE_GPU") == "1":
+        local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    opt = load_options(os.path.join(root, "option", "output_GPEMSR_x8.yml"))
+    model = build_model(opt, load_prior_files=False).to(dev)
+    # option/train_stage1.yml train: block
+    topt = dict(lr_G=1e-4, lr_D=4e-4, beta1=0.9, beta2=0.99, T_period=[40000, 80000, 120000, 120000, 120000], restarts=[40000, 120000, 240000, 360000],
+                restart_weights=[1, 1, 1, 1], eta_min=1e-7, rec_loss_factor=1.0, codebook_loss_factor=1.0, gan_start=40000, gan_loss_factor=0.05,
+                generator_update_rate=1, r1_reg_weight=1e-4, net_d_reg_every=16)
+    disc = Discriminator(dict(im_channel=1, num_filters_last=64, n_layers=3), init_seed=0).to(dev)
+    trainer = Stage1Trainer(model, topt, dev, beta=1.0, world=world, discriminator=disc)
+    B, size = args.train_batch, args.stage1_size
+    imgs = synth_lr_tiles(B, 1, size, size, seed=6000 + rank, kind="smooth")[:, 0].contiguous().to(dev)
+
+    def timed(first_step, steps):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            o = trainer.step(imgs, current_step=first_step + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, o
+
+    for i in range(args.warmup):
+        trainer.step(imgs, current_step=1 + i)
+    gsteps = max(args.steps // 2, 1)
+    gdt, go = timed(100, gsteps)                                                         # generator phase
+    for i in range(max(args.warmup, 1)):
+        trainer.step(imgs, current_step=40016 + i)                                       # warm the discriminator kernels, incl. one R1 step
+    cycles = max(1, (args.steps + 15) // 16)
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = None if args.no_profile else prof
+    dt, o = timed(40033, 16 * cycles)                                                    # 40048 % 16 == 0: one R1 step per 16
+    ops.PROFILER = None
+    steps = 16 * cycles
+    summ = prof.summary()
+    fam = {k: summ.get(k, {"launches": 0, "ms": 0.0, "flops": 0.0}) for k in ("conv_mfma", "conv_wgrad")}
+    flops, ms = sum(v["flops"] for v in fam.values()), sum(v["ms"] for v in fam.values())
+    launches = sum(v["launches"] for v in fam.values())
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    def tf(d):
+        return round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2) if d["ms"] > 0 else 0.0
+    if args.layer_report and rank == 0:
+        rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
+        with open(args.layer_report, "w") as f:
+            f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\n")
+            for (kern, tag), d in rows:
+                f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{tf(d)}\n")
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"stage-1 (VQGAN) training samples/sec, adversarial phase, {size}x{size} crops, batch {B}/GPU",
+            "value": round(world * B * steps / dt, 3), "unit": "samples/s", "n_gpus": world,
+            "rccl_world": torch.distributed.get_world_size() if world > 1 else 1, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"stage-1 training step (train_stage1.py:291-357), current_step > gan_start: Encoder -> Codebook -> Decoder, L1 + codebook "
+                                   f"loss + 0.05 * mean(-D(decoded)), backward, Adam (G); 0.5 * (mean(-D(imgs)) + mean(D(decoded))) backward, R1 penalty "
+                                   f"(gradient of a gradient) on 1 step in 16, Adam (D); batch {B}/GPU, {size}x{size} (option/train_stage1.yml geometry)",
+                       "batch_per_gpu": B, "size": size, "trainable_parameters": trainer.n_params,
+                       "discriminator_parameters": sum(p.numel() for p in disc.parameters()),
+                       "parallelism": f"data parallel over {world} GPU(s), RCCL all-reduce of the two flat gradient buffers" if world > 1 else "single GPU"},
+            "losses_last_step": {k: float(v.item()) for k, v in o.items() if hasattr(v, "item")},
+            "roofline": {"bound": "mfma", "kernel": "f32 MFMA convolution family (forward incl. attention and discriminator GEMMs, data gradients, wgrad_kernel)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None, "launches_per_step": launches // max(steps, 1),
+                         "forward_and_dgrad_tflops": tf(fam["conv_mfma"]), "wgrad_tflops": tf(fam["conv_wgrad"]),
+                         "kernel_time_share_of_step": round(ms * 1e-3 / dt, 3)},
+            "extras": {"generator_phase": {"value": round(world * B * gsteps / gdt, 3), "unit": "samples/s", "ms_per_step": round(1e3 * gdt / gsteps, 2),
+                                           "steps": gsteps, "what": "current_step <= gan_start (train_stage1.py:313-326): no discriminator"}},
+            "cpu_baseline": None}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
