@@ -41,11 +41,18 @@ __device__ unsigned long long g_xstamps[8 * 65536];
 #define XSEG_DECL unsigned long long xs_t = __builtin_amdgcn_s_memtime(), xs_acc[6] = {0, 0, 0, 0, 0, 0}
 #define XSEG(k) do { const unsigned long long xs_n = __builtin_amdgcn_s_memtime(); xs_acc[k] += xs_n - xs_t; xs_t = xs_n; } while (0)
 #define XSEG_FLUSH do { if (threadIdx.x == 0 && blockIdx.x < 65536) { for (int k = 0; k < 6; ++k) g_xstamps[8 * blockIdx.x + k] = xs_acc[k]; g_xstamps[8 * blockIdx.x + 6] = T_me; } } while (0)
+// resident2's loader wave 8 (thread 512): 0 issue | 1 wait for the DMA to land | 2 barrier; rows 1024 + blockIdx.x
+#define R2L_DECL unsigned long long r2_t = __builtin_amdgcn_s_memtime(), r2_acc[3] = {0, 0, 0}
+#define R2L(k) do { const unsigned long long r2_n = __builtin_amdgcn_s_memtime(); r2_acc[k] += r2_n - r2_t; r2_t = r2_n; } while (0)
+#define R2L_FLUSH do { if (threadIdx.x == 512 && blockIdx.x < 1024) { for (int k = 0; k < 3; ++k) g_xstamps[8 * (1024 + blockIdx.x) + k] = r2_acc[k]; g_xstamps[8 * (1024 + blockIdx.x) + 6] = NI; } } while (0)
 #else
 #define XST(i)
 #define XSEG_DECL
 #define XSEG(k)
 #define XSEG_FLUSH
+#define R2L_DECL
+#define R2L(k)
+#define R2L_FLUSH
 #endif
 
 constexpr int XA_LOADS = 10;      // 16-B A slots per DMA thread (halo_px * R / DMA threads; 3x3 16x32 tile on 4 loader waves: 10)
@@ -82,6 +89,7 @@ struct XParams {
   int nblocks;
   int nbias;                                 // true output channels (bias entries)
   int gpt, ns;                               // resident kernel: workgroups per cout slab, spatial tiles
+  int dbg;                                   // diagnostic builds (-DGP16_STAMP) only: descriptor.variant (101: no MFMA loop, 102: no epilogue)
   const float* axs; const float* axh;        // AXF kernels: per (image, input channel) scale / shift applied to the source while it is staged
   int ax_relu;                               // ... followed by ReLU
 };
@@ -1043,11 +1051,13 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
 // a tile spends 42 % of its time in the MFMA stages, 26 % waiting for halo images, 8 % issuing them and 24 % in the epilogue
 // (store-throughput bound: 64 KB of results per tile) -- one after the other, because all eight waves are in the same phase.
 // Here a 768-thread workgroup holds TWO groups of four multiplying waves (one wave per SIMD each) and four loader waves:
-//   * group g walks its own stream of 8 x 32-pixel tiles in three intervals per tile -- chunk 0, chunk 1, epilogue -- and
-//     group 1 runs one interval behind group 0, so in every interval at least one group feeds the matrix pipe while the other
-//     stores its results:  (C0 | E) (C1 | C0) (E | C1) ...  One workgroup-wide barrier ends each interval.
+//   * group g walks its own stream of 8 x 32-pixel tiles in FOUR intervals per tile -- chunk 0, chunk 1, epilogue of the wave's first
+//     pixel row, epilogue of its second -- and group 1 runs two intervals behind group 0:  (C0 | Ea) (C1 | Eb) (Ea | C0) (Eb | C1) ...
+//     In every interval exactly one group feeds the matrix pipe while the other stores half of its results.  One workgroup-wide
+//     barrier ends each interval.  (Round 3's stamps of the three-interval form (C0 | E) (C1 | C0) (E | C1): a whole epilogue took 1.9x
+//     a chunk's MFMAs, so two of three intervals were epilogue-long and the third had both groups queueing for the matrix pipe.)
 //   * the loader waves issue the halo images (10 x 34 pixels x 32 channels, two buffers per group) for tile k + 1 as soon as
-//     the barrier has freed a buffer -- three intervals before it is needed -- and absorb the DMA issue stalls and the waits.
+//     the barrier has freed a buffer -- four intervals before it is needed -- and absorb the DMA issue stalls and the waits.
 // LDS: weights 73,728 + 4 x 21,760 + bias <= 163,840 bytes.
 // AXF: the halo images are staged through the loader waves' registers and get the per-(image, channel) affine map + ReLU of a folded
 // GroupNorm apply on the way (see conv_bf16_kernel): loads go out one interval before the transformed image is written, two before
@@ -1071,7 +1081,7 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   const int gpt = P.gpt, NS = P.ns;
   const int T_me = (NS - sg + gpt - 1) / gpt;          // 8 x 32 tiles of this workgroup: tile j = 2 k + g goes to group g
   const int T0 = (T_me + 1) / 2, T1 = T_me / 2;
-  const int NI = (3 * T0 > 3 * T1 + 1) ? 3 * T0 : 3 * T1 + 1;      // intervals (T1 <= T0 <= T1 + 1)
+  const int NI = (4 * T0 > 4 * T1 + 2) ? 4 * T0 : 4 * T1 + 2;      // intervals (T1 <= T0 <= T1 + 1)
 
   x_stage_bias(P, bias_lds, P.nbias, 768);
 
@@ -1174,12 +1184,12 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     end_interval();
     for (int i = 0; i < NI; ++i) {
       write(0); write(1);                                // images loaded during the previous interval; read from the next one on
-      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-g) % 3 of its tile (i-1-g) / 3 in interval i-1
+      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-2g) % 4 of its tile (i-1-2g) / 4 in interval i-1
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int u = i - 1 - g;
+        const int u = i - 1 - 2 * g;
         if (u >= 0) {
-          const int k = u / 3, c = u - 3 * k;
+          const int k = u >> 2, c = u & 3;
           if (c < 2 && k + 1 < (g ? T1 : T0)) {
             if (c == 0) { enter(g, k + 1); load(g, 0); } else load(g, 1);
           }
@@ -1252,31 +1262,36 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     if (T1 > 0) { enter(1, 0); issue(1, 0); issue(1, 1); }
     xwait_vmcnt(issued - mark[0][0]);
     end_interval();
+    R2L_DECL;
     for (int i = 0; i < NI; ++i) {
-      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-g) % 3 of its tile (i-1-g) / 3 in interval i-1
+      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-2g) % 4 of its tile (i-1-2g) / 4 in interval i-1
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int u = i - 1 - g;
+        const int u = i - 1 - 2 * g;
         if (u >= 0) {
-          const int k = u / 3, c = u - 3 * k;
+          const int k = u >> 2, c = u & 3;
           if (c < 2 && k + 1 < (g ? T1 : T0)) {
             if (c == 0) { enter(g, k + 1); issue(g, 0); } else issue(g, 1);
           }
         }
       }
+      R2L(0);
       // the images interval i + 1 reads must have landed
       int need = 0;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int u = i + 1 - g;
+        const int u = i + 1 - 2 * g;
         if (u >= 0) {
-          const int k = u / 3, c = u - 3 * k;
+          const int k = u >> 2, c = u & 3;
           if (c < 2 && k < (g ? T1 : T0)) { const int m = c ? mark[g][1] : mark[g][0]; need = m > need ? m : need; }
         }
       }
       xwait_vmcnt(issued - need);
+      R2L(1);
       end_interval();
+      R2L(2);
     }
+    R2L_FLUSH;
     return;
   }
 
@@ -1296,7 +1311,8 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   const unsigned b_frag = (unsigned)(li * 16 + lh * 1024);
 
   end_interval();                                      // prologue barrier (weights + first image have landed)
-  for (int s = 0; s < g; ++s) end_interval();          // group 1 runs one interval behind
+  for (int s = 0; s < 2 * g; ++s) end_interval();      // group 1 runs two intervals behind
+  XSEG_DECL;
   for (int k = 0; k < T_g; ++k) {
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -1338,10 +1354,26 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     // have -- the spill reloads then sit behind the epilogue's own stores on the in-order vmcnt (measured: 1.35x slower)
     int li2 = li, lh2 = lh;
     asm volatile("" : "+v"(li2), "+v"(lh2));
-    x_epilogue<MT, NT, false, false, LEAN, true>(P, geo, acc, w4 * 64, 0, geo.tile_in_img * 4 + w4, bias_lds, li2, lh2);
+#ifdef GP16_STAMP
+    if (P.dbg == 102) { XSEG(5); end_interval(); XSEG(4); XSEG(5); end_interval(); XSEG(4); continue; }
+#endif
+    if (P.gn_ws) {                                       // (GroupNorm partial sums run over both pixel rows of the wave: one piece)
+      x_epilogue<MT, NT, false, false, LEAN, true>(P, geo, acc, w4 * 64, 0, geo.tile_in_img * 4 + w4, bias_lds, li2, lh2);
+      end_interval();
+    } else {
+      x_epilogue<1, NT, false, false, LEAN, true>(P, geo, reinterpret_cast<f32x16 (&)[1][NT]>(acc[0]), w4 * 64, 0, 0, bias_lds, li2, lh2);
+      XSEG(5);
+      end_interval();
+      XSEG(4);
+      asm volatile("" : "+v"(li2), "+v"(lh2));
+      x_epilogue<1, NT, false, false, LEAN, true>(P, geo, reinterpret_cast<f32x16 (&)[1][NT]>(acc[1]), w4 * 64 + 32, 0, 0, bias_lds, li2, lh2);
+    }
+    XSEG(5);
     end_interval();
+    XSEG(4);
   }
-  for (int s = 3 * T_g + g; s < NI; ++s) end_interval();
+  XSEG_FLUSH;
+  for (int s = 4 * T_g + 2 * g; s < NI; ++s) end_interval();
 }
 
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false>
@@ -1609,6 +1641,7 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (gpt < 1) gpt = 1;
     if (gpt > P.ns) gpt = P.ns;
     P.gpt = gpt;
+    P.dbg = d->variant;
     if (L.res_form == 2) {
       if (L.axf) hipLaunchKernelGGL((conv64_resident2_kernel<true, true>), dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
       else if (L.lean) hipLaunchKernelGGL(conv64_resident2_kernel<true>, dim3(gpt * P.tiles_n), dim3(768), lds, st, P);
