@@ -1046,6 +1046,130 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
   XSEG_FLUSH;
 }
 
+// conv64_resident2_kernel's LEAN epilogue for one pixel row of a wave (32 pixels x 64 couts, the bias already inside the
+// accumulators): stamps showed the general x_epilogue costing as many issue cycles as the tile's MFMAs (~700 vector instructions
+// per wave and tile), and on one SIMD the other group's pending MFMA and these instructions take turns.  Here: pack to bf16 FIRST,
+// ReLU as a packed signed-integer max, half-wave swaps on packed pairs, one address per pixel with immediate offsets
+// (PACKED: 8 cvt + 8 max + 4 swaps + 2 stores per 32 x 32 accumulator tile instead of ~125).  Residual / per-pixel multiplier /
+// LeakyReLU layers keep fp32 arithmetic (PACKED = false); their loads go out before the first store (in-order vmcnt).
+template <int NT, bool PACKED>
+__device__ __forceinline__ void r2_store_row(const XParams& P, const XGeo& g, f32x16 (&acc)[NT], int pix_base, int li, int lh) {
+  const int p = pix_base + li;
+  const int oy = g.oy0 + (p >> 5), ox = g.ox0 + (p & 31);
+  const bool pok = oy < P.oh && ox < P.ow;
+  const long long opl = (long long)g.img * P.OH * P.OW + (long long)oy * P.OW + ox;
+  unsigned short* const op = reinterpret_cast<unsigned short*>(P.out) + opl * P.out_ld + g.n0 + 8 * lh;
+  if (PACKED) {
+    const bool relu = P.act == GPEMSR_ACT_RELU;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      unsigned pk[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pk[q][0] = xcvt_pk_bf16(acc[nt][4 * q], acc[nt][4 * q + 1]);
+        pk[q][1] = xcvt_pk_bf16(acc[nt][4 * q + 2], acc[nt][4 * q + 3]);
+      }
+      if (relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) asm("v_pk_max_i16 %0, %1, 0" : "=v"(pk[q][j]) : "v"(pk[q][j]));      // bf16 sign bit = int16 sign bit
+      }
+#pragma unroll
+      for (int gp = 0; gp < 4; gp += 2) {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[gp][0], pk[gp + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[gp][1], pk[gp + 1][1], false, false);
+        if (pok) *reinterpret_cast<uint4*>(op + nt * 32 + 8 * gp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+    }
+  } else {
+    const unsigned short* const rp = reinterpret_cast<const unsigned short*>(P.residual) + opl * P.res_ld + g.n0 + 8 * lh;
+    uint4 rpre[NT][2];
+    float mpre = 1.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const bool use = P.residual != nullptr && pok;                       // branch-free: see x_epilogue_stores
+        const unsigned short* ap = use ? rp + nt * 32 + 16 * h2 : P.weight;
+        uint4 u = *reinterpret_cast<const uint4*>(ap);
+        if (!use) u = make_uint4(0u, 0u, 0u, 0u);
+        rpre[nt][h2] = u;
+      }
+    {
+      const bool usem = P.pixmul != nullptr && pok;
+      const float mv = *(usem ? P.pixmul + opl : reinterpret_cast<const float*>(P.weight));
+      mpre = usem ? mv : 1.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[nt][r];
+      if (P.act == GPEMSR_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (P.act == GPEMSR_ACT_LRELU) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.1f * v[r]);
+      }
+#pragma unroll
+      for (int gp = 0; gp < 4; gp += 2) {
+        float w8[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * gp + j]), __float_as_uint(v[4 * gp + 4 + j]), false, false);
+          w8[j] = __uint_as_float(sw[0]); w8[4 + j] = __uint_as_float(sw[1]);
+        }
+        const uint4 u = rpre[nt][gp >> 1];
+        w8[0] += xbf_lo(u.x); w8[1] += xbf_hi(u.x); w8[2] += xbf_lo(u.y); w8[3] += xbf_hi(u.y);
+        w8[4] += xbf_lo(u.z); w8[5] += xbf_hi(u.z); w8[6] += xbf_lo(u.w); w8[7] += xbf_hi(u.w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w8[k] *= mpre;
+        if (pok) *reinterpret_cast<uint4*>(op + nt * 32 + 8 * gp) =
+            make_uint4(xcvt_pk_bf16(w8[0], w8[1]), xcvt_pk_bf16(w8[2], w8[3]), xcvt_pk_bf16(w8[4], w8[5]), xcvt_pk_bf16(w8[6], w8[7]));
+      }
+    }
+  }
+}
+
+// conv64_resident2_kernel's k loop, software-pipelined BY HAND.  Only one wave of a SIMD multiplies at a time there, so nothing but the
+// wave's own reads-ahead can cover the LDS latency; hipcc folds a source-level double buffer back into ONE fragment set and every
+// MFMA then waits for a read issued one or two MFMAs earlier (stamps: 46 instead of ~32 clocks per MFMA, with or without
+// sched_group_barrier).  All reads and MFMAs of a chunk are asm volatile (program order = issue order): the fragments of step st + 2
+// are requested before the MFMAs of step st, three register sets rotate, and the waits count what may still be in flight.
+template <int ST>
+__device__ __forceinline__ void r2_reads(bf16x8 (&fa)[2], bf16x8 (&fb)[2], const unsigned (&arow)[4][3], unsigned bbase) {
+  constexpr int tap = ST >> 1, ks = ST & 1;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const unsigned o = arow[mt + tap / 3][tap % 3];
+    const unsigned ad = ks ? (o ^ 32u) : o;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[mt]) : "v"(ad));
+  }
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0]) : "v"(bbase), "n"((tap * 4 + 2 * ks) * 1024));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1]) : "v"(bbase), "n"((tap * 4 + 2 * ks) * 1024 + 512));
+}
+template <int ST>
+__device__ __forceinline__ void r2_steps(f32x16 (&acc)[2][2], bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2], const unsigned (&arow)[4][3], unsigned bbase) {
+  if constexpr (ST < 18) {
+    if constexpr (ST + 2 < 18) {
+      r2_reads<ST + 2>(fa[(ST + 2) % 3], fb[(ST + 2) % 3], arow, bbase);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    } else if constexpr (ST + 1 < 18) {
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    constexpr int c = ST % 3;
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][0]) : "v"(fb[c][0]), "v"(fa[c][0]));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][0]) : "v"(fb[c][0]), "v"(fa[c][1]));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][1]) : "v"(fb[c][1]), "v"(fa[c][0]));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][1]) : "v"(fb[c][1]), "v"(fa[c][1]));
+    r2_steps<ST + 1>(acc, fa, fb, arow, bbase);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The same layer (3x3, stride 1, 64 input channels, weights resident) with its phases OVERLAPPED.  Stamps of the kernel above:
 // a tile spends 42 % of its time in the MFMA stages, 26 % waiting for halo images, 8 % issuing them and 24 % in the epilogue
@@ -1054,8 +1178,9 @@ __global__ __launch_bounds__(512, 2) void conv64_resident_kernel(XParams P) {
 //   * group g walks its own stream of 8 x 32-pixel tiles in FOUR intervals per tile -- chunk 0, chunk 1, epilogue of the wave's first
 //     pixel row, epilogue of its second -- and group 1 runs two intervals behind group 0:  (C0 | Ea) (C1 | Eb) (Ea | C0) (Eb | C1) ...
 //     In every interval exactly one group feeds the matrix pipe while the other stores half of its results.  One workgroup-wide
-//     barrier ends each interval.  (Round 3's stamps of the three-interval form (C0 | E) (C1 | C0) (E | C1): a whole epilogue took 1.9x
-//     a chunk's MFMAs, so two of three intervals were epilogue-long and the third had both groups queueing for the matrix pipe.)
+//     barrier ends each interval.  (Round 3's stamps of the three-interval form (C0 | E) (C1 | C0) (E | C1) with the general epilogue: a
+//     whole epilogue took 1.9x a chunk's MFMAs, so two of three intervals were epilogue-long.  With r2_store_row the epilogue is a
+//     quarter of that and both forms measure the same; -DR2_IV=3 builds the three-interval one.)
 //   * the loader waves issue the halo images (10 x 34 pixels x 32 channels, two buffers per group) for tile k + 1 as soon as
 //     the barrier has freed a buffer -- four intervals before it is needed -- and absorb the DMA issue stalls and the waits.
 // LDS: weights 73,728 + 4 x 21,760 + bias <= 163,840 bytes.
@@ -1081,7 +1206,12 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   const int gpt = P.gpt, NS = P.ns;
   const int T_me = (NS - sg + gpt - 1) / gpt;          // 8 x 32 tiles of this workgroup: tile j = 2 k + g goes to group g
   const int T0 = (T_me + 1) / 2, T1 = T_me / 2;
-  const int NI = (4 * T0 > 4 * T1 + 2) ? 4 * T0 : 4 * T1 + 2;      // intervals (T1 <= T0 <= T1 + 1)
+  // IV intervals per tile, group 1 DL intervals behind group 0: (3, 1) = (C0 | E) (C1 | C0) (E | C1); (4, 2) = (C0 | Ea) (C1 | Eb) (Ea | C0) (Eb | C1)
+#ifndef R2_IV
+#define R2_IV 4
+#endif
+  constexpr int IV = R2_IV, DL = IV == 4 ? 2 : 1;
+  const int NI = (IV * T0 > IV * T1 + DL) ? IV * T0 : IV * T1 + DL;      // intervals (T1 <= T0 <= T1 + 1)
 
   x_stage_bias(P, bias_lds, P.nbias, 768);
 
@@ -1184,12 +1314,12 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     end_interval();
     for (int i = 0; i < NI; ++i) {
       write(0); write(1);                                // images loaded during the previous interval; read from the next one on
-      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-2g) % 4 of its tile (i-1-2g) / 4 in interval i-1
+      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-DL g) % IV of its tile (i-1-DL g) / IV in interval i-1
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int u = i - 1 - 2 * g;
+        const int u = i - 1 - DL * g;
         if (u >= 0) {
-          const int k = u >> 2, c = u & 3;
+          const int k = u / IV, c = u - IV * k;
           if (c < 2 && k + 1 < (g ? T1 : T0)) {
             if (c == 0) { enter(g, k + 1); load(g, 0); } else load(g, 1);
           }
@@ -1264,12 +1394,15 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     end_interval();
     R2L_DECL;
     for (int i = 0; i < NI; ++i) {
-      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-2g) % 4 of its tile (i-1-2g) / 4 in interval i-1
+      // refill the buffers the last barrier freed: group g multiplied chunk (i-1-DL g) % IV of its tile (i-1-DL g) / IV in interval i-1
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int u = i - 1 - 2 * g;
+        const int u = i - 1 - DL * g;
         if (u >= 0) {
-          const int k = u >> 2, c = u & 3;
+          const int k = u / IV, c = u - IV * k;
+#ifdef GP16_STAMP
+          if (P.dbg == 103 || P.dbg == 104) continue;   // diagnostic: no refills (stale images; timing only)
+#endif
           if (c < 2 && k + 1 < (g ? T1 : T0)) {
             if (c == 0) { enter(g, k + 1); issue(g, 0); } else issue(g, 1);
           }
@@ -1280,9 +1413,9 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
       int need = 0;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int u = i + 1 - 2 * g;
+        const int u = i + 1 - DL * g;
         if (u >= 0) {
-          const int k = u >> 2, c = u & 3;
+          const int k = u / IV, c = u - IV * k;
           if (c < 2 && k < (g ? T1 : T0)) { const int m = c ? mark[g][1] : mark[g][0]; need = m > need ? m : need; }
         }
       }
@@ -1311,42 +1444,46 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   const unsigned b_frag = (unsigned)(li * 16 + lh * 1024);
 
   end_interval();                                      // prologue barrier (weights + first image have landed)
-  for (int s = 0; s < 2 * g; ++s) end_interval();      // group 1 runs two intervals behind
+  for (int s = 0; s < DL * g; ++s) end_interval();     // group 1 runs DL intervals behind
   XSEG_DECL;
   for (int k = 0; k < T_g; ++k) {
-    f32x16 acc[MT][NT];
+    f32x16 acc[MT][NT];                                  // start from the bias (zeros when the layer has none: x_stage_bias)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int q = 0; q < 4; ++q) {
+        int bi = n0 + nt * 32 + 8 * q + 4 * lh;              // (couts past the end of a ragged slab: any valid entry, never stored)
+        bi = bi < P.nbias ? bi : 0;
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + bi);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        for (int mt = 0; mt < MT; ++mt) { acc[mt][nt][4 * q] = b4.x; acc[mt][nt][4 * q + 1] = b4.y; acc[mt][nt][4 * q + 2] = b4.z; acc[mt][nt][4 * q + 3] = b4.w; }
+      }
 #pragma unroll 1
     for (int chunk = 0; chunk < 2; ++chunk) {
       const unsigned A = (unsigned)(chunk * A_BYTES);
       const unsigned B = b_frag + (unsigned)(chunk * (9 * 4 * 1024));
-      bf16x8 fa[2][MT], fb[2][NT];
-      auto load_step = [&](int set, int st) {
-        const int tap = st >> 1, ks = st & 1;
+      unsigned arow[MT + 2][3];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const unsigned o = aoff[mt + tap / 3][tap % 3];
-          fa[set][mt] = xlds_read16(xsm_lds + A + (ks ? (o ^ 32u) : o));
-        }
+      for (int rr = 0; rr < MT + 2; ++rr)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fb[set][nt] = xlds_read16(xsm_lds + B + (unsigned)((tap * 4 + 2 * ks) * 1024 + nt * 512));
-      };
-      load_step(0, 0);
-#pragma unroll
-      for (int st = 0; st < 18; ++st) {
-        if (st + 1 < 18) load_step((st + 1) & 1, st + 1);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[st & 1][nt], fa[st & 1][mt], acc[mt][nt], 0, 0, 0);
+        for (int kx = 0; kx < 3; ++kx) arow[rr][kx] = xsm_lds + A + aoff[rr][kx];
+      const unsigned bbase = xsm_lds + B;
+      bf16x8 fa[3][MT], fb[3][NT];
+#ifdef GP16_STAMP
+      if (P.dbg != 101) {
+#endif
+      r2_reads<0>(fa[0], fb[0], arow, bbase);
+      r2_reads<1>(fa[1], fb[1], arow, bbase);
+      asm volatile("s_nop 4" ::: "memory");              // (VALU-written accumulators -> first MFMA: the hazard recognizer does not see into asm)
+      r2_steps<0>(acc, fa, fb, arow, bbase);
+      // (the accumulators were written by asm: the compiler does not know that VALU reads of them need the matrix pipe drained)
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef GP16_STAMP
       }
+#endif
+      XSEG(2);
       end_interval();
+      XSEG(3);
     }
     const XGeo geo = tile_geo(2 * k + g);
     // opaque per-tile copies of the lane coordinates: everything the epilogue derives from them (8 store addresses, residual
@@ -1355,25 +1492,38 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
     int li2 = li, lh2 = lh;
     asm volatile("" : "+v"(li2), "+v"(lh2));
 #ifdef GP16_STAMP
-    if (P.dbg == 102) { XSEG(5); end_interval(); XSEG(4); XSEG(5); end_interval(); XSEG(4); continue; }
+    if (P.dbg == 102 || P.dbg == 104) { XSEG(5); end_interval(); XSEG(4); XSEG(5); end_interval(); XSEG(4); continue; }
 #endif
-    if (P.gn_ws) {                                       // (GroupNorm partial sums run over both pixel rows of the wave: one piece)
-      x_epilogue<MT, NT, false, false, LEAN, true>(P, geo, acc, w4 * 64, 0, geo.tile_in_img * 4 + w4, bias_lds, li2, lh2);
-      end_interval();
-    } else {
-      x_epilogue<1, NT, false, false, LEAN, true>(P, geo, reinterpret_cast<f32x16 (&)[1][NT]>(acc[0]), w4 * 64, 0, 0, bias_lds, li2, lh2);
-      XSEG(5);
-      end_interval();
-      XSEG(4);
+    if (P.gn_ws || !LEAN || P.cout - n0 < 64) {          // general epilogue, in one piece (the bias is in the accumulators already)
+      XParams Q = P;
+      Q.bias = nullptr;
+      x_epilogue<MT, NT, false, false, LEAN, true>(Q, geo, acc, w4 * 64, 0, geo.tile_in_img * 4 + w4, bias_lds, li2, lh2);
+      if (IV == 4) end_interval();
+    } else if (P.residual || P.pixmul || P.act == GPEMSR_ACT_LRELU) {
+      r2_store_row<NT, false>(P, geo, acc[0], w4 * 64, li2, lh2);
+      if (IV == 4) {
+        XSEG(5);
+        end_interval();
+        XSEG(4);
+      }
       asm volatile("" : "+v"(li2), "+v"(lh2));
-      x_epilogue<1, NT, false, false, LEAN, true>(P, geo, reinterpret_cast<f32x16 (&)[1][NT]>(acc[1]), w4 * 64 + 32, 0, 0, bias_lds, li2, lh2);
+      r2_store_row<NT, false>(P, geo, acc[1], w4 * 64 + 32, li2, lh2);
+    } else {
+      r2_store_row<NT, true>(P, geo, acc[0], w4 * 64, li2, lh2);
+      if (IV == 4) {
+        XSEG(5);
+        end_interval();
+        XSEG(4);
+      }
+      asm volatile("" : "+v"(li2), "+v"(lh2));
+      r2_store_row<NT, true>(P, geo, acc[1], w4 * 64 + 32, li2, lh2);
     }
     XSEG(5);
     end_interval();
     XSEG(4);
   }
   XSEG_FLUSH;
-  for (int s = 4 * T_g + 2 * g; s < NI; ++s) end_interval();
+  for (int s = IV * T_g + DL * g; s < NI; ++s) end_interval();
 }
 
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false>

@@ -20,8 +20,8 @@ dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(0)
 lib = _abi.load()
 lib.gpemsr_debug_read_xstamps.argtypes = [C.c_void_p, C.c_int]
-VAR = {"relu-nomfma": 101, "relu-noepi": 102}
-for (n, h, w, mode) in ((80, 512, 512, "relu"), (80, 512, 512, "relu-nomfma"), (80, 512, 512, "relu-noepi"), (80, 512, 512, "residual"), (80, 512, 512, "gn"), (80, 128, 128, "relu")):
+VAR = {"relu-nomfma": 101, "relu-noepi": 102, "relu-noload": 103, "relu-noload-noepi": 104}
+for (n, h, w, mode) in ((80, 512, 512, "relu"), (80, 512, 512, "relu-nomfma"), (80, 512, 512, "relu-noepi"), (80, 512, 512, "relu-noload"), (80, 512, 512, "relu-noload-noepi"), (80, 512, 512, "residual"), (80, 512, 512, "gn"), (80, 128, 128, "relu")):
     wt = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / (64 * 9) ** 0.5
     pc = pack_conv(wt, torch.rand(64), dev)
     pc.wb = pack_conv_bf16(wt, dev)
