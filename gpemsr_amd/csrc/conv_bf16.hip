@@ -160,8 +160,9 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
     // bf16 FIRST, ReLU as a packed signed-integer max (bf16 sign bit = int16 sign bit), half-wave swaps on packed pairs, one output
     // address per pixel -- 16 + 8 + 8 + 4 vector instructions per 32 x 32 accumulator tile instead of ~125 (stamps of the
     // weights-resident kernel: the general form cost as many issue cycles as a 64-channel tile's MFMAs)
-    if (LEAN && !CONVT && PRE != 1 && P.residual == nullptr && P.pixmul == nullptr && P.act != GPEMSR_ACT_LRELU) {
-      const int opix = GEMM ? ox : oy * P.OW + ox;
+    if (LEAN && PRE != 1 && P.residual == nullptr && P.pixmul == nullptr && P.act != GPEMSR_ACT_LRELU) {
+      // (transposed convolution: an accumulator tile's 32 rows are 32 channels of ONE output phase q = (row >> 5) & 3 of a 128-row block)
+      const int opix = GEMM ? ox : (CONVT ? 2 * oy * P.OW + 2 * ox : oy * P.OW + ox);
       unsigned short* const op = reinterpret_cast<unsigned short*>(P.out) + (img_pix0 + opix) * P.out_ld;
       const bool relu = P.act == GPEMSR_ACT_RELU;
 #pragma unroll
@@ -172,7 +173,8 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
         for (int q = 0; q < 4; ++q) {
           float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
           const int c0 = cb0 + 8 * q + 4 * lh;
-          if (P.bias && c0 < P.cout) b4 = *reinterpret_cast<const float4*>(bias_lds + c0);
+          const int bc = CONVT ? (c0 >> 7) * 32 + (c0 & 31) : c0;
+          if (P.bias && c0 < P.cout) b4 = *reinterpret_cast<const float4*>(bias_lds + bc);
           pk[q][0] = xcvt_pk_bf16(acc[mt][nt][4 * q] + b4.x, acc[mt][nt][4 * q + 1] + b4.y);
           pk[q][1] = xcvt_pk_bf16(acc[mt][nt][4 * q + 2] + b4.z, acc[mt][nt][4 * q + 3] + b4.w);
         }
@@ -187,7 +189,9 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
           const auto s0 = __builtin_amdgcn_permlane32_swap(pk[gp][0], pk[gp + 1][0], false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(pk[gp][1], pk[gp + 1][1], false, false);
           const int nidx = cb0 + 8 * (gp + lh);
-          if (pok && nidx < P.cout) *reinterpret_cast<uint4*>(op + nidx) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          long long off = nidx;
+          if (CONVT) { const int ph = (nidx & 127) >> 5; off = (long long)((ph >> 1) * P.OW + (ph & 1)) * P.out_ld + (nidx >> 7) * 32 + (nidx & 31); }
+          if (pok && nidx < P.cout) *reinterpret_cast<uint4*>(op + off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
       }
       continue;
