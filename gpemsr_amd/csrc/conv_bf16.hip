@@ -126,6 +126,21 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
   if (LEAN && PRE == 2) { P.residual = nullptr; P.pixmul = nullptr; }
   const long long img_pix0 = (long long)g.img * P.OH * P.OW;
   const bool up = P.store_mode == XS_PIXSHUF || P.store_mode == XS_CONVT;
+  // packed fast path (below): its bias values, ALL requested before the first use (one LDS round trip per wave and tile, not one
+  // per four channels; reads are branch-free)
+  const bool packed = LEAN && PRE != 1 && P.residual == nullptr && P.pixmul == nullptr && P.act != GPEMSR_ACT_LRELU;
+  float4 bpre[NT][4];
+  if (packed) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = g.n0 + cout_base + nt * 32 + 8 * q + 4 * lh;
+        const int bc = CONVT ? (c0 >> 7) * 32 + (c0 & 31) : c0;
+        bpre[nt][q] = *reinterpret_cast<const float4*>(bias_lds + (c0 < P.cout ? bc : 0));
+        if (!P.bias) bpre[nt][q] = make_float4(0.f, 0.f, 0.f, 0.f);     // (uniform; a caller may have folded the bias into the accumulators)
+      }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = pix_base + mt * 32 + li;
@@ -160,7 +175,7 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
     // bf16 FIRST, ReLU as a packed signed-integer max (bf16 sign bit = int16 sign bit), half-wave swaps on packed pairs, one output
     // address per pixel -- 16 + 8 + 8 + 4 vector instructions per 32 x 32 accumulator tile instead of ~125 (stamps of the
     // weights-resident kernel: the general form cost as many issue cycles as a 64-channel tile's MFMAs)
-    if (LEAN && PRE != 1 && P.residual == nullptr && P.pixmul == nullptr && P.act != GPEMSR_ACT_LRELU) {
+    if (packed) {
       // (transposed convolution: an accumulator tile's 32 rows are 32 channels of ONE output phase q = (row >> 5) & 3 of a 128-row block)
       const int opix = GEMM ? ox : (CONVT ? 2 * oy * P.OW + 2 * ox : oy * P.OW + ox);
       unsigned short* const op = reinterpret_cast<unsigned short*>(P.out) + (img_pix0 + opix) * P.out_ld;
@@ -171,10 +186,7 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
         unsigned pk[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          const int c0 = cb0 + 8 * q + 4 * lh;
-          const int bc = CONVT ? (c0 >> 7) * 32 + (c0 & 31) : c0;
-          if (P.bias && c0 < P.cout) b4 = *reinterpret_cast<const float4*>(bias_lds + bc);
+          const float4 b4 = bpre[nt][q];
           pk[q][0] = xcvt_pk_bf16(acc[mt][nt][4 * q] + b4.x, acc[mt][nt][4 * q + 1] + b4.y);
           pk[q][1] = xcvt_pk_bf16(acc[mt][nt][4 * q + 2] + b4.z, acc[mt][nt][4 * q + 3] + b4.w);
         }
