@@ -388,6 +388,43 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
   for (int i = threadIdx.x; i < npad; i += nthreads) bias_lds[i] = (P.bias && i < nbias) ? P.bias[i] : 0.f;
 }
 
+// conv64_resident2_kernel's k loop, software-pipelined BY HAND.  Only one wave of a SIMD multiplies at a time there, so nothing but the
+// wave's own reads-ahead can cover the LDS latency; hipcc folds a source-level double buffer back into ONE fragment set and every
+// MFMA then waits for a read issued one or two MFMAs earlier (stamps: 46 instead of ~32 clocks per MFMA, with or without
+// sched_group_barrier).  All reads and MFMAs of a chunk are asm volatile (program order = issue order): the fragments of step st + 2
+// are requested before the MFMAs of step st, three register sets rotate, and the waits count what may still be in flight.
+template <int ST, typename TA>
+__device__ __forceinline__ void r2_reads(bf16x8 (&fa)[2], bf16x8 (&fb)[2], const TA (&arow)[4][3], unsigned abase, unsigned bbase) {
+  constexpr int tap = ST >> 1, ks = ST & 1;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const unsigned o = (unsigned)arow[mt + tap / 3][tap % 3];
+    const unsigned ad = abase + (ks ? (o ^ 32u) : o);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[mt]) : "v"(ad));
+  }
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0]) : "v"(bbase), "n"((tap * 4 + 2 * ks) * 1024));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1]) : "v"(bbase), "n"((tap * 4 + 2 * ks) * 1024 + 512));
+}
+template <int ST, typename TA>
+__device__ __forceinline__ void r2_steps(f32x16 (&acc)[2][2], bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2], const TA (&arow)[4][3], unsigned abase, unsigned bbase) {
+  if constexpr (ST < 18) {
+    if constexpr (ST + 2 < 18) {
+      r2_reads<ST + 2>(fa[(ST + 2) % 3], fb[(ST + 2) % 3], arow, abase, bbase);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    } else if constexpr (ST + 1 < 18) {
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    constexpr int c = ST % 3;
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][0]) : "v"(fb[c][0]), "v"(fa[c][0]));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][0]) : "v"(fb[c][0]), "v"(fa[c][1]));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][1]) : "v"(fb[c][1]), "v"(fa[c][0]));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][1]) : "v"(fb[c][1]), "v"(fa[c][1]));
+    r2_steps<ST + 1>(acc, fa, fb, arow, abase, bbase);
+  }
+}
+
 // CK: channels per chunk (32; 16 for sources that are odd multiples of 16).  TPS: taps per stage.  CONVT / GEMM: see above.
 // Filter width and stride follow from the instantiation: GEMM -> 1x1, CONVT -> 2x2 taps, TPS == 7 -> 7x7, TH == 2 -> 3x3 stride 2.
 //
@@ -829,6 +866,9 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
       const unsigned A = xsm_lds + (TABLE ? 0u : (unsigned)(a_slot * A_BYTES));
       const unsigned B = xsm_lds + (unsigned)(n_abuf * A_BYTES + b_slot * B_BYTES + b_frag);
       const int tap0 = grp * TPS;
+      // (The hand-pipelined asm loop of the weights-resident kernel -- r2_steps, same fragment geometry -- was tried here for the wide
+      // 3x3 tile: the step went from 109.3 to 115.9 ms.  With two multiplying waves per SIMD the other wave already covers the LDS
+      // latency, and three fragment sets do not fit this kernel's 168-register budget beside its address tables.)
       bf16x8 fa[2][MT], fb[2][NT];
       if (!TABLE) {                                    // 7x7: a stage is filter row ky = grp
 #pragma unroll
@@ -1185,43 +1225,6 @@ __device__ __forceinline__ void r2_store_row(const XParams& P, const XGeo& g, f3
   }
 }
 
-// conv64_resident2_kernel's k loop, software-pipelined BY HAND.  Only one wave of a SIMD multiplies at a time there, so nothing but the
-// wave's own reads-ahead can cover the LDS latency; hipcc folds a source-level double buffer back into ONE fragment set and every
-// MFMA then waits for a read issued one or two MFMAs earlier (stamps: 46 instead of ~32 clocks per MFMA, with or without
-// sched_group_barrier).  All reads and MFMAs of a chunk are asm volatile (program order = issue order): the fragments of step st + 2
-// are requested before the MFMAs of step st, three register sets rotate, and the waits count what may still be in flight.
-template <int ST>
-__device__ __forceinline__ void r2_reads(bf16x8 (&fa)[2], bf16x8 (&fb)[2], const unsigned (&arow)[4][3], unsigned bbase) {
-  constexpr int tap = ST >> 1, ks = ST & 1;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const unsigned o = arow[mt + tap / 3][tap % 3];
-    const unsigned ad = ks ? (o ^ 32u) : o;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[mt]) : "v"(ad));
-  }
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0]) : "v"(bbase), "n"((tap * 4 + 2 * ks) * 1024));
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1]) : "v"(bbase), "n"((tap * 4 + 2 * ks) * 1024 + 512));
-}
-template <int ST>
-__device__ __forceinline__ void r2_steps(f32x16 (&acc)[2][2], bf16x8 (&fa)[3][2], bf16x8 (&fb)[3][2], const unsigned (&arow)[4][3], unsigned bbase) {
-  if constexpr (ST < 18) {
-    if constexpr (ST + 2 < 18) {
-      r2_reads<ST + 2>(fa[(ST + 2) % 3], fb[(ST + 2) % 3], arow, bbase);
-      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    } else if constexpr (ST + 1 < 18) {
-      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    constexpr int c = ST % 3;
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][0]) : "v"(fb[c][0]), "v"(fa[c][0]));
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][0]) : "v"(fb[c][0]), "v"(fa[c][1]));
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][1]) : "v"(fb[c][1]), "v"(fa[c][0]));
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][1]) : "v"(fb[c][1]), "v"(fa[c][1]));
-    r2_steps<ST + 1>(acc, fa, fb, arow, bbase);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // The same layer (3x3, stride 1, 64 input channels, weights resident) with its phases OVERLAPPED.  Stamps of the kernel above:
 // a tile spends 42 % of its time in the MFMA stages, 26 % waiting for halo images, 8 % issuing them and 24 % in the epilogue
@@ -1524,10 +1527,10 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
 #ifdef GP16_STAMP
       if (P.dbg != 101) {
 #endif
-      r2_reads<0>(fa[0], fb[0], arow, bbase);
-      r2_reads<1>(fa[1], fb[1], arow, bbase);
+      r2_reads<0>(fa[0], fb[0], arow, 0u, bbase);
+      r2_reads<1>(fa[1], fb[1], arow, 0u, bbase);
       asm volatile("s_nop 4" ::: "memory");              // (VALU-written accumulators -> first MFMA: the hazard recognizer does not see into asm)
-      r2_steps<0>(acc, fa, fb, arow, bbase);
+      r2_steps<0>(acc, fa, fb, arow, 0u, bbase);
       // (the accumulators were written by asm: the compiler does not know that VALU reads of them need the matrix pipe drained)
       asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #ifdef GP16_STAMP
