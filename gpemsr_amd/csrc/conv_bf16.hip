@@ -129,17 +129,20 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
   // packed fast path (below): its bias values, ALL requested before the first use (one LDS round trip per wave and tile, not one
   // per four channels; reads are branch-free)
   const bool packed = LEAN && PRE != 1 && P.residual == nullptr && P.pixmul == nullptr && P.act != GPEMSR_ACT_LRELU;
-  float4 bpre[NT][4];
-  if (packed) {
+  constexpr bool HOIST_ALL = NT <= 2;          // (four accumulator tiles per wave, the transposed form: 64 registers of bias spill)
+  float4 bpre[HOIST_ALL ? NT : 1][4];
+  auto bias_of = [&](int nt, int q) -> float4 {
+    const int c0 = g.n0 + cout_base + nt * 32 + 8 * q + 4 * lh;
+    const int bc = CONVT ? (c0 >> 7) * 32 + (c0 & 31) : c0;
+    float4 b = *reinterpret_cast<const float4*>(bias_lds + (c0 < P.cout ? bc : 0));
+    if (!P.bias) b = make_float4(0.f, 0.f, 0.f, 0.f);                    // (uniform; a caller may have folded the bias into the accumulators)
+    return b;
+  };
+  if (packed && HOIST_ALL) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < (HOIST_ALL ? NT : 1); ++nt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = g.n0 + cout_base + nt * 32 + 8 * q + 4 * lh;
-        const int bc = CONVT ? (c0 >> 7) * 32 + (c0 & 31) : c0;
-        bpre[nt][q] = *reinterpret_cast<const float4*>(bias_lds + (c0 < P.cout ? bc : 0));
-        if (!P.bias) bpre[nt][q] = make_float4(0.f, 0.f, 0.f, 0.f);     // (uniform; a caller may have folded the bias into the accumulators)
-      }
+      for (int q = 0; q < 4; ++q) bpre[nt][q] = bias_of(nt, q);
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -184,9 +187,13 @@ __device__ __forceinline__ void x_epilogue_stores(const XParams& Pfull, const XG
       for (int nt = 0; nt < NT; ++nt) {
         const int cb0 = g.n0 + cout_base + nt * 32;
         unsigned pk[4][2];
+        if (!HOIST_ALL) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bpre[0][q] = bias_of(nt, q);        // one LDS round trip per accumulator tile
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 b4 = bpre[nt][q];
+          const float4 b4 = bpre[HOIST_ALL ? nt : 0][q];
           pk[q][0] = xcvt_pk_bf16(acc[mt][nt][4 * q] + b4.x, acc[mt][nt][4 * q + 1] + b4.y);
           pk[q][1] = xcvt_pk_bf16(acc[mt][nt][4 * q + 2] + b4.z, acc[mt][nt][4 * q + 3] + b4.w);
         }
