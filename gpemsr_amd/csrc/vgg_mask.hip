@@ -336,7 +336,10 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         for (int j = 0; j < 8; ++j) {
           const int k = 16 * s + 8 * lh + j;
           const int tap = k < 9 ? k : k - 9;
-          const float v = k < 18 ? P.w1[(ct * 32 + li) * 9 + tap] : 0.f;
+          // k slots 18 / 19: conv1_1's bias as a bf16 pair (hi + lo) against a constant 1 in the pixel operand -- the matrix pipe adds it
+          const float bv = P.b1[ct * 32 + li];
+          const float bh = xbf_lo(xcvt_pk_bf16(bv, 0.f) & 0xFFFFu);
+          const float v = k < 18 ? P.w1[(ct * 32 + li) * 9 + tap] : (k == 18 ? bh : (k == 19 ? bv - bh : 0.f));
           w1f[ct][s][j] = (short)(xcvt_pk_bf16(v, 0.f) & 0xFFFFu);
         }
     // One producer wave owns halo-pixel groups pw, pw + NPROD (11 groups of 32 over NPROD waves: one or two per item).  The 3x3 windows of
@@ -444,7 +447,7 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const unsigned v0 = lh == 0 ? hi[j] : (j == 0 ? hi[8] : lo[j - 1]);
-          const unsigned v1 = lh == 0 ? (j == 0 ? lo[7] : (j == 1 ? lo[8] : 0u)) : 0u;
+          const unsigned v1 = lh == 0 ? (j == 0 ? lo[7] : (j == 1 ? lo[8] : (j < 4 ? 0x3F80u : 0u))) : 0u;     // slots 18, 19 = 1.0 (bias)
           f0[j] = (short)v0; f1[j] = (short)v1;
         }
         const bool inside = exists && Y >= 0 && Y < P.H && X >= 0 && X < P.W;        // else: conv1_2's zero padding
@@ -461,10 +464,8 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               float v[4];
-              const float4 bb = *reinterpret_cast<const float4*>(cst + ct * 32 + 8 * g + 4 * lh);       // conv1_1 bias (LDS)
-              const float bj[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = inside ? fmaxf(d[4 * g + j] + bj[j], 0.f) : 0.f;
+              for (int j = 0; j < 4; ++j) v[j] = inside ? fmaxf(d[4 * g + j], 0.f) : 0.f;
               *reinterpret_cast<uint2*>(arow + ((g ^ ((hp >> 2) & 3)) * 16) + lh * 8) = make_uint2(xcvt_pk_bf16(v[0], v[1]), xcvt_pk_bf16(v[2], v[3]));
             }
           }
@@ -501,18 +502,20 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
   const unsigned b_frag = (unsigned)(li * 16 + lh * 1024);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   end_interval();
-  auto b2 = [&](int nt, int r) -> float { return cst[64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]; };       // conv1_2 bias (LDS)
   unsigned pa[2][8];                      // relu1_2 features of the prior image at this lane's pixel, packed bf16 pairs
   float dot = 0.f, na = 0.f, nb = 0.f;
   VSEG_DECL;
   for (int i = 0; i <= NWI; ++i) {
     VSEG(3);
     if (i < NWI) {
-      f32x16 acc[2];
+      f32x16 acc[2];                      // start from conv1_2's bias (the epilogue below then has no adds and no LDS reads)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(cst + 64 + nt * 32 + 8 * q + 4 * lh);
+          acc[nt][4 * q] = t.x; acc[nt][4 * q + 1] = t.y; acc[nt][4 * q + 2] = t.z; acc[nt][4 * q + 3] = t.w;
+        }
       const unsigned bufo = (unsigned)((i & 1) * 2 * A_BYTES);
 #pragma unroll 1
       for (int chunk = 0; chunk < (P.dbg == 2 ? 0 : 2); ++chunk) {
@@ -540,19 +543,21 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            pa[nt][k] = xcvt_pk_bf16(fmaxf(acc[nt][2 * k] + b2(nt, 2 * k), 0.f), fmaxf(acc[nt][2 * k + 1] + b2(nt, 2 * k + 1), 0.f));
+            pa[nt][k] = xcvt_pk_bf16(fmaxf(acc[nt][2 * k], 0.f), fmaxf(acc[nt][2 * k + 1], 0.f));
       } else {                            // up-sampled LR: products with the prior image's features, summed over the 64 couts
         int img, oy0, ox0, tx, ty;
         item_geo(i, img, oy0, ox0, tx, ty);
         const float okf = (ox0 + li < P.W && oy0 + wave < P.H) ? 1.f : 0.f;        // (pixels beyond a ragged last tile: masked out)
+        float d1 = 0.f, a1 = 0.f, b1 = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float a = okf * ((r & 1) ? xbf_hi(pa[nt][r >> 1]) : xbf_lo(pa[nt][r >> 1]));
-            const float b = okf * fmaxf(acc[nt][r] + b2(nt, r), 0.f);
-            dot = fmaf(a, b, dot); na = fmaf(a, a, na); nb = fmaf(b, b, nb);
+            const float a = (r & 1) ? xbf_hi(pa[nt][r >> 1]) : xbf_lo(pa[nt][r >> 1]);
+            const float b = fmaxf(acc[nt][r], 0.f);
+            d1 = fmaf(a, b, d1); a1 = fmaf(a, a, a1); b1 = fmaf(b, b, b1);
           }
+        dot = fmaf(okf, d1, dot); na = fmaf(okf, a1, na); nb = fmaf(okf, b1, nb);
         if ((i & 3) == 3) {               // both halves of the super-tile are in: per-wave patch sums -> LDS
 #pragma unroll
           for (int o = 1; o <= 8; o <<= 1) { dot += __shfl_xor(dot, o); na += __shfl_xor(na, o); nb += __shfl_xor(nb, o); }
