@@ -1263,7 +1263,11 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int tn = (int)blockIdx.x % P.tiles_n, sg = (int)blockIdx.x / P.tiles_n;
+  // XCD-aware order (bijective; workgroup b runs on XCD b % 8): logically consecutive workgroups -- they walk neighbouring tiles at the
+  // same time -- share an XCD, so the halo rows / columns two tiles have in common are L2 hits instead of a second HBM read
+  int bid = (int)blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+  const int tn = bid % P.tiles_n, sg = bid / P.tiles_n;
   const int n0 = tn * 64;
   const int gpt = P.gpt, NS = P.ns;
   const int T_me = (NS - sg + gpt - 1) / gpt;          // 8 x 32 tiles of this workgroup: tile j = 2 k + g goes to group g
