@@ -79,6 +79,7 @@ struct XParams {
   float* gn_ws; int gn_parts, gn_cpg;        // [n][gn_parts = tiles per image][cout][2]; channels per GroupNorm group
   long long kpack_img_stride;                // XS_KPACK: elements between images of the packed output
   int tiles_x, tiles_y, tiles_n;
+  unsigned mg_x, mg_y, mg_n;                 // floor((2^32 - 1) / tiles_*): division by a run-time tile count as mulhi + one correction (xdivmod)
   int halo_h, halo_w, halo_px;
   int tw_lg;
   int na, nb;                                // DMA slots per thread: A image, B stage image
@@ -389,6 +390,16 @@ __device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x
   }
 }
 
+// t / d and t % d for a run-time divisor with its host-side reciprocal m = floor((2^32 - 1) / d): q = mulhi(t, m) is floor(t / d) or one less
+// (t * (2^32 - m d) / (d 2^32) < 1 for every 32-bit t).  The compiler's own run-time division is ~35 instructions; a persistent workgroup
+// decodes a tile index (three divisions) per tile -- stamps: ~1,000 cycles per tile and wave with the matrix pipe idle.
+__device__ __forceinline__ void xdivmod(int t, int d, unsigned m, int& q, int& r) {
+  unsigned qq = __umulhi((unsigned)t, m);
+  unsigned rr = (unsigned)t - qq * (unsigned)d;
+  if (rr >= (unsigned)d) { ++qq; rr -= (unsigned)d; }
+  q = (int)qq; r = (int)rr;
+}
+
 // bias -> LDS (zero-padded to a multiple of 8 floats); nbias = number of true output channels
 __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, int nbias, int nthreads) {
   const int npad = (nbias + 7) & ~7;
@@ -542,9 +553,10 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
       const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8;
       t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + t / 8;
     }
-    const int tn = t % P.tiles_n; t /= P.tiles_n;
-    const int tx = t % P.tiles_x; t /= P.tiles_x;
-    const int ty = t % P.tiles_y; t /= P.tiles_y;
+    int tn, tx, ty;
+    xdivmod(t, P.tiles_n, P.mg_n, t, tn);
+    xdivmod(t, P.tiles_x, P.mg_x, t, tx);
+    xdivmod(t, P.tiles_y, P.mg_y, t, ty);
     Geo g;
     g.img = t; g.n0 = tn * BN;
     g.oy0 = GEMM ? 0 : ty * TH; g.ox0 = GEMM ? tx * NPIX : tx * 32;
@@ -1282,9 +1294,9 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   x_stage_bias(P, bias_lds, P.nbias, 768);
 
   auto tile_geo = [&](int j) -> XGeo {
-    int t = sg + j * gpt;
-    const int tx = t % P.tiles_x; t /= P.tiles_x;
-    const int ty = t % P.tiles_y; t /= P.tiles_y;
+    int t = sg + j * gpt, tx, ty;
+    xdivmod(t, P.tiles_x, P.mg_x, t, tx);
+    xdivmod(t, P.tiles_y, P.mg_y, t, ty);
     XGeo g;
     g.img = t; g.n0 = n0; g.oy0 = ty * 8; g.ox0 = tx * 32; g.tile_in_img = ty * P.tiles_x + tx;
     return g;
@@ -1740,6 +1752,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     P.tiles_x = cdiv(P.ow, 32); P.tiles_y = cdiv(P.oh, TH);
   }
   P.tiles_n = cdiv(P.cout, BN);
+  P.mg_x = 0xFFFFFFFFu / (unsigned)P.tiles_x; P.mg_y = 0xFFFFFFFFu / (unsigned)P.tiles_y; P.mg_n = 0xFFFFFFFFu / (unsigned)P.tiles_n;
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d_bf16: grid too large");
   P.nblocks = (int)nb;
@@ -1785,6 +1798,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     const int rows = L.res_form == 2 ? 8 : 16;
     P.tiles_n = cdiv(P.cout, 64);
     P.tiles_x = cdiv(P.ow, 32); P.tiles_y = cdiv(P.oh, rows);
+    P.mg_x = 0xFFFFFFFFu / (unsigned)P.tiles_x; P.mg_y = 0xFFFFFFFFu / (unsigned)P.tiles_y; P.mg_n = 0xFFFFFFFFu / (unsigned)P.tiles_n;
     const long long ns = (long long)d->n * P.tiles_y * P.tiles_x;
     GP_REQUIRE(ns < (1ll << 31), "conv2d_bf16: grid too large");
     P.ns = (int)ns;
