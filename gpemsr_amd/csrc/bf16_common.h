@@ -55,6 +55,16 @@ __device__ __forceinline__ unsigned xcvt_pk_bf16(float a, float b) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// t / d and t % d for a run-time divisor with its host-side reciprocal m = floor((2^32 - 1) / d): q = mulhi(t, m) is floor(t / d) or one less
+// (t * (2^32 - m d) / (d 2^32) < 1 for every 32-bit t).  The compiler's own run-time division is ~35 instructions; a persistent workgroup
+// decodes a tile index (three divisions) per tile -- stamps: ~1,000 cycles per tile and wave with the matrix pipe idle.
+__device__ __forceinline__ void xdivmod(int t, int d, unsigned m, int& q, int& r) {
+  unsigned qq = __umulhi((unsigned)t, m);
+  unsigned rr = (unsigned)t - qq * (unsigned)d;
+  if (rr >= (unsigned)d) { ++qq; rr -= (unsigned)d; }
+  q = (int)qq; r = (int)rr;
+}
+
 __device__ __forceinline__ float xbf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float xbf_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 

@@ -390,16 +390,6 @@ __device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x
   }
 }
 
-// t / d and t % d for a run-time divisor with its host-side reciprocal m = floor((2^32 - 1) / d): q = mulhi(t, m) is floor(t / d) or one less
-// (t * (2^32 - m d) / (d 2^32) < 1 for every 32-bit t).  The compiler's own run-time division is ~35 instructions; a persistent workgroup
-// decodes a tile index (three divisions) per tile -- stamps: ~1,000 cycles per tile and wave with the matrix pipe idle.
-__device__ __forceinline__ void xdivmod(int t, int d, unsigned m, int& q, int& r) {
-  unsigned qq = __umulhi((unsigned)t, m);
-  unsigned rr = (unsigned)t - qq * (unsigned)d;
-  if (rr >= (unsigned)d) { ++qq; rr -= (unsigned)d; }
-  q = (int)qq; r = (int)rr;
-}
-
 // bias -> LDS (zero-padded to a multiple of 8 floats); nbias = number of true output channels
 __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, int nbias, int nthreads) {
   const int npad = (nbias + 7) & ~7;

@@ -42,6 +42,7 @@ struct VggParams {
   const unsigned short* w2; const float* b2; // conv1_2: staged bf16 [2][9][4][64][8], [64]
   float* out;                                // [n][H/16][W/16]
   int tiles_x, tiles_y, ns;
+  unsigned mg_x, mg_y;                       // floor((2^32 - 1) / tiles_*) for xdivmod
   int dbg;                                   // timing experiments only (GPEMSR_VGG_DBG): 1 = producers idle, 2 = no conv1_2
   int hr2;                                   // `lr` is already at the HR size (scale == 1): both images are read the same way
 };
@@ -302,8 +303,8 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
   const int NWI = 4 * T_me;
   auto item_geo = [&](int wi, int& img, int& oy0, int& ox0, int& tx, int& ty) {
     int q = (int)blockIdx.x + (wi >> 2) * (int)gridDim.x;
-    tx = q % P.tiles_x; q /= P.tiles_x;
-    ty = q % P.tiles_y; q /= P.tiles_y;
+    xdivmod(q, P.tiles_x, P.mg_x, q, tx);
+    xdivmod(q, P.tiles_y, P.mg_y, q, ty);
     img = q; oy0 = ty * 16 + ((wi >> 1) & 1) * 8; ox0 = tx * 32;
   };
   auto end_interval = [&]() {
@@ -603,6 +604,7 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
   P.w1 = w1; P.b1 = b1; P.w2 = reinterpret_cast<const unsigned short*>(w2_bf16); P.b2 = b2; P.out = out;
   P.hr2 = scale == 1 ? 1 : 0;
   P.tiles_x = cdiv(W, 32); P.tiles_y = H / 16;
+  P.mg_x = 0xFFFFFFFFu / (unsigned)P.tiles_x; P.mg_y = 0xFFFFFFFFu / (unsigned)P.tiles_y;
   const long long ns = (long long)n * P.tiles_x * P.tiles_y;
   GP_REQUIRE(ns < (1ll << 31), "vgg_mask_bf16: grid too large");
   P.ns = (int)ns;
