@@ -1701,7 +1701,9 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
         if (var != 4 && CK == 16) NL = 4;
         // 32-channel chunks, couts <= 32 (SpyNet 64 -> 32 and 32 -> 16): EIGHT loader waves (7 halo slots per loader thread, 16 waves per
         // CU = 128 registers, which the 32-accumulator multiplying waves fit)
-        if (var == 6 && CK == 32 && BN == 64) BN = 32;         // A/B: 64 couts as two 32-cout tiles on the 8-loader form
+        // 64 couts (SpyNet 32 -> 64): two 32-cout tiles on the 8-loader form -- since the packed epilogue 1.02 vs 0.91 PFLOP/s for the
+        // 64-cout tile whose multiplying waves issue their own DMA (22 % of its time; variant 7 keeps that form for A/B)
+        if (var != 7 && CK == 32 && BN == 64) BN = 32;
         if (var != 4 && CK == 32 && BN == 32) NL = 8;
       }
     }

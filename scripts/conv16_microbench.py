@@ -36,7 +36,7 @@ SHAPES = [
     ("convT 256->128 @128^2 x80", "convT", 80, 256, 128, 3, 1, 128, 128, (0, 2)),
     ("convT 128->64 @256^2 x80", "convT", 80, 128, 64, 3, 1, 256, 256, (0, 2)),
     ("convT 64->64 @256^2 x80", "convT", 80, 64, 64, 3, 1, 256, 256, (0, 2)),
-    ("spy 32->64 7x7 @512^2 x16", "conv", 16, 32, 64, 7, 1, 512, 512, (0, 8)),
+    ("spy 32->64 7x7 @512^2 x16", "conv", 16, 32, 64, 7, 1, 512, 512, (0, 7, 8)),
     ("spy 64->32 7x7 @512^2 x16", "conv", 16, 64, 32, 7, 1, 512, 512, (0, 1, 4)),
     ("spy 16->32 7x7 @512^2 x16", "conv", 16, 16, 32, 7, 1, 512, 512, (0, 8)),
     ("spy 32->16 7x7 @512^2 x16", "conv", 16, 32, 16, 7, 1, 512, 512, (0, 8)),
