@@ -75,6 +75,9 @@ def parse_args(argv=None):
                     help="launcher self-test (tests/test_bench_launcher_cpu.py): a per-tile stand-in model on the CPU with "
                          "--backend gloo; exercises spawn, rendezvous, barrier, all-gather and max-over-ranks timing only")
     ap.add_argument("--rank-timeout", type=float, default=3000.0, help="seconds the launcher waits for its ranks")
+    ap.add_argument("--gather", type=str, default="f32", choices=("f32", "u8"),
+                    help="what the step's all-gather exchanges: the fp32 HR slabs (default; 4 MiB per 1024^2 tile, the north_star's slabs) or the "
+                         "8-bit image the last kernel writes (1 MiB per tile: what output_GPEMSR.py saves)")
     return ap.parse_args(argv)
 
 
@@ -157,9 +160,12 @@ class _StubModel:
     """Per-tile stand-in (launcher self-test on the CPU): out depends on the tile only, so sharded == unsharded."""
     precision = "stub"
 
-    def __call__(self, x):
+    def __call__(self, x, want_u8=False):
         b = x.shape[0]
-        return (x[:, 2].mean(dim=(1, 2, 3)).view(b, 1, 1, 1) + x[:, 2, :, :8, :8]).contiguous(), x
+        out = (x[:, 2].mean(dim=(1, 2, 3)).view(b, 1, 1, 1) + x[:, 2, :, :8, :8]).contiguous()
+        if want_u8:
+            return out, x, (out[:, 0].clamp(0, 1) * 255.0).round().to(__import__("torch").uint8)
+        return out, x
 
 
 def timed_steps(step, steps: int, world: int, dev, sync):
@@ -196,11 +202,14 @@ def _tf(d):
     return d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
 
 
+PMC_ROUND = "r04"                   # profiles/<PMC_ROUND>_<precision>_pmc_summary.json: the counter summary taken on THIS tree
+
+
 def pmc_traffic(tag: str, launches_per_step: int):
     """HBM bytes per launch of the dominant kernel family from the rocprofv3 --pmc summary committed for THIS tree
-    (profiles/r03_<tag>_pmc_summary.json, scripts/pmc_round2.sh; separate passes, FETCH_SIZE x2 gfx950 correction).  The
+    (profiles/r04_<tag>_pmc_summary.json, scripts/pmc_round2.sh; separate passes, FETCH_SIZE x2 gfx950 correction).  The
     summary records the family's launches per step; a mismatch means it was taken on another tree -> null."""
-    path = os.path.join(ROOT, "profiles", f"r03_{tag}_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_{tag}_pmc_summary.json")
     try:
         doc = json.load(open(path))
         fam = doc["dominant_family"]
@@ -246,15 +255,40 @@ def build_roofline(args, prof, dt, B, s, precision=None):
                   "time_share_of_step": round(v["ms"] * 1e-3 / dt, 3)} for k, v in summ.items() if k not in fam_names}
     if others:
         r["other_profiled_kernels"] = others
+    # what a reader needs to audit the family figure: algorithmic bytes beside the counter bytes, and the kernels one by one
+    steps = max(args.steps, 1)
+    alg_bytes = sum(v["bytes"] for v in summ.values()) / steps
+    r["algorithmic_bytes_per_step"] = round(alg_bytes)
+    r["algorithmic_bytes_note"] = ("sum over every profiled launch (all convolution / product / fused-mask layers) of its unique inputs + outputs + weights "
+                                   "at the dtypes stored; element-wise passes between layers (GroupNorm apply, resamplers, gathers) are not in it")
+    all_b = (traffic_src or {}).get("hbm_bytes_per_step_all_kernels")
+    r["counter_bytes_per_step_all_kernels"] = all_b
+    r["counter_over_algorithmic_bytes"] = round(all_b / alg_bytes, 2) if (all_b and alg_bytes) else None
+    r["kernels"] = kernel_table(prof, steps, peak)
     return r
+
+
+def kernel_table(prof, steps: int, peak_tflops: float, top: int = 8):
+    """The `top` kernel instantiations of a leg by time: name, launches/step, ms/step, algorithmic GFLOP/step, achieved TFLOP/s and its
+    fraction of the leg's matrix peak, algorithmic GB/step and GB/s (HIP events on the launch stream, same data as `roofline`)."""
+    rows = sorted(prof.summary(by_name=True).items(), key=lambda kv: -kv[1]["ms"])[:top]
+    out = []
+    for name, d in rows:
+        tf = _tf(d)
+        out.append({"name": name, "family": d["family"], "launches_per_step": round(d["launches"] / steps, 2), "ms_per_step": round(d["ms"] / steps, 3),
+                    "algorithmic_gflop_per_step": round(d["flops"] / 1e9 / steps, 1), "tflops": round(tf, 1), "frac": round(tf / peak_tflops, 4),
+                    "algorithmic_gb_per_step": round(d["bytes"] / 1e9 / steps, 3),
+                    "algorithmic_gbps": round(d["bytes"] / 1e9 / (d["ms"] * 1e-3), 1) if d["ms"] > 0 else 0.0})
+    return out
 
 
 def write_layer_report(prof, path):
     rows = sorted(prof.summary(by_tag=True).items(), key=lambda kv: -kv[1]["ms"])
     with open(path, "w") as f:
-        f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\n")
+        f.write("kernel\ttag\tlaunches\tms_total\tGFLOP\tTFLOP/s\tinstantiation\talgorithmic_GB\tGB/s\n")
         for (kern, tag), d in rows:
-            f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{_tf(d):.1f}\n")
+            gbps = d["bytes"] / 1e9 / (d["ms"] * 1e-3) if d["ms"] > 0 else 0.0
+            f.write(f"{kern}\t{tag}\t{d['launches']}\t{d['ms']:.3f}\t{d['flops'] / 1e9:.1f}\t{_tf(d):.1f}\t{d['name']}\t{d['bytes'] / 1e9:.3f}\t{gbps:.0f}\n")
 
 
 def _volume_bench(model, fr, win, steps):
@@ -285,7 +319,7 @@ def run_precision_leg(args, opt, x, rank, world, dev, mode, sync):
         m3 = build_model(opt, load_prior_files=False, precision=mode).eval().to(dev)
 
     def step3():
-        return gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True)[0]
+        return gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True, gather_u8=args.gather == "u8")[0]
     for _ in range(max(args.warmup, 2)):          # the allocator re-grows its pools after empty_cache(): keep that out of the timing
         step3()
     if not args.stub:
@@ -294,11 +328,15 @@ def run_precision_leg(args, opt, x, rank, world, dev, mode, sync):
     d3, o3 = timed_steps(step3, args.steps, world, dev, sync)
     if not args.stub:
         ops.PROFILER = None
+        if args.layer_report and rank == 0:
+            write_layer_report(prof, args.layer_report + "." + mode)
     assert o3.shape[0] == B * world
     opix = o3.shape[-1] * o3.shape[-2]
     entry = {"value": round(world * B * opix / 1e6 * args.steps / d3, 3), "unit": "MP/s", "n_gpus": world,
              "ms_per_step": round(1e3 * d3 / args.steps, 2), "tiles_per_gpu": B, "scaling": "weak",
-             "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the HR slabs), synchronize + barrier; max over ranks",
+             "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the " +
+                             ("uint8 HR images [tiles,H,W] (tensor2img of SR, from the last kernel)" if args.gather == "u8" else "fp32 HR slabs [tiles,1,H,W]") +
+                             "), synchronize + barrier; max over ranks", "gather": args.gather,
              "roofline": None if args.stub else build_roofline(args, prof, d3, B, s, precision=mode)}
     return entry, m3, o3
 
@@ -311,7 +349,7 @@ def run_extras(args, model, opt, x, out, dt, dev, rank=0, world=1, sync=None):
     import torch
     B, s, lr = args.tiles, args.scale, args.lr
     modes = [m for m in args.extras.split(",") if m]
-    if world > 1 or args.stub:
+    if world > 1 or args.stub or args.gather == "u8":      # (u8 gather: `out` is the 8-bit image, the fp32 comparisons below do not apply)
         extras = {}
         if args.precision == "fp32" or args.stub:
             del model
@@ -394,7 +432,7 @@ def run_cpu_baseline(args, model_sd, x, out):
     cb = {"value": round(cpu_mp, 5), "unit": "output megapixels/s", "cores": torch.get_num_threads(), "kind": "port",
           "sample": f"1 window [1,5,1,{args.cpu_lr},{args.cpu_lr}] -> {args.cpu_lr * s}^2: same-size warm-up pass + 2 timed passes "
                     f"({times[0]:.1f} s, {times[1]:.1f} s) of oracle/gpemsr_oracle.py (torch CPU fp32; SpyNet de-duplicated, VGG slice1 only)"}
-    if args.cpu_lr == lr and args.precision == "fp32":
+    if args.cpu_lr == lr and args.precision == "fp32" and out.dtype == torch.float32:
         err = float((out[:1].cpu() - o_cpu).abs().max() / o_cpu.abs().max())
         cb["gpu_vs_cpu_rel_err_free_running"] = float(f"{err:.3e}")
     return cb
@@ -407,6 +445,8 @@ def run_forward(args) -> int:
     rank, world, local = gdist.init_from_env(backend=args.backend or None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     B, s, lr = args.tiles, args.scale, args.lr
+    if args.stub and os.environ.get("GPEMSR_BENCH_TEST_HANG_RANK") == str(rank):
+        time.sleep(3600)                    # launcher self-test: this rank never arrives (tests/test_bench_launcher_cpu.py)
     if args.stub:
         dev = torch.device("cpu")
         sync = lambda: None                                                        # noqa: E731
@@ -427,7 +467,7 @@ def run_forward(args) -> int:
         x = synth_lr_tiles(B, 5, lr, lr, seed=1000 + rank, kind="uniform").to(dev)     # resident in HBM before timing
 
     def step():
-        out, _ = gdist.forward_sharded(model, x, rank, world, already_local=True, gather=True)
+        out, _ = gdist.forward_sharded(model, x, rank, world, already_local=True, gather=True, gather_u8=args.gather == "u8")
         return out
 
     for _ in range(args.warmup):
@@ -469,6 +509,9 @@ def run_forward(args) -> int:
             "metric": "output megapixels/sec, 8x EMSR 128->1024 tiles" if s == 8 else "output megapixels/sec, 16x EMSR 64->1024 tiles",
             "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "rccl_world": rccl_world, "dist_backend": dist_backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the " +
+                            ("uint8 HR images" if args.gather == "u8" else "fp32 HR slabs") + " at N > 1), synchronize + barrier; max over ranks",
+            "gather": args.gather,
             "vs_baseline": None, "dtype": "stub" if args.stub else dtype, "data": "synthetic",
             "config": {"workload": ("launcher self-test (stub model, CPU, gloo)" if args.stub else
                                     f"{s}x EMSR stage-3 forward, batch={B} synthetic 5x1x{lr}x{lr} LR windows per GPU -> "
@@ -476,7 +519,14 @@ def run_forward(args) -> int:
                        "tiles_per_gpu": B, "global_tiles": B * world, "lr": lr, "scale": s,
                        "weights": "deterministic synthetic init (reference checkpoints are not redistributable)",
                        "parallelism": f"tiles sharded over {world} GPU(s), one process per GPU, RCCL all-gather of HR slabs" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            # the bf16 leg's own blocks at the TOP level (a driver that keeps only the top-level keys keeps them): BASELINE configs[2]
+            "roofline_bf16": ((extras or {}).get("bf16") or {}).get("roofline") if isinstance(extras, dict) else None,
+            "value_bf16": ((extras or {}).get("bf16") or {}).get("value") if isinstance(extras, dict) else None,
+            "ms_per_step_bf16": ((extras or {}).get("bf16") or {}).get("ms_per_step") if isinstance(extras, dict) else None,
+            "kernels": (roofline or {}).get("kernels"),
+            "algorithmic_bytes_per_step": (roofline or {}).get("algorithmic_bytes_per_step"),
+            "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

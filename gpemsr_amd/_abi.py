@@ -40,6 +40,7 @@ SYMBOLS = [
     "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
     "gpemsr_copy_channels_f32_bf16", "gpemsr_conv2d_stem1_bf16", "gpemsr_conv2d_direct_bf16", "gpemsr_vgg_mask_bf16",
     "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32", "gpemsr_split_f32_bf16x2", "gpemsr_conv2d_gn_parts", "gpemsr_patch_cosine_finish",
+    "gpemsr_conv2d_kernel_name", "gpemsr_conv2d_bf16_kernel_name",
 ]
 
 
@@ -103,6 +104,7 @@ def load():
     p, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     lib.gpemsr_conv2d.argtypes = [C.POINTER(ConvDesc), p]
     lib.gpemsr_conv2d_gn_parts.argtypes = [C.POINTER(ConvDesc)]
+    lib.gpemsr_conv2d_kernel_name.argtypes = [C.POINTER(ConvDesc), C.c_char_p, C.c_int]
     lib.gpemsr_patch_cosine_finish.argtypes = [p, i32, i32, i32, p, p]
     lib.gpemsr_conv2d_split.argtypes = [C.POINTER(ConvDesc), p, i64, i32, p]
     lib.gpemsr_conv2d_direct.argtypes = [p, i32, i32, i32, i32, i32, p, p, i32, i32, i32, i32, p, i32, p, i32, p]
@@ -163,6 +165,7 @@ def load():
     lib.gpemsr_device_info.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     lib.gpemsr_conv2d_bf16.argtypes = [C.POINTER(ConvDesc16), p]
     lib.gpemsr_conv2d_bf16_gn_parts.argtypes = [C.POINTER(ConvDesc16)]
+    lib.gpemsr_conv2d_bf16_kernel_name.argtypes = [C.POINTER(ConvDesc16), C.c_char_p, C.c_int]
     lib.gpemsr_groupnorm_stats_bf16.argtypes = [p, i32, i32, i32, i32, p, i32, p]
     lib.gpemsr_groupnorm_finish.argtypes = [p, i32, i32, i32, i32, i32, f32, p, p]
     lib.gpemsr_groupnorm_scale_shift.argtypes = [p, p, p, i32, i32, i32, p, p, p]

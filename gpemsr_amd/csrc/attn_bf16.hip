@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256, 1) void flash_attn512_kernel(AttnParams P) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // sn was written by inline-asm MFMAs: the hazard recognizer does not count wait states for the VALU copy below.  32 P.V MFMAs and a
+    // barrier lie in between, so these nops never delay anything -- they make the distance a property of the source, not of scheduling.
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sn));
     sc = sn;
   }
 
@@ -238,12 +241,9 @@ extern "C" int gpemsr_flash_attention_bf16(const void* q, int q_ld, const void* 
              "flash_attention_bf16: needs channels == 512 and tokens %% 128 == 0 (got %d, %d)", channels, tokens);
   GP_REQUIRE(q_ld % 8 == 0 && out_ld % 8 == 0 && q_ld >= AT_C && out_ld >= AT_C && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(kp) |
              reinterpret_cast<uintptr_t>(vtp) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias_v)) & 15) == 0, "flash_attention_bf16: alignment");
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return fail(GPEMSR_ELAUNCH, "flash_attention_bf16: cannot raise the dynamic LDS limit");
-    attr = true;
-  }
+  // the attribute is per device and the call is cheap: set it on every launch (a process may drive more than one GPU, from more than one thread)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return fail(GPEMSR_ELAUNCH, "flash_attention_bf16: cannot raise the dynamic LDS limit");
   AttnParams P{};
   P.q = reinterpret_cast<const unsigned short*>(q); P.q_ld = q_ld;
   P.kp = reinterpret_cast<const unsigned short*>(kp); P.vtp = reinterpret_cast<const unsigned short*>(vtp);

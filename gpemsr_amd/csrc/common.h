@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "gpemsr_hip.h"
 
 namespace gpemsr {
@@ -29,6 +30,20 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case GPEMSR_ACT_LRELU_SIGMOID: { float t = v > 0.f ? v : 0.1f * v; return 1.f / (1.f + expf(-t)); }
     default: return v;
   }
+}
+
+// Per-DEVICE "done once" flags for per-device settings (hipFuncSetAttribute of the dynamic LDS limit): bit d = done on device d.
+// A plain static bool would leave a second device of the same process at the default limit; two threads racing here both set the
+// attribute, which is harmless.  Devices >= 64 simply redo the call every time.
+typedef std::atomic<unsigned long long> dev_once_t;
+inline bool dev_once_begin(dev_once_t& m) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  return (m.load(std::memory_order_acquire) & (1ull << dev)) == 0ull;
+}
+inline void dev_once_done(dev_once_t& m) {
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) m.fetch_or(1ull << dev, std::memory_order_release);
 }
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

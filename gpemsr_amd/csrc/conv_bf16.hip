@@ -1598,11 +1598,11 @@ template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, b
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
   auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS, AXF>;
   if (lds > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
+    static dev_once_t done{0};
+    if (dev_once_begin(done)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(GPEMSR_ELAUNCH, "conv2d_bf16: cannot raise the dynamic LDS limit");
-      done = true;
+      dev_once_done(done);
     }
   }
   // persistent workgroups: as many as the chip holds at once (two per CU when the LDS footprint allows), each walking
@@ -1830,6 +1830,22 @@ extern "C" int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d) {
   return rc == GPEMSR_OK ? P.gn_parts : rc;
 }
 
+// the kernel instantiation gpemsr_conv2d_bf16 would launch for `d`, as text (bench.py's per-kernel table); nothing is launched
+extern "C" int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char* buf, int cap) {
+  GP_REQUIRE(buf != nullptr && cap > 0, "conv2d_bf16_kernel_name: no buffer");
+  XParams P{}; XPlan L{};
+  const int rc = plan_x(d, P, L);
+  if (rc != GPEMSR_OK) return rc;
+  if (L.resident) {
+    if (L.res_form == 2) snprintf(buf, (size_t)cap, "conv64_resident2_kernel<%s,%s>", (L.lean || L.axf) ? "true" : "false", L.axf ? "true" : "false");
+    else snprintf(buf, (size_t)cap, "conv64_resident_kernel<%s>", L.lean ? "true" : "false");
+  } else {
+    snprintf(buf, (size_t)cap, "conv_bf16_kernel<CK=%d,BN=%d,WM=%d,WN=%d,TH=%d,TPS=%d,%s,NL=%d%s>", L.CK, L.BN, L.WM, L.WN, L.TH, L.TPS,
+             L.tr ? "CONVT" : (L.gemm ? "GEMM" : (d->stride == 2 ? "S2" : "CONV")), L.NL, L.axf ? ",AXF" : "");
+  }
+  return GPEMSR_OK;
+}
+
 static int device_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -1847,15 +1863,15 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = L.lds;
   if (L.resident) {
-    static bool attr = false;
-    if (!attr) {
+    static dev_once_t attr{0};
+    if (dev_once_begin(attr)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(conv64_resident2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(GPEMSR_ELAUNCH, "conv2d_bf16: cannot raise the dynamic LDS limit");
-      attr = true;
+      dev_once_done(attr);
     }
     // one workgroup per CU; workgroups of a cout slab split the spatial tiles between them
     const int cus = device_cus();

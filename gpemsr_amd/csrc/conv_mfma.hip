@@ -720,11 +720,11 @@ template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA, int XEP
 static int launch(const ConvParams& P, size_t lds_bytes, hipStream_t st) {
   auto kfn = conv_mfma_kernel<CK, BN, WM, WN, TH, MASKED, DMA, XEPI>;
   if (lds_bytes > 64 * 1024) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static dev_once_t attr_done{0};
+    if (dev_once_begin(attr_done)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(GPEMSR_ELAUNCH, "conv2d: cannot raise the dynamic LDS limit");
-      attr_done = true;
+      dev_once_done(attr_done);
     }
   }
   hipLaunchKernelGGL(kfn, dim3(P.nblocks), dim3(256), lds_bytes, st, P);
@@ -742,9 +742,18 @@ static bool env_flag_once(const char* name) {
 }
 
 
-static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only);
+struct ConvPlanName { char* buf; int cap; };
+static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only, ConvPlanName* name_only = nullptr);
 
 extern "C" int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream) { return conv2d_impl(d, stream, nullptr); }
+
+// the kernel instantiation gpemsr_conv2d would launch for `d`, as text (bench.py's per-kernel table); nothing is launched
+extern "C" int gpemsr_conv2d_kernel_name(const gpemsr_conv_desc* d, char* buf, int cap) {
+  GP_REQUIRE(buf != nullptr && cap > 0, "conv2d_kernel_name: no buffer");
+  ConvPlanName nm{buf, cap};
+  buf[0] = 0;
+  return conv2d_impl(d, nullptr, nullptr, &nm);
+}
 
 // number of partial-sum records per image (`parts`) a launch of this descriptor leaves in d->gn_partials: [n][parts][cout][2]
 extern "C" int gpemsr_conv2d_gn_parts(const gpemsr_conv_desc* d) {
@@ -753,7 +762,7 @@ extern "C" int gpemsr_conv2d_gn_parts(const gpemsr_conv_desc* d) {
   return rc < 0 ? rc : parts;
 }
 
-static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only) {
+static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only, ConvPlanName* name_only) {
   GP_REQUIRE(d != nullptr, "conv2d: null descriptor");
   GP_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "conv2d: bad geometry n=%d h=%d w=%d cout=%d", d->n, d->h, d->w, d->cout);
   GP_REQUIRE(d->nsrc >= 1 && d->nsrc <= GPEMSR_MAX_SRC, "conv2d: nsrc=%d", d->nsrc);
@@ -875,13 +884,18 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
   const size_t lds = lds_floats * sizeof(float);
   GP_REQUIRE(lds <= 160 * 1024, "conv2d: LDS %zu too large", lds);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // (name_only: the same dispatch below, but the "launch" writes the instantiation's name)
+#define GP_NAME(CKv, BNv, WMv, WNv, THv, MK, DMAv, XE) \
+  (snprintf(name_only->buf, (size_t)name_only->cap, "conv_mfma_kernel<%d,%d,%d,%d,%d,%s,%s,%d>", CKv, BNv, WMv, WNv, THv, (MK) ? "true" : "false", (DMAv) ? "true" : "false", XE), 0)
 #define GP_LAUNCH(CKv, BNv, WMv, WNv, THv, MK) \
-  (dma ? launch<CKv, BNv, WMv, WNv, THv, MK, true>(P, lds, st) : launch<CKv, BNv, WMv, WNv, THv, MK, false>(P, lds, st))
-#define GP_LAUNCH_X(CKv, BNv, WMv, WNv, THv) launch<CKv, BNv, WMv, WNv, THv, false, true, 1>(P, lds, st)
+  (name_only ? GP_NAME(CKv, BNv, WMv, WNv, THv, MK, dma, 0) : \
+   (dma ? launch<CKv, BNv, WMv, WNv, THv, MK, true>(P, lds, st) : launch<CKv, BNv, WMv, WNv, THv, MK, false>(P, lds, st)))
+#define GP_LAUNCH_X(CKv, BNv, WMv, WNv, THv) (name_only ? GP_NAME(CKv, BNv, WMv, WNv, THv, false, true, 1) : launch<CKv, BNv, WMv, WNv, THv, false, true, 1>(P, lds, st))
   if (P.gn_ws || P.cos_ws) {        // the partial-sum epilogue lives in its own instantiations (DMA staging only)
     GP_REQUIRE(dma && BN >= 32, "conv2d: partial sums need 16-byte aligned sources with channel counts that are multiples of the chunk");
     if (P.cos_ws) {                 // (3x3, 64-column blocks: checked above)
       GP_REQUIRE(CK == 8 && BN == 64, "conv2d: patch-cosine sums are a 3x3 form");
+      if (name_only) return TH == 8 ? GP_NAME(8, 64, 4, 1, 8, false, true, 2) : GP_NAME(8, 64, 2, 2, 4, false, true, 2);
       return TH == 8 ? launch<8, 64, 4, 1, 8, false, true, 2>(P, lds, st) : launch<8, 64, 2, 2, 4, false, true, 2>(P, lds, st);
     }
     if (CK == 8) {
@@ -904,6 +918,7 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only)
   return GP_LAUNCH(32, 128, 2, 2, 4, false);
 #undef GP_LAUNCH
 #undef GP_LAUNCH_X
+#undef GP_NAME
 }
 
 namespace gpemsr {

@@ -398,11 +398,11 @@ template <int BN, int WM, int WN, int TH, int NSPLIT, int KW, bool CONVT = false
 static int launch_split(const SplitParams& P, size_t lds, hipStream_t st) {
   auto kfn = conv_split_kernel<BN, WM, WN, TH, NSPLIT, KW, CONVT, GEMM>;
   if (lds > 64 * 1024) {
-    static bool done = false;
-    if (!done) {
+    static dev_once_t done{0};
+    if (dev_once_begin(done)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return fail(GPEMSR_ELAUNCH, "conv2d_split: cannot raise the dynamic LDS limit");
-      done = true;
+      dev_once_done(done);
     }
   }
   hipLaunchKernelGGL(kfn, dim3(P.nblocks), dim3(256), lds, st, P);

@@ -610,13 +610,13 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
   P.ns = (int)ns;
   const size_t lds = 73728 + 2 * (18 * 34 * 64) + (20 * 36 + 128 + 48) * 4;
   const size_t lds2 = 73728 + 4 * (10 * 34 * 64) + (128 + 48) * 4;
-  static bool attr = false;
-  if (!attr) {
+  static dev_once_t attr{0};
+  if (dev_once_begin(attr)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_mask2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(GPEMSR_ELAUNCH, "vgg_mask_bf16: cannot raise the dynamic LDS limit");
-    attr = true;
+    dev_once_done(attr);
   }
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_VGG_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
   static int form = -1;                 // GPEMSR_VGG_FORM=1 selects the lockstep kernel (A/B measurements)

@@ -354,24 +354,24 @@ extern "C" int gpemsr_conv2d_wgrad(const float* x, int x_ld, int cin, const floa
     const size_t ldsd = 2 * (size_t)((P.th * 32 + ((P.th * P.hc + 3) & ~3)) * 64 + 64) * 4;
     const dim3 gridd((unsigned)(slabs * ksize), (unsigned)(cout / 64), (unsigned)(cin / 64));
     if (ksize == 3) {
-      static bool a3 = false;
-      if (!a3) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a3 = true; }
+      static dev_once_t a3{0};
+      if (dev_once_begin(a3)) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dev_once_done(a3); }
       hipLaunchKernelGGL(wgrad_dma_kernel<3>, gridd, dim3(256), ldsd, st, P);
     } else {
-      static bool a1 = false;
-      if (!a1) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a1 = true; }
+      static dev_once_t a1{0};
+      if (dev_once_begin(a1)) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dev_once_done(a1); }
       hipLaunchKernelGGL(wgrad_dma_kernel<1>, gridd, dim3(256), ldsd, st, P);
     }
   } else {
   const size_t lds = lds_bytes(P.th);
   const dim3 grid((unsigned)(slabs * ksize), (unsigned)((cout + 63) / 64), (unsigned)((cin + 63) / 64));
   if (ksize == 3) {
-    static bool attr3 = false;
-    if (!attr3) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
+    static dev_once_t attr3{0};
+    if (dev_once_begin(attr3)) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dev_once_done(attr3); }
     hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), lds, st, P);
   } else {
-    static bool attr1 = false;
-    if (!attr1) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    static dev_once_t attr1{0};
+    if (dev_once_begin(attr1)) { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dev_once_done(attr1); }
     hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), lds, st, P);
   }
   }

@@ -82,16 +82,22 @@ def all_gather_ragged(local: torch.Tensor, total: int, rank: int, world: int) ->
 
 
 def forward_sharded(model, x_all_or_local: torch.Tensor, rank: int, world: int, already_local: bool = False,
-                    gather: bool = True):
+                    gather: bool = True, gather_u8: bool = False):
     """Run the stage-3 forward on this rank's tiles and (optionally) all-gather the SR slabs.
-    x: [B,N,1,H,W]; returns (out_all [B,1,sH,sW] on every rank, ref_img_local)."""
+    x: [B,N,1,H,W]; returns (out_all [B,1,sH,sW] on every rank, ref_img_local).
+    gather_u8: exchange the 8-bit image the network's last kernel writes (``model(x, want_u8=True)``, the reference's tensor2img of
+    SR: what output_GPEMSR.py saves) instead of the fp32 slab -- 1 MiB instead of 4 MiB per 1024^2 tile over xGMI; the first return
+    value is then uint8 [B, sH, sW]."""
     B = x_all_or_local.shape[0] * (world if already_local else 1)
     if already_local:
         x = x_all_or_local
     else:
         lo, hi = shard_range(B, rank, world)
         x = x_all_or_local[lo:hi]
-    out, ref = model(x)
+    if gather_u8:
+        _, ref, out = model(x, want_u8=True)
+    else:
+        out, ref = model(x)
     if not gather or world == 1:
         return out, ref
     if B % world == 0:

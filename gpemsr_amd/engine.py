@@ -250,7 +250,8 @@ class Engine:
         if c % 32 != 0 or T % 4 != 0:
             raise RuntimeError(f"gpemsr_amd: non-local block needs channels ({c}) % 32 == 0 and latent tokens ({T}) % 4 == 0")
         if self.bf16:
-            if T % 16 == 0 and T <= self.BF16_SOFTMAX_MAX_COLS:
+            # the flash kernel has no row-length limit (C = 512, T % 128 == 0); the layered form's bf16 softmax holds <= 16384 columns
+            if T % 16 == 0 and (T <= self.BF16_SOFTMAX_MAX_COLS or (self.flash_attn and self.o.flash_attention_ok(T, c))):
                 return self._nonlocal_bf16(x, p)
             # token counts the bf16 matrix-product tiles cannot take (e.g. CREMI's 156 x 156 LR slices -> 78 x 78 = 6084 tokens) or
             # rows longer than the bf16 softmax kernel holds in registers: this one block runs on the exact-fp32 kernels (zero-padded
@@ -648,29 +649,6 @@ class Engine:
         ref_img = torch.empty(nfr, 1, H * s, W * s, dtype=torch.float32, device=self.dev)
         ref_act = Act(ref_img, nfr, H * s, W * s, 1, 1, 0)
         lat = (H // 2) * (W // 2) if s == 8 else H * W
-        nstreams = int(os.environ.get("GPEMSR_FRONT_STREAMS", "1"))
-        if nstreams > 1 and trace is None and nfr >= 2 * nstreams:
-            # EXPERIMENT: the per-frame half of independent frame groups on several HIP streams (tails / memory-bound phases of one group
-            # under the matrix-bound phases of another)
-            if not hasattr(self, "_streams"):
-                self._streams = [torch.cuda.Stream(device=self.dev) for _ in range(nstreams)]
-            cur = torch.cuda.current_stream(self.dev)
-            per = (nfr + nstreams - 1) // nstreams
-            for si, st in enumerate(self._streams):
-                f0 = si * per
-                m = min(per, nfr - f0)
-                if m <= 0:
-                    continue
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    fi = None if forced_idx is None else forced_idx.reshape(-1)[f0 * lat:(f0 + m) * lat]
-                    r = self.front(xa.images(f0, m), fi, None)
-                    self.o.copy_channels(r["L1"], L1.images(f0, m)); self.o.copy_channels(r["L2"], L2.images(f0, m))
-                    self.o.copy_channels(r["L3"], L3.images(f0, m)); self.o.copy_channels(r["ref_img"], ref_act.images(f0, m))
-                    del r
-            for st in self._streams:
-                cur.wait_stream(st)
-            return (L1, L2, L3), ref_img
         for f0 in range(0, nfr, self.frame_chunk):
             m = min(self.frame_chunk, nfr - f0)
             fi = None if forced_idx is None else forced_idx.reshape(-1)[f0 * lat:(f0 + m) * lat]

@@ -130,23 +130,54 @@ class LaunchProfiler:
     def __init__(self):
         self.items = []
 
-    def run(self, kernel: str, tag: str, flops: float, fn):
+    def run(self, kernel: str, tag: str, flops: float, fn, name: Optional[str] = None, nbytes: float = 0.0):
+        """kernel: family (the bench line's roofline families); name: the kernel instantiation really launched (the per-kernel table);
+        nbytes: ALGORITHMIC bytes of the launch = unique inputs + outputs + weights of the layer at the dtypes it is stored in."""
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.items.append((kernel, tag, flops, s, e))
+        self.items.append((kernel, tag, flops, s, e, name or kernel, nbytes))
 
-    def summary(self, by_tag: bool = False):
+    def summary(self, by_tag: bool = False, by_name: bool = False):
         torch.cuda.synchronize()
         out = {}
-        for kernel, tag, flops, s, e in self.items:
-            key = (kernel, tag) if by_tag else kernel
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for kernel, tag, flops, s, e, name, nbytes in self.items:
+            key = name if by_name else ((kernel, tag) if by_tag else kernel)
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "family": kernel, "name": name})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += flops
+            d["bytes"] += nbytes
         return out
+
+
+_KNAME_CACHE: dict = {}
+
+
+def _kernel_name(fn, desc, key) -> str:
+    """Name of the kernel instantiation the library picks for this descriptor (gpemsr_conv2d*_kernel_name), cached per geometry."""
+    nm = _KNAME_CACHE.get(key)
+    if nm is None:
+        buf = C.create_string_buffer(160)
+        rc = fn(C.byref(desc), buf, 160)
+        nm = buf.value.decode() if rc == 0 and buf.value else "?"
+        _KNAME_CACHE[key] = nm
+    return nm
+
+
+def _layer_bytes(srcs, src_image_stride, out_elems: int, out_esize: int, w_elems: int, w_esize: int, residual, pixmul) -> float:
+    """Algorithmic HBM bytes of one layer: every source once, the result once, the weights once, residual / multiplier once."""
+    b = 0.0
+    for i, s_ in enumerate(srcs):
+        imgs = 1 if (src_image_stride is not None and int(src_image_stride[i]) == 0) else s_.n
+        b += imgs * s_.h * s_.w * s_.c * s_.esize
+    b += out_elems * out_esize + w_elems * w_esize
+    if residual is not None:
+        b += residual.n * residual.h * residual.w * residual.c * residual.esize
+    if pixmul is not None:
+        b += pixmul.n * pixmul.h * pixmul.w * 4
+    return b
 
 
 PROFILER: Optional[LaunchProfiler] = None
@@ -228,7 +259,9 @@ def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str) -> "Act
     d.cos_partials = ws.data_ptr()
     flops = 2.0 * n * h * w * pc.cout * pc.cin * 9.0
     if PROFILER is not None:
-        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"))
+        nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32cos", n, h, w, s0.c, pc.cout))
+        nb = 4.0 * (n * h * w * (s0.c + pc.cout) + pc.cout * pc.cin * 9)          # source + the operand map read; the result is not stored
+        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"), name=nm, nbytes=nb)
     else:
         _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
     out = new_act(n, h // 16, w // 16, 1, device=s0.buf.device)
@@ -280,7 +313,8 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             _abi.check(lib.gpemsr_conv2d_stem1(s0.ptr, n, h, w, pc.w.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
                                                pc.cout, act, out.ptr, out.ld, _stream()), "conv2d_stem1")
         if PROFILER is not None:
-            PROFILER.run("conv_stem1", tag, 2.0 * n * oh * ow * pc.cout * 9, _go_stem)
+            PROFILER.run("conv_stem1", tag, 2.0 * n * oh * ow * pc.cout * 9, _go_stem, name="conv_stem1_kernel<float>",
+                         nbytes=4.0 * (n * h * w + n * oh * ow * pc.cout))
         else:
             _go_stem()
         return out
@@ -294,7 +328,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
                                                       residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
                                                       out.ptr, out.ld, _stream()), "conv7_c16_cout2_f32")
         if PROFILER is not None:
-            PROFILER.run("tap_sum", tag, flops, _go_row7_32)
+            PROFILER.run("tap_sum", tag, flops, _go_row7_32, name="rowsum7_kernel<float>", nbytes=4.0 * n * h * w * (16 + 2 + (2 if residual is not None else 0)))
         else:
             _go_row7_32()
         return out
@@ -307,7 +341,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         if out_u8 is not None and out.ld == 1:
             _u8_fused[0] = True
         if PROFILER is not None:
-            PROFILER.run("tap_sum", tag, flops, _go_taps32)
+            PROFILER.run("tap_sum", tag, flops, _go_taps32, name="tap_sum_kernel<false,float>", nbytes=4.0 * n * h * w * (64 + 1 + (1 if residual is not None else 0)))
         else:
             _go_taps32()
         return out
@@ -319,7 +353,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
                                                 residual.ld if residual is not None else 0, out.ptr, out.ld, _stream()),
                        "conv2d_direct")
         if PROFILER is not None:
-            PROFILER.run("conv_direct", tag, flops, _go)
+            PROFILER.run("conv_direct", tag, flops, _go, name="conv_direct_kernel<float>", nbytes=4.0 * (n * h * w * s0.c + n * OH * OW * oc))
         else:
             _go()
         return out
@@ -356,7 +390,8 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         def _go_split():
             _abi.check(lib.gpemsr_conv2d_split(C.byref(d), pc.w16.data_ptr(), plane, nsplit, _stream()), "conv2d_split")
         if PROFILER is not None:
-            PROFILER.run("conv_split", tag, flops, _go_split)
+            PROFILER.run("conv_split", tag, flops, _go_split, name="conv_split_kernel",
+                         nbytes=_layer_bytes(srcs, src_image_stride, n * OH * OW * oc, 4, int(pc.cout * pc.cin * taps), 2 * nsplit, residual, pixmul))
         else:
             _go_split()
         return out
@@ -375,7 +410,11 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             and (residual is None or (residual.ld % 4 == 0 and residual.ptr % 16 == 0))):
         d.transposed, d.weight = 2, pc.wpair7.data_ptr()       # row-pair form: both halves of the 32-row matrix tile do useful work
     if PROFILER is not None:
-        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"))
+        nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32", n, h, w, tuple((s_.c, s_.ld % 4, s_.ptr % 16) for s_ in srcs), pc.cout, k, stride, int(d.transposed),
+                                                             int(pc.pixel_shuffle), bool(d.gn_partials), out.ld % 4, residual is not None))
+        wimgs = n if weight_image_stride != 0 else 1
+        nb = _layer_bytes(srcs, src_image_stride, n * OH * OW * oc, 4, int(wimgs * pc.cout * pc.cin * taps), 4, residual, pixmul)
+        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"), name=nm, nbytes=nb)
     else:
         _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
     return out
@@ -864,7 +903,8 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
             _abi.check(lib.gpemsr_conv2d_stem1_bf16(s0.ptr, n, h, w, pc.w.data_ptr(), pc.b.data_ptr() if pc.b is not None else None,
                                                     pc.cout, act, out.ptr, out.ld, _stream()), "conv2d_stem1_bf16")
         if PROFILER is not None:
-            PROFILER.run("conv_stem1", tag, 2.0 * n * oh * ow * pc.cout * 9, _go_stem)
+            PROFILER.run("conv_stem1", tag, 2.0 * n * oh * ow * pc.cout * 9, _go_stem, name="conv_stem1_kernel<bf16>",
+                         nbytes=4.0 * n * h * w + 2.0 * n * oh * ow * pc.cout)
         else:
             _go_stem()
         return out
@@ -882,7 +922,7 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
                                                        residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
                                                        out.ptr, out.ld, _stream()), "conv7_c16_cout2_bf16")
         if PROFILER is not None:
-            PROFILER.run("tap_sum", tag, flops, _go_row7)
+            PROFILER.run("tap_sum", tag, flops, _go_row7, name="rowsum7_kernel<bf16>", nbytes=n * h * w * (2.0 * 16 + 4.0 * 2 + (8.0 if residual is not None else 0.0)))
         else:
             _go_row7()
         return out
@@ -905,7 +945,7 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
             if out_u8 is not None and out.ld == 1:
                 _u8_fused[0] = True
             if PROFILER is not None:
-                PROFILER.run("tap_sum", tag, flops, _go_taps)
+                PROFILER.run("tap_sum", tag, flops, _go_taps, name="tap_sum_kernel<false,bf16>", nbytes=n * h * w * (2.0 * 64 + 4.0 + (4.0 if residual is not None else 0.0)))
             else:
                 _go_taps()
             return out
@@ -916,7 +956,8 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
                                                      residual.ptr if residual is not None else None, residual.ld if residual is not None else 0,
                                                      out.ptr, int(o32), out.ld, _stream()), "conv2d_direct_bf16")
         if PROFILER is not None:
-            PROFILER.run("conv_direct", tag, flops, _go_direct)
+            PROFILER.run("conv_direct", tag, flops, _go_direct, name="conv_direct_kernel<bf16>",
+                         nbytes=float(n * h * w * s0.c * s0.esize + n * OH * OW * oc * (4 if o32 else 2)))
         else:
             _go_direct()
         return out
@@ -972,7 +1013,15 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
     def _go():
         _abi.check(lib.gpemsr_conv2d_bf16(C.byref(d), _stream()), "conv2d_bf16")
     if PROFILER is not None:
-        PROFILER.run("conv_bf16", tag, flops, _go)
+        nm = _kernel_name(lib.gpemsr_conv2d_bf16_kernel_name, d, ("bf16", n, h, w, tuple((s_.c, s_.ld) for s_ in srcs), pc.cout, k, stride, int(pc.transposed),
+                                                                  int(pc.pixel_shuffle), int(kpack), int(out_f32), out32 is not None, gn_stats, variant,
+                                                                  a_affine is not None, residual is not None and residual.bf16, pixmul is not None, act,
+                                                                  weight_image_stride != 0, None if src_image_stride is None else tuple(src_image_stride)))
+        wimgs = n if weight_image_stride != 0 else 1
+        nb = _layer_bytes(srcs, src_image_stride, n * OH * OW * oc, 4 if out_f32 else 2, int(wimgs * pc.cout * pc.cin * taps), 2, residual, pixmul)
+        if out32 is not None:
+            nb += 4.0 * n * OH * OW * oc
+        PROFILER.run("conv_bf16", tag, flops, _go, name=nm, nbytes=nb)
     else:
         _go()
     return ret
@@ -1030,7 +1079,8 @@ def upconv_out_bf16(x: Act, frag: torch.Tensor, consts: torch.Tensor, out: Optio
                                                           _stream()), "upconv_out_c64_bf16")
     if PROFILER is not None:
         # the arithmetic of the layered form it replaces: 2.25 taps x 64 x 64 for the up-block + 9 x 64 for the output conv
-        PROFILER.run("tap_sum", tag, 2.0 * x.n * 4 * x.h * x.w * (64 * 64 * 2.25 + 64 * 9), _go)
+        PROFILER.run("tap_sum", tag, 2.0 * x.n * 4 * x.h * x.w * (64 * 64 * 2.25 + 64 * 9), _go, name="tap_sum_kernel<true,bf16>",
+                     nbytes=x.n * x.h * x.w * (2.0 * 64 + 4.0 * 4))
     else:
         _go()
     return out
@@ -1048,7 +1098,8 @@ def upconv_out_f32(x: Act, frag: torch.Tensor, consts: torch.Tensor, out: Option
         _abi.check(_abi.load().gpemsr_upconv_out_c64_f32(x.ptr, x.n, x.h, x.w, x.ld, frag.data_ptr(), consts.data_ptr(), out.ptr, out.ld,
                                                          _stream()), "upconv_out_c64_f32")
     if PROFILER is not None:
-        PROFILER.run("tap_sum", tag, 2.0 * x.n * 4 * x.h * x.w * (64 * 64 * 2.25 + 64 * 9), _go)
+        PROFILER.run("tap_sum", tag, 2.0 * x.n * 4 * x.h * x.w * (64 * 64 * 2.25 + 64 * 9), _go, name="tap_sum_kernel<true,float>",
+                     nbytes=x.n * x.h * x.w * (4.0 * 64 + 4.0 * 4))
     else:
         _go()
     return out
@@ -1103,7 +1154,8 @@ def flash_attention_bf16(q: Act, kp: torch.Tensor, vtp: torch.Tensor, bias_v: Op
         _abi.check(_abi.load().gpemsr_flash_attention_bf16(q.ptr, q.ld, kp.data_ptr(), vtp.data_ptr(), bias_v.data_ptr() if bias_v is not None else None,
                                                            n, T, c, out.ptr, out.ld, _stream()), "flash_attention_bf16")
     if PROFILER is not None:
-        PROFILER.run("conv_bf16", tag, 4.0 * n * T * T * c, _go)      # q.k^T and P.v: 2 x (2 T^2 C) FLOPs per image
+        PROFILER.run("conv_bf16", tag, 4.0 * n * T * T * c, _go, name="flash_attn512_kernel",     # q.k^T and P.v: 2 x (2 T^2 C) FLOPs per image
+                     nbytes=2.0 * 4 * n * T * c)                                                  # q, k, v^T read, the result written (bf16)
     else:
         _go()
     return out
@@ -1157,7 +1209,8 @@ def vgg_mask_bf16(ref_img: Act, lr: Act, scale: int, w1: torch.Tensor, b1: torch
                                                     out.ptr, _stream()), "vgg_mask_bf16")
     flops = 2.0 * 2 * n * (h * scale) * (w * scale) * 64 * (64 * 9 + 9)          # both images: conv1_2 + conv1_1
     if PROFILER is not None:
-        PROFILER.run("vgg_mask", tag, flops, _go)
+        PROFILER.run("vgg_mask", tag, flops, _go, name="vgg_mask2_kernel",
+                     nbytes=4.0 * n * (h * scale * w * scale + h * w) + 2.0 * 64 * 64 * 9)        # the two 1-channel images + W2; the cosine map is tiny
     else:
         _go()
     return out

@@ -103,6 +103,19 @@ class MultiStepLRRestart:
         return self.lr
 
 
+def make_scheduler(opt_train: dict):
+    """The scheduler R:train_stage3.py:165-181 builds from the option file's ``train:`` block (lr_G, lr_scheme, T_period / lr_steps,
+    restarts, restart_weights, eta_min / lr_gamma).  Host-only (no device): tests/test_train_cpu.py drives it with the reference's blocks."""
+    o = opt_train
+    lr = float(o.get("lr_G", 4e-4))
+    scheme = o.get("lr_scheme") or "CosineAnnealingLR_Restart"
+    if scheme == "MultiStepLR":
+        return MultiStepLRRestart(lr, o["lr_steps"], o.get("restarts"), o.get("restart_weights"), o.get("lr_gamma", 0.1))
+    if scheme == "CosineAnnealingLR_Restart":
+        return CosineAnnealingLRRestart(lr, o.get("T_period", [1 << 30]), o.get("restarts"), o.get("restart_weights"), o.get("eta_min", 0.0))
+    raise NotImplementedError(f"lr_scheme {scheme!r} (the reference knows MultiStepLR and CosineAnnealingLR_Restart)")
+
+
 # ------------------------------------------------------------------------------------------------- the tape
 class TapeOps:
     """The engine's operator namespace in training: same calls as ``gpemsr_amd.ops``; operators on the trainable part of
@@ -707,11 +720,7 @@ class Stage3Trainer(_TrainerState):
         self.step_count = 0
         o = self.opt
         self.lr = float(o.get("lr_G", 4e-4))
-        if o.get("lr_scheme", "CosineAnnealingLR_Restart") == "MultiStepLR":
-            self.sched = MultiStepLRRestart(self.lr, o["lr_steps"], o.get("restarts"), o.get("restart_weights"), o.get("lr_gamma", 0.1))
-        else:
-            self.sched = CosineAnnealingLRRestart(self.lr, o.get("T_period", [1 << 30]), o.get("restarts"), o.get("restart_weights"),
-                                                  o.get("eta_min", 0.0))
+        self.sched = make_scheduler(o)
 
     # -- loss network --------------------------------------------------------------------------------------------------
     def _vgg_relu3_4(self, a: Act) -> Act:

@@ -106,6 +106,9 @@ int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream);
 int gpemsr_patch_cosine_finish(const float* ws, int n, int ph, int pw, float* out, void* stream);
 /* records per image a launch of `d` writes to d->gn_partials (the tiling is chosen by the library); < 0: error */
 int gpemsr_conv2d_gn_parts(const gpemsr_conv_desc* d);
+/* introspection (no reference counterpart; bench.py's per-kernel roofline table): the name of the kernel instantiation
+ * gpemsr_conv2d would launch for `d`, written to buf[cap] as text.  Nothing is launched.  0 or a negative error code */
+int gpemsr_conv2d_kernel_name(const gpemsr_conv_desc* d, char* buf, int cap);
 
 /* The same 3x3 stride-1 convolution on the bf16 matrix pipe.  nsplit = 2: every fp32 operand is split into hi + lo bf16 and the
  * product evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation (relative error ~2^-16 per product: fp32-grade for the 1e-3
@@ -181,6 +184,8 @@ int gpemsr_groupnorm_scale_shift(const float* mean_rstd, const float* gamma, con
                                  float* scale, float* shift, void* stream);
 /* rows of the gn_partials workspace per image for this launch geometry (>= 1), or a negative error code */
 int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d);
+/* the same introspection as gpemsr_conv2d_kernel_name for the bf16 family (tile choice of plan_x as text); nothing is launched */
+int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char* buf, int cap);
 
 /* GroupNorm on bf16 tensors (model/blocks.py:5-6,13-28).  The first pass (per-channel sum / sum of squares) comes either from
  * the producing convolution's epilogue (gpemsr_conv16_desc.gn_partials) or from gpemsr_groupnorm_stats_bf16; both fill

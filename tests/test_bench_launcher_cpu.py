@@ -64,3 +64,35 @@ def test_under_torchrun_env_it_is_a_rank_not_a_launcher():
     d = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["rccl_world"] == 2
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+
+
+def test_eight_ranks_rehearsal_gloo():
+    """The driver's N = 8 form cannot be rehearsed on hardware from here (no 8-GPU node): eight gloo ranks of the stub model exercise what
+    is NOT kernel work at that width -- port choice, rendezvous, barrier, the all-gather of 8 slabs, max-over-ranks timing, the bf16 leg."""
+    r = _run(["--gpus", "8", "--rank-timeout", "240"], timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_world"] == 8 and d["dist_backend"] == "gloo" and d["config"]["global_tiles"] == 24
+    assert d["gather"] == "f32" and "fp32 HR slabs" in d["timed_region"]
+    assert d["extras"]["bf16"]["n_gpus"] == 8 and d["extras"]["bf16"]["gather"] == "f32"
+
+
+def test_uint8_gather_option_two_ranks():
+    """--gather u8: the step exchanges the 8-bit image of the last kernel (1/4 of the bytes); stated in `timed_region`."""
+    r = _run(["--gpus", "2", "--gather", "u8"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["gather"] == "u8" and "uint8" in d["timed_region"] and d["value"] > 0
+    assert "uint8" in d["extras"]["bf16"]["timed_region"]
+
+
+def test_rank_timeout_stops_a_hung_launch():
+    """A rank that never finishes must not hang the launcher: --rank-timeout ends it with a non-zero code and no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GPEMSR_BENCH_CHILD")}
+    env["GPEMSR_BENCH_TEST_HANG_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--backend", "gloo", "--gpus", "2", "--tiles", "2", "--lr", "16",
+                        "--steps", "1", "--warmup", "0", "--rank-timeout", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

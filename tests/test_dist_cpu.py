@@ -114,3 +114,42 @@ def test_volume_shard_plan_every_world_size():
                     assert [int(v) + s_lo for v in rel[k]] == rows[lo + k]
                     assert all(0 <= int(v) < s_hi - s_lo for v in rel[k])
             assert covered == list(range(n))
+
+
+def _volume8_worker(rank, world, port, n_slices, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from gpemsr_amd.dist import plan_volume_shard, volume_window_rows
+    lo, hi, s_lo, s_hi, rows = plan_volume_shard(n_slices, rank, world)
+    vol = torch.arange(n_slices, dtype=torch.float32)                    # "slice k" = the number k
+    local = vol[s_lo:s_hi]                                               # what this rank reads from disk: its slices + halo
+    got = local[rows.long()] if rows.numel() else torch.zeros(0, 5)
+    want = vol[torch.tensor(volume_window_rows(n_slices)[lo:hi], dtype=torch.long)] if hi > lo else torch.zeros(0, 5)
+    cnt = torch.tensor([hi - lo, s_hi - s_lo], dtype=torch.int64)
+    dist.all_reduce(cnt)                                                 # every rank took part; totals checked by the parent
+    q.put((rank, lo, hi, s_lo, s_hi, bool(torch.equal(got, want)), int(cnt[0]), int(cnt[1])))
+    dist.destroy_process_group()
+
+
+def test_ragged_125_slice_volume_over_eight_gloo_ranks():
+    """CREMI's 125-slice volumes on the 8 ranks of one node: 125 = 8 x 15 + 5, so five ranks write 16 slices and three write 15; every
+    rank's LR read set is its slices plus a 2-slice halo on interior sides only, and windows indexed relative to that read set are the
+    reference's windows (R:output_GPEMSR.py:54-84,98-128)."""
+    world, n = 8, 125
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_volume8_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(30)
+    assert [r[2] - r[1] for r in res] == [16] * 5 + [15] * 3
+    assert res[0][1] == 0 and res[-1][2] == n and all(res[i][2] == res[i + 1][1] for i in range(world - 1))
+    assert all(r[5] for r in res)
+    assert all(r[6] == n for r in res)
+    for r in res:
+        rank, lo, hi, s_lo, s_hi = r[:5]
+        assert s_lo == max(lo - 2, 0) and s_hi == min(hi + 2, n)
+    assert res[0][7] == n + 2 * 2 * (world - 1)                           # the halo costs 4 extra slice reads per interior boundary
