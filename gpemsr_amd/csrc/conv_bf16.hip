@@ -30,7 +30,7 @@
 //     replace the separate statistics pass over the tensor (R:model/blocks.py:5-6).
 //
 // Replaces, for bf16 tensors, the same ATen calls as gpemsr_conv2d (R:model/GPEMSR.py:323-456 and the modules it calls).
-#include "bf16_common.h"
+#include "conv_bf16.h"
 
 namespace gpemsr {
 
@@ -54,48 +54,6 @@ __device__ unsigned long long g_xstamps[8 * 65536];
 #define R2L(k)
 #define R2L_FLUSH
 #endif
-
-constexpr int XA_LOADS = 10;      // 16-B A slots per DMA thread (halo_px * R / DMA threads; 3x3 16x32 tile on 4 loader waves: 10)
-constexpr int XB_LOADS = 9;       // 16-B B slots per thread per stage (TPS * R * BN / 256; 7x7 row stage of 64 couts: 7)
-
-enum { XS_PLAIN = 0, XS_PIXSHUF = 1, XS_CONVT = 2, XS_KPACK = 3 };
-
-struct XParams {
-  const unsigned short* src[GPEMSR_MAX_SRC];
-  long long img_stride[GPEMSR_MAX_SRC];      // elements
-  int ld[GPEMSR_MAX_SRC];
-  int c[GPEMSR_MAX_SRC];
-  int nsrc;
-  int n, h, w, oh, ow, OH, OW;
-  int cout;                                  // GEMM N (4*Cout for the transposed form)
-  int kw, kk, stride, pad;                   // filter width, taps per chunk, stride, padding
-  const unsigned short* weight; long long w_img_stride;
-  const float* bias; int act;
-  const void* residual; int res_ld, res_f32;
-  const float* pixmul;
-  int store_mode, cq;
-  void* out; int out_ld, out_f32;
-  float* out32; int out32_ld;
-  float* gn_ws; int gn_parts, gn_cpg;        // [n][gn_parts = tiles per image][cout][2]; channels per GroupNorm group
-  long long kpack_img_stride;                // XS_KPACK: elements between images of the packed output
-  int tiles_x, tiles_y, tiles_n;
-  unsigned mg_x, mg_y, mg_n;                 // floor((2^32 - 1) / tiles_*): division by a run-time tile count as mulhi + one correction (xdivmod)
-  int halo_h, halo_w, halo_px;
-  int tw_lg;
-  int na, nb;                                // DMA slots per thread: A image, B stage image
-  int a_bytes, b_bytes;                      // LDS bytes of one A image / one B stage image
-  int ring;                                  // B (and, GEMM form, A) ring depth
-  int n_abuf;                                // A images in LDS: GEMM: ring; conv: 2 (1 when there is a single chunk)
-  int spc;                                   // stages per chunk = kk / TPS
-  int nblocks;
-  int nbias;                                 // true output channels (bias entries)
-  int gpt, ns;                               // resident kernel: workgroups per cout slab, spatial tiles
-  int dbg;                                   // diagnostic builds (-DGP16_STAMP) only: descriptor.variant (101: no MFMA loop, 102: no epilogue)
-  const float* axs; const float* axh;        // AXF kernels: per (image, input channel) scale / shift applied to the source while it is staged
-  int ax_relu;                               // ... followed by ReLU
-};
-
-struct XGeo { int img, oy0, ox0, n0, tile_in_img; };
 
 // Epilogue of one wave's MT x NT accumulator tiles, straight from registers.  The accumulators are D^T (registers = 16 couts
 // (r&3) + 8 (r>>2) + 4 lh of a 32-cout tile, lanes = 32 pixels): bias (from LDS: a global load here would drain the DMA
@@ -388,12 +346,6 @@ __device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x
       }
     }
   }
-}
-
-// bias -> LDS (zero-padded to a multiple of 8 floats); nbias = number of true output channels
-__device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, int nbias, int nthreads) {
-  const int npad = (nbias + 7) & ~7;
-  for (int i = threadIdx.x; i < npad; i += nthreads) bias_lds[i] = (P.bias && i < nbias) ? P.bias[i] : 0.f;
 }
 
 // conv64_resident2_kernel's k loop, software-pipelined BY HAND.  Only one wave of a SIMD multiplies at a time there, so nothing but the
@@ -1594,6 +1546,7 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
   for (int s = IV * T_g + DL * g; s < NI; ++s) end_interval();
 }
 
+
 template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false>
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
   auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS, AXF>;
@@ -1625,7 +1578,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
 using namespace gpemsr;
 
 namespace {
-struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean, axf, axf_ok; int res_form; size_t lds; };
+struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean, axf, axf_ok, tres; int res_form; size_t lds; };
 
 // geometry + tile choice of one launch (shared by the launcher and by gpemsr_conv2d_bf16_gn_parts)
 int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
@@ -1803,6 +1756,21 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
            (d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU);
   if (tr) L.lean = !d->out_f32 && !d->out32 && !d->residual && !d->pixmul && !d->gn_partials &&
                    (d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU);
+  // transposed, 64 input channels, 64-cout slabs, resident-form weights present behind the staged form: the weights-resident kernel
+  L.tres = tr && L.lean && (d->weight_forms & 1) && d->nsrc == 1 && d->src[0].c == 64 && d->cout % 64 == 0 && var != 3 && bias_bytes <= 4096 &&
+           d->out_ld % 8 == 0;
+  if (L.tres) {
+    P.tiles_n = d->cout / 64;
+    P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, 8);
+    P.mg_x = 0xFFFFFFFFu / (unsigned)P.tiles_x; P.mg_y = 0xFFFFFFFFu / (unsigned)P.tiles_y; P.mg_n = 0xFFFFFFFFu / (unsigned)P.tiles_n;
+    const long long ns = (long long)d->n * P.tiles_y * P.tiles_x;
+    GP_REQUIRE(ns < (1ll << 31), "conv2d_bf16: grid too large");
+    P.ns = (int)ns;
+    P.nbias = d->cout;
+    // the resident slabs follow the staged form [cin/CK][4 taps][CK/8][4 cout][8] = 16 cin cout elements
+    P.weight = reinterpret_cast<const unsigned short*>(d->weight) + 16ll * 64 * d->cout;
+    L.lds = 73728 + 4 * 19008 + bias_bytes;
+  }
   // source transform (a_scale / a_shift: a folded GroupNorm apply): kernels that stage the halo image through registers exist for the
   // 64-channel weights-resident form and for the wide 3x3 loader-wave tile -- every second convolution of a VQGAN block
   L.axf_ok = !tr && !gemm && d->ksize == 3 && d->stride == 1 && d->nsrc == 1 && d->src_image_stride[0] < 0 && d->weight_image_stride == 0 && L.lean &&
@@ -1836,7 +1804,8 @@ extern "C" int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char*
   XParams P{}; XPlan L{};
   const int rc = plan_x(d, P, L);
   if (rc != GPEMSR_OK) return rc;
-  if (L.resident) {
+  if (L.tres) snprintf(buf, (size_t)cap, "convt64_resident_kernel");
+  else if (L.resident) {
     if (L.res_form == 2) snprintf(buf, (size_t)cap, "conv64_resident2_kernel<%s,%s>", (L.lean || L.axf) ? "true" : "false", L.axf ? "true" : "false");
     else snprintf(buf, (size_t)cap, "conv64_resident_kernel<%s>", L.lean ? "true" : "false");
   } else {
@@ -1846,7 +1815,7 @@ extern "C" int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char*
   return GPEMSR_OK;
 }
 
-static int device_cus() {
+int gpemsr::device_cus() {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0; hipDeviceProp_t prop;
@@ -1862,6 +1831,7 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
   if (rc != GPEMSR_OK) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = L.lds;
+  if (L.tres) return launch_convt64_resident(P, lds, st);
   if (L.resident) {
     static dev_once_t attr{0};
     if (dev_once_begin(attr)) {

@@ -30,7 +30,7 @@ import torch
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
 from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3, pack_rowpair7,
-                      pack_vgg_first, pack_cout1_taps, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
+                      pack_vgg_first, pack_cout1_taps, pack_conv7_c32_cout16, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -194,6 +194,8 @@ class Engine:
             if self.precision == "fp32" and w.shape[0] == 16 and tuple(w.shape[2:]) == (7, 7) and getattr(self, "fuse_tail_f32", True) \
                     and os.environ.get("GPEMSR_ROWPAIR7", "1") != "0":
                 self.pc[name].wpair7 = pack_rowpair7(w, dev)            # SpyNet 32 -> 16: row-pair form (16 couts fill half a matrix tile)
+            if self.bf16 and tuple(w.shape) == (16, 32, 7, 7) and os.environ.get("GPEMSR_CONV7_C16", "1") != "0":
+                self.pc[name].w7c16 = pack_conv7_c32_cout16(w, dev)     # SpyNet 32 -> 16 on the 16x16x32 MFMA shape (csrc/conv7_bf16.hip)
             if self.bf16 and tuple(w.shape) == (2, 16, 7, 7):
                 self.pc[name].wrow7 = pack_rowsum7(w, dev)              # SpyNet flow update as row sums (csrc/tap_sum.hip)
         elif w.dim() == 2 and name.endswith("indexer.embedding"):

@@ -210,6 +210,7 @@ class PackedConv:
     wrow7: Optional[torch.Tensor] = None   # bf16 data path, 16 -> 2 7x7 (SpyNet flow update): row-sum fragments (packing.pack_rowsum7)
     wtap32: Optional[torch.Tensor] = None  # fp32 activations, 64 -> 1 3x3: fp32 tap fragments (packing.pack_cout1_taps_f32)
     wrow7_32: Optional[torch.Tensor] = None  # fp32 activations, 16 -> 2 7x7: row-sum fragments (packing.pack_rowsum7_f32)
+    w7c16: Optional[torch.Tensor] = None   # bf16 data path, 32 -> 16 7x7: 16x16x32 MFMA fragments (packing.pack_conv7_c32_cout16)
     wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
                                            # the profiler's flop count uses this, so split products are not credited as extra work
@@ -926,6 +927,21 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
         else:
             _go_row7()
         return out
+    # SpyNet's 32 -> 16 7x7 layers: the 16x16x32 MFMA shape with resident weights (csrc/conv7_bf16.hip); variant 9 keeps the ring kernel
+    if (pc.w7c16 is not None and plain and s0.bf16 and s0.c == 32 and pc.cout == 16 and k == 7 and stride == 1 and residual is None and not out_f32
+            and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and variant != 9 and s0.ld % 8 == 0 and s0.ptr % 16 == 0):
+        if out is None:
+            out = new_act(n, OH, OW, 16, device=dev, bf16=True)
+        assert out.bf16 and (out.n, out.h, out.w, out.c) == (n, OH, OW, 16) and out.ld % 4 == 0 and out.ptr % 8 == 0
+
+        def _go_c7():
+            _abi.check(lib.gpemsr_conv7_c32_cout16_bf16(s0.ptr, n, h, w, s0.ld, pc.w7c16.data_ptr(), pc.b.data_ptr() if pc.b is not None else None, act,
+                                                        out.ptr, out.ld, _stream()), "conv7_c32_cout16_bf16")
+        if PROFILER is not None:
+            PROFILER.run("conv_bf16", tag, flops, _go_c7, name="conv7_c32_cout16_kernel", nbytes=2.0 * (n * h * w * 48 + 49 * 512))
+        else:
+            _go_c7()
+        return out
     # tiny channel counts: VALU kernel with fp32 packed weights (1-channel results are fp32 images)
     use_direct = (plain and not force_mfma and pc.cout <= 16 and (pc.cout <= 2 or pc.cin <= 16) and k >= 3 and pc.ck == 8
                   and (residual is None or (pc.cin == 64 and pc.cout == 1 and k == 3 and stride == 1 and not residual.bf16)))
@@ -971,6 +987,8 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
         d.src_image_stride[i] = -1 if src_image_stride is None else int(src_image_stride[i])
     d.cout, d.ksize, d.stride, d.transposed = pc.cout, k, stride, int(pc.transposed)
     d.weight, d.weight_image_stride = pc.wb.data_ptr(), int(weight_image_stride)
+    if pc.transposed and pc.wb.numel() == 16 * pc.cin * pc.cout + 9 * pc.cin * pc.cout:
+        d.weight_forms = 1              # the resident (tap, phase)-block form follows the staged form (packing.pack_convT_bf16)
     d.bias = pc.b.data_ptr() if pc.b is not None else None
     d.act = act
     if residual is not None:

@@ -200,7 +200,33 @@ def pack_convT_bf16(w: torch.Tensor, device) -> torch.Tensor:
                 for px in range(dx, 2):
                     rows = (co // 32) * 128 + (2 * py + px) * 32 + (co % 32)
                     out[2 * dy + dx, rows] = wf[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()
-    return _stage_order_bf16(out, bf16_chunk((cin,))).to(torch.bfloat16).to(device)
+    staged = _stage_order_bf16(out, bf16_chunk((cin,))).to(torch.bfloat16)
+    if convT_resident_form_ok(cin, cout):
+        # behind the staged form: the nine non-zero (tap, phase) blocks per 64-cout slab for the weights-resident kernel
+        # (gpemsr_conv16_desc.weight_forms bit 0; csrc/conv_bf16.hip::convt64_resident_kernel)
+        staged = torch.cat([staged.reshape(-1), pack_convT_resident_bf16(wf).reshape(-1)])
+    return staged.to(device)
+
+
+def convT_resident_form_ok(cin: int, cout: int) -> bool:
+    return cin == 64 and cout % 64 == 0
+
+
+# (phase q = 2 py + px, tap (dy, dx)) of the nine non-zero blocks, in the order the kernel walks them
+CONVT_BLOCKS = ((0, 0, 0), (1, 0, 0), (1, 0, 1), (2, 0, 0), (2, 1, 0), (3, 0, 0), (3, 0, 1), (3, 1, 0), (3, 1, 1))
+
+
+def pack_convT_resident_bf16(wf: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d [Cin = 64, Cout, 3, 3] fp32 -> [Cout/64][chunk 2][block 9][piece 4][64 couts][8] bf16: block (q, dy, dx) holds
+    W[:, :, py+1-2dy, px+1-2dx]^T (rows = couts of the slab, columns = the chunk's 32 input channels in four 8-channel pieces)."""
+    cin, cout = wf.shape[0], wf.shape[1]
+    assert convT_resident_form_ok(cin, cout)
+    out = torch.zeros(cout // 64, 2, 9, 4, 64, 8, dtype=torch.float32)
+    for b, (q, dy, dx) in enumerate(CONVT_BLOCKS):
+        py, px = q >> 1, q & 1
+        m = wf[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()                   # [cout][cin]
+        out[:, :, b] = m.reshape(cout // 64, 64, 2, 4, 8).permute(0, 2, 3, 1, 4)
+    return out.to(torch.bfloat16)
 
 
 def _tap_fragments(rows: torch.Tensor) -> torch.Tensor:
@@ -277,6 +303,15 @@ def pack_rowsum7(w: torch.Tensor, device) -> torch.Tensor:
         full[0:14], full[16:30] = hi, lo
         frags.append(full.reshape(32, 2, 8).permute(1, 0, 2).reshape(64, 8))      # lane = half * 32 + row
     return torch.stack(frags).to(torch.bfloat16).contiguous().to(device)
+
+
+def pack_conv7_c32_cout16(w: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d(32 -> 16, 7x7) weight [16][32][7][7] -> the A-operand fragments of v_mfma_f32_16x16x32_bf16 for
+    gpemsr_conv7_c32_cout16_bf16: [tap = 7 ky + kx][k-group 4][16 couts][8] bf16 -- lane l of the fragment of a tap holds cout l % 16,
+    input channels 8 (l // 16) .. + 7."""
+    assert tuple(w.shape) == (16, 32, 7, 7)
+    wf = w.detach().to(torch.float32).cpu()
+    return wf.permute(2, 3, 0, 1).reshape(49, 16, 4, 8).permute(0, 2, 1, 3).contiguous().to(torch.bfloat16).to(device)
 
 
 def _tap_fragments_f32(rows: torch.Tensor) -> torch.Tensor:

@@ -172,7 +172,10 @@ typedef struct {
                                     * Only for layers gpemsr_conv2d_bf16_axf_ok() admits (3x3, stride 1, one dense source of 64 or k*32 channels). */
   const float* a_shift;
   int32_t a_relu;                  /* with a_scale: 1 = ReLU after the affine map */
-  int32_t reserved0;
+  int32_t weight_forms;            /* bit 0 (transposed, 64 input channels, cout % 64 == 0): the weight buffer carries, behind the staged form's
+                                    * 16 * cin * cout elements, the nine non-zero (tap, phase) blocks per 64-cout slab
+                                    * [cout/64][cin/32][block 9][4][64 couts][8] (gpemsr_amd/packing.py::pack_convT_bf16): the layer runs
+                                    * on the weights-resident transposed kernel.  0: staged form only */
 } gpemsr_conv16_desc;
 
 int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream);
@@ -279,6 +282,11 @@ int gpemsr_upconv_out_c64_f32(const float* x, int n, int h, int w, int ld, const
  * wfrag from packing.pack_rowsum7. */
 int gpemsr_conv7_c16_cout2_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, const float* residual,
                                 int res_ld, float* out, int out_ld, void* stream);
+/* Conv2d(32 -> 16, 7x7, pad 3) on bf16 NHWC tensors (basicsr SpyNet BasicModule's fourth convolution, R:model/GPEMSR.py:67,99) on
+ * v_mfma_f32_16x16x32_bf16 with the weights resident in LDS (csrc/conv7_bf16.hip): x [n][h][w][ld >= 32], wfrag = [49 taps][4 k-groups]
+ * [16 couts][8] bf16 (packing.pack_conv7_c32_cout16), bias fp32 [16] or NULL, act NONE / RELU / LRELU, out bf16 [n][h][w][out_ld >= 16]. */
+int gpemsr_conv7_c32_cout16_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, int act,
+                                 void* out, int out_ld, void* stream);
 /* the same for fp32 activations (exact-fp32 path): v_mfma_f32_32x32x2_f32, wfrag [7 kx][8 k-steps][64 lanes] floats (packing.pack_rowsum7_f32) */
 int gpemsr_conv7_c16_cout2_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, const float* residual,
                                int res_ld, float* out, int out_ld, void* stream);

@@ -31,17 +31,19 @@ SHAPES = [
     ("down 64->64 3x3 s2 @512^2 x16", "conv", 16, 64, 64, 3, 2, 512, 512, (0, 2)),
     ("down 64->64 3x3 s2 @512^2 x80", "conv", 80, 64, 64, 3, 2, 512, 512, (0, 2)),
     ("down 128->64 3x3 s2 @256^2 x80", "conv", 80, 128, 64, 3, 2, 256, 256, (0, 2)),
-    ("convT 64->64 @512^2 x8", "convT", 8, 64, 64, 3, 1, 512, 512, (0, 2)),
+    ("convT 64->64 @512^2 x8", "convT", 8, 64, 64, 3, 1, 512, 512, (0, 3)),
     ("convT 512->256 @64^2 x80", "convT", 80, 512, 256, 3, 1, 64, 64, (0, 2)),
     ("convT 256->128 @128^2 x80", "convT", 80, 256, 128, 3, 1, 128, 128, (0, 2)),
     ("convT 128->64 @256^2 x80", "convT", 80, 128, 64, 3, 1, 256, 256, (0, 2)),
-    ("convT 64->64 @256^2 x80", "convT", 80, 64, 64, 3, 1, 256, 256, (0, 2)),
+    ("convT 64->64 @256^2 x80", "convT", 80, 64, 64, 3, 1, 256, 256, (0, 3)),
+    ("convT 64->64 @128^2 x80", "convT", 80, 64, 64, 3, 1, 128, 128, (0, 3)),
     ("spy 32->64 7x7 @512^2 x16", "conv", 16, 32, 64, 7, 1, 512, 512, (0, 7, 8)),
     ("spy 64->32 7x7 @512^2 x16", "conv", 16, 64, 32, 7, 1, 512, 512, (0, 1, 4)),
     ("spy 16->32 7x7 @512^2 x16", "conv", 16, 16, 32, 7, 1, 512, 512, (0, 8)),
-    ("spy 32->16 7x7 @512^2 x16", "conv", 16, 32, 16, 7, 1, 512, 512, (0, 8)),
+    ("spy 32->16 7x7 @512^2 x16", "conv", 16, 32, 16, 7, 1, 512, 512, (0, 9)),
     ("spy 16->32 7x7 @512^2 x80", "conv", 80, 16, 32, 7, 1, 512, 512, (0, 8)),
-    ("spy 32->16 7x7 @512^2 x80", "conv", 80, 32, 16, 7, 1, 512, 512, (0, 8)),
+    ("spy 32->16 7x7 @512^2 x80", "conv", 80, 32, 16, 7, 1, 512, 512, (0, 9)),
+    ("spy 32->16 7x7 @256^2 x80", "conv", 80, 32, 16, 7, 1, 256, 256, (0, 9)),
     ("off 32->64 3x3 @128^2 x80", "conv", 80, 32, 64, 3, 1, 128, 128, (0, 8)),
 ]
 
@@ -73,6 +75,9 @@ def main():
             ps = kind == "ps"
             pc = pack_conv(wt, b, dev, pixel_shuffle=ps)
             pc.wb = pack_conv_bf16(wt, dev, pixel_shuffle=ps)
+            if (cout, cin, k) == (16, 32, 7):
+                from gpemsr_amd.packing import pack_conv7_c32_cout16
+                pc.w7c16 = pack_conv7_c32_cout16(wt, dev)          # variant 9 keeps the ring kernel
             if stride == 1 and (k in (3, 7) and cin % 16 == 0 or k == 1 and cin % 32 == 0):
                 pc.w16 = pack_conv_split(pc, wt, dev, pixel_shuffle=ps)
             oh, ow = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1

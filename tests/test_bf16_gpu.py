@@ -141,6 +141,9 @@ STREAM_CASES = [
     (8, (128,), 256, 3, 1, 96, 128, False),         # loader-wave form, three tiles per workgroup
     (9, (48,), 128, 3, 1, 80, 96, False),           # loader-wave form with 16-channel chunks (three of them)
     (12, (64,), 64, 3, 1, 64, 64, True),            # transposed: 4 stages per tile == ring depth
+    (40, (64,), 64, 3, 1, 96, 80, True),            # transposed, weights-resident kernel: ~5 tiles per workgroup, ragged tile columns
+    (10, (64,), 128, 3, 1, 72, 96, True),           # transposed, weights-resident kernel: two cout slabs
+    (6, (128,), 64, 3, 1, 64, 96, True),            # transposed ring kernel, four chunks
     (5, (64,), 64, 1, 1, 192, 160, False),          # 1x1: two chunks, two stages per tile
     (6, (64,), 64, 3, 2, 192, 128, False),          # stride 2
     (4, (32,), 64, 7, 1, 128, 160, False),          # 7x7, single chunk
@@ -244,19 +247,31 @@ def test_conv_with_folded_groupnorm_apply(n, c, cout, h, w):
     _close(got2.nchw(), F.leaky_relu(F.conv2d(y2, wt, b, 1, 1), 0.1) + res, 3 * BF, "affine only + residual epilogue")
 
 
-@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 16, 32), (128, 64, 9, 20), (512, 256, 8, 8), (64, 32, 5, 33)])
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 16, 32), (128, 64, 9, 20), (512, 256, 8, 8), (64, 32, 5, 33), (64, 64, 13, 45), (64, 128, 9, 20), (64, 64, 1, 1)])
 def test_conv_transpose_bf16(cin, cout, h, w):
+    """ConvTranspose2d(k3,s2,p1,op1) (R:model/blocks.py:32-38, R:model/GPEMSR.py:252-253) against torch; 64 -> 64k goes to the
+    weights-resident kernel (ragged tiles, one pixel, two cout slabs), everything else to the ring kernel; all three activations."""
     from gpemsr_amd import ops
     from gpemsr_amd.packing import pack_convT, pack_convT_bf16
     dev = _dev()
     x = _r(_rand(2, cin, h, w, seed=21))
     wt = _r(_rand(cin, cout, 3, 3, seed=22, scale=1.0 / np.sqrt(cin * 2.25)))
     b = _rand(cout, seed=23, scale=0.1)
-    want = F.leaky_relu(F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1), 0.1)
+    lin = F.conv_transpose2d(x, wt, b, stride=2, padding=1, output_padding=1)
     pc = pack_convT(wt, b, dev)
     pc.wb = pack_convT_bf16(wt, dev)
-    got = ops.conv2d([_act16(x, dev)], pc, 2, precision="bf16")
-    _close(got.nchw(), want, BF, "convT")
+    for act, want in ((2, F.leaky_relu(lin, 0.1)), (0, lin), (1, F.relu(lin))):
+        got = ops.conv2d([_act16(x, dev)], pc, act, precision="bf16")
+        _close(got.nchw(), want, BF, f"convT act {act}")
+    if cin == 64 and cout % 64 == 0:
+        # the same layer on the ring kernel (variant 3 keeps it off the resident one): both must agree to bf16 rounding of the result
+        ring = ops.conv2d([_act16(x, dev)], pc, 2, precision="bf16", variant=3)
+        _close(ring.nchw(), F.leaky_relu(lin, 0.1), BF, "convT ring kernel")
+        # a result written into a channel slice of a wider buffer (out_ld > cout)
+        wide = ops.new_act(2, 2 * h, 2 * w, cout + 64, device=dev, bf16=True, zero=True)
+        ops.conv2d([_act16(x, dev)], pc, 0, precision="bf16", out=wide.slice(64, cout))
+        _close(wide.slice(64, cout).nchw(), lin, BF, "convT into a slice")
+        assert float(wide.slice(0, 64).nchw().abs().max()) == 0.0
 
 
 def test_pixel_shuffle_bf16():
@@ -603,3 +618,37 @@ def test_linear_as_three_bf16_products_keeps_fp32_precision(rows_hw, cin, cout):
     assert not got.bf16 and got.c == cout
     want = torch.einsum("nchw,oc->nohw", x.double(), wt.double()) + b.double().view(1, -1, 1, 1)
     _close(got.nchw(), want, 2e-5, "three-product linear")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 16, 32), (3, 37, 70), (1, 5, 5), (9, 64, 96)])
+def test_conv7_c32_cout16_on_the_16x16x32_shape(n, h, w):
+    """SpyNet's 32 -> 16 7x7 layers (basicsr BasicModule via R:model/GPEMSR.py:67,99) on v_mfma_f32_16x16x32_bf16 with resident weights
+    (csrc/conv7_bf16.hip): against torch on the bf16-rounded operands, against the ring kernel (variant 9), ragged tiles, several
+    tiles per workgroup (the last case: 9 x 4 x 3 tiles... on a 256-CU chip one each; the persistent loop is exercised by n = 80 in the
+    forward), all three activations, a result written into a channel slice, bit-stable."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv7_c32_cout16
+    dev = _dev()
+    x = _r(_rand(n, 32, h, w, seed=41))
+    wt = _r(_rand(16, 32, 7, 7, seed=42, scale=1.0 / np.sqrt(32 * 49)))
+    b = _rand(16, seed=43, scale=0.2)
+    lin = F.conv2d(x, wt, b, 1, 3)
+    pc = _pc(wt, b, dev)
+    pc.w7c16 = pack_conv7_c32_cout16(wt, dev)
+    xa = _act16(x, dev)
+    for act, want in ((1, F.relu(lin)), (0, lin), (2, F.leaky_relu(lin, 0.1))):
+        got = ops.conv2d([xa], pc, act, precision="bf16")
+        _close(got.nchw(), want, BF, f"conv7 32->16 act {act}")
+    ring = ops.conv2d([xa], pc, 1, precision="bf16", variant=9)
+    _close(ring.nchw(), F.relu(lin), BF, "ring kernel")
+    a1 = ops.conv2d([xa], pc, 1, precision="bf16")
+    a2 = ops.conv2d([xa], pc, 1, precision="bf16")
+    assert torch.equal(a1.buf, a2.buf), "not bit-stable run to run"
+    wide = ops.new_act(n, h, w, 48, device=dev, bf16=True, zero=True)
+    ops.conv2d([xa], pc, 0, precision="bf16", out=wide.slice(16, 16))
+    _close(wide.slice(16, 16).nchw(), lin, BF, "into a slice")
+    assert float(wide.slice(0, 16).nchw().abs().max()) == 0.0 and float(wide.slice(32, 16).nchw().abs().max()) == 0.0
+    # a source that is a channel slice of a wider buffer (ld > 32)
+    xw = _act16(torch.cat([x, _r(_rand(n, 32, h, w, seed=44))], 1), dev)
+    got = ops.conv2d([xw.slice(0, 32)], pc, 0, precision="bf16")
+    _close(got.nchw(), lin, BF, "sliced source")
