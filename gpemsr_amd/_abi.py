@@ -40,7 +40,7 @@ SYMBOLS = [
     "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
     "gpemsr_copy_channels_f32_bf16", "gpemsr_conv2d_stem1_bf16", "gpemsr_conv2d_direct_bf16", "gpemsr_vgg_mask_bf16",
     "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32", "gpemsr_split_f32_bf16x2", "gpemsr_conv2d_gn_parts", "gpemsr_patch_cosine_finish",
-    "gpemsr_conv2d_kernel_name", "gpemsr_conv2d_bf16_kernel_name", "gpemsr_conv7_c32_cout16_bf16",
+    "gpemsr_conv2d_kernel_name", "gpemsr_conv2d_bf16_kernel_name", "gpemsr_conv7_c32_cout16_bf16", "gpemsr_conv2d_bf16_rowmax_parts", "gpemsr_rowmax_finish",
 ]
 
 
@@ -77,7 +77,7 @@ class ConvDesc16(C.Structure):
         ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_f32", C.c_int32),
         ("out32", C.c_void_p), ("out32_ld", C.c_int32),
         ("gn_partials", C.c_void_p), ("variant", C.c_int32), ("gn_cpg", C.c_int32),
-        ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_relu", C.c_int32), ("weight_forms", C.c_int32),
+        ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_relu", C.c_int32), ("weight_forms", C.c_int32), ("rowmax", C.c_void_p),
     ]
 
 
@@ -166,6 +166,8 @@ def load():
     lib.gpemsr_conv2d_bf16.argtypes = [C.POINTER(ConvDesc16), p]
     lib.gpemsr_conv2d_bf16_gn_parts.argtypes = [C.POINTER(ConvDesc16)]
     lib.gpemsr_conv2d_bf16_kernel_name.argtypes = [C.POINTER(ConvDesc16), C.c_char_p, C.c_int]
+    lib.gpemsr_conv2d_bf16_rowmax_parts.argtypes = [C.POINTER(ConvDesc16)]
+    lib.gpemsr_rowmax_finish.argtypes = [p, C.c_longlong, i32, p, p]
     lib.gpemsr_groupnorm_stats_bf16.argtypes = [p, i32, i32, i32, i32, p, i32, p]
     lib.gpemsr_groupnorm_finish.argtypes = [p, i32, i32, i32, i32, i32, f32, p, p]
     lib.gpemsr_groupnorm_scale_shift.argtypes = [p, p, p, i32, i32, i32, p, p, p]

@@ -37,6 +37,10 @@ def build_model(opt: dict, load_prior_files: bool = True, **extra):
     prec = net.get("precision") or opt.get("precision")
     if prec and "precision" not in extra:
         extra["precision"] = str(prec)
+    # additive: `indexer_precision: bf16 | bf16x3:N | fp32:N` (bf16 path: the indexer's last N units at a higher precision)
+    ip = net.get("indexer_precision") or opt.get("indexer_precision")
+    if ip and "indexer_precision" not in extra:
+        extra["indexer_precision"] = str(ip)
     return GPEMSR(ref_path_G=net["ref_path_G"] if load_prior_files else None,
                   ref_path_Indexer=net["ref_path_Indexer"] if load_prior_files else None,
                   argref=net["argref"], nf=net["nf"], nframes=net["nframes"], groups=net["groups"],

@@ -45,6 +45,7 @@ struct XParams {
   int dbg;                                   // diagnostic builds (-DGP16_STAMP) only: descriptor.variant (101: no MFMA loop, 102: no epilogue)
   const float* axs; const float* axh;        // AXF kernels: per (image, input channel) scale / shift applied to the source while it is staged
   int ax_relu;                               // ... followed by ReLU
+  float* rowmax;                             // XEPI == 1: [n][rows][tiles_n * WN] (value, column) pairs instead of a stored result
 };
 
 struct XGeo { int img, oy0, ox0, n0, tile_in_img; };

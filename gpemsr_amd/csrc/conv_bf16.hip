@@ -348,6 +348,49 @@ __device__ __forceinline__ void x_epilogue(const XParams& P, const XGeo& g, f32x
   }
 }
 
+// XEPI == 1: row maxima instead of a stored result (GEMM form; the arg-max of the indexer's logits, R:model/codebook.py:34-43 via
+// R:model/indexer.py:100).  The accumulators are D^T: lane = GEMM row (pixel), registers = 16 of the 32 columns of a tile (the other
+// 16 sit in the partner half-wave).  Every lane scans its columns in increasing order (strict >, so the lowest column wins a tie),
+// one v_permlane32_swap joins the halves, and lanes 0-31 write (value, column) for their row: ws[row][part = column tile * WN + wn].
+template <int MT, int NT>
+__device__ __forceinline__ void x_epilogue_rowmax(const XParams& P, const XGeo& g, f32x16 (&acc)[MT][NT], int pix_base, int cout_base, int wn, int WN_,
+                                                  const float* bias_lds, int li, int lh) {
+  const int parts = P.tiles_n * WN_;
+  const int part = (g.n0 / (NT * 32 * WN_)) * WN_ + wn;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float best = -3.4e38f;
+    int bcol = 0x7fffffff;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = g.n0 + cout_base + nt * 32 + 8 * q + 4 * lh;
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + (c0 < P.cout ? c0 : 0));
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[mt][nt][4 * q + j] + (P.bias ? bb[j] : 0.f);
+          const bool take = (c0 + j < P.cout) && v > best;
+          best = take ? v : best; bcol = take ? c0 + j : bcol;
+        }
+      }
+    // join the two half-waves (columns 8q + 4 lh ...: the partner holds the other 4 of every 8)
+    const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    const auto sc = __builtin_amdgcn_permlane32_swap((unsigned)bcol, (unsigned)bcol, false, false);
+    const float v0 = __uint_as_float(sv[0]), v1 = __uint_as_float(sv[1]);
+    const int c0 = (int)sc[0], c1 = (int)sc[1];
+    const bool second = v1 > v0 || (v1 == v0 && c1 < c0);
+    const float bv = second ? v1 : v0;
+    const int bc = second ? c1 : c0;
+    const int row = g.ox0 + pix_base + mt * 32 + li;
+    if (lh == 0 && row < P.oh * P.ow) {
+      float2* wsp = reinterpret_cast<float2*>(P.rowmax) + ((long long)g.img * (P.oh * P.ow) + row) * parts + part;
+      *wsp = make_float2(bv, __int_as_float(bc));
+    }
+  }
+}
+
 // conv64_resident2_kernel's k loop, software-pipelined BY HAND.  Only one wave of a SIMD multiplies at a time there, so nothing but the
 // wave's own reads-ahead can cover the LDS latency; hipcc folds a source-level double buffer back into ONE fragment set and every
 // MFMA then waits for a read issued one or two MFMAs earlier (stamps: 46 instead of ~32 clocks per MFMA, with or without
@@ -411,7 +454,14 @@ __device__ __forceinline__ void r2_steps(f32x16 (&acc)[2][2], bf16x8 (&fa)[3][2]
 // into the same swizzled image the DMA form builds.  A loader thread keeps ONE logical 8-channel piece (dtid % R), so its 8 scales and
 // shifts are loaded once per chunk; padding pixels are written as zeros (zero padding applies to the NORMALISED tensor).  Weights
 // still arrive by LDS-DMA; the in-order vmcnt sees the register loads and the DMA instructions in one queue (all counted below).
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false>
+// TCOMP (CONVT, TPS == 4, CK == 32): the stage image holds only the NINE non-zero (tap, phase) weight blocks of a chunk, tap by tap
+// [tap][piece][rows_t][8] with rows_t = 128 / 64 / 64 / 32 (tap (0,0) feeds all four phases, (0,1) phases 1 and 3, (1,0) phases 2 and 3,
+// (1,1) phase 3): 18 KB instead of the 32 KB of the phase-stacked form whose zero blocks were staged like the others (a stage of the
+// transposed layers moved 51 KB by LDS-DMA for 18 MFMAs of a wave).  Weights: packing.pack_convT_bf16's compact form.
+// XEPI == 1 (GEMM): the result is NOT stored; every wave leaves, per GEMM row, the maximum of (acc + bias) over its columns and the
+// column where it is (lowest on ties) -- the arg-max of the codebook logits without the logits in memory (R:model/codebook.py:34-43).
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT, bool GEMM, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false, bool TCOMP = false,
+          int XEPI = 0>
 __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM * WN + NL) > 8 ? 3 : 2)) void conv_bf16_kernel(XParams P) {
   constexpr int NC = WM * WN;          // multiplying waves
   constexpr bool SPEC = NL > 0;
@@ -435,9 +485,11 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
   constexpr int HALO_H = GEMM ? 1 : (TH - 1) * S + KW;
   constexpr int HALO_PX = HALO_W * HALO_H;
   constexpr int NA = (HALO_PX * R + DTH - 1) / DTH;   // A slots (16 B) per DMA thread
-  constexpr int NB = (TPS * R * BN + DTH - 1) / DTH;  // B slots per DMA thread per stage
+  static_assert(!TCOMP || (CONVT && TPS == 4 && CK == 32 && BN == 128 && WN == 1), "compact transposed weights: the 8x32 loader-wave tile");
+  constexpr int B_SLOTS = TCOMP ? R * 288 : TPS * R * BN;   // 16-byte pieces of a stage's weight image
+  constexpr int NB = (B_SLOTS + DTH - 1) / DTH;       // B slots per DMA thread per stage
   constexpr int A_BYTES = HALO_PX * R * 16;
-  constexpr int B_BYTES = TPS * R * BN * 16;
+  constexpr int B_BYTES = B_SLOTS * 16;
   static_assert(NA <= XA_LOADS && NB <= XB_LOADS, "tile too large");
 
   extern __shared__ __attribute__((aligned(16))) char xsm[];
@@ -478,7 +530,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
   // accumulator rows that are never stored) -- wave-uniform and constant
   int nb_w = 0;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) nb_w += (i * DTH + dwave * 64 < TPS * R * BN) ? 1 : 0;
+  for (int i = 0; i < NB; ++i) nb_w += (i * DTH + dwave * 64 < B_SLOTS) ? 1 : 0;
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)xsm + (unsigned)dwave * 1024u);
 
@@ -597,12 +649,22 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
   auto issue_b_begin = [&]() {
     if (b_cross) { const Geo gb = tile_geo(b_ti); b_img = gb.img; b_n0 = gb.n0; b_cross = false; }
     const unsigned short* wp = P.weight + (long long)b_img * P.w_img_stride + ((long long)b_chunk * KK + b_grp * TPS) * (R * 8) * P.cout;
+    if (TCOMP) wp = P.weight + (long long)b_chunk * (B_SLOTS * 8) * (P.cout >> 7);        // [chunk][tap][piece][cout/32][rows_t][8]
     ib_wp = reinterpret_cast<const unsigned short*>(xuni_ptr(wp));
     ib_lb = xuni(lds0 + (unsigned)(n_abuf * A_BYTES + b_dst * B_BYTES));
   };
   auto issue_b_slot = [&](int i) {
     const int e = dtid + i * DTH;
-    if (e < TPS * R * BN) {
+    if (TCOMP) {
+      if (e < B_SLOTS) {
+        // tap t owns slots [512 t', ...): 4 pieces x rows_t rows; source = the same slot inside this cout block's share of the tap region
+        const int t = e < 512 ? 0 : (e < 768 ? 1 : (e < 1024 ? 2 : 3));
+        const int base = t == 0 ? 0 : (t == 1 ? 512 : (t == 2 ? 768 : 1024)), lg = t == 0 ? 7 : (t == 3 ? 5 : 6);
+        const int piece = (e - base) >> lg, row = (e - base) & ((1 << lg) - 1);
+        const int nblk = P.cout >> 7, blk = b_n0 >> 7;
+        xglds16((unsigned)(base * nblk + ((piece * nblk + blk) << lg) + row) * 16u, ib_wp, ib_lb + i * (DTH * 16u));
+      }
+    } else if (e < TPS * R * BN) {
       int row = b_n0 + e % BN;
       row = row < P.cout ? row : P.cout - 1;
       xglds16((unsigned)((e / BN) * P.cout + row) * 16u, ib_wp, ib_lb + i * (DTH * 16u));
@@ -646,7 +708,7 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
   constexpr bool TABLE = KK <= 9;
   constexpr int AR = !TABLE || GEMM ? MT : (MT - 1) * S + KW, AC = !TABLE ? TPS : (GEMM ? 1 : KW);
   int a_off[AR][AC];                 // TABLE: (re)built at the top of every tile, so it is not live across the epilogue
-  const int b_frag = (wn * WNT + li) * 16 + lh * (BN * 16);
+  const int b_frag = TCOMP ? li * 16 : (wn * WNT + li) * 16 + lh * (BN * 16);     // TCOMP: the piece stride depends on the tap (load_step)
   const unsigned xsm_lds = xlds_addr(xsm);
 
   if constexpr (AXF) {
@@ -852,7 +914,15 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           if (CONVT && !((mask >> nt) & 1u)) continue;
-          fb[set][nt] = xlds_read16(B + (unsigned)((tt * R + 2 * ks) * (BN * 16) + nt * 512));
+          if (TCOMP) {
+            // tap tt: rows_t rows per piece, the fed phases in increasing order -> slot of phase nt inside the tap's image
+            const int tap = tap0 + tt;
+            const int rt = tap == 0 ? 128 : (tap == 3 ? 32 : 64), tb = tap == 0 ? 0 : (tap == 1 ? 512 : (tap == 2 ? 768 : 1024));
+            const int slot = tap == 0 ? nt : (tap == 1 ? (nt - 1) / 2 : (tap == 2 ? nt - 2 : 0));
+            fb[set][nt] = xlds_read16(B + (unsigned)(tb * 16 + 2 * ks * rt * 16 + slot * 512) + (unsigned)(lh * (rt * 16)));
+          } else {
+            fb[set][nt] = xlds_read16(B + (unsigned)((tt * R + 2 * ks) * (BN * 16) + nt * 512));
+          }
         }
       };
       auto mma_step = [&](int set, int tt) {
@@ -902,7 +972,8 @@ __global__ __launch_bounds__((WM * WN + NL) * 64, (WM * WN + NL) > 12 ? 4 : ((WM
     {
       int li2 = li, lh2 = lh;           // opaque per-tile copies: keeps the epilogue's tile-invariant addressing out of the MFMA loop's live set
       asm volatile("" : "+v"(li2), "+v"(lh2));
-      x_epilogue<MT, NT, GEMM, CONVT, LEAN>(P, g, acc, wm * PM, wn * WNT, g.tile_in_img * WM + wm, bias_lds, li2, lh2);
+      if constexpr (XEPI == 1) x_epilogue_rowmax<MT, NT>(P, g, acc, wm * PM, wn * WNT, wn, WN, bias_lds, li2, lh2);
+      else x_epilogue<MT, NT, GEMM, CONVT, LEAN>(P, g, acc, wm * PM, wn * WNT, g.tile_in_img * WM + wm, bias_lds, li2, lh2);
     }
     XSEG(5);
   }
@@ -1547,9 +1618,10 @@ __global__ __launch_bounds__(768, 3) void conv64_resident2_kernel(XParams P) {
 }
 
 
-template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false>
+template <int CK, int BN, int WM, int WN, int TH, int TPS, bool CONVT = false, bool GEMM = false, int NL = 0, bool LEAN = false, int SS = 0, bool AXF = false,
+          bool TCOMP = false, int XEPI = 0>
 static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
-  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS, AXF>;
+  auto kfn = conv_bf16_kernel<CK, BN, WM, WN, TH, TPS, CONVT, GEMM, NL, LEAN, SS, AXF, TCOMP, XEPI>;
   if (lds > 64 * 1024) {
     static dev_once_t done{0};
     if (dev_once_begin(done)) {
@@ -1578,7 +1650,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
 using namespace gpemsr;
 
 namespace {
-struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean, axf, axf_ok, tres; int res_form; size_t lds; };
+struct XPlan { int CK, BN, TH, TPS, WM, WN, NL; bool tr, gemm, resident, lean, axf, axf_ok, tres, tcomp; int res_form; size_t lds; };
 
 // geometry + tile choice of one launch (shared by the launcher and by gpemsr_conv2d_bf16_gn_parts)
 int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
@@ -1616,11 +1688,12 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   P.out = d->out; P.out_ld = d->out_ld; P.out_f32 = d->out_f32; P.out32 = d->out32; P.out32_ld = d->out32_ld;
   P.gn_ws = d->gn_partials; P.gn_cpg = d->gn_cpg;
   P.axs = d->a_scale; P.axh = d->a_shift; P.ax_relu = d->a_relu;
+  P.rowmax = d->rowmax;
   L.axf = d->a_scale != nullptr || d->a_shift != nullptr;
   P.nbias = d->cout;
   const int bias_bytes = ((d->cout + 7) & ~7) * 4;
   int BN, TH, TPS, WM, WN, NL = 0;
-  L.resident = false;
+  L.resident = false; L.tcomp = false;
   const int var = d->variant;                // 0 = default tile choice; > 0: alternatives (A/B tuning, scripts/conv16_microbench.py)
   if (tr) {
     P.kw = 2; P.kk = 4; P.stride = 1; P.pad = 0; P.cout = 4 * d->cout;
@@ -1628,6 +1701,10 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
     P.store_mode = XS_CONVT; P.cq = d->cout; BN = 128; TH = 4; TPS = 2; WM = 4; WN = 1;
     if (var != 1) { TH = 8; WM = 8; NL = 4; TPS = (var == 2) ? 2 : 4; }   // 8x32 px x (4 phases x 32 couts), 8 multiplying + 4 loader waves;
                                                             // a stage = all four taps of a chunk (variant 2: tap pairs, round 2's form)
+    // whole-chunk stages with 32-channel chunks read the COMPACT weight form (nine non-zero (tap, phase) blocks, behind the staged
+    // form; weight_forms bit 1); without it the layer takes the tap-pair stages of the staged form
+    L.tcomp = var != 1 && TPS == 4 && CK == 32 && (d->weight_forms & 2) != 0;
+    if (var != 1 && TPS == 4 && CK == 32 && !L.tcomp) TPS = 2;
   } else {
     P.kw = d->ksize; P.kk = d->ksize * d->ksize; P.stride = d->stride; P.pad = d->ksize / 2; P.cout = d->cout;
     P.oh = (d->h + 2 * P.pad - d->ksize) / P.stride + 1; P.ow = (d->w + 2 * P.pad - d->ksize) / P.stride + 1;
@@ -1664,7 +1741,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
       TH = 2; WM = 2; WN = 2; TPS = (BN == 128) ? 1 : 3;
       // loader-wave form: 4 x 32 output pixels (9 x 65 halo) x 128 / 64 couts on 4 x 2 multiplying waves
       // (64 couts: a stage is the whole 32-channel chunk -- 18 instead of 6 MFMAs of a wave between barriers; variant 2: row stages)
-      if (var != 1 && BN >= 64 && CK == 32) { TH = 4; WM = 4; WN = 2; TPS = (BN == 64 && var != 2 && nchunk_total >= 2) ? 9 : 3; NL = 4; }
+      if (var != 1 && BN >= 64 && CK == 32) { TH = 4; WM = 4; WN = 2; TPS = (BN == 64 && var != 2 && var != 12 && nchunk_total >= 2) ? 9 : 3; NL = 4; }
     }
     else if (BN == 128) {
       if (var == 1) { TH = 8; TPS = 1; WM = 4; WN = 1; }          // 8x32 px, wave = 64 px x 128 couts, tap stages
@@ -1708,10 +1785,11 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   const int nth = (WM * WN + NL) * 64;
   const int dth = NL ? NL * 64 : nth;                       // threads that issue DMA
   P.na = cdiv((long long)P.halo_px * R, dth);
-  P.nb = cdiv((long long)TPS * R * BN, dth);
+  P.nb = cdiv(L.tcomp ? (long long)R * 288 : (long long)TPS * R * BN, dth);
   GP_REQUIRE(P.na <= XA_LOADS && P.nb <= XB_LOADS, "conv2d_bf16: tile too large (na=%d nb=%d)", P.na, P.nb);
   P.a_bytes = P.halo_px * R * 16;                          // lanes past the image are masked: no padding to whole DMA pieces
-  P.b_bytes = TPS * R * BN * 16;
+  P.b_bytes = L.tcomp ? R * 288 * 16 : TPS * R * BN * 16;
+  if (L.tcomp) P.weight = reinterpret_cast<const unsigned short*>(d->weight) + 16ll * nchunk_total * CK * d->cout;    // behind the staged form
   GP_REQUIRE(P.kk % TPS == 0, "conv2d_bf16: taps per stage must divide the tap count");
   P.spc = P.kk / TPS;
   // Ring depth / number of halo images: as deep as 80 KiB per workgroup (two workgroups per CU) allows, at most 4; the
@@ -1722,6 +1800,11 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
   // conv: two halo images; a single-chunk layer (SpyNet's 16 / 32-channel 7x7 convolutions) used to keep ONE and to wait for the next
   // tile's image with the matrix pipe idle -- its cursor now runs two tiles ahead (variant 8: the single image)
   int n_abuf = gemm ? (nchunk_total < 4 ? nchunk_total : 4) : 2;
+  // transposed, whole-chunk stages: 18 MFMAs of a wave per stage (~1.5k cycles) cannot cover the round trip of the NEXT chunk's halo image
+  // (in-kernel stamps, 128 -> 64 at 256^2: 32 % of a tile in the stages, 46 % waiting for images issued one stage earlier): keep up to
+  // four images, i.e. issue three stages ahead (the compact weight stages leave the LDS for it); variant 5: the two-image form
+  if (tr && L.tcomp && var != 5) n_abuf = nchunk_total < 4 ? (nchunk_total < 2 ? 2 : nchunk_total) : 4;
+  if (!tr && !gemm && d->ksize == 3 && d->stride == 2 && var == 12 && nchunk_total >= 3) n_abuf = 3;     // experiment: row stages, three halo images
   if (!gemm && nchunk_total < 2 && (var == 8 || 2 * P.a_bytes + 2 * P.b_bytes > budget)) n_abuf = 1;
   while (n_abuf * P.a_bytes + ring * P.b_bytes > budget && (ring > 2 || (gemm && n_abuf > 2))) {
     if (gemm && n_abuf > 2 && n_abuf >= ring) --n_abuf;      // matrix products: both rings advance per stage, keep them level
@@ -1782,7 +1865,7 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
 }
 }  // namespace
 
-static_assert(sizeof(gpemsr_conv16_desc) == 264, "gpemsr_conv16_desc layout changed: update gpemsr_amd/_abi.py");
+static_assert(sizeof(gpemsr_conv16_desc) == 272, "gpemsr_conv16_desc layout changed: update gpemsr_amd/_abi.py");
 
 extern "C" int gpemsr_conv2d_bf16_axf_ok(const gpemsr_conv16_desc* d) {
   XParams P{}; XPlan L{};
@@ -1798,6 +1881,38 @@ extern "C" int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d) {
   return rc == GPEMSR_OK ? P.gn_parts : rc;
 }
 
+// (value, column) records per GEMM row a launch with d->rowmax leaves: tiles_n x WN; < 0: error / no such kernel for this geometry
+extern "C" int gpemsr_conv2d_bf16_rowmax_parts(const gpemsr_conv16_desc* d) {
+  XParams P{}; XPlan L{};
+  const int rc = plan_x(d, P, L);
+  if (rc != GPEMSR_OK) return rc;
+  if (!(L.NL == 4 && L.gemm && L.BN == 128 && L.WM == 4 && L.WN == 2 && L.TH == 8 && L.TPS == 1 && L.CK == 64))
+    return fail(GPEMSR_EUNSUPPORTED, "conv2d_bf16: row maxima need the 1x1 form with cout > 64 and 64-channel sources");
+  return P.tiles_n * L.WN;
+}
+
+namespace gpemsr {
+__global__ __launch_bounds__(256) void rowmax_finish_kernel(const float2* ws, long long rows, int parts, int* idx) {
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+    float best = -3.4e38f; int bc = 0x7fffffff;
+    for (int p = 0; p < parts; ++p) {
+      const float2 v = ws[r * parts + p];
+      const int c = __float_as_int(v.y);
+      if (v.x > best || (v.x == best && c < bc)) { best = v.x; bc = c; }
+    }
+    idx[r] = bc;
+  }
+}
+}  // namespace gpemsr
+
+extern "C" int gpemsr_rowmax_finish(const float* ws, int64_t rows, int parts, int32_t* idx, void* stream) {
+  GP_REQUIRE(ws && idx && rows > 0 && parts > 0 && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, "rowmax_finish: bad args");
+  const long long nb = (rows + 255) / 256;
+  hipLaunchKernelGGL(gpemsr::rowmax_finish_kernel, dim3((unsigned)(nb < 65535 ? nb : 65535)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float2*>(ws), (long long)rows, parts, idx);
+  return check_launch("rowmax_finish_kernel");
+}
+
 // the kernel instantiation gpemsr_conv2d_bf16 would launch for `d`, as text (bench.py's per-kernel table); nothing is launched
 extern "C" int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char* buf, int cap) {
   GP_REQUIRE(buf != nullptr && cap > 0, "conv2d_bf16_kernel_name: no buffer");
@@ -1810,7 +1925,7 @@ extern "C" int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char*
     else snprintf(buf, (size_t)cap, "conv64_resident_kernel<%s>", L.lean ? "true" : "false");
   } else {
     snprintf(buf, (size_t)cap, "conv_bf16_kernel<CK=%d,BN=%d,WM=%d,WN=%d,TH=%d,TPS=%d,%s,NL=%d%s>", L.CK, L.BN, L.WM, L.WN, L.TH, L.TPS,
-             L.tr ? "CONVT" : (L.gemm ? "GEMM" : (d->stride == 2 ? "S2" : "CONV")), L.NL, L.axf ? ",AXF" : "");
+             L.tr ? (L.tcomp ? "CONVT,TCOMP" : "CONVT") : (L.gemm ? (d->rowmax ? "GEMM,ROWMAX" : "GEMM") : (d->stride == 2 ? "S2" : "CONV")), L.NL, L.axf ? ",AXF" : "");
   }
   return GPEMSR_OK;
 }
@@ -1881,10 +1996,16 @@ extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {
     if (L.NL == 0 && !L.tr && !L.gemm && GP_IS(64, 8, 1, 16, 7) && L.CK == 32) return launch_x<32, 64, 8, 1, 16, 7, false, false, 0, true>(P, lds, st);
     if (L.NL == 4 && !L.tr && !L.gemm && GP_IS(32, 8, 1, 16, 7) && L.CK == 16) return launch_x<16, 32, 8, 1, 16, 7, false, false, 4, true>(P, lds, st);
   }
+  if (d->rowmax) {            // row maxima instead of a stored result: the 256 x 128 GEMM tile with 64-deep stages (the logits GEMM)
+    if (L.NL == 4 && L.gemm && GP_IS(128, 4, 2, 8, 1) && L.CK == 64) return launch_x<64, 128, 4, 2, 8, 1, false, true, 4, false, 0, false, false, 1>(P, lds, st);
+    return fail(GPEMSR_EUNSUPPORTED, "conv2d_bf16: row maxima need the 1x1 form with cout > 64 and 64-channel sources");
+  }
   if (L.NL == 4) {            // loader-wave forms
-    if (L.tr && L.TPS == 4 && L.lean)
-      return L.CK == 32 ? launch_x<32, 128, 8, 1, 8, 4, true, false, 4, true>(P, lds, st) : launch_x<16, 128, 8, 1, 8, 4, true, false, 4, true>(P, lds, st);
-    if (L.tr && L.TPS == 4) return GP_XL(128, 8, 1, 8, 4, true, false);
+    if (L.tr && L.tcomp)
+      return L.lean ? launch_x<32, 128, 8, 1, 8, 4, true, false, 4, true, 0, false, true>(P, lds, st)
+                    : launch_x<32, 128, 8, 1, 8, 4, true, false, 4, false, 0, false, true>(P, lds, st);
+    if (L.tr && L.TPS == 4 && L.lean) return launch_x<16, 128, 8, 1, 8, 4, true, false, 4, true>(P, lds, st);
+    if (L.tr && L.TPS == 4) return launch_x<16, 128, 8, 1, 8, 4, true, false, 4>(P, lds, st);
     if (L.tr) return GP_XL(128, 8, 1, 8, 2, true, false);
     if (L.gemm) {
       if (GP_IS(128, 4, 2, 8, 1) && L.CK == 64) return launch_x<64, 128, 4, 2, 8, 1, false, true, 4>(P, lds, st);

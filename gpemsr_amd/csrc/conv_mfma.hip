@@ -470,6 +470,17 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
 
   GP_ST(2);
   // ---- epilogue: accumulators -> LDS [pixel][EW+4] (64 output columns per pass) -> coalesced rows ----
+  // Everything the epilogue derives from the thread index is tile-invariant; hoisted above the main loop by the compiler it cost the
+  // 168-register instantiations five spilled registers (20 bytes per lane of scratch in the two instantiations that run 40 % of the fp32
+  // step: profiles/r03_scratch.txt).  An opaque copy of the thread index keeps that arithmetic here.
+  int tid_epi = threadIdx.x;
+  asm volatile("" : "+v"(tid_epi));
+  {
+  const int tid = tid_epi;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
   constexpr int EW = BN < 64 ? BN : 64;
   constexpr int EPIX = EW + 4;
   constexpr int NCP = BN / EW;         // column passes
@@ -644,28 +655,17 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
     }
     const int nvalid = (P.cout - nidx) < 4 ? (P.cout - nidx) : 4;      // <= 0: this thread's columns are past cout
     const bool full = nvalid == 4;
+    // (the GENERAL path is the rare one -- ragged channel counts, unaligned rows, sigmoid: its residual / multiplier operands are loaded
+    // where they are used; the eight float4 it used to prefetch per thread were what pushed the 168-register instantiations into scratch)
     int opix[ITER];                                                     // pixel index inside the image, or -1
-    float4 rres[ITER];
-    float rmul[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int p = ppass * 128 + ep0 + it * PSTEP;
       const int oy = oy0 + (p >> tw_lg), ox = ox0 + (p & tw_mask);
-      opix[it] = -1; rres[it] = make_float4(0.f, 0.f, 0.f, 0.f); rmul[it] = 1.f;
+      opix[it] = -1;
       if (oy < P.oh && ox < P.ow && nvalid > 0) {
         const int Y = P.store_mode == STORE_PLAIN ? oy : 2 * oy + sy, X = P.store_mode == STORE_PLAIN ? ox : 2 * ox + sx;
         opix[it] = Y * P.OW + X;
-        if (P.residual) {
-          const float* rp = res_img + (long long)opix[it] * P.res_ld + ch;
-          if (P.res_vec && full) rres[it] = *reinterpret_cast<const float4*>(rp);
-          else {
-            if (nvalid > 0) rres[it].x = rp[0];
-            if (nvalid > 1) rres[it].y = rp[1];
-            if (nvalid > 2) rres[it].z = rp[2];
-            if (nvalid > 3) rres[it].w = rp[3];
-          }
-        }
-        if (P.pixmul) rmul[it] = mul_img[opix[it]];
       }
     }
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -694,15 +694,19 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
     __syncthreads();
     if (pass == 0) GP_ST(5);
     // ---- (3) coalesced rows: bias, activation, residual, multiplier, store ----
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < ITER; ++it) {
       if (opix[it] < 0) continue;
       const float4 a4 = *reinterpret_cast<const float4*>(E + (ep0 + it * PSTEP) * EPIX + 4 * ej);
       float v[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k] + bv[k], P.act);
-      v[0] += rres[it].x; v[1] += rres[it].y; v[2] += rres[it].z; v[3] += rres[it].w;
-      v[0] *= rmul[it]; v[1] *= rmul[it]; v[2] *= rmul[it]; v[3] *= rmul[it];
+      if (P.residual) {
+        const float* rp = res_img + (long long)opix[it] * P.res_ld + ch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < nvalid) v[k] += rp[k];
+      }
+      if (P.pixmul) { const float m = mul_img[opix[it]]; v[0] *= m; v[1] *= m; v[2] *= m; v[3] *= m; }
       float* op = out_img + (long long)opix[it] * P.out_ld + ch;
       if (P.out_vec && full) {
         *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
@@ -714,6 +718,7 @@ __global__ __launch_bounds__(256, (MASKED && TH == 8) ? 2 : 3) void conv_mfma_ke
     if (pass == 0) GP_ST(6);
   }
   GP_ST(3);
+  }
 }
 
 template <int CK, int BN, int WM, int WN, int TH, bool MASKED, bool DMA, int XEPI = 0>

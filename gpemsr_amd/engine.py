@@ -51,7 +51,7 @@ class Engine:
 
     def __init__(self, sd: Dict[str, torch.Tensor], device, scale: int, nframes: int = 5, groups: int = 8,
                  nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 80, tile_chunk: int = 16,
-                 precision: str = "fp32"):
+                 precision: str = "fp32", indexer_precision: str = "bf16"):
         assert scale in (8, 16)
         assert nf == 64, "kernels are specialised for nf=64 (every shipped option file)"
         self.sd = sd
@@ -71,8 +71,20 @@ class Engine:
         #       pipe with operands converted in LDS (split hi+lo = fp32-grade, or plain bf16 operands).
         self.precision = precision
         self.bf16 = precision == "bf16"
+        # bf16 path only: "<mode>:<N>" runs the LAST N units of the indexer (R:model/indexer.py:89-96: output_layer's three ResidualBlocks
+        # and its 1x1 convolution, counted from the end) on fp32 activations with `mode` = bf16x3 (split hi + lo products, fp32-grade) or
+        # fp32 (exact kernel): the argmax over 1024 logits is discontinuous, so the code indices a free-running bf16 forward picks differ
+        # from the reference's wherever the top-2 margin is below the logit error; the tail's precision trades time for agreement.
+        # "bf16" (default): everything on the bf16 data path, logits GEMM as three products (always).
+        self.indexer_precision = indexer_precision or "bf16"
+        self._hp_mode, self._hp_n = None, 0
+        if self.bf16 and self.indexer_precision != "bf16":
+            mode, _, cnt = self.indexer_precision.partition(":")
+            assert mode in ("bf16x3", "fp32") and (cnt == "" or cnt.isdigit()), f"indexer_precision {indexer_precision!r}: bf16 | bf16x3:N | fp32:N"
+            self._hp_mode, self._hp_n = mode, int(cnt or 1)
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
         self.flash_attn = os.environ.get("GPEMSR_FLASH_ATTN", "1") != "0"   # bf16 path: NonLocalBlock products + softmax as one kernel (C = 512, T % 128 == 0)
+        self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.split = precision in ("bf16x3", "bf16op")
         self._forced_flow = None
@@ -180,8 +192,8 @@ class Engine:
                 w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 8))
             self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
             kk = w.shape[2]
-            if self.split and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
-                               or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
+            if (self.split or self._is_hp_layer(name)) and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
+                                                            or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
                 self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             if self.bf16 and all(c % 16 == 0 for c in self.pc[name].splits):
                 self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
@@ -211,6 +223,16 @@ class Engine:
             self.par[k] = w.detach().to(torch.float32).contiguous().to(dev)
             self.par[name + ".bias"] = b.detach().to(torch.float32).contiguous().to(dev)
 
+    def _hp_first_unit(self) -> int:
+        """Index of the first indexer output_layer unit that runs at the higher precision (n_out: none)."""
+        n_out = _seq_len(self.sd, "refmodel.indexer.output_layer")
+        return n_out if self._hp_mode is None else max(0, n_out - self._hp_n)
+
+    def _is_hp_layer(self, name: str) -> bool:
+        if self._hp_mode != "bf16x3" or not name.startswith("refmodel.indexer.output_layer."):
+            return False
+        return int(name.split(".")[3]) >= self._hp_first_unit()
+
     # ------------------------------------------------------------------ helpers
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
         kw.setdefault("precision", self.precision)
@@ -226,7 +248,14 @@ class Engine:
         return x
 
     # ------------------------------------------------------------------ VQGAN prior
-    def vq_resblock(self, x: Act, p: str) -> Act:
+    def vq_resblock(self, x: Act, p: str, precision: Optional[str] = None) -> Act:
+        if precision is not None and precision != self.precision:
+            # a block at another precision than the engine's (the indexer's tail, `indexer_precision`): fp32 activations, plain sequence
+            t = self.conv(x, p + ".block.0", precision=precision)
+            self.o.groupnorm_relu(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"], True, out=t)
+            u = self.conv(t, p + ".block.3", precision=precision)
+            skip = self.conv(x, p + ".channel_up", precision=precision) if (p + ".channel_up") in self.pc else x
+            return self.o.groupnorm_relu(u, self.par[p + ".block.4.weight"], self.par[p + ".block.4.bias"], True, residual=skip, out=u)
         # the conv epilogue leaves the GroupNorm partial sums (no statistics pass over the tensor): bf16 path and exact-fp32 path
         epi = self.gn_epi
         if self.bf16 and epi and int(os.environ.get("GPEMSR_GN_EPI_MIN_C", "100")) > self.pc[p + ".block.0"].cout:
@@ -373,15 +402,22 @@ class Engine:
             return self.conv(x, p)
         raise KeyError(p)
 
-    def indexer_logits(self, xf: Act) -> Act:
+    def indexer_logits(self, xf: Act, argmax: bool = False):
+        """Indexer8/16.forward (R:model/indexer.py:98-102).  argmax=True (bf16 path, three-product logits GEMM): returns the int32 code
+        indices instead -- the arg-max rides in the GEMM's epilogue and the [cells][1024] logits never reach memory."""
         p = "refmodel.indexer"
         h = self.conv(xf, p + ".input_layer.0", ACT_RELU)
         for i in range(_seq_len(self.sd, p + ".feat_extract")):
             h = self.vq_layer(h, f"{p}.feat_extract.{i}")
         n_out = _seq_len(self.sd, p + ".output_layer")
+        hp0 = self._hp_first_unit()
         for i in range(n_out):
             name = f"{p}.output_layer.{i}"
-            if self.bf16 and i == n_out - 1 and name in self.pc:
+            if i >= hp0:                                   # the tail at `indexer_precision`: fp32 activations from here on
+                if h.bf16:
+                    h = self.o.cast_f32(h)
+                h = self.vq_resblock(h, name, precision=self._hp_mode) if (name + ".block.0") in self.pc else self.conv(h, name, precision=self._hp_mode)
+            elif self.bf16 and i == n_out - 1 and name in self.pc:
                 h = self.conv(h, name, out_f32=True)       # the logits GEMM + argmax stay fp32 (SURVEY section 7)
             else:
                 h = self.vq_layer(h, name)
@@ -390,20 +426,30 @@ class Engine:
             # accumulation (packing.pack_linear_bf16x3; ~2^-16 of the logit scale, the bf16 activations upstream move logits by ~1e-2)
             hi, lo = self.o.split_hi_lo_bf16(h)
             del h
+            if argmax:
+                return self.o.conv2d([hi, lo, hi], self.pc[p + ".embedding@x3"], ACT_NONE, tag=p + ".embedding+argmax", precision="bf16", argmax=True)
             return self.o.conv2d([hi, lo, hi], self.pc[p + ".embedding@x3"], ACT_NONE, tag=p + ".embedding", precision="bf16", out_f32=True)
         if h.bf16:
             h = self.o.cast_f32(h)
         return self.conv(h, p + ".embedding", precision="fp32")    # nn.Linear on NHWC == 1x1 conv (indexer.py:100)
 
     def ref_extract(self, xf: Act, forced_idx: Optional[torch.Tensor], trace: Optional[dict]) -> List[Act]:
-        logits = self.indexer_logits(xf)
-        idx = self.o.argmax_rows(logits) if forced_idx is None else forced_idx.to(torch.int32).contiguous()
-        if trace is not None:
-            trace.setdefault("logits", []).append(logits.torch().clone())
-            trace.setdefault("code_idx", []).append(idx.clone())
+        s = self.scale
+        ln, lh_, lw_ = xf.n, (xf.h // 2 if s == 8 else xf.h), (xf.w // 2 if s == 8 else xf.w)     # latent grid (R:model/indexer.py:78-79: x8 halves once)
+        fused = (self.bf16 and self.fuse_argmax and forced_idx is None and trace is None and ("refmodel.indexer.embedding@x3") in self.pc
+                 and self.o is ops)
+        if fused:
+            idx = self.indexer_logits(xf, argmax=True)             # arg-max in the logits GEMM's epilogue: no [cells][1024] tensor
+        else:
+            logits = self.indexer_logits(xf)
+            assert (logits.n, logits.h, logits.w) == (ln, lh_, lw_)
+            idx = self.o.argmax_rows(logits) if forced_idx is None else forced_idx.to(torch.int32).contiguous()
+            if trace is not None:
+                trace.setdefault("logits", []).append(logits.torch().clone())
+                trace.setdefault("code_idx", []).append(idx.clone())
+            del logits
         gather = self.o.gather_rows_bf16 if self.bf16 else self.o.gather_rows
-        x = gather(self.par["refmodel.codebook.embedding.weight"], idx, logits.n, logits.h, logits.w)
-        del logits
+        x = gather(self.par["refmodel.codebook.embedding.weight"], idx, ln, lh_, lw_)
         p = "refmodel.decoder"
         for i in range(_seq_len(self.sd, p + ".input_layer")):
             x = self.vq_layer(x, f"{p}.input_layer.{i}")

@@ -875,7 +875,7 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
                 src_image_stride: Optional[Sequence[int]] = None, force_mfma: bool = False, tag: str = "",
                 out_f32: bool = False, out32: Optional[Act] = None, gn_stats: bool = False, kpack: bool = False,
                 variant: int = 0, out_u8: Optional[torch.Tensor] = None, _u8_fused: Optional[list] = None,
-                a_affine: Optional[tuple] = None) -> Act:
+                a_affine: Optional[tuple] = None, argmax: bool = False) -> Act:
     """Convolution of the bf16 path.  out_f32: fp32 result (logits input, deformable offsets, flows, 1-channel images);
     out32: additionally store the un-rounded fp32 result there; gn_stats: leave GroupNorm partial sums on the result
     (``out.gn``); kpack: store as the B operand [n][cout/8][pixels][8] of a later 1x1 product (returns the raw tensor);
@@ -988,7 +988,8 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
     d.cout, d.ksize, d.stride, d.transposed = pc.cout, k, stride, int(pc.transposed)
     d.weight, d.weight_image_stride = pc.wb.data_ptr(), int(weight_image_stride)
     if pc.transposed and pc.wb.numel() == 16 * pc.cin * pc.cout + 9 * pc.cin * pc.cout:
-        d.weight_forms = 1              # the resident (tap, phase)-block form follows the staged form (packing.pack_convT_bf16)
+        # a second form follows the staged one (packing.pack_convT_bf16): bit 0 = resident slabs (64 -> 64k), bit 1 = compact stage images
+        d.weight_forms = 1 if (pc.cin == 64 and pc.cout % 64 == 0) else 2
     d.bias = pc.b.data_ptr() if pc.b is not None else None
     d.act = act
     if residual is not None:
@@ -1001,6 +1002,29 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
     d.kpack = int(kpack)
     d.variant = int(variant)
     ret = None
+    if argmax:
+        # the product is not stored: int32 column of every row's maximum (gpemsr_conv16_desc.rowmax + gpemsr_rowmax_finish)
+        assert out is None and k == 1 and not kpack and residual is None and pixmul is None and act == ACT_NONE and not gn_stats
+        d.out, d.out_ld, d.out_f32 = srcs[0].ptr, pc.cout, 1          # (never written; the descriptor wants a valid aligned pointer)
+        d.rowmax = 1                                                   # (placeholder: the geometry query below looks at it)
+        parts = lib.gpemsr_conv2d_bf16_rowmax_parts(C.byref(d))
+        if parts < 1:
+            _abi.check(parts, "conv2d_bf16_rowmax_parts")
+        rows = n * OH * OW
+        ws = torch.empty(rows * parts * 2, dtype=torch.float32, device=dev)
+        d.rowmax = ws.data_ptr()
+        idx = torch.empty(rows, dtype=torch.int32, device=dev)
+
+        def _go_rm():
+            _abi.check(lib.gpemsr_conv2d_bf16(C.byref(d), _stream()), "conv2d_bf16")
+            _abi.check(lib.gpemsr_rowmax_finish(ws.data_ptr(), rows, parts, idx.data_ptr(), _stream()), "rowmax_finish")
+        if PROFILER is not None:
+            nm = _kernel_name(lib.gpemsr_conv2d_bf16_kernel_name, d, ("bf16rowmax", n, h, w, tuple((s_.c, s_.ld) for s_ in srcs), pc.cout))
+            nb = _layer_bytes(srcs, src_image_stride, rows, 4, int(pc.cout * pc.cin), 2, None, None)
+            PROFILER.run("conv_bf16", tag, flops, _go_rm, name=nm, nbytes=nb)
+        else:
+            _go_rm()
+        return idx
     if kpack:
         assert out is None and not out_f32
         ret = torch.empty(n, oc // 8, OH * OW, 8, dtype=torch.bfloat16, device=dev)

@@ -201,6 +201,10 @@ def pack_convT_bf16(w: torch.Tensor, device) -> torch.Tensor:
                     rows = (co // 32) * 128 + (2 * py + px) * 32 + (co % 32)
                     out[2 * dy + dx, rows] = wf[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()
     staged = _stage_order_bf16(out, bf16_chunk((cin,))).to(torch.bfloat16)
+    if cin % 32 == 0 and not convT_resident_form_ok(cin, cout):
+        # behind the staged form: the COMPACT form of the loader-wave kernel's whole-chunk stages (weight_forms bit 1): only the nine
+        # non-zero (tap, phase) blocks, [cin/32][tap][piece][cout/32][rows_t][8] with the phases a tap feeds in increasing order
+        staged = torch.cat([staged.reshape(-1), pack_convT_compact_bf16(wf).reshape(-1)])
     if convT_resident_form_ok(cin, cout):
         # behind the staged form: the nine non-zero (tap, phase) blocks per 64-cout slab for the weights-resident kernel
         # (gpemsr_conv16_desc.weight_forms bit 0; csrc/conv_bf16.hip::convt64_resident_kernel)
@@ -214,6 +218,26 @@ def convT_resident_form_ok(cin: int, cout: int) -> bool:
 
 # (phase q = 2 py + px, tap (dy, dx)) of the nine non-zero blocks, in the order the kernel walks them
 CONVT_BLOCKS = ((0, 0, 0), (1, 0, 0), (1, 0, 1), (2, 0, 0), (2, 1, 0), (3, 0, 0), (3, 0, 1), (3, 1, 0), (3, 1, 1))
+
+
+def pack_convT_compact_bf16(wf: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d [Cin % 32 == 0, Cout % 32 == 0, 3, 3] fp32 -> flat bf16 [cin/32][tap = 2 dy + dx][piece 4][cout/32][rows_t][8]:
+    rows_t = (phases fed by the tap, increasing q = 2 py + px) x 32 couts; row (q-slot, co % 32) of block co // 32 holds
+    W[:, co, py+1-2dy, px+1-2dx] for the chunk's 32 input channels in four 8-channel pieces."""
+    cin, cout = wf.shape[0], wf.shape[1]
+    assert cin % 32 == 0 and cout % 32 == 0
+    nchunk, nblk = cin // 32, cout // 32
+    parts = []
+    for dy in range(2):
+        for dx in range(2):
+            qs = [2 * py + px for py in range(dy, 2) for px in range(dx, 2)]
+            t = torch.zeros(nchunk, 4, nblk, len(qs), 32, 8, dtype=torch.float32)           # [chunk][piece][blk][q-slot][co % 32][8]
+            for si, q in enumerate(qs):
+                py, px = q >> 1, q & 1
+                m = wf[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()                          # [cout][cin]
+                t[:, :, :, si] = m.reshape(nblk, 32, nchunk, 4, 8).permute(2, 3, 0, 1, 4)
+            parts.append(t.reshape(nchunk, -1))
+    return torch.cat(parts, dim=1).contiguous().to(torch.bfloat16)                            # per chunk: tap 0 | tap 1 | tap 2 | tap 3
 
 
 def pack_convT_resident_bf16(wf: torch.Tensor) -> torch.Tensor:

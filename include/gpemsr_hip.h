@@ -175,7 +175,16 @@ typedef struct {
   int32_t weight_forms;            /* bit 0 (transposed, 64 input channels, cout % 64 == 0): the weight buffer carries, behind the staged form's
                                     * 16 * cin * cout elements, the nine non-zero (tap, phase) blocks per 64-cout slab
                                     * [cout/64][cin/32][block 9][4][64 couts][8] (gpemsr_amd/packing.py::pack_convT_bf16): the layer runs
-                                    * on the weights-resident transposed kernel.  0: staged form only */
+                                    * on the weights-resident transposed kernel.
+                                    * bit 1 (transposed, cin % 32 == 0): behind the staged form, the COMPACT form
+                                    * [cin/32][tap 4][piece 4][cout/32][rows_t][8], rows_t = 128, 64, 64, 32 = the phases a tap feeds
+                                    * (increasing q) x 32 couts: the loader-wave kernel stages 18 KB per chunk instead of 32 KB.
+                                    * 0: staged form only */
+  float* rowmax;                   /* optional (1x1 form, cout > 64, sources % 64 == 0): do NOT store the result; leave, per GEMM row and
+                                    * column part, the maximum of (product + bias) and its column (lowest on ties) as float pairs
+                                    * (value, column bits): [n][oh*ow][parts], parts = gpemsr_conv2d_bf16_rowmax_parts(d) -- the arg-max of
+                                    * the codebook logits (R:model/indexer.py:100 + R:model/codebook.py:34-43) without the
+                                    * [rows][1024] logits in memory; gpemsr_rowmax_finish folds the parts.  NULL = none */
 } gpemsr_conv16_desc;
 
 int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream);
@@ -187,6 +196,10 @@ int gpemsr_groupnorm_scale_shift(const float* mean_rstd, const float* gamma, con
                                  float* scale, float* shift, void* stream);
 /* rows of the gn_partials workspace per image for this launch geometry (>= 1), or a negative error code */
 int gpemsr_conv2d_bf16_gn_parts(const gpemsr_conv16_desc* d);
+/* row-maximum records per GEMM row for d->rowmax (>= 1), or a negative error code; gpemsr_rowmax_finish: ws[rows][parts] (value,
+ * column) pairs -> idx[rows] int32, the column of the row maximum (lowest column on ties: torch's argmax on CPU) */
+int gpemsr_conv2d_bf16_rowmax_parts(const gpemsr_conv16_desc* d);
+int gpemsr_rowmax_finish(const float* ws, int64_t rows, int parts, int32_t* idx, void* stream);
 /* the same introspection as gpemsr_conv2d_kernel_name for the bf16 family (tile choice of plan_x as text); nothing is launched */
 int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char* buf, int cap);
 

@@ -27,10 +27,10 @@ SHAPES = [
     ("up 64->256 3x3+ps @512^2 x4", "ps", 4, 64, 256, 3, 1, 512, 512, (0, 6)),
     ("1x1 512->512 @64^2 x80", "conv", 80, 512, 512, 1, 1, 64, 64, (0, 1)),
     ("1x1 320->64 @128^2 x16", "conv", 16, 320, 64, 1, 1, 128, 128, (0, 1)),
-    ("down 256->512 3x3 s2 @128^2 x80", "conv", 80, 256, 512, 3, 2, 128, 128, (0,)),
+    ("down 256->512 3x3 s2 @128^2 x80", "conv", 80, 256, 512, 3, 2, 128, 128, (0, 12)),
     ("down 64->64 3x3 s2 @512^2 x16", "conv", 16, 64, 64, 3, 2, 512, 512, (0, 2)),
     ("down 64->64 3x3 s2 @512^2 x80", "conv", 80, 64, 64, 3, 2, 512, 512, (0, 2)),
-    ("down 128->64 3x3 s2 @256^2 x80", "conv", 80, 128, 64, 3, 2, 256, 256, (0, 2)),
+    ("down 128->64 3x3 s2 @256^2 x80", "conv", 80, 128, 64, 3, 2, 256, 256, (0, 2, 12)),
     ("convT 64->64 @512^2 x8", "convT", 8, 64, 64, 3, 1, 512, 512, (0, 3)),
     ("convT 512->256 @64^2 x80", "convT", 80, 512, 256, 3, 1, 64, 64, (0, 2)),
     ("convT 256->128 @128^2 x80", "convT", 80, 256, 128, 3, 1, 128, 128, (0, 2)),

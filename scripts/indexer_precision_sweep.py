@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""free-running fidelity of precision="bf16" against the cost of running the indexer's tail at a higher precision.
+For every setting of `indexer_precision` (bf16 | bf16x3:N | fp32:N, N = trailing units of R:model/indexer.py:89-96's output_layer):
+  * code-index agreement and free-running relative error / |dPSNR| against the REFERENCE's own vectors (tests/golden/full_x8_lr128.npz,
+    full_x16_lr64.npz: one 5-frame window each, emitted by the unmodified reference; oracle/gen_golden_full.py);
+  * ms per step of the bench workload (16 windows of 5 x 1 x 128 x 128, x8), interleaved rounds in one process.
+    python3 scripts/indexer_precision_sweep.py [--steps 3] > profiles/r04_indexer_precision_sweep.log"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gpemsr_amd import ops  # noqa: E402
+from gpemsr_amd.config import build_model, load_options  # noqa: E402
+from gpemsr_amd.imgutil import calculate_psnr  # noqa: E402
+from gpemsr_amd.synth import synth_lr_tiles  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--modes", type=str, default="bf16,bf16x3:1,bf16x3:2,bf16x3:3,bf16x3:4,fp32:1,fp32:4")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    modes = args.modes.split(",")
+    gold = {8: np.load(os.path.join(ROOT, "tests", "golden", "full_x8_lr128.npz")), 16: np.load(os.path.join(ROOT, "tests", "golden", "full_x16_lr64.npz"))}
+    xb = synth_lr_tiles(16, 5, 128, 128, seed=1000, kind="uniform").to(dev)
+    print(f"{'indexer_precision':18s} {'ms/step x8':>11s} {'agree x8':>9s} {'rel x8':>9s} {'dPSNR x8':>9s} {'agree x16':>10s} {'rel x16':>9s} {'dPSNR x16':>10s}", flush=True)
+    models = {}
+    for m in modes:
+        for s in (8, 16):
+            opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{s}.yml"))
+            models[(m, s)] = build_model(opt, load_prior_files=False, precision="bf16", indexer_precision=m).eval().to(dev)
+    times = {m: [] for m in modes}
+    for m in modes:
+        models[(m, 8)](xb)
+    torch.cuda.synchronize()
+    for _ in range(3):                                   # interleaved rounds (guide rule 24)
+        for m in modes:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                models[(m, 8)](xb)
+            torch.cuda.synchronize()
+            times[m].append((time.perf_counter() - t0) / args.steps * 1e3)
+    for m in modes:
+        row = [f"{m:18s}", f"{sorted(times[m])[1]:11.2f}"]
+        for s in (8, 16):
+            d = gold[s]
+            x = torch.from_numpy(d["x"]).to(dev)
+            tr = {}
+            out, _ = models[(m, s)](x, trace=tr)
+            idx = torch.cat(tr["code_idx"]).cpu().numpy()
+            agree = float((idx == d["code_idx"]).mean())
+            st = int(d["out__stride"][0])
+            rel = float((out.cpu().reshape(-1)[::st] - torch.from_numpy(d["out__sub"]).reshape(-1)).abs().max() / np.abs(d["out__sub"]).max())
+            u8 = ops.tensor2img_u8(out[0, 0]).cpu().numpy()
+            base = torch.nn.functional.interpolate(torch.from_numpy(d["x"])[0:1, 2], scale_factor=s, mode="bilinear", align_corners=False)
+            b8 = (base.squeeze().clamp(0, 1).numpy() * 255.0).round().astype(np.uint8)
+            dps = abs(calculate_psnr(u8, b8) - float(d["psnr_vs_base"]))
+            row += [f"{agree:{9 if s == 8 else 10}.4f}", f"{rel:9.2e}", f"{dps:{9 if s == 8 else 10}.4f}"]
+        print(" ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

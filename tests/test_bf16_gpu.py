@@ -652,3 +652,30 @@ def test_conv7_c32_cout16_on_the_16x16x32_shape(n, h, w):
     xw = _act16(torch.cat([x, _r(_rand(n, 32, h, w, seed=44))], 1), dev)
     got = ops.conv2d([xw.slice(0, 32)], pc, 0, precision="bf16")
     _close(got.nchw(), lin, BF, "sliced source")
+
+
+@pytest.mark.parametrize("n,h,w,cout", [(3, 16, 24, 1024), (2, 9, 7, 1024), (1, 64, 64, 1000), (5, 32, 32, 256)])
+def test_argmax_in_the_logits_gemm_epilogue(n, h, w, cout):
+    """R:model/indexer.py:100 + R:model/codebook.py:34-43 without the logits in memory: gpemsr_conv16_desc.rowmax + gpemsr_rowmax_finish must
+    return exactly the indices gpemsr_argmax_rows finds in the stored logits of the same three-product GEMM (same accumulators, same
+    bias add), incl. ragged row tiles, a column count that is not a multiple of the 128-column tile, and exact ties (lowest column)."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_linear_bf16x3
+    dev = _dev()
+    cin = 512
+    x = _rand(n, cin, h, w, seed=700 + cout, scale=2.0)
+    wt = _rand(cout, cin, seed=701, scale=1.0 / cin ** 0.5); b = _rand(cout, seed=702)
+    wt[5] = wt[900 % cout]; b[5] = b[900 % cout]                   # two identical columns: an exact tie wherever they hold the maximum
+    wt[5] *= 3.0; wt[900 % cout] *= 3.0                            # ... which they often do
+    hi, lo = ops.split_hi_lo_bf16(_act32(x, dev))
+    pc = pack_linear_bf16x3(wt, b, dev)
+    logits = ops.conv2d([hi, lo, hi], pc, 0, precision="bf16", out_f32=True)
+    want = ops.argmax_rows(logits)
+    got = ops.conv2d([hi, lo, hi], pc, 0, precision="bf16", argmax=True)
+    assert got.dtype == torch.int32 and got.numel() == n * h * w
+    assert torch.equal(got, want.to(torch.int32).reshape(-1)), int((got != want.reshape(-1)).sum())
+    ties = int((want.reshape(-1) == 5).sum())
+    assert ties > 0, "the tie columns never won: the test does not exercise the tie rule"
+    assert int((got == 900 % cout).sum()) == 0 or cout <= 5
+    ref = logits.torch().reshape(-1, cout).argmax(dim=1).to(torch.int32)
+    assert float((ref == got).float().mean()) > 0.999               # (torch's CUDA argmax may break ties differently)

@@ -899,3 +899,48 @@ def test_validation_between_training_steps_uses_the_current_weights():
     torch.cuda.synchronize()
     assert torch.equal(v2, vf), float((v2 - vf).abs().max())
     assert float((v2 - v1).abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_geometry_batch8_of_32_to_256(precision):
+    """BASELINE configs[4] at its REAL geometry (R:option/train_stage3_x8.yml: batch_size 8, LQ_size 32, GT_size 256; the step of
+    R:train_stage3.py:343-366), driven by the `train:` block of option/train_stage3_x8.yml: finite losses and gradient; repeatable to
+    1e-4 (the deformable scatter is the only float-atomic kernel); and -- both losses are batch means -- the gradient of the batch equals
+    the mean of the eight single-sample gradients to 1e-4 of its largest entry.  fp32 and the bf16 frozen-sub-network mode."""
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
+    dev = _dev()
+    topt_all = load_options(os.path.join(ROOT, "option", "train_stage3_x8.yml"))
+    ds = topt_all["datasets"]["train"]
+    B, lq, gt = int(ds["batch_size"]), int(ds["LQ_size"]), int(ds["GT_size"])
+    assert (B, lq, gt, int(topt_all["scale"])) == (8, 32, 256, 8)
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    tr = Stage3Trainer(build_model(opt, load_prior_files=False, precision=precision).to(dev), dict(topt_all["train"]), dev)
+    assert tr.lr == 4e-4 and tr.adam_hparams()[:2] == (0.9, 0.99)
+    LR = synth_lr_tiles(B, 5, lq, lq, seed=55, kind="smooth").to(dev)
+    GT = torch.rand(B, 1, gt, gt, generator=torch.Generator().manual_seed(56)).to(dev)
+
+    def grad_of(lr_, gt_):
+        rec, ref = tr.forward_backward(lr_, gt_)
+        torch.cuda.synchronize()
+        return float(rec.item()), float(ref.item()), tr.flat_g.detach().clone()
+    rec, ref, g = grad_of(LR, GT)
+    assert np.isfinite(rec) and np.isfinite(ref) and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    rec2, ref2, g2 = grad_of(LR, GT)
+    gmax = float(g.abs().max())
+    assert abs(rec - rec2) <= 1e-4 * abs(rec) and abs(ref - ref2) <= 1e-4 * abs(ref)
+    assert float((g - g2).abs().max()) <= 1e-4 * gmax, float((g - g2).abs().max()) / gmax
+    acc, recs, refs = torch.zeros_like(g), [], []
+    for i in range(B):
+        r1, f1, gi = grad_of(LR[i:i + 1], GT[i:i + 1])
+        acc += gi; recs.append(r1); refs.append(f1)
+    acc /= B
+    err = float((g - acc).abs().max()) / gmax
+    print(f"config 5 geometry, {precision}: rec {rec:.5f} ref {ref:.5f}; |grad(batch) - mean grad(sample)| / max|grad| = {err:.2e}")
+    assert abs(rec - float(np.mean(recs))) <= 1e-5 * abs(rec) and abs(ref - float(np.mean(refs))) <= 1e-4 * abs(ref)
+    assert err <= 1e-4, err
+    before = tr.flat_p.detach().clone()
+    o = tr.step(LR, GT)
+    torch.cuda.synchronize()
+    assert np.isfinite(o["rec_loss"].item()) and float((tr.flat_p - before).abs().max()) > 0 and bool(torch.isfinite(tr.flat_p).all())
