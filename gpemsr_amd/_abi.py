@@ -40,7 +40,7 @@ SYMBOLS = [
     "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
     "gpemsr_copy_channels_f32_bf16", "gpemsr_conv2d_stem1_bf16", "gpemsr_conv2d_direct_bf16", "gpemsr_vgg_mask_bf16",
     "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32", "gpemsr_split_f32_bf16x2", "gpemsr_conv2d_gn_parts", "gpemsr_patch_cosine_finish",
-    "gpemsr_conv2d_kernel_name", "gpemsr_conv2d_bf16_kernel_name", "gpemsr_conv7_c32_cout16_bf16", "gpemsr_conv2d_bf16_rowmax_parts", "gpemsr_rowmax_finish",
+    "gpemsr_conv2d_kernel_name", "gpemsr_conv2d_bf16_kernel_name", "gpemsr_conv7_c32_cout16_bf16", "gpemsr_conv7_c8_cout32_bf16", "gpemsr_conv2d_bf16_rowmax_parts", "gpemsr_rowmax_finish",
 ]
 
 
@@ -205,6 +205,7 @@ def load():
     lib.gpemsr_upconv_out_c64_bf16.argtypes = [p, i32, i32, i32, i32, p, p, p, i32, p]
     lib.gpemsr_conv7_c16_cout2_bf16.argtypes = [p, i32, i32, i32, i32, p, p, p, i32, p, i32, p]
     lib.gpemsr_conv7_c32_cout16_bf16.argtypes = [p, i32, i32, i32, i32, p, p, i32, p, i32, p]
+    lib.gpemsr_conv7_c8_cout32_bf16.argtypes = [p, i32, i32, i32, i32, p, p, i32, p, i32, p]
     lib.gpemsr_conv7_c16_cout2_f32.argtypes = [p, i32, i32, i32, i32, p, p, p, i32, p, i32, p]
     lib.gpemsr_conv_c64_cout1_f32.argtypes = [p, i32, i32, i32, i32, p, p, i32, p, i32, p, i32, p, p]
     lib.gpemsr_upconv_out_c64_f32.argtypes = [p, i32, i32, i32, i32, p, p, p, i32, p]

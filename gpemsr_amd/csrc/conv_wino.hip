@@ -1,0 +1,595 @@
+// Winograd F(2x2, 3x3) form of the 3x3 stride-1 convolution on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// The fp32 path (BASELINE.json configs[1], the official bench value) sits at 0.8 of the fp32 matrix peak on every large layer: nothing
+// is left to tune towards, only arithmetic to remove.  F(2x2, 3x3) computes a 2x2 output block from a 4x4 input block with 16
+// multiplies per (cin, cout) instead of 36:
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray; correlation form, pad 1: d starts one pixel up / left of the block)
+// i.e. sixteen independent GEMMs  M_p[tile][cout] = sum_cin V_p[tile][cin] U_p[cin][cout],  p = 4 xi + nu, on 1/4 of the pixels.
+// Executed MFMA FLOPs = 16/36 of the algorithmic ones (both are reported: bench.py `executed_tflops`).  All arithmetic is fp32; the
+// transforms add and subtract only (G's halves are folded into U on the host in float64), error ~1e-6 of the result (bar: 1e-3).
+//
+//   * workgroup = 8 waves, output tile 16 x 32 pixels = 128 Winograd blocks (4 MFMA row tiles of 32) x 32 couts;
+//     wave w owns position row xi = w & 3 (its four positions nu = 0..3) for the two row tiles of half w >> 2: 8 accumulator tiles;
+//   * NO transformed-input buffer: a lane builds its A operand V[xi][nu] (one block, 4 channels = 4 k-steps) in registers from eight
+//     float4 of the raw halo image -- the row combination B^T[xi] of two image rows (one fma with a wave-uniform sign), then the four
+//     column combinations: 32 vector operations per 16 MFMAs (the f32 MFMA runs at the vector rate, so this is ~6 % on top);
+//   * raw halo image of a chunk of 8 channels in LDS as [channel quad][column parity][row][column / 2] 16-byte slots: the 16 blocks of
+//     a row tile read consecutive slots (a plain [pixel][8 ch] image would be read at a 64-byte stride: 4-way bank conflicts).  LDS-DMA
+//     writes lane-linear, so the layout is a permutation of the per-lane SOURCE address;
+//   * U_p rows of the workgroup's 32 couts ride beside it ([pos][cout][8 ch], 16 KB per chunk); images in a 4-deep ring (fragments of the next chunk are read one stage early), one counted
+//     vmcnt + barrier per chunk (32 MFMAs of a wave = 2k cycles of matrix time per SIMD between barriers);
+//   * epilogue: column half of A^T M A in registers (same lane, same register index across the four nu tiles), the row half across the
+//     four xi waves through LDS, then bias / activation / residual / per-pixel multiplier and float4 stores of whole 128-byte pixel rows.
+//
+// Replaces gpemsr_conv2d's direct form for the 3x3 stride-1 layers of R:model/GPEMSR.py:323-456 whose sources are multiples of 8
+// channels and whose cout is a multiple of 32 (descriptor.transposed = 3; weight = packing.pack_winograd).
+#include "common.h"
+#include <stdlib.h>
+
+namespace gpemsr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WinoParams {
+  const float* src[GPEMSR_MAX_SRC];
+  long long img_stride[GPEMSR_MAX_SRC];
+  int ld[GPEMSR_MAX_SRC];
+  int c[GPEMSR_MAX_SRC];
+  int nsrc;
+  int n, h, w;
+  int cin_pad, cout;
+  const float* weight;            // U [16][cout][cin_pad]
+  const float* bias; int act;
+  const float* residual; int res_ld;
+  const float* pixmul;
+  float* out; int out_ld;
+  int tiles_x, tiles_y, tiles_n;
+  int nblocks;
+  int pixshuf, cq;                // wide kernel: store as PixelShuffle(2) (cout index = (2i + j) * cq + c, out is [n][2h][2w][cq])
+  int dbg;                        // timing experiments only (GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
+};
+
+constexpr int WN_HH = 18, WN_HW2 = 17;                       // halo rows, halo columns per parity
+constexpr int WN_ASLOTS = 2 * 2 * WN_HH * WN_HW2;            // 1224 16-byte slots: [quad][parity][row][col / 2]
+constexpr int WN_ABYTES = WN_ASLOTS * 16;                    // 19,584
+constexpr int WN_BSLOTS = 16 * 32 * 2;                       // [pos][cout][quad]
+constexpr int WN_BBYTES = WN_BSLOTS * 16;                    // 16,384
+constexpr int WN_STAGE = WN_ABYTES + WN_BBYTES;              // 35,968
+constexpr int WN_RING = 4;
+constexpr int WN_NA = (WN_ASLOTS + 511) / 512;               // 3 slots per thread
+constexpr int WN_NB = WN_BSLOTS / 512;                       // 2
+constexpr int WN_EPIX = 36;                                  // floats per (tile) row of the exchange buffer: 32 couts + 4 (bank spread)
+constexpr int WN_EBYTES = 4 * 2 * 128 * WN_EPIX * 4;         // 147,456
+
+__device__ __forceinline__ void wn_glds16(unsigned voff, const void* base, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void wn_wait_vmcnt(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wino_f32_kernel(WinoParams P) {
+  extern __shared__ __attribute__((aligned(16))) char wsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int xi = wave & 3, mh = wave >> 2;
+
+  // ---- block -> (image, tile row, tile column, cout block); XCD-aware (consecutive logical blocks share an L2: the cout blocks of a tile) ----
+  int bid = blockIdx.x;
+  {
+    const int nwg = P.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  int t = bid;
+  const int tn = t % P.tiles_n; t /= P.tiles_n;
+  const int tx0 = t % P.tiles_x; t /= P.tiles_x;
+  const int ty0 = t % P.tiles_y; t /= P.tiles_y;
+  const int img = t;
+  const int oy0 = ty0 * 16, ox0 = tx0 * 32, n0 = tn * 32;
+
+  // ---- DMA slots (constant per thread): raw image slot -> pixel inside the source image (or -1), channel quad; U slot -> float offset ----
+  int a_pix[WN_NA], a_q[WN_NA];
+#pragma unroll
+  for (int i = 0; i < WN_NA; ++i) {
+    const int s = tid + i * 512;
+    a_pix[i] = -1; a_q[i] = 0;
+    if (s < WN_ASLOTS) {
+      const int hx2 = s % WN_HW2, r1 = s / WN_HW2;
+      const int hy = r1 % WN_HH, r2 = r1 / WN_HH;
+      const int par = r2 & 1, qd = r2 >> 1;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + 2 * hx2 + par;
+      a_q[i] = qd;
+      if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) a_pix[i] = iy * P.w + ix;
+    }
+  }
+  int b_off[WN_NB];
+#pragma unroll
+  for (int i = 0; i < WN_NB; ++i) {
+    const int s = tid + i * 512;                       // [pos][cout][quad]
+    const int qd = s & 1, co = (s >> 1) & 31, pos = s >> 6;
+    b_off[i] = (pos * P.cout + n0 + co) * P.cin_pad + 4 * qd;
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+  // out-of-image halo slots: zero once in every ring slot, never written again (their lanes stay masked in every DMA)
+  {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < WN_NA; ++i)
+      if (tid + i * 512 < WN_ASLOTS && a_pix[i] < 0)
+        for (int rs = 0; rs < WN_RING; ++rs) *reinterpret_cast<float4*>(wsm + rs * WN_STAGE + (tid + i * 512) * 16) = z;
+  }
+  int na_w = 0;
+#pragma unroll
+  for (int i = 0; i < WN_NA; ++i) na_w += (__ballot(a_pix[i] >= 0) != 0ull) ? 1 : 0;
+  const int n_issue = na_w + WN_NB;                    // DMA instructions this wave issues per chunk
+
+  // ---- chunk cursor over the virtual concat of the sources ----
+  int nchunks = 0;
+  for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / 8;
+  int f_src = 0, f_c0 = 0, f_cpad = 0, f_chunk = 0;    // next chunk to issue
+  auto issue_chunk = [&]() {
+    const unsigned la = lds0 + (unsigned)((f_chunk % WN_RING) * WN_STAGE);
+    const float* sp = P.src[f_src] + (long long)img * P.img_stride[f_src] + f_c0;
+    const unsigned pixb = (unsigned)P.ld[f_src] * 4u;
+#pragma unroll
+    for (int i = 0; i < WN_NA; ++i)
+      if (a_pix[i] >= 0) wn_glds16((unsigned)a_pix[i] * pixb + 16u * (unsigned)a_q[i], sp, la + i * 8192u);
+    const float* wp = P.weight + f_cpad + f_c0;
+#pragma unroll
+    for (int i = 0; i < WN_NB; ++i) wn_glds16((unsigned)b_off[i] * 4u, wp, la + (unsigned)WN_ABYTES + i * 8192u);
+    ++f_chunk; f_c0 += 8;
+    if (f_c0 >= P.c[f_src] && f_src + 1 < P.nsrc) { f_cpad += P.c[f_src]; f_c0 = 0; ++f_src; }
+  };
+
+  // ---- fragment addressing (tile-invariant) ----
+  // row combination of position row xi: V-row = d[aA] + sB * d[aB]
+  const int aA = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+  const int aB = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+  const float sB = xi == 1 ? 1.f : -1.f;
+  // lane's block inside row tile mtl (= 2 mh + mtl): ty = 2 (2 mh + mtl) + (li >> 4), tx = li & 15; d[a][b] = slot ((lh * 2 + (b & 1)) * 18 + 2 ty + a) * 17 + tx + (b >> 1)
+  unsigned d_base[2];
+#pragma unroll
+  for (int mtl = 0; mtl < 2; ++mtl) {
+    const int ty = 2 * (2 * mh + mtl) + (li >> 4), tx = li & 15;
+    d_base[mtl] = (unsigned)((((lh * 2) * WN_HH + 2 * ty) * WN_HW2 + tx) * 16);
+  }
+  const unsigned u_base = (unsigned)(WN_ABYTES + ((4 * xi * 32 + li) * 2 + lh) * 16);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int mtl = 0; mtl < 2; ++mtl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nu][mtl][r] = 0.f;
+
+  // ---- main loop, software-pipelined across the stage barrier ----
+  // Fragments of a chunk are needed 32 MFMAs apart only; with both waves of a SIMD leaving the barrier together, a stage that starts with
+  // its own 20 LDS reads + transform leaves the matrix pipe idle for their latency (first version: 58 % of the fp32 peak on the executed
+  // work).  So the raw rows of row tile 0 and the four U fragments of chunk c + 1 are read during stage c, behind the MFMAs of row tile 1:
+  // a stage opens with 16 vector operations and its first MFMA.  Ring of four images: chunk c + 3 is issued at the top of stage c into the
+  // slot chunk c - 1 left at the last barrier; the wait at the end of stage c leaves only that chunk in flight (c + 1, c + 2 have landed).
+  auto load_raw = [&](const char* st, int mtl, float4 (&r4)[4]) {          // row combination B^T[xi] of the two image rows, four columns
+    const char* dp = st + d_base[mtl];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int cofs = ((b & 1) * WN_HH * WN_HW2 + (b >> 1)) * 16;
+      const float4 va = *reinterpret_cast<const float4*>(dp + cofs + aA * (WN_HW2 * 16));
+      const float4 vb = *reinterpret_cast<const float4*>(dp + cofs + aB * (WN_HW2 * 16));
+      r4[b] = make_float4(fmaf(sB, vb.x, va.x), fmaf(sB, vb.y, va.y), fmaf(sB, vb.z, va.z), fmaf(sB, vb.w, va.w));
+    }
+  };
+  auto load_u = [&](const char* st, float4 (&U)[4]) {
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) U[nu] = *reinterpret_cast<const float4*>(st + u_base + nu * (32 * 2 * 16));
+  };
+  auto mma = [&](const float4 (&r4)[4], const float4 (&U)[4], int mtl) {
+    float4 V[4];                                         // column combinations
+    V[0] = make_float4(r4[0].x - r4[2].x, r4[0].y - r4[2].y, r4[0].z - r4[2].z, r4[0].w - r4[2].w);
+    V[1] = make_float4(r4[1].x + r4[2].x, r4[1].y + r4[2].y, r4[1].z + r4[2].z, r4[1].w + r4[2].w);
+    V[2] = make_float4(r4[2].x - r4[1].x, r4[2].y - r4[1].y, r4[2].z - r4[1].z, r4[2].w - r4[1].w);
+    V[3] = make_float4(r4[1].x - r4[3].x, r4[1].y - r4[3].y, r4[1].z - r4[3].z, r4[1].w - r4[3].w);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      acc[nu][mtl] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].x, U[nu].x, acc[nu][mtl], 0, 0, 0);
+      acc[nu][mtl] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].y, U[nu].y, acc[nu][mtl], 0, 0, 0);
+      acc[nu][mtl] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].z, U[nu].z, acc[nu][mtl], 0, 0, 0);
+      acc[nu][mtl] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].w, U[nu].w, acc[nu][mtl], 0, 0, 0);
+    }
+  };
+  issue_chunk();
+  if (nchunks > 1) issue_chunk();
+  int infl = 0;
+  if (nchunks > 2) { issue_chunk(); infl = n_issue; }
+  wn_wait_vmcnt(infl);                                   // chunks 0 and 1 have landed
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float4 U_cur[4], r0_cur[4];
+  load_u(wsm, U_cur);
+  load_raw(wsm, 0, r0_cur);
+
+  for (int ck = 0; ck < nchunks; ++ck) {
+    int issued = 0;
+    if (ck + 3 < nchunks) { issue_chunk(); issued = n_issue; }        // -> slot (ck + 3) % 4, left by chunk ck - 1 at the last barrier
+    const char* st = wsm + (ck % WN_RING) * WN_STAGE;
+    float4 r1[4];
+    load_raw(st, 1, r1);
+    mma(r0_cur, U_cur, 0);
+    float4 U_nxt[4], r0_nxt[4];
+    if (ck + 1 < nchunks) {                              // (wave-uniform) next chunk's first fragments: their latency lies under the MFMAs below
+      const char* sn = wsm + ((ck + 1) % WN_RING) * WN_STAGE;
+      load_u(sn, U_nxt);
+      load_raw(sn, 0, r0_nxt);
+    }
+    mma(r1, U_cur, 1);
+    // everything issued BEFORE this stage has landed (this wave's part); the barrier publishes all parts and frees chunk ck's slot
+    wn_wait_vmcnt(issued);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { U_cur[q] = U_nxt[q]; r0_cur[q] = r0_nxt[q]; }
+  }
+
+  // ---- epilogue ----
+  // column half of A^T M A in registers: Z[0] = M0 + M1 + M2, Z[1] = M1 - M2 - M3 (per lane and register index); the row half (over
+  // the four xi waves) through LDS: E[xi][j][block 0..127][cout 0..31 (+4)]
+  float* E = reinterpret_cast<float*>(wsm);
+#pragma unroll
+  for (int mtl = 0; mtl < 2; ++mtl) {
+    const int mt = 2 * mh + mtl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float z0 = (acc[0][mtl][r] + acc[1][mtl][r]) + acc[2][mtl][r];
+      const float z1 = (acc[1][mtl][r] - acc[2][mtl][r]) - acc[3][mtl][r];
+      E[((xi * 2 + 0) * 128 + mt * 32 + row) * WN_EPIX + li] = z0;
+      E[((xi * 2 + 1) * 128 + mt * 32 + row) * WN_EPIX + li] = z1;
+    }
+  }
+  __syncthreads();
+  const long long img_pix0 = (long long)img * P.h * P.w;
+  const float* res_img = P.residual ? P.residual + img_pix0 * P.res_ld : nullptr;
+  const float* mul_img = P.pixmul ? P.pixmul + img_pix0 : nullptr;
+  float* out_img = P.out + img_pix0 * P.out_ld;
+  const int act = P.act;
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + it * 512;                   // (block, cout quad): 8 consecutive threads = the 128 bytes of one pixel
+    const int blk = item >> 3, cq = item & 7;
+    const int ty = blk >> 4, tx = blk & 15;
+    const int ch = n0 + 4 * cq;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + ch);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 z[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) z[x] = *reinterpret_cast<const float4*>(E + ((x * 2 + j) * 128 + blk) * WN_EPIX + 4 * cq);
+      const int ox = ox0 + 2 * tx + j;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oy = oy0 + 2 * ty + i;
+        float4 v;
+        if (i == 0) v = make_float4((z[0].x + z[1].x) + z[2].x, (z[0].y + z[1].y) + z[2].y, (z[0].z + z[1].z) + z[2].z, (z[0].w + z[1].w) + z[2].w);
+        else v = make_float4((z[1].x - z[2].x) - z[3].x, (z[1].y - z[2].y) - z[3].y, (z[1].z - z[2].z) - z[3].z, (z[1].w - z[2].w) - z[3].w);
+        if (oy < P.h && ox < P.w) {
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (act == GPEMSR_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (act == GPEMSR_ACT_LRELU) { v.x = fmaxf(v.x, 0.1f * v.x); v.y = fmaxf(v.y, 0.1f * v.y); v.z = fmaxf(v.z, 0.1f * v.z); v.w = fmaxf(v.w, 0.1f * v.w); }
+          else if (act != GPEMSR_ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+          const long long pix = (long long)oy * P.w + ox;
+          if (res_img) { const float4 rr = *reinterpret_cast<const float4*>(res_img + pix * P.res_ld + ch); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+          if (mul_img) { const float m = mul_img[pix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+          *reinterpret_cast<float4*>(out_img + pix * P.out_ld + ch) = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same form with 64 couts per workgroup (cout % 64 == 0: every large layer of the network).  The first kernel's lane builds one
+// V fragment (32 vector operations per row tile and chunk) for 16 MFMAs; the f32 MFMA shares the vector ALUs, so those two vector
+// operations per MFMA cost ~30 % (measured: 0.53 of the fp32 peak on the executed work).  Here a wave owns ONE row tile x TWO cout
+// tiles: the same V feeds 32 MFMAs (one vector operation per MFMA).  Workgroup = 8 x 32 output pixels (64 blocks, two row tiles) x 64
+// couts; raw image [2 quads][2 parities][10 rows][17] = 10.9 KB, U image [16 positions][64 couts][8 ch] = 32 KB per chunk, ring of
+// three; ALL fragments of chunk c + 1 (the row-combined image rows and the eight U fragments) are read during stage c, so chunk c's
+// slot is free at the top of stage c and receives chunk c + 3.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int W2_HH = 10;
+constexpr int W2_ASLOTS = 2 * 2 * W2_HH * WN_HW2;            // 680
+constexpr int W2_ABYTES = W2_ASLOTS * 16;                    // 10,880
+constexpr int W2_BSLOTS = 16 * 64 * 2;                       // 2048
+constexpr int W2_BBYTES = W2_BSLOTS * 16;                    // 32,768
+constexpr int W2_STAGE = W2_ABYTES + W2_BBYTES;              // 43,648
+constexpr int W2_RING = 3;
+constexpr int W2_NA = (W2_ASLOTS + 511) / 512;               // 2
+constexpr int W2_NB = W2_BSLOTS / 512;                       // 4
+constexpr int W2_EPIX = 68;
+constexpr int W2_EBYTES = 4 * 2 * 64 * W2_EPIX * 4;          // 139,264
+
+__global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
+  extern __shared__ __attribute__((aligned(16))) char wsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int xi = wave & 3, mh = wave >> 2;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = P.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  int t = bid;
+  const int tn = t % P.tiles_n; t /= P.tiles_n;
+  const int tx0 = t % P.tiles_x; t /= P.tiles_x;
+  const int ty0 = t % P.tiles_y; t /= P.tiles_y;
+  const int img = t;
+  const int oy0 = ty0 * 8, ox0 = tx0 * 32, n0 = tn * 64;
+
+  int a_pix[W2_NA], a_q[W2_NA];
+#pragma unroll
+  for (int i = 0; i < W2_NA; ++i) {
+    const int s = tid + i * 512;
+    a_pix[i] = -1; a_q[i] = 0;
+    if (s < W2_ASLOTS) {
+      const int hx2 = s % WN_HW2, r1 = s / WN_HW2;
+      const int hy = r1 % W2_HH, r2 = r1 / W2_HH;
+      const int par = r2 & 1, qd = r2 >> 1;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + 2 * hx2 + par;
+      a_q[i] = qd;
+      if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) a_pix[i] = iy * P.w + ix;
+    }
+  }
+  int b_off[W2_NB];
+#pragma unroll
+  for (int i = 0; i < W2_NB; ++i) {
+    const int s = tid + i * 512;                       // [pos][cout 64][quad]
+    const int qd = s & 1, co = (s >> 1) & 63, pos = s >> 7;
+    b_off[i] = (pos * P.cout + n0 + co) * P.cin_pad + 4 * qd;
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+  {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < W2_NA; ++i)
+      if (tid + i * 512 < W2_ASLOTS && a_pix[i] < 0)
+        for (int rs = 0; rs < W2_RING; ++rs) *reinterpret_cast<float4*>(wsm + rs * W2_STAGE + (tid + i * 512) * 16) = z;
+  }
+  int na_w = 0;
+#pragma unroll
+  for (int i = 0; i < W2_NA; ++i) na_w += (__ballot(a_pix[i] >= 0) != 0ull) ? 1 : 0;
+  const int n_issue = na_w + W2_NB;
+
+  int nchunks = 0;
+  for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / 8;
+  int f_src = 0, f_c0 = 0, f_cpad = 0, f_chunk = 0, f_slot = 0;
+  auto issue_chunk = [&]() {
+    const unsigned la = lds0 + (unsigned)(f_slot * W2_STAGE);
+    const float* sp = P.src[f_src] + (long long)img * P.img_stride[f_src] + f_c0;
+    const unsigned pixb = (unsigned)P.ld[f_src] * 4u;
+#pragma unroll
+    for (int i = 0; i < W2_NA; ++i)
+      if (a_pix[i] >= 0) wn_glds16((unsigned)a_pix[i] * pixb + 16u * (unsigned)a_q[i], sp, la + i * 8192u);
+    const float* wp = P.weight + f_cpad + f_c0;
+#pragma unroll
+    for (int i = 0; i < W2_NB; ++i) wn_glds16((unsigned)b_off[i] * 4u, wp, la + (unsigned)W2_ABYTES + i * 8192u);
+    ++f_chunk; f_c0 += 8;
+    f_slot = f_slot == W2_RING - 1 ? 0 : f_slot + 1;
+    if (f_c0 >= P.c[f_src] && f_src + 1 < P.nsrc) { f_cpad += P.c[f_src]; f_c0 = 0; ++f_src; }
+  };
+
+  const int aA = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+  const int aB = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+  const float sB = xi == 1 ? 1.f : -1.f;
+  const int ty = 2 * mh + (li >> 4), tx = li & 15;
+  const unsigned d_base = (unsigned)((((lh * 2) * W2_HH + 2 * ty) * WN_HW2 + tx) * 16);
+  const unsigned u_base = (unsigned)(W2_ABYTES + ((4 * xi * 64 + li) * 2 + lh) * 16);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nu][nt][r] = 0.f;
+
+  auto load_raw = [&](const char* st, float4 (&r4)[4]) {
+    const char* dp = st + d_base;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int cofs = ((b & 1) * W2_HH * WN_HW2 + (b >> 1)) * 16;
+      const float4 va = *reinterpret_cast<const float4*>(dp + cofs + aA * (WN_HW2 * 16));
+      const float4 vb = *reinterpret_cast<const float4*>(dp + cofs + aB * (WN_HW2 * 16));
+      r4[b] = make_float4(fmaf(sB, vb.x, va.x), fmaf(sB, vb.y, va.y), fmaf(sB, vb.z, va.z), fmaf(sB, vb.w, va.w));
+    }
+  };
+  auto load_u = [&](const char* st, float4 (&U)[4][2]) {
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) U[nu][nt] = *reinterpret_cast<const float4*>(st + u_base + nu * (64 * 2 * 16) + nt * (32 * 2 * 16));
+  };
+
+  issue_chunk();
+  if (nchunks > 1) issue_chunk();
+  int infl = 0;
+  if (nchunks > 2) { issue_chunk(); infl = n_issue; }
+  wn_wait_vmcnt(infl);                                   // chunks 0 and 1 have landed
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float4 U_cur[4][2], r_cur[4];
+  load_u(wsm, U_cur);
+  load_raw(wsm, r_cur);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                          // every wave holds chunk 0's fragments: its slot may be refilled
+  asm volatile("" ::: "memory");
+
+  int slot_n = 1;                                        // ring slot of chunk ck + 1
+  // one stage; (Uc, rc) = this chunk's fragments, (Un, rn) receive the next chunk's.  The loop below alternates two register sets
+  // (a copy "cur = next" per stage was 48 vector moves per wave on the pipe the f32 MFMA shares)
+  auto stage = [&](const int ck, float4 (&Uc)[4][2], float4 (&rc)[4], float4 (&Un)[4][2], float4 (&rn)[4]) {
+    int issued = 0;
+    if (ck + 3 < nchunks && !(P.dbg & 4)) { issue_chunk(); issued = n_issue; }        // -> the slot of chunk ck (its fragments are in registers)
+    const char* sn = wsm + slot_n * W2_STAGE;
+    const bool more = ck + 1 < nchunks && !(P.dbg & 1);  // (wave-uniform)
+    if (more) {                                          // next chunk's image rows and the U fragments of cout tile 0: under the first 16 MFMAs
+      load_raw(sn, rn);
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) Un[nu][0] = *reinterpret_cast<const float4*>(sn + u_base + nu * (64 * 2 * 16));
+    }
+    float4 V[4];
+    V[0] = make_float4(rc[0].x - rc[2].x, rc[0].y - rc[2].y, rc[0].z - rc[2].z, rc[0].w - rc[2].w);
+    V[1] = make_float4(rc[1].x + rc[2].x, rc[1].y + rc[2].y, rc[1].z + rc[2].z, rc[1].w + rc[2].w);
+    V[2] = make_float4(rc[2].x - rc[1].x, rc[2].y - rc[1].y, rc[2].z - rc[1].z, rc[2].w - rc[1].w);
+    V[3] = make_float4(rc[1].x - rc[3].x, rc[1].y - rc[3].y, rc[1].z - rc[3].z, rc[1].w - rc[3].w);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {                     // cout tile 0 first: its U registers are free for the second half of the prefetch
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].x, Uc[nu][nt].x, acc[nu][nt], 0, 0, 0);
+        acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].y, Uc[nu][nt].y, acc[nu][nt], 0, 0, 0);
+        acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].z, Uc[nu][nt].z, acc[nu][nt], 0, 0, 0);
+        acc[nu][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[nu].w, Uc[nu][nt].w, acc[nu][nt], 0, 0, 0);
+      }
+      if (nt == 0 && more) {
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) Un[nu][1] = *reinterpret_cast<const float4*>(sn + u_base + nu * (64 * 2 * 16) + 32 * 2 * 16);
+      }
+    }
+    // chunk ck + 2 must have landed before the next stage reads it: only this stage's issues may stay in flight
+    wn_wait_vmcnt(issued);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(P.dbg & 2)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    slot_n = slot_n == W2_RING - 1 ? 0 : slot_n + 1;
+  };
+  float4 U_alt[4][2], r_alt[4];
+  for (int ck = 0; ck < nchunks; ck += 2) {
+    stage(ck, U_cur, r_cur, U_alt, r_alt);
+    if (ck + 1 < nchunks) stage(ck + 1, U_alt, r_alt, U_cur, r_cur);
+  }
+
+  float* E = reinterpret_cast<float*>(wsm);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float z0 = (acc[0][nt][r] + acc[1][nt][r]) + acc[2][nt][r];
+      const float z1 = (acc[1][nt][r] - acc[2][nt][r]) - acc[3][nt][r];
+      E[((xi * 2 + 0) * 64 + mh * 32 + row) * W2_EPIX + nt * 32 + li] = z0;
+      E[((xi * 2 + 1) * 64 + mh * 32 + row) * W2_EPIX + nt * 32 + li] = z1;
+    }
+  __syncthreads();
+  const long long img_pix0 = (long long)img * P.h * P.w;
+  const float* res_img = P.residual ? P.residual + img_pix0 * P.res_ld : nullptr;
+  const float* mul_img = P.pixmul ? P.pixmul + img_pix0 : nullptr;
+  float* out_img = P.out + img_pix0 * (P.pixshuf ? 4 : 1) * P.out_ld;
+  const int act = P.act;
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + it * 512;                   // (block, cout quad): 16 consecutive threads = the 256 bytes of one pixel
+    const int blk = item >> 4, cq = item & 15;
+    const int by = blk >> 4, bx = blk & 15;
+    const int ch = n0 + 4 * cq;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + ch);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 z[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) z[x] = *reinterpret_cast<const float4*>(E + ((x * 2 + j) * 64 + blk) * W2_EPIX + 4 * cq);
+      const int ox = ox0 + 2 * bx + j;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int oy = oy0 + 2 * by + i;
+        float4 v;
+        if (i == 0) v = make_float4((z[0].x + z[1].x) + z[2].x, (z[0].y + z[1].y) + z[2].y, (z[0].z + z[1].z) + z[2].z, (z[0].w + z[1].w) + z[2].w);
+        else v = make_float4((z[1].x - z[2].x) - z[3].x, (z[1].y - z[2].y) - z[3].y, (z[1].z - z[2].z) - z[3].z, (z[1].w - z[2].w) - z[3].w);
+        if (oy < P.h && ox < P.w) {
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (act == GPEMSR_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (act == GPEMSR_ACT_LRELU) { v.x = fmaxf(v.x, 0.1f * v.x); v.y = fmaxf(v.y, 0.1f * v.y); v.z = fmaxf(v.z, 0.1f * v.z); v.w = fmaxf(v.w, 0.1f * v.w); }
+          else if (act != GPEMSR_ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
+          const long long pix = (long long)oy * P.w + ox;
+          if (P.pixshuf) {                               // PixelShuffle(2): cout block q = ch / cq goes to sub-pixel (q >> 1, q & 1)
+            const int q = ch / P.cq, c2 = ch - q * P.cq;
+            *reinterpret_cast<float4*>(out_img + ((long long)(2 * oy + (q >> 1)) * (2 * P.w) + 2 * ox + (q & 1)) * P.out_ld + c2) = v;
+            continue;
+          }
+          if (res_img) { const float4 rr = *reinterpret_cast<const float4*>(res_img + pix * P.res_ld + ch); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+          if (mul_img) { const float m = mul_img[pix]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+          *reinterpret_cast<float4*>(out_img + pix * P.out_ld + ch) = v;
+        }
+      }
+    }
+  }
+}
+
+// descriptor.transposed == 3: called from gpemsr_conv2d (conv_mfma.hip)
+int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap) {
+  GP_REQUIRE(d->ksize == 3 && d->stride == 1 && !d->gn_partials && !d->cos_partials && d->weight_image_stride == 0,
+             "conv2d (Winograd form): 3x3, stride 1, no partial sums, one weight set");
+  GP_REQUIRE(!d->pixel_shuffle || (d->cout % 64 == 0 && (d->cout / 4) % 4 == 0 && !d->residual && !d->pixmul),
+             "conv2d (Winograd form): pixel_shuffle needs cout %% 64 == 0 and no residual / multiplier");
+  GP_REQUIRE(d->cout % 32 == 0, "conv2d (Winograd form): cout %% 32 == 0 (got %d)", d->cout);
+  WinoParams P{};
+  int cin = 0;
+  for (int s = 0; s < d->nsrc; ++s) {
+    GP_REQUIRE(d->src[s].ptr && d->src[s].c > 0 && d->src[s].c % 8 == 0 && d->src[s].ld % 4 == 0 && d->src[s].ld >= d->src[s].c &&
+               (reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) == 0, "conv2d (Winograd form): source %d needs c %% 8 == 0, 16-byte aligned rows", s);
+    P.src[s] = d->src[s].ptr; P.ld[s] = d->src[s].ld; P.c[s] = d->src[s].c;
+    P.img_stride[s] = d->src_image_stride[s] < 0 ? (long long)d->h * d->w * d->src[s].ld : d->src_image_stride[s];
+    GP_REQUIRE(P.img_stride[s] % 4 == 0 && (long long)d->h * d->w * P.ld[s] * 4 < (1ll << 32), "conv2d (Winograd form): source %d too large / misaligned", s);
+    cin += d->src[s].c;
+  }
+  GP_REQUIRE((long long)16 * d->cout * cin * 4 < (1ll << 32), "conv2d (Winograd form): weight tensor too large for 32-bit offsets");
+  GP_REQUIRE((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0 && d->out_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->out) & 15) == 0 &&
+             (!d->bias || (reinterpret_cast<uintptr_t>(d->bias) & 15) == 0) &&
+             (!d->residual || (d->res_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->residual) & 15) == 0)), "conv2d (Winograd form): 16-byte alignment of weight / out / bias / residual");
+  static int force1 = -1;
+  if (force1 < 0) { const char* e = getenv("GPEMSR_WINO_FORM"); force1 = (e && e[0] == '1') ? 1 : 0; }      // A/B: the 32-cout kernel everywhere
+  const bool wide = d->cout % 64 == 0 && (!force1 || d->pixel_shuffle);      // 64 couts per workgroup: one vector operation per MFMA instead of two
+  if (name_buf) { snprintf(name_buf, (size_t)name_cap, wide ? "conv_wino2_f32_kernel" : "conv_wino_f32_kernel"); return GPEMSR_OK; }
+  P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cin_pad = cin; P.cout = d->cout;
+  P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;
+  P.out = d->out; P.out_ld = d->out_ld;
+  P.pixshuf = d->pixel_shuffle; P.cq = d->cout / 4;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_WINO_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
+  P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, wide ? 8 : 16); P.tiles_n = d->cout / (wide ? 64 : 32);
+  const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
+  GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (Winograd form): grid too large");
+  P.nblocks = (int)nb;
+  static dev_once_t attr{0};
+  if (dev_once_begin(attr)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return fail(GPEMSR_ELAUNCH, "conv2d (Winograd form): cannot raise the dynamic LDS limit");
+    dev_once_done(attr);
+  }
+  if (wide) {
+    const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE);
+    hipLaunchKernelGGL(conv_wino2_f32_kernel, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
+    return check_launch("conv_wino2_f32_kernel");
+  }
+  const size_t lds = (size_t)(WN_EBYTES > WN_RING * WN_STAGE ? WN_EBYTES : WN_RING * WN_STAGE);
+  hipLaunchKernelGGL(conv_wino_f32_kernel, dim3(P.nblocks), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), P);
+  return check_launch("conv_wino_f32_kernel");
+}
+
+}  // namespace gpemsr

@@ -30,7 +30,7 @@ import torch
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
 from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3, pack_rowpair7,
-                      pack_vgg_first, pack_cout1_taps, pack_conv7_c32_cout16, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
+                      pack_vgg_first, pack_cout1_taps, pack_winograd, pack_conv7_c32_cout16, pack_conv7_c8_cout32, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -84,6 +84,10 @@ class Engine:
             self._hp_mode, self._hp_n = mode, int(cnt or 1)
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
         self.flash_attn = os.environ.get("GPEMSR_FLASH_ATTN", "1") != "0"   # bf16 path: NonLocalBlock products + softmax as one kernel (C = 512, T % 128 == 0)
+        # exact-fp32 path: 3x3 stride-1 layers in the Winograd F(2x2,3x3) form (16 instead of 36 multiplies per 2x2 outputs, fp32 arithmetic,
+        # ~1e-6 of the result; csrc/conv_wino.hip).  Inference engine only: the training engines keep the direct form their tapes were
+        # validated against.  GPEMSR_WINOGRAD=0: the direct form everywhere.
+        self.winograd = precision == "fp32" and type(self) is Engine and os.environ.get("GPEMSR_WINOGRAD", "1") != "0"
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.split = precision in ("bf16x3", "bf16op")
@@ -187,16 +191,22 @@ class Engine:
         elif w.dim() == 4:
             if name.endswith("_offset_conv1") and w.shape[1] == 2 * nf + 34:
                 w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, self._ffc - 34))   # 162 -> 176 (bf16: 192) input channels
+            w7c8 = None
             if self.precision != "fp32" and w.shape[1] == 8 and w.shape[2] == 7 and ".spynet." in name:
+                if self.bf16 and tuple(w.shape) == (32, 8, 7, 7) and os.environ.get("GPEMSR_CONV7_C8", "1") != "0":
+                    w7c8 = pack_conv7_c8_cout32(w, dev)     # four taps per 16x16x32 MFMA (csrc/conv7_bf16.hip)
                 # SpyNet stems (8 -> 32, 7x7): zero-pad cin to 16 so they run on the split-bf16 kernel too
                 w = torch.nn.functional.pad(w.detach(), (0, 0, 0, 0, 0, 8))
             self.pc[name] = pack_conv(w, b, dev, splits.get(name), pixel_shuffle=name in ps)
+            self.pc[name].w7c8 = w7c8
             kk = w.shape[2]
             if (self.split or self._is_hp_layer(name)) and (kk in (3, 7) and all(c % 16 == 0 for c in self.pc[name].splits)
                                                             or kk == 1 and all(c % 32 == 0 for c in self.pc[name].splits)):
                 self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             if self.bf16 and all(c % 16 == 0 for c in self.pc[name].splits):
                 self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
+            if self.winograd and kk == 3 and w.shape[0] % 32 == 0 and (name not in ps or w.shape[0] % 64 == 0) and all(c % 8 == 0 for c in self.pc[name].splits):
+                self.pc[name].wino = pack_winograd(w, dev, pixel_shuffle=name in ps)      # Winograd form of the 3x3 stride-1 layers (fp32 path)
             if self.bf16 and tuple(w.shape) == (1, 64, 3, 3):
                 self.pc[name].wtap = pack_cout1_taps(w, dev)            # 64 -> 1 on the matrix cores (csrc/tap_sum.hip)
             if not self.bf16 and tuple(w.shape) == (1, 64, 3, 3) and getattr(self, "fuse_tail_f32", True):
@@ -236,6 +246,8 @@ class Engine:
     # ------------------------------------------------------------------ helpers
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
         kw.setdefault("precision", self.precision)
+        if self.winograd and kw["precision"] == "fp32" and self.pc[name].wino is not None and "cos_with" not in kw:
+            kw.setdefault("winograd", True)
         return self.o.conv2d(srcs, self.pc[name], act, tag=name, **kw)
 
     def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:

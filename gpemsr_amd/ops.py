@@ -130,25 +130,27 @@ class LaunchProfiler:
     def __init__(self):
         self.items = []
 
-    def run(self, kernel: str, tag: str, flops: float, fn, name: Optional[str] = None, nbytes: float = 0.0):
+    def run(self, kernel: str, tag: str, flops: float, fn, name: Optional[str] = None, nbytes: float = 0.0, executed: Optional[float] = None):
         """kernel: family (the bench line's roofline families); name: the kernel instantiation really launched (the per-kernel table);
         nbytes: ALGORITHMIC bytes of the launch = unique inputs + outputs + weights of the layer at the dtypes it is stored in."""
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.items.append((kernel, tag, flops, s, e, name or kernel, nbytes))
+        # flops: ALGORITHMIC work of the layer (direct-convolution count); executed: what the matrix pipe really multiplies (Winograd: 16/36)
+        self.items.append((kernel, tag, flops, s, e, name or kernel, nbytes, flops if executed is None else executed))
 
     def summary(self, by_tag: bool = False, by_name: bool = False):
         torch.cuda.synchronize()
         out = {}
-        for kernel, tag, flops, s, e, name, nbytes in self.items:
+        for kernel, tag, flops, s, e, name, nbytes, executed in self.items:
             key = name if by_name else ((kernel, tag) if by_tag else kernel)
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "family": kernel, "name": name})
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "family": kernel, "name": name, "executed": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += flops
             d["bytes"] += nbytes
+            d["executed"] += executed
         return out
 
 
@@ -210,7 +212,9 @@ class PackedConv:
     wrow7: Optional[torch.Tensor] = None   # bf16 data path, 16 -> 2 7x7 (SpyNet flow update): row-sum fragments (packing.pack_rowsum7)
     wtap32: Optional[torch.Tensor] = None  # fp32 activations, 64 -> 1 3x3: fp32 tap fragments (packing.pack_cout1_taps_f32)
     wrow7_32: Optional[torch.Tensor] = None  # fp32 activations, 16 -> 2 7x7: row-sum fragments (packing.pack_rowsum7_f32)
+    w7c8: Optional[torch.Tensor] = None    # bf16 data path, 8 -> 32 7x7 (SpyNet stems): four taps per MFMA (packing.pack_conv7_c8_cout32)
     w7c16: Optional[torch.Tensor] = None   # bf16 data path, 32 -> 16 7x7: 16x16x32 MFMA fragments (packing.pack_conv7_c32_cout16)
+    wino: Optional[torch.Tensor] = None    # fp32, 3x3 stride 1: Winograd F(2x2,3x3) weights U[16][cout][cin] (packing.pack_winograd; descriptor.transposed = 3)
     wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
                                            # the profiler's flop count uses this, so split products are not credited as extra work
@@ -284,6 +288,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         return conv2d_bf16(srcs, pc, act, stride, residual, pixmul, out, weight_image_stride, src_image_stride, force_mfma, tag, out_u8=out_u8,
                            _u8_fused=_u8_fused, **kw16)
     gn_stats = bool(kw16.pop("gn_stats", False))          # fp32 too: GroupNorm partial sums from the epilogue (gpemsr_conv_desc.gn_partials)
+    winograd = bool(kw16.pop("winograd", False))          # fp32: the Winograd F(2x2,3x3) form where the layer qualifies (winograd_ok)
     cos_with = kw16.pop("cos_with", None)                  # fp32: patch cosine of the result against this tensor, result not stored
     if cos_with is not None:
         return _conv2d_cosine(srcs, pc, act, cos_with, tag)
@@ -406,6 +411,12 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             gws = torch.empty(n * parts * pc.cout * 2, dtype=torch.float32, device=s0.buf.device)
             d.gn_partials = gws.data_ptr()
             out.gn = (gws, parts)
+    executed = None
+    if winograd and precision == "fp32" and winograd_ok(srcs, pc, stride, out, residual) and weight_image_stride == 0 and src_image_stride is None:
+        d.transposed, d.weight = 3, pc.wino.data_ptr()          # 16 multiplies per 2x2 outputs instead of 36 (csrc/conv_wino.hip)
+        d.gn_partials = None
+        out.gn = None
+        executed = flops * 16.0 / 36.0
     if (pc.wpair7 is not None and precision == "fp32" and k == 7 and stride == 1 and pc.cout == 16 and not pc.transposed and not pc.pixel_shuffle
             and pixmul is None and weight_image_stride == 0 and src_image_stride is None and out.ld % 4 == 0 and out.ptr % 16 == 0
             and (residual is None or (residual.ld % 4 == 0 and residual.ptr % 16 == 0))):
@@ -415,10 +426,26 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
                                                              int(pc.pixel_shuffle), bool(d.gn_partials), out.ld % 4, residual is not None))
         wimgs = n if weight_image_stride != 0 else 1
         nb = _layer_bytes(srcs, src_image_stride, n * OH * OW * oc, 4, int(wimgs * pc.cout * pc.cin * taps), 4, residual, pixmul)
-        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"), name=nm, nbytes=nb)
+        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"), name=nm, nbytes=nb, executed=executed)
     else:
         _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
     return out
+
+
+def winograd_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None) -> bool:
+    """Layers the Winograd form of gpemsr_conv2d takes: 3x3, stride 1, fp32 sources of c % 8 == 0 with 16-byte aligned rows, cout % 32 == 0,
+    plain store; `pc.wino` packed."""
+    if pc.wino is None or pc.ksize != 3 or stride != 1 or pc.transposed or pc.cout % 32 != 0:
+        return False
+    if pc.pixel_shuffle and (pc.cout % 64 != 0 or residual is not None):
+        return False
+    if any(s_.bf16 or s_.c % 8 != 0 or s_.ld % 4 != 0 or s_.ptr % 16 != 0 for s_ in srcs):
+        return False
+    if out is not None and (out.ld % 4 != 0 or out.ptr % 16 != 0):
+        return False
+    if residual is not None and (residual.ld % 4 != 0 or residual.ptr % 16 != 0):
+        return False
+    return pc.b is None or pc.b.data_ptr() % 16 == 0
 
 
 def groupnorm_relu(x: Act, gamma: torch.Tensor, beta: torch.Tensor, relu: bool = True, residual: Optional[Act] = None,
@@ -941,6 +968,22 @@ def conv2d_bf16(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, resi
             PROFILER.run("conv_bf16", tag, flops, _go_c7, name="conv7_c32_cout16_kernel", nbytes=2.0 * (n * h * w * 48 + 49 * 512))
         else:
             _go_c7()
+        return out
+    # SpyNet's 8 -> 32 7x7 stems (input padded to a 16-channel tensor by spynet_prep_bf16): four taps per 16x16x32 MFMA; variant 9: ring kernel
+    if (pc.w7c8 is not None and plain and s0.bf16 and s0.c == 16 and pc.cout == 32 and k == 7 and stride == 1 and residual is None and not out_f32
+            and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and variant != 9 and s0.ld % 8 == 0 and s0.ptr % 16 == 0):
+        if out is None:
+            out = new_act(n, OH, OW, 32, device=dev, bf16=True)
+        assert out.bf16 and (out.n, out.h, out.w, out.c) == (n, OH, OW, 32) and out.ld % 4 == 0 and out.ptr % 8 == 0
+
+        def _go_c8():
+            _abi.check(lib.gpemsr_conv7_c8_cout32_bf16(s0.ptr, n, h, w, s0.ld, pc.w7c8.data_ptr(), pc.b.data_ptr() if pc.b is not None else None, act,
+                                                       out.ptr, out.ld, _stream()), "conv7_c8_cout32_bf16")
+        if PROFILER is not None:
+            # (algorithmic work of the LAYER: 8 input channels; the ring kernel's table counted its zero-padded 16)
+            PROFILER.run("conv_bf16", tag, 2.0 * n * h * w * 32 * 8 * 49, _go_c8, name="conv7_c8_cout32_kernel", nbytes=2.0 * (n * h * w * (8 + 32) + 49 * 256))
+        else:
+            _go_c8()
         return out
     # tiny channel counts: VALU kernel with fp32 packed weights (1-channel results are fp32 images)
     use_direct = (plain and not force_mfma and pc.cout <= 16 and (pc.cout <= 2 or pc.cin <= 16) and k >= 3 and pc.ck == 8

@@ -49,6 +49,21 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, splits: Option
                       transposed=False, pixel_shuffle=pixel_shuffle)
 
 
+def pack_winograd(w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch.Tensor:
+    """Conv2d(3x3) weight OIHW fp32 -> U = G g G^T for the Winograd F(2x2, 3x3) form of gpemsr_conv2d (descriptor.transposed = 3;
+    csrc/conv_wino.hip): [position p = 4 xi + nu][cout][cin] fp32, computed in float64 (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]).
+    Concat sources need no padding here: the form requires every source to be a multiple of 8 channels."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    g = w.detach().to(torch.float64).cpu()
+    if pixel_shuffle:                                                    # the same row permutation as pack_conv: (2i + j) * C/4 + c
+        cq = cout // 4
+        g = g[torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)]
+    U = torch.einsum("xa,ocab,yb->xyoc", G, g, G)                      # [xi][nu][cout][cin]
+    return U.reshape(16, cout, cin).to(torch.float32).contiguous().to(device)
+
+
 def pack_rowpair7(w: torch.Tensor, device) -> torch.Tensor:
     """Conv2d(cin -> 16, 7x7, stride 1, pad 3) fp32 weight -> the ROW-PAIR form of gpemsr_conv2d (descriptor.transposed = 2):
     out(2i, x) = sum_{ky'=0..6} in(2i-3+ky') W[ky'] and out(2i+1, x) = sum_{ky'=1..7} in(2i-3+ky') W[ky'-1] share the 8-row window of
@@ -336,6 +351,17 @@ def pack_conv7_c32_cout16(w: torch.Tensor, device) -> torch.Tensor:
     assert tuple(w.shape) == (16, 32, 7, 7)
     wf = w.detach().to(torch.float32).cpu()
     return wf.permute(2, 3, 0, 1).reshape(49, 16, 4, 8).permute(0, 2, 1, 3).contiguous().to(torch.bfloat16).to(device)
+
+
+def pack_conv7_c8_cout32(w: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d(8 -> 32, 7x7) weight [32][8][7][7] -> A-operand fragments for gpemsr_conv7_c8_cout32_bf16: [tap group j 13][cout tile m 2]
+    [64 lanes][8] bf16 -- lane l holds cout 16 m + l % 16 and the 8 input channels of tap 4 j + l // 16 (taps 49..51: zeros)."""
+    assert tuple(w.shape) == (32, 8, 7, 7)
+    wf = w.detach().to(torch.float32).cpu().reshape(32, 8, 49)
+    wt = torch.zeros(32, 8, 52)
+    wt[:, :, :49] = wf
+    # [cout = m*16 + l16][c][tap = j*4 + g] -> [j][m][g][l16][c]
+    return wt.reshape(2, 16, 8, 13, 4).permute(3, 0, 4, 1, 2).contiguous().reshape(13, 2, 64, 8).to(torch.bfloat16).to(device)
 
 
 def _tap_fragments_f32(rows: torch.Tensor) -> torch.Tensor:

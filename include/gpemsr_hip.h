@@ -76,7 +76,11 @@ typedef struct {
                                       basicsr spynet_arch.BasicModule via R:model/GPEMSR.py:67): same result, but the 32-row matrix tile
                                       computes the 16 couts of output rows 2i AND 2i+1 from an 8 x 7-tap window; weight =
                                       [tap = ky'*7+kx, ky' < 8][32][cin_pad], rows 0..15 = W[ky'] (0 for ky' = 7), rows 16..31 = W[ky'-1]
-                                      (0 for ky' = 0) (gpemsr_amd/packing.py::pack_rowpair7); cout stays 16, out is h x w */
+                                      (0 for ky' = 0) (gpemsr_amd/packing.py::pack_rowpair7); cout stays 16, out is h x w.
+                                      3 = WINOGRAD F(2x2, 3x3) form of a 3x3 stride-1 convolution (same result to fp32 rounding, 16/36 of
+                                      the multiplies; csrc/conv_wino.hip): every source c % 8 == 0, cout % 32 == 0, no pixel_shuffle /
+                                      gn_partials / cos_partials; weight = U[16 positions][cout][cin] = G g G^T
+                                      (gpemsr_amd/packing.py::pack_winograd) */
   const float* weight;             /* packed [tap][cout][cin_pad], tap = ky*k+kx, cin fastest, cin padded per source to 8
                                       (k>=3) or 32 (k=1).  transposed: [tap = 2*dy+dx][n' = (co/32)*128 + q*32 + co%32][cin_pad],
                                       q = 2*py+px, the phase-stacked 2x2-tap form (gpemsr_amd/packing.py::pack_convT) */
@@ -300,6 +304,11 @@ int gpemsr_conv7_c16_cout2_bf16(const void* x, int n, int h, int w, int ld, cons
  * [16 couts][8] bf16 (packing.pack_conv7_c32_cout16), bias fp32 [16] or NULL, act NONE / RELU / LRELU, out bf16 [n][h][w][out_ld >= 16]. */
 int gpemsr_conv7_c32_cout16_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, int act,
                                  void* out, int out_ld, void* stream);
+/* Conv2d(8 -> 32, 7x7, pad 3): the first convolution of a SpyNet BasicModule.  x bf16 NHWC with pixel stride ld >= 8 (the first 8
+ * channels of every pixel are read: gpemsr_spynet_prep_bf16's 16-channel tensor qualifies), four taps per v_mfma_f32_16x16x32_bf16;
+ * wfrag = [13 tap groups][2 cout tiles][64 lanes][8] bf16 (packing.pack_conv7_c8_cout32), out bf16 [n][h][w][out_ld >= 32]. */
+int gpemsr_conv7_c8_cout32_bf16(const void* x, int n, int h, int w, int ld, const void* wfrag, const float* bias, int act,
+                                void* out, int out_ld, void* stream);
 /* the same for fp32 activations (exact-fp32 path): v_mfma_f32_32x32x2_f32, wfrag [7 kx][8 k-steps][64 lanes] floats (packing.pack_rowsum7_f32) */
 int gpemsr_conv7_c16_cout2_f32(const float* x, int n, int h, int w, int ld, const float* wfrag, const float* bias, const float* residual,
                                int res_ld, float* out, int out_ld, void* stream);

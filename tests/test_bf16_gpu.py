@@ -332,7 +332,8 @@ def test_attention_products_bf16():
     _close(out.torch().reshape(n, T, c), torch.bmm(p_dev, v_ref) + bv, 1e-4, "P.v")
 
 
-@pytest.mark.parametrize("n,h,w,spike", [(3, 16, 16, False), (2, 32, 32, False), (9, 8, 16, False), (2, 16, 24, True), (1, 64, 64, True)])
+@pytest.mark.parametrize("n,h,w,spike", [(3, 16, 16, False), (2, 32, 32, False), (9, 8, 16, False), (2, 16, 24, True), (1, 64, 64, True),
+                                         (1, 144, 128, False)])        # 18,432 tokens: beyond the layered form's 16,384-column softmax
 def test_flash_attention_bf16(n, h, w, spike):
     """the NonLocalBlock products + softmax (R:model/blocks.py:75-80) as ONE kernel, score matrix on chip.  Against
     torch on the bf16-rounded operands (fp32 softmax); operands come from the same kpack / perm16 producers the engine uses.  `spike`
@@ -362,8 +363,10 @@ def test_flash_attention_bf16(n, h, w, spike):
     vtp = v[:, src].reshape(n, T // 8, 8, c).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).to(dev)
     got = ops.flash_attention_bf16(qa, kp, vtp, bv.to(dev))
     torch.cuda.synchronize()
-    S = torch.bmm(q.double(), k.double().transpose(1, 2))
-    want = torch.bmm(torch.softmax(S, dim=2), v.double()) + bv.double()
+    ref_dev = torch.device("cuda") if T > 8192 else torch.device("cpu")            # (the long case: 2.7 GB of float64 scores)
+    S = torch.bmm(q.double().to(ref_dev), k.double().to(ref_dev).transpose(1, 2))
+    want = (torch.bmm(torch.softmax(S, dim=2), v.double().to(ref_dev)) + bv.double().to(ref_dev)).cpu()
+    S = S.cpu() if spike else None
     assert torch.isfinite(got.torch().float()).all()
     _close(got.torch().float().reshape(n, T, c), want.float(), 2 * BF, "flash attention")
     if spike:
@@ -679,3 +682,31 @@ def test_argmax_in_the_logits_gemm_epilogue(n, h, w, cout):
     assert int((got == 900 % cout).sum()) == 0 or cout <= 5
     ref = logits.torch().reshape(-1, cout).argmax(dim=1).to(torch.int32)
     assert float((ref == got).float().mean()) > 0.999               # (torch's CUDA argmax may break ties differently)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 16, 32), (3, 37, 70), (1, 5, 5), (20, 64, 96)])
+def test_conv7_c8_cout32_four_taps_per_mfma(n, h, w):
+    """SpyNet's 8 -> 32 7x7 stems (basicsr BasicModule's first convolution, R:model/GPEMSR.py:67,99) with four taps per
+    v_mfma_f32_16x16x32_bf16 (csrc/conv7_bf16.hip): x is the 16-channel tensor spynet_prep_bf16 makes (channels 8..15 zero -- here set to
+    GARBAGE to prove the kernel never reads them), against torch, against the ring kernel on the zero-padded input, ragged tiles,
+    several tiles per workgroup (three halo buffers in rotation), activations, bit-stable."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv7_c8_cout32
+    dev = _dev()
+    x8 = _r(_rand(n, 8, h, w, seed=51))
+    wt = _r(_rand(32, 8, 7, 7, seed=52, scale=1.0 / np.sqrt(8 * 49)))
+    b = _rand(32, seed=53, scale=0.2)
+    lin = F.conv2d(x8, wt, b, 1, 3)
+    wpad = F.pad(wt, (0, 0, 0, 0, 0, 8))
+    pc = _pc(wpad, b, dev)
+    pc.w7c8 = pack_conv7_c8_cout32(wt, dev)
+    xg = _act16(torch.cat([x8, 50.0 * _rand(n, 8, h, w, seed=54)], 1), dev)          # garbage in the padding channels
+    xz = _act16(torch.cat([x8, torch.zeros(n, 8, h, w)], 1), dev)
+    for act, want in ((1, F.relu(lin)), (0, lin), (2, F.leaky_relu(lin, 0.1))):
+        got = ops.conv2d([xg], pc, act, precision="bf16")
+        _close(got.nchw(), want, BF, f"conv7 8->32 act {act}")
+    ring = ops.conv2d([xz], pc, 1, precision="bf16", variant=9)
+    _close(ring.nchw(), F.relu(lin), BF, "ring kernel")
+    a1 = ops.conv2d([xg], pc, 1, precision="bf16")
+    a2 = ops.conv2d([xg], pc, 1, precision="bf16")
+    assert torch.equal(a1.buf, a2.buf), "not bit-stable run to run"

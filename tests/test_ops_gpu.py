@@ -655,3 +655,80 @@ def test_patch_cosine_from_the_conv_epilogue(n, h, w):
     want = ((pa * pb).sum(-1) / (pa.norm(dim=-1).clamp_min(1e-12) * pb.norm(dim=-1).clamp_min(1e-12))).unsqueeze(1)
     _close(got.nchw(), want.float(), tol=1e-5, what="epilogue patch cosine vs fp64")
     _close(got.nchw(), want32, tol=2e-6, what="epilogue patch cosine vs the stored-map kernel")
+
+
+WINO_CASES = [
+    # (n, cins, cout, h, w, act, residual, pixmul)
+    (2, (64,), 64, 16, 32, 1, False, False),            # exactly one 16 x 32 tile per image
+    (3, (64,), 64, 37, 70, 0, True, True),              # ragged tiles both ways, odd height (a 2x2 block across the bottom edge), residual + multiplier
+    (1, (8,), 32, 5, 5, 2, False, False),               # one chunk, one block row
+    (2, (64, 128, 64), 64, 17, 33, 0, False, False),    # concat of three sources, odd sizes
+    (1, (512,), 512, 24, 40, 1, False, False),          # 64 chunks, 16 cout blocks (the VQGAN layers)
+    (5, (128,), 256, 48, 64, 2, True, False),           # several images x tiles x cout blocks
+    (1, (64,), 64, 1, 1, 0, False, False),              # a single pixel
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv2d_winograd_form(case):
+    """gpemsr_conv_desc.transposed = 3: the Winograd F(2x2, 3x3) form of the 3x3 stride-1 convolution (csrc/conv_wino.hip) against
+    torch in float64 (tolerance 2e-5 of the result's scale: fp32 transforms of both operands; the direct kernel sits at ~1e-6), against
+    the direct kernel, source / output / residual embedded in wider buffers, and run-to-run bit-stable."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd
+    n, cins, cout, h, w, act, use_res, use_mul = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _rand(n, cin, h, w, seed=11)
+    wt = _rand(cout, cin, 3, 3, seed=12, scale=1.0 / np.sqrt(cin * 9))
+    b = _rand(cout, seed=13, scale=0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    if act == 1:
+        want = F.relu(want)
+    elif act == 2:
+        want = F.leaky_relu(want, 0.1)
+    res = _rand(n, cout, h, w, seed=14) if use_res else None
+    mul = _rand(n, 1, h, w, seed=15).abs() + 0.5 if use_mul else None
+    if res is not None:
+        want = want + res.double()
+    if mul is not None:
+        want = want * mul.double()
+    srcs, o = [], 0
+    for i, c in enumerate(cins):
+        srcs.append(_to_act(x[:, o:o + c], dev, ld=c + (8 if i == 0 else 0), off=8 if i == 0 else 0))
+        o += c
+    pc = pack_conv(wt, b, dev, cins)
+    pc.wino = pack_winograd(wt, dev)
+    assert ops.winograd_ok(srcs, pc)
+    r_act = None if res is None else _to_act(res, dev, ld=cout + 4, off=4)
+    m_act = None if mul is None else ops.Act(mul.reshape(-1).to(dev), n, h, w, 1, 1, 0)
+    out = _to_act(torch.zeros(n, cout, h, w), dev, ld=cout + 12, off=4)
+    got = ops.conv2d(srcs, pc, act, residual=r_act, pixmul=m_act, out=out, winograd=True)
+    _close(got.nchw(), want, 2e-5, f"winograd {case}")
+    assert float((out.buf.view(n, h, w, cout + 12)[..., :4] - 7.0).abs().max()) == 0.0       # neighbours of the slice untouched
+    direct = ops.conv2d(srcs, pc, act, residual=r_act, pixmul=m_act)
+    _close(got.nchw(), direct.nchw(), 2e-5, "winograd vs direct")
+    again = _to_act(torch.zeros(n, cout, h, w), dev, ld=cout + 12, off=4)
+    ops.conv2d(srcs, pc, act, residual=r_act, pixmul=m_act, out=again, winograd=True)
+    assert torch.equal(out.buf, again.buf), "not bit-stable run to run"
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 16, 32), (1, 13, 21)])
+def test_conv2d_winograd_form_pixel_shuffle(n, h, w):
+    """upconv1-3 (R:model/GPEMSR.py:304-316,442-448: conv 64 -> 256 + PixelShuffle(2) + LeakyReLU) in the Winograd form: the store map
+    of the 64-cout kernel against torch's pixel_shuffle."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd
+    dev = _dev()
+    x = _rand(n, 64, h, w, seed=21)
+    wt = _rand(256, 64, 3, 3, seed=22, scale=1.0 / 24)
+    b = _rand(256, seed=23, scale=0.1)
+    want = F.leaky_relu(F.pixel_shuffle(F.conv2d(x.double(), wt.double(), b.double(), 1, 1), 2), 0.1)
+    pc = pack_conv(wt, b, dev, pixel_shuffle=True)
+    pc.wino = pack_winograd(wt, dev, pixel_shuffle=True)
+    xa = _to_act(x, dev)
+    assert ops.winograd_ok([xa], pc)
+    got = ops.conv2d([xa], pc, 2, winograd=True)
+    assert (got.n, got.h, got.w, got.c) == (n, 2 * h, 2 * w, 64)
+    _close(got.nchw(), want, 2e-5, "winograd + pixel shuffle")
+    _close(got.nchw(), ops.conv2d([xa], pc, 2).nchw(), 2e-5, "vs direct")
