@@ -45,6 +45,7 @@ struct WinoParams {
   float* out; int out_ld;
   int tiles_x, tiles_y, tiles_n;
   int nblocks;
+  float* cos_ws;                  // wide kernel, cout == 64: patch-cosine partial sums against `residual` INSTEAD of storing (conv_mfma.hip XEPI = 2)
   int pixshuf, cq;                // wide kernel: store as PixelShuffle(2) (cout index = (2i + j) * cq + c, out is [n][2h][2w][cq])
   int dbg;                        // timing experiments only (GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
 };
@@ -501,6 +502,54 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
   const float* mul_img = P.pixmul ? P.pixmul + img_pix0 : nullptr;
   float* out_img = P.out + img_pix0 * (P.pixshuf ? 4 : 1) * P.out_ld;
   const int act = P.act;
+  if (P.cos_ws) {
+    // R:model/GPEMSR.py:387-395 without the second relu1_2 map in memory (the direct kernel's XEPI = 2 epilogue, same record layout
+    // [n][h/4 strips][w/16 patch columns][4] for gpemsr_patch_cosine_finish): b = act(this convolution + bias), a = the `residual` operand;
+    // sums of a.b, a.a, b.b over the 4-row strips and 16-pixel patch columns of this 8 x 32 tile (64 couts = all channels).  Item `it` of a
+    // thread lies in strip `it`, a wave's items in patch column (wave >> 1) & 1; fixed reduction order -> bit-stable.
+    float* red = reinterpret_cast<float*>(wsm + W2_EBYTES);        // [8 waves][2 strips][3]
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + it * 512;
+      const int blk = item >> 4, cq = item & 15;
+      const int by = blk >> 4, bx = blk & 15;
+      const int ch = 4 * cq;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + ch);
+      float ab = 0.f, aa = 0.f, bb = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float4 z[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) z[x] = *reinterpret_cast<const float4*>(E + ((x * 2 + j) * 64 + blk) * W2_EPIX + 4 * cq);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float4 v;
+          if (i == 0) v = make_float4((z[0].x + z[1].x) + z[2].x, (z[0].y + z[1].y) + z[2].y, (z[0].z + z[1].z) + z[2].z, (z[0].w + z[1].w) + z[2].w);
+          else v = make_float4((z[1].x - z[2].x) - z[3].x, (z[1].y - z[2].y) - z[3].y, (z[1].z - z[2].z) - z[3].z, (z[1].w - z[2].w) - z[3].w);
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (act == GPEMSR_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          else if (act == GPEMSR_ACT_LRELU) { v.x = fmaxf(v.x, 0.1f * v.x); v.y = fmaxf(v.y, 0.1f * v.y); v.z = fmaxf(v.z, 0.1f * v.z); v.w = fmaxf(v.w, 0.1f * v.w); }
+          const long long pix = (long long)(oy0 + 2 * by + i) * P.w + (ox0 + 2 * bx + j);
+          const float4 r = *reinterpret_cast<const float4*>(res_img + pix * P.res_ld + ch);
+          ab += (v.x * r.x + v.y * r.y) + (v.z * r.z + v.w * r.w);
+          aa += (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
+          bb += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+      }
+      for (int o = 1; o < 64; o <<= 1) { ab += __shfl_xor(ab, o); aa += __shfl_xor(aa, o); bb += __shfl_xor(bb, o); }
+      if (lane == 0) { red[(wave * 2 + it) * 3] = ab; red[(wave * 2 + it) * 3 + 1] = aa; red[(wave * 2 + it) * 3 + 2] = bb; }
+    }
+    __syncthreads();
+    if (tid < 12) {                                    // (strip, patch column, quantity)
+      const int k = tid % 3, pc = (tid / 3) & 1, st = tid / 6;
+      float tot = 0.f;
+      for (int wv = 0; wv < 8; ++wv)
+        if (((wv >> 1) & 1) == pc) tot += red[(wv * 2 + st) * 3 + k];
+      P.cos_ws[(((long long)img * (P.tiles_y * 2) + ty0 * 2 + st) * (P.tiles_x * 2) + tx0 * 2 + pc) * 4 + k] = tot;
+    }
+    return;
+  }
 #pragma unroll 1
   for (int it = 0; it < 2; ++it) {
     const int item = tid + it * 512;                   // (block, cout quad): 16 consecutive threads = the 256 bytes of one pixel
@@ -543,8 +592,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
 
 // descriptor.transposed == 3: called from gpemsr_conv2d (conv_mfma.hip)
 int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap) {
-  GP_REQUIRE(d->ksize == 3 && d->stride == 1 && !d->gn_partials && !d->cos_partials && d->weight_image_stride == 0,
-             "conv2d (Winograd form): 3x3, stride 1, no partial sums, one weight set");
+  GP_REQUIRE(d->ksize == 3 && d->stride == 1 && !d->gn_partials && d->weight_image_stride == 0,
+             "conv2d (Winograd form): 3x3, stride 1, no GroupNorm partial sums, one weight set");
+  GP_REQUIRE(!d->cos_partials || (d->cout == 64 && d->h % 16 == 0 && d->w % 32 == 0 && d->residual && !d->pixel_shuffle && !d->pixmul &&
+                                  (reinterpret_cast<uintptr_t>(d->cos_partials) & 15) == 0),
+             "conv2d (Winograd form): patch-cosine sums need 64 output channels, the operand in `residual`, height %% 16 == 0, width %% 32 == 0");
   GP_REQUIRE(!d->pixel_shuffle || (d->cout % 64 == 0 && (d->cout / 4) % 4 == 0 && !d->residual && !d->pixmul),
              "conv2d (Winograd form): pixel_shuffle needs cout %% 64 == 0 and no residual / multiplier");
   GP_REQUIRE(d->cout % 32 == 0, "conv2d (Winograd form): cout %% 32 == 0 (got %d)", d->cout);
@@ -564,12 +616,13 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
              (!d->residual || (d->res_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->residual) & 15) == 0)), "conv2d (Winograd form): 16-byte alignment of weight / out / bias / residual");
   static int force1 = -1;
   if (force1 < 0) { const char* e = getenv("GPEMSR_WINO_FORM"); force1 = (e && e[0] == '1') ? 1 : 0; }      // A/B: the 32-cout kernel everywhere
-  const bool wide = d->cout % 64 == 0 && (!force1 || d->pixel_shuffle);      // 64 couts per workgroup: one vector operation per MFMA instead of two
+  const bool wide = d->cout % 64 == 0 && (!force1 || d->pixel_shuffle || d->cos_partials);      // 64 couts per workgroup: one vector operation per MFMA instead of two
   if (name_buf) { snprintf(name_buf, (size_t)name_cap, wide ? "conv_wino2_f32_kernel" : "conv_wino_f32_kernel"); return GPEMSR_OK; }
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cin_pad = cin; P.cout = d->cout;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;
   P.out = d->out; P.out_ld = d->out_ld;
   P.pixshuf = d->pixel_shuffle; P.cq = d->cout / 4;
+  P.cos_ws = d->cos_partials;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_WINO_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
   P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, wide ? 8 : 16); P.tiles_n = d->cout / (wide ? 64 : 32);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
@@ -583,7 +636,7 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
     dev_once_done(attr);
   }
   if (wide) {
-    const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE);
+    const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE) + 256;      // + the patch-cosine partials' exchange
     hipLaunchKernelGGL(conv_wino2_f32_kernel, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
     return check_launch("conv_wino2_f32_kernel");
   }

@@ -246,7 +246,7 @@ class Engine:
     # ------------------------------------------------------------------ helpers
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
         kw.setdefault("precision", self.precision)
-        if self.winograd and kw["precision"] == "fp32" and self.pc[name].wino is not None and "cos_with" not in kw:
+        if self.winograd and kw["precision"] == "fp32" and self.pc[name].wino is not None:
             kw.setdefault("winograd", True)
         return self.o.conv2d(srcs, self.pc[name], act, tag=name, **kw)
 

@@ -243,7 +243,7 @@ def conv_cosine_ok(src: "Act", pc: "PackedConv") -> bool:
             and src.h % 16 == 0 and src.w % 32 == 0 and src.ld % 4 == 0 and src.ptr % 16 == 0 and len(pc.splits) == 1 and src.c % 8 == 0)
 
 
-def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str) -> "Act":
+def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str, winograd: bool = False) -> "Act":
     """act(conv(src)) is NOT stored: its 16x16-patch cosine against `a` (R:model/GPEMSR.py:387-395) comes from partial sums formed in the
     convolution's epilogue (gpemsr_conv_desc.cos_partials) + gpemsr_patch_cosine_finish -> [n, h/16, w/16, 1]."""
     lib = _abi.load()
@@ -263,10 +263,14 @@ def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str) -> "Act
     d.out, d.out_ld = a.ptr, a.ld                  # (never written in this mode; the descriptor wants a valid aligned row layout)
     d.cos_partials = ws.data_ptr()
     flops = 2.0 * n * h * w * pc.cout * pc.cin * 9.0
+    executed = None
+    if winograd and pc.wino is not None and pc.cout == 64 and s0.c % 8 == 0 and h % 16 == 0 and w % 32 == 0:
+        d.transposed, d.weight = 3, pc.wino.data_ptr()          # the Winograd form leaves the same records (csrc/conv_wino.hip)
+        executed = flops * 16.0 / 36.0
     if PROFILER is not None:
-        nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32cos", n, h, w, s0.c, pc.cout))
+        nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32cos", n, h, w, s0.c, pc.cout, int(d.transposed)))
         nb = 4.0 * (n * h * w * (s0.c + pc.cout) + pc.cout * pc.cin * 9)          # source + the operand map read; the result is not stored
-        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"), name=nm, nbytes=nb)
+        PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"), name=nm, nbytes=nb, executed=executed)
     else:
         _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
     out = new_act(n, h // 16, w // 16, 1, device=s0.buf.device)
@@ -291,7 +295,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     winograd = bool(kw16.pop("winograd", False))          # fp32: the Winograd F(2x2,3x3) form where the layer qualifies (winograd_ok)
     cos_with = kw16.pop("cos_with", None)                  # fp32: patch cosine of the result against this tensor, result not stored
     if cos_with is not None:
-        return _conv2d_cosine(srcs, pc, act, cos_with, tag)
+        return _conv2d_cosine(srcs, pc, act, cos_with, tag, winograd=winograd)
     assert not kw16 or not any(kw16.values()), f"{sorted(kw16)} are options of the bf16 data path"
     s0 = srcs[0]
     n, h, w = s0.n, s0.h, s0.w

@@ -655,6 +655,13 @@ def test_patch_cosine_from_the_conv_epilogue(n, h, w):
     want = ((pa * pb).sum(-1) / (pa.norm(dim=-1).clamp_min(1e-12) * pb.norm(dim=-1).clamp_min(1e-12))).unsqueeze(1)
     _close(got.nchw(), want.float(), tol=1e-5, what="epilogue patch cosine vs fp64")
     _close(got.nchw(), want32, tol=2e-6, what="epilogue patch cosine vs the stored-map kernel")
+    # the same sums from the Winograd form's epilogue (csrc/conv_wino.hip; width % 32 == 0 as for the direct form)
+    from gpemsr_amd.packing import pack_winograd
+    pc.wino = pack_winograd(wt, dev)
+    gw = ops.conv2d([ta], pc, ops.ACT_RELU, cos_with=aa, winograd=True)
+    assert torch.equal(aa.nchw(), a_before)
+    _close(gw.nchw(), want.float(), tol=1e-5, what="Winograd epilogue patch cosine vs fp64")
+    assert torch.equal(gw.buf, ops.conv2d([ta], pc, ops.ACT_RELU, cos_with=aa, winograd=True).buf), "not bit-stable"
 
 
 WINO_CASES = [
