@@ -333,11 +333,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
     const int nwg = P.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   }
+  // pixel tile fastest, cout block slowest: the workgroups that run together on an XCD read the SAME U slice (16 positions x 64 couts x cin:
+  // 2 MB at 512 channels, it stays in the XCD's 4 MB L2) and different image tiles.  With the cout block fastest every workgroup of an XCD
+  // streamed a different slice -- the whole 16.8 MB U tensor per pixel tile, 265 GB of fabric reads per step (profiles/r04a_fp32_pmc_summary.json)
   int t = bid;
-  const int tn = t % P.tiles_n; t /= P.tiles_n;
   const int tx0 = t % P.tiles_x; t /= P.tiles_x;
   const int ty0 = t % P.tiles_y; t /= P.tiles_y;
-  const int img = t;
+  const int img = t % P.n; t /= P.n;
+  const int tn = t;
   const int oy0 = ty0 * 8, ox0 = tx0 * 32, n0 = tn * 64;
 
   int a_pix[W2_NA], a_q[W2_NA];

@@ -7,7 +7,7 @@ tallied at 64 B).  Infinity-cache hits are counted as traffic by these counters,
 import collections, csv, glob, json, sys
 
 root, out_path, precision, passes, note = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
-FAMILY = {"fp32": ("conv_mfma_kernel", "conv_wino_f32_kernel"), "bf16": ("conv_bf16_kernel", "conv64_resident", "convt64_resident", "conv7_c32_cout16", "conv7_c8_cout32", "vgg_mask", "flash_attn512")}[precision]
+FAMILY = {"fp32": ("conv_mfma_kernel", "conv_wino"), "bf16": ("conv_bf16_kernel", "conv64_resident", "convt64_resident", "conv7_c32_cout16", "conv7_c8_cout32", "vgg_mask", "flash_attn512")}[precision]
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
