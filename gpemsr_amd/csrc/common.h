@@ -49,6 +49,6 @@ inline void dev_once_done(dev_once_t& m) {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // gpemsr_conv_desc.transposed == 3: the Winograd F(2x2, 3x3) form (conv_wino.hip); name_buf != NULL: write the kernel's name, launch nothing
-int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap);
+int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap, int* parts_only = nullptr);
 
 }  // namespace gpemsr

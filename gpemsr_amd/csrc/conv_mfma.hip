@@ -774,8 +774,7 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only,
   GP_REQUIRE(d->ksize == 1 || d->ksize == 3 || d->ksize == 7, "conv2d: ksize=%d unsupported", d->ksize);
   GP_REQUIRE(d->weight && d->out, "conv2d: null weight/out");
   if (d->transposed == 3) {          // Winograd F(2x2, 3x3) form of a 3x3 stride-1 convolution (conv_wino.hip)
-    GP_REQUIRE(parts_only == nullptr, "conv2d: the Winograd form leaves no partial sums");
-    return conv2d_winograd(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0);
+    return conv2d_winograd(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0, parts_only);
   }
   ConvParams P{};
   const bool tr = d->transposed == 1;

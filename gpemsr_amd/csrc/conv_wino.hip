@@ -45,6 +45,7 @@ struct WinoParams {
   float* out; int out_ld;
   int tiles_x, tiles_y, tiles_n;
   int nblocks;
+  float* gn_ws; int gn_parts;     // wide kernel: GroupNorm partial sums of (conv + bias) per (tile, channel): [n][gn_parts][cout][2] (conv_mfma.hip XEPI = 1)
   float* cos_ws;                  // wide kernel, cout == 64: patch-cosine partial sums against `residual` INSTEAD of storing (conv_mfma.hip XEPI = 2)
   int pixshuf, cq;                // wide kernel: store as PixelShuffle(2) (cout index = (2i + j) * cq + c, out is [n][2h][2w][cq])
   int dbg;                        // timing experiments only (GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
     }
     return;
   }
+  float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};      // GroupNorm partial sums of this thread's 4 channels (both items share the cout quad)
 #pragma unroll 1
   for (int it = 0; it < 2; ++it) {
     const int item = tid + it * 512;                   // (block, cout quad): 16 consecutive threads = the 256 bytes of one pixel
@@ -575,6 +577,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
         else v = make_float4((z[1].x - z[2].x) - z[3].x, (z[1].y - z[2].y) - z[3].y, (z[1].z - z[2].z) - z[3].z, (z[1].w - z[2].w) - z[3].w);
         if (oy < P.h && ox < P.w) {
           v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (P.gn_ws) {                                 // first pass of the GroupNorm that follows (R:model/blocks.py:5-6): sums of conv + bias
+            gs[0] += v.x; gs[1] += v.y; gs[2] += v.z; gs[3] += v.w;
+            gq[0] = fmaf(v.x, v.x, gq[0]); gq[1] = fmaf(v.y, v.y, gq[1]); gq[2] = fmaf(v.z, v.z, gq[2]); gq[3] = fmaf(v.w, v.w, gq[3]);
+          }
           if (act == GPEMSR_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           else if (act == GPEMSR_ACT_LRELU) { v.x = fmaxf(v.x, 0.1f * v.x); v.y = fmaxf(v.y, 0.1f * v.y); v.z = fmaxf(v.z, 0.1f * v.z); v.w = fmaxf(v.w, 0.1f * v.w); }
           else if (act != GPEMSR_ACT_NONE) { v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act); }
@@ -591,12 +597,44 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
       }
     }
   }
+  if (P.gn_ws) {
+    // per (tile, channel) sums over the tile's valid pixels: lanes with the same cout quad (lane & 15) by shuffles, the 8 waves through LDS
+    // behind the exchange buffer, fixed order (bit-stable); one record per 8 x 32 tile: gn_parts = tiles per image
+    float* red = reinterpret_cast<float*>(wsm + W2_EBYTES);        // [8 waves][16 quads][8]
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int o = 16; o < 64; o <<= 1) { gs[k] += __shfl_xor(gs[k], o); gq[k] += __shfl_xor(gq[k], o); }
+    __syncthreads();                                               // (the patch-cosine path shares this corner of LDS; E reads are done)
+    if (lane < 16) {
+      float* r = red + (wave * 16 + lane) * 8;
+      *reinterpret_cast<float4*>(r) = make_float4(gs[0], gq[0], gs[1], gq[1]);
+      *reinterpret_cast<float4*>(r + 4) = make_float4(gs[2], gq[2], gs[3], gq[3]);
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float4 a = *reinterpret_cast<const float4*>(red + tid * 8), b = *reinterpret_cast<const float4*>(red + tid * 8 + 4);
+#pragma unroll
+      for (int wv = 1; wv < 8; ++wv) {
+        const float4 a2 = *reinterpret_cast<const float4*>(red + (wv * 16 + tid) * 8), b2 = *reinterpret_cast<const float4*>(red + (wv * 16 + tid) * 8 + 4);
+        a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+      }
+      const int part = ty0 * P.tiles_x + tx0;
+      float* wsp = P.gn_ws + (((long long)img * P.gn_parts + part) * P.cout + n0 + 4 * tid) * 2;
+      *reinterpret_cast<float4*>(wsp) = a;
+      *reinterpret_cast<float4*>(wsp + 4) = b;
+    }
+  }
 }
 
 // descriptor.transposed == 3: called from gpemsr_conv2d (conv_mfma.hip)
-int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap) {
-  GP_REQUIRE(d->ksize == 3 && d->stride == 1 && !d->gn_partials && d->weight_image_stride == 0,
-             "conv2d (Winograd form): 3x3, stride 1, no GroupNorm partial sums, one weight set");
+int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap, int* parts_only) {
+  GP_REQUIRE(d->ksize == 3 && d->stride == 1 && d->weight_image_stride == 0, "conv2d (Winograd form): 3x3, stride 1, one weight set");
+  if (d->gn_partials || parts_only) {
+    GP_REQUIRE(d->cout % 64 == 0 && d->act == GPEMSR_ACT_NONE && !d->residual && !d->pixmul && !d->pixel_shuffle && !d->cos_partials,
+               "conv2d (Winograd form): GroupNorm partial sums need cout %% 64 == 0, the plain store, no activation / residual / multiplier");
+    if (parts_only) { *parts_only = cdiv(d->h, 8) * cdiv(d->w, 32); return GPEMSR_OK; }
+    GP_REQUIRE((reinterpret_cast<uintptr_t>(d->gn_partials) & 15) == 0, "conv2d (Winograd form): gn_partials must be 16-byte aligned");
+  }
   GP_REQUIRE(!d->cos_partials || (d->cout == 64 && d->h % 16 == 0 && d->w % 32 == 0 && d->residual && !d->pixel_shuffle && !d->pixmul &&
                                   (reinterpret_cast<uintptr_t>(d->cos_partials) & 15) == 0),
              "conv2d (Winograd form): patch-cosine sums need 64 output channels, the operand in `residual`, height %% 16 == 0, width %% 32 == 0");
@@ -619,13 +657,14 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
              (!d->residual || (d->res_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->residual) & 15) == 0)), "conv2d (Winograd form): 16-byte alignment of weight / out / bias / residual");
   static int force1 = -1;
   if (force1 < 0) { const char* e = getenv("GPEMSR_WINO_FORM"); force1 = (e && e[0] == '1') ? 1 : 0; }      // A/B: the 32-cout kernel everywhere
-  const bool wide = d->cout % 64 == 0 && (!force1 || d->pixel_shuffle || d->cos_partials);      // 64 couts per workgroup: one vector operation per MFMA instead of two
+  const bool wide = d->cout % 64 == 0 && (!force1 || d->pixel_shuffle || d->cos_partials || d->gn_partials);      // 64 couts per workgroup: one vector operation per MFMA instead of two
   if (name_buf) { snprintf(name_buf, (size_t)name_cap, wide ? "conv_wino2_f32_kernel" : "conv_wino_f32_kernel"); return GPEMSR_OK; }
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cin_pad = cin; P.cout = d->cout;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;
   P.out = d->out; P.out_ld = d->out_ld;
   P.pixshuf = d->pixel_shuffle; P.cq = d->cout / 4;
   P.cos_ws = d->cos_partials;
+  P.gn_ws = d->gn_partials; P.gn_parts = cdiv(d->h, 8) * cdiv(d->w, 32);
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_WINO_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
   P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, wide ? 8 : 16); P.tiles_n = d->cout / (wide ? 64 : 32);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
@@ -639,7 +678,7 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
     dev_once_done(attr);
   }
   if (wide) {
-    const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE) + 256;      // + the patch-cosine partials' exchange
+    const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE) + 4096;     // + the partial sums' cross-wave exchange
     hipLaunchKernelGGL(conv_wino2_f32_kernel, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
     return check_launch("conv_wino2_f32_kernel");
   }

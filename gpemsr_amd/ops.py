@@ -405,6 +405,10 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         else:
             _go_split()
         return out
+    executed = None
+    if winograd and precision == "fp32" and winograd_ok(srcs, pc, stride, out, residual) and weight_image_stride == 0 and src_image_stride is None:
+        d.transposed, d.weight = 3, pc.wino.data_ptr()          # 16 multiplies per 2x2 outputs instead of 36 (csrc/conv_wino.hip)
+        executed = flops * 16.0 / 36.0
     if (gn_stats and precision == "fp32" and act == ACT_NONE and residual is None and pixmul is None and not pc.transposed and not pc.pixel_shuffle
             and pc.cout % 4 == 0 and out.ld % 4 == 0 and out.ptr % 16 == 0 and (pc.b is None or pc.b.data_ptr() % 16 == 0)
             # the partial-sum epilogue exists only in the LDS-DMA instantiations (conv_mfma.hip: GP_REQUIRE(dma && BN >= 32)): sources it
@@ -415,12 +419,6 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             gws = torch.empty(n * parts * pc.cout * 2, dtype=torch.float32, device=s0.buf.device)
             d.gn_partials = gws.data_ptr()
             out.gn = (gws, parts)
-    executed = None
-    if winograd and precision == "fp32" and winograd_ok(srcs, pc, stride, out, residual) and weight_image_stride == 0 and src_image_stride is None:
-        d.transposed, d.weight = 3, pc.wino.data_ptr()          # 16 multiplies per 2x2 outputs instead of 36 (csrc/conv_wino.hip)
-        d.gn_partials = None
-        out.gn = None
-        executed = flops * 16.0 / 36.0
     if (pc.wpair7 is not None and precision == "fp32" and k == 7 and stride == 1 and pc.cout == 16 and not pc.transposed and not pc.pixel_shuffle
             and pixmul is None and weight_image_stride == 0 and src_image_stride is None and out.ld % 4 == 0 and out.ptr % 16 == 0
             and (residual is None or (residual.ld % 4 == 0 and residual.ptr % 16 == 0))):

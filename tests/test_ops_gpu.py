@@ -628,6 +628,36 @@ def test_groupnorm_statistics_from_the_fp32_conv_epilogue(n, cin, cout, k, h, w)
     _close(y1.nchw(), y0, tol=2e-6, what="GN from epilogue sums vs the statistics pass")
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 37, 70), (1, 128, 256, 20, 36), (1, 512, 512, 16, 16), (3, 128, 128, 8, 32), (1, 64, 64, 1, 1)])
+def test_groupnorm_statistics_from_the_winograd_epilogue(n, cin, cout, h, w):
+    """gpemsr_conv_desc.gn_partials with transposed = 3 (csrc/conv_wino.hip, wide kernel): the conv output equals the Winograd launch without
+    partial sums bit for bit, one record per 8 x 32 tile, and groupnorm_relu on it (finish + apply, no statistics pass) equals
+    GroupNorm(32, eps 1e-6)(conv) + ReLU in fp64 to 2e-5 and the statistics-pass result on the same conv output to 2e-6."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=820 + h)
+    wt = _rand(cout, cin, 3, 3, seed=821, scale=1.0 / (3 * cin ** 0.5)); b = _rand(cout, seed=822)
+    g = (1.0 + 0.2 * _rand(cout, seed=823)).to(dev); be = (0.2 * _rand(cout, seed=824)).to(dev)
+    pc = pack_conv(wt, b, dev)
+    pc.wino = pack_winograd(wt, dev)
+    plain = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_NONE, winograd=True)
+    assert plain.gn is None
+    y0 = ops.groupnorm_relu(plain, g, be, True).nchw().clone()
+    got = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_NONE, gn_stats=True, winograd=True)
+    assert got.gn is not None and got.gn[1] == -(-h // 8) * -(-w // 32)
+    assert torch.equal(got.nchw(), plain.nchw())
+    sums = got.gn[0].clone()
+    y1 = ops.groupnorm_relu(got, g, be, True)
+    assert got.gn is None
+    conv = F.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    want = torch.relu(F.group_norm(conv, 32, g.double().cpu(), be.double().cpu(), 1e-6))
+    _close(y1.nchw(), want.float(), tol=2e-5, what="GN from Winograd epilogue sums vs fp64")
+    _close(y1.nchw(), y0, tol=2e-6, what="GN from Winograd epilogue sums vs the statistics pass")
+    again = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_NONE, gn_stats=True, winograd=True)
+    assert torch.equal(again.gn[0], sums), "partial sums not bit-stable"
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 64, 64), (1, 128, 96), (3, 16, 32), (1, 48, 160)])
 def test_patch_cosine_from_the_conv_epilogue(n, h, w):
     """gpemsr_conv_desc.cos_partials + gpemsr_patch_cosine_finish (R:model/GPEMSR.py:387-395): the cosine of relu(conv(t)) against a second
