@@ -117,6 +117,25 @@ def run(args, root: str, effective_cores):
         # the step's FLOPs, constants of the backward) on the split-bf16 kernel; trainable layers and all gradients stay f32
         del trainer, model
         torch.cuda.empty_cache()
+        # exact-fp32 step with the FROZEN 3x3 layers (prior, mask, flow and loss networks: forward and data gradients) in the Winograd
+        # F(2x2,3x3) form (train option `winograd_frozen`, off by default: see gpemsr_amd/train.py TrainEngine)
+        mw = build_model(opt, load_prior_files=False, precision="fp32").to(dev)
+        tw = Stage3Trainer(mw, dict(TRAIN_OPT, winograd_frozen=True), dev, world=world)
+        for _ in range(max(args.warmup, 1)):
+            tw.step(LR, GT)
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for _ in range(args.steps):
+            ow = tw.step(LR, GT)
+        torch.cuda.synchronize()
+        dw = time.perf_counter() - tq
+        extras_w = {"value": round(B * args.steps / dw, 3), "unit": "samples/s", "ms_per_step": round(1e3 * dw / args.steps, 2),
+                    "dtype": "f32; frozen 3x3 stride-1 layers (forward and data gradients) in the Winograd F(2x2,3x3) form on the f32 matrix "
+                             "pipe: gradient distance to float64 2.2e-4 median instead of 1.5e-5 (the reference's own: 1.4e-4)",
+                    "losses_last_step": {"rec": float(ow["rec_loss"].item()), "ref": float(ow["ref_loss"].item())},
+                    "speedup_vs_fp32_step": round((dt / args.steps) / (dw / args.steps), 3)}
+        del tw, mw
+        torch.cuda.empty_cache()
         m3 = build_model(opt, load_prior_files=False, precision="bf16x3").to(dev)
         t3 = Stage3Trainer(m3, TRAIN_OPT, dev, world=world)
         for _ in range(max(args.warmup, 1)):
@@ -127,7 +146,7 @@ def run(args, root: str, effective_cores):
             o3 = t3.step(LR, GT)
         torch.cuda.synchronize()
         d3 = time.perf_counter() - ta
-        extras = {"bf16x3_frozen_forward": {
+        extras = {"fp32_winograd_frozen": extras_w, "bf16x3_frozen_forward": {
             "value": round(B * args.steps / d3, 3), "unit": "samples/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
             "dtype": "frozen sub-networks' forward convolutions: fp32 operands split hi+lo bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate "
                      "(fp32-grade, DESIGN 3.3); trainable layers, data and weight gradients: f32 MFMA",

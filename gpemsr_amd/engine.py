@@ -85,9 +85,10 @@ class Engine:
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
         self.flash_attn = os.environ.get("GPEMSR_FLASH_ATTN", "1") != "0"   # bf16 path: NonLocalBlock products + softmax as one kernel (C = 512, T % 128 == 0)
         # exact-fp32 path: 3x3 stride-1 layers in the Winograd F(2x2,3x3) form (16 instead of 36 multiplies per 2x2 outputs, fp32 arithmetic,
-        # ~1e-6 of the result; csrc/conv_wino.hip).  Inference engine only: the training engines keep the direct form their tapes were
-        # validated against.  GPEMSR_WINOGRAD=0: the direct form everywhere.
-        self.winograd = precision == "fp32" and type(self) is Engine and os.environ.get("GPEMSR_WINOGRAD", "1") != "0"
+        # ~1e-6 of the result; csrc/conv_wino.hip).  The training engines use it for their FROZEN layers only (`_wino_layer`: the transformed
+        # weights of a trainable layer are not a permutation of its master weights, so the one-gather repack cannot refresh them).
+        # GPEMSR_WINOGRAD=0: the direct form everywhere.
+        self.winograd = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD", "1") != "0"
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.split = precision in ("bf16x3", "bf16op")
@@ -205,7 +206,8 @@ class Engine:
                 self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             if self.bf16 and all(c % 16 == 0 for c in self.pc[name].splits):
                 self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
-            if self.winograd and kk == 3 and w.shape[0] % 32 == 0 and (name not in ps or w.shape[0] % 64 == 0) and all(c % 8 == 0 for c in self.pc[name].splits):
+            if (self.winograd and self._wino_layer(name) and kk == 3 and w.shape[0] % 32 == 0 and (name not in ps or w.shape[0] % 64 == 0)
+                    and all(c % 8 == 0 for c in self.pc[name].splits)):
                 self.pc[name].wino = pack_winograd(w, dev, pixel_shuffle=name in ps)      # Winograd form of the 3x3 stride-1 layers (fp32 path)
             if self.bf16 and tuple(w.shape) == (1, 64, 3, 3):
                 self.pc[name].wtap = pack_cout1_taps(w, dev)            # 64 -> 1 on the matrix cores (csrc/tap_sum.hip)
@@ -244,11 +246,24 @@ class Engine:
         return int(name.split(".")[3]) >= self._hp_first_unit()
 
     # ------------------------------------------------------------------ helpers
+    def _wino_layer(self, name: str) -> bool:
+        """Layers that may keep a Winograd weight form (every eligible one; the training engines exclude their trainable layers)."""
+        return True
+
+    @staticmethod
+    def wino_geometry_ok(x: Act, cout: int) -> bool:
+        """The Winograd kernels cut the image into 8 x 32 (cout % 64 == 0) or 16 x 32 pixel tiles: a map that fills less than 2/3 of its
+        tiles (the 16 x 16 levels of the training crops) is faster on the direct kernel."""
+        th = 8 if cout % 64 == 0 else 16
+        return 3 * x.h * x.w >= 2 * (-(-x.h // th) * th) * (-(-x.w // 32) * 32)
+
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
         kw.setdefault("precision", self.precision)
-        if self.winograd and kw["precision"] == "fp32" and self.pc[name].wino is not None:
+        pc = self.pc[name]
+        if self.winograd and kw["precision"] == "fp32" and pc.wino is not None \
+                and self.wino_geometry_ok(srcs if isinstance(srcs, Act) else srcs[0], pc.cout):
             kw.setdefault("winograd", True)
-        return self.o.conv2d(srcs, self.pc[name], act, tag=name, **kw)
+        return self.o.conv2d(srcs, pc, act, tag=name, **kw)
 
     def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:
         """basicsr ResidualBlockNoBN chain; ``pixmul`` multiplies the output of the LAST block

@@ -35,7 +35,7 @@ from . import ops
 from .dist import average_gradients
 from .engine import Engine
 from .ops import ACT_NONE, ACT_RELU, Act
-from .packing import _pad_split, pack_conv, pack_conv_split
+from .packing import _pad_split, pack_conv, pack_conv_split, pack_winograd
 
 VGG_MEAN = (0.485, 0.456, 0.406)
 VGG_STD = (0.229, 0.224, 0.225)
@@ -225,8 +225,14 @@ class TrainEngine(Engine):
     ``gw`` / ``gb``: name -> gradient tensor in the reference's own layout (views of the flat gradient buffer)."""
 
     def __init__(self, sd, device, scale, nframes, groups, nf, dec_nrb, trainable, gw: Dict[str, torch.Tensor],
-                 gb: Dict[str, torch.Tensor], precision: str = "fp32"):
+                 gb: Dict[str, torch.Tensor], precision: str = "fp32", wino_train: int = 0):
         self.trainable = set(trainable)                        # before the base constructor packs the weights
+        # Winograd form (fp32 path) of FROZEN 3x3 layers, opt-in (`winograd_frozen`; GPEMSR_WINO_TRAIN overrides): bit 0 the prior / mask /
+        # flow networks' forward, bit 1 the loss network's forward, bit 2 data gradients through frozen layers.  Off by default: the
+        # direct kernel's gradients lie CLOSER to the float64 gradients than the reference's own fp32 step (median 1.5e-5 vs 1.4e-4,
+        # test_gradient_distance_to_fp64_against_the_references_own); with the Winograd forms they lie at 2.2e-4 (fp32-grade, 1.5x the
+        # reference's distance) for a step 7 % shorter (profiles/r04_winograd_training_sweep.log).
+        self.wino_train = int(os.environ.get("GPEMSR_WINO_TRAIN", str(int(wino_train))))
         self.fuse_tail_f32 = False                             # training keeps the layered decoder tail / VALU 64 -> 1 convs: the tape's
         #                                                        backward kernels were validated against exactly that forward (DESIGN 3.6)
         # precision "bf16": the FROZEN sub-networks whose inputs carry no gradient -- the VQGAN prior (indexer, codebook, decoder), the
@@ -243,6 +249,7 @@ class TrainEngine(Engine):
         self.tape: Optional[list] = None
         self.o = TapeOps(self)
         self._dpc: Dict[tuple, ops.PackedConv] = {}
+        self._dpc_frozen: Dict[tuple, ops.PackedConv] = {}
         self.wscale: Dict[str, float] = {}                     # layers whose packed forward weights carry a folded scale
         for sl, idx, kind in _VGG_TO_RELU3_4:                  # the loss network sees RGB: pack slices 1-3 as they are
             if kind == "conv":
@@ -250,6 +257,9 @@ class TrainEngine(Engine):
                 if (key + ".weight") not in sd:              # stage-2 generator objects carry no VGG
                     continue
                 self.pc[key + "@rgb"] = pack_conv(sd[key + ".weight"], sd[key + ".bias"], device)
+                wv = sd[key + ".weight"]
+                if self.winograd and (self.wino_train & 2) and wv.shape[2] == 3 and wv.shape[0] % 32 == 0 and wv.shape[1] % 8 == 0:
+                    self.pc[key + "@rgb"].wino = pack_winograd(wv, device)      # frozen loss network: Winograd form (fp32 path)
                 if precision != "fp32" and sd[key + ".weight"].shape[1] % 16 == 0:
                     self.pc[key + "@rgb"].w16 = pack_conv_split(self.pc[key + "@rgb"], sd[key + ".weight"], device)
 
@@ -396,7 +406,8 @@ class TrainEngine(Engine):
 
     def _dgrad_pc(self, name: str, si: int, c0: int, c1: int, kind: str) -> ops.PackedConv:
         key = (name, si)
-        pc = self._dpc.get(key)
+        frozen = name.split("@")[0] not in self.trainable      # constant weights: packed once, not once per step
+        pc = (self._dpc_frozen if frozen else self._dpc).get(key)
         if pc is not None:
             return pc
         w = self.sd[name.split("@")[0] + ".weight"].detach().to(torch.float32)
@@ -405,7 +416,10 @@ class TrainEngine(Engine):
         if name in self.wscale:                                # weights packed with a folded scale (attention q)
             w = w * self.wscale[name]
         if kind == "s1":          # stride-1 conv: rotate the taps, swap in/out channels
-            pc = pack_conv(w[:, c0:c1].permute(1, 0, 2, 3).flip(2, 3), None, self.dev)
+            wd = w[:, c0:c1].permute(1, 0, 2, 3).flip(2, 3)
+            pc = pack_conv(wd, None, self.dev)
+            if frozen and self.winograd and (self.wino_train & 4) and wd.shape[2] == 3 and wd.shape[0] % 32 == 0 and wd.shape[1] % 8 == 0:
+                pc.wino = pack_winograd(wd.contiguous(), self.dev)      # data gradient through a frozen 3x3 layer: Winograd form too
         elif kind == "s2":        # stride-2 conv k3 p1: its data gradient is ConvTranspose2d(k3,s2,p1,op1) with the same tensor
             wt = w[:, c0:c1]
             if wt.shape[1] % 32:
@@ -419,8 +433,11 @@ class TrainEngine(Engine):
             pc = pack_conv(w1.t().reshape(-1, cout, 1, 1), None, self.dev)
         else:
             raise ValueError(kind)
-        self._dpc[key] = pc
+        (self._dpc_frozen if frozen else self._dpc)[key] = pc
         return pc
+
+    def _wino_layer(self, name: str) -> bool:
+        return bool(self.wino_train & 1) and name not in getattr(self, "trainable", ())
 
     def _conv_backward(self, srcs: List[Act], name: str, act: int, stride: int, y: Act, residual: Optional[Act], trainable: bool):
         pc = self.pc[name]
@@ -487,7 +504,9 @@ class TrainEngine(Engine):
             if s.requires_grad:
                 g = xs.grad()
                 if stride == 1:
-                    ops.conv2d([dZ], self._dgrad_pc(name, si, c0, c0 + ci, "s1"), ACT_NONE, residual=g, out=g, tag=name + ".dgrad")
+                    pcd = self._dgrad_pc(name, si, c0, c0 + ci, "s1")
+                    ops.conv2d([dZ], pcd, ACT_NONE, residual=g, out=g, tag=name + ".dgrad",
+                               winograd=pcd.wino is not None and self.precision == "fp32" and self.wino_geometry_ok(dZ, pcd.cout))
                 elif stride == 2:
                     assert k == 3 and xs.h == 2 * dZ.h and xs.w == 2 * dZ.w, "stride-2 data gradient needs even input sizes"
                     pcd = self._dgrad_pc(name, si, c0, c0 + ci, "s2")
@@ -713,7 +732,7 @@ class Stage3Trainer(_TrainerState):
         model._train_state = None
         sd = {k: v.detach() for k, v in model.state_dict().items()}
         self.eng = TrainEngine(sd, device, model.scale, model.nframes, model.groups, model.nf, model._dec_nrb, names, gw, gb,
-                               precision=model.precision)
+                               precision=model.precision, wino_train=7 if opt_train.get("winograd_frozen") else 0)
         self.gw, self.gb = gw, gb
         if os.environ.get("GPEMSR_FAST_REFRESH", "1") != "0":
             self.eng.enable_fast_refresh(self.flat_p)
