@@ -76,7 +76,12 @@ __device__ __forceinline__ void wn_wait_vmcnt(int n) {
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
   }
 }
 
@@ -318,16 +323,23 @@ constexpr int W2_BSLOTS = 16 * 64 * 2;                       // 2048
 constexpr int W2_BBYTES = W2_BSLOTS * 16;                    // 32,768
 constexpr int W2_STAGE = W2_ABYTES + W2_BBYTES;              // 43,648
 constexpr int W2_RING = 3;
-constexpr int W2_NA = (W2_ASLOTS + 511) / 512;               // 2
-constexpr int W2_NB = W2_BSLOTS / 512;                       // 4
 constexpr int W2_EPIX = 68;
 constexpr int W2_EBYTES = 4 * 2 * 64 * W2_EPIX * 4;          // 139,264
 
+// ASYM: only waves 0-3 (one per SIMD) issue the LDS-DMA of a stage, twice as many instructions each; waves 4-7 go straight to their
+// MFMAs.  The DMA intake of a CU is ~27 B/clk whoever issues (43 KB per stage = ~1,600 of the stage's 4,096 matrix clocks) and an issuing wave
+// sits in the queue for that long: with all eight waves issuing, both waves of every SIMD sat there together and the matrix pipe idled;
+// with one issuer per SIMD the other wave's 32 MFMAs cover the queue time.
+template <bool ASYM>
 __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
+  constexpr int NTI = ASYM ? 256 : 512;                        // issuing threads
+  constexpr int W2_NA = (W2_ASLOTS + NTI - 1) / NTI;           // 3 : 2
+  constexpr int W2_NB = W2_BSLOTS / NTI;                       // 8 : 4
   extern __shared__ __attribute__((aligned(16))) char wsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int xi = wave & 3, mh = wave >> 2;
+  const bool issuer = !ASYM || wave < 4;                       // (wave-uniform)
 
   int bid = blockIdx.x;
   {
@@ -344,40 +356,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
   const int tn = t;
   const int oy0 = ty0 * 8, ox0 = tx0 * 32, n0 = tn * 64;
 
-  int a_pix[W2_NA], a_q[W2_NA];
+  int a_pk[W2_NA];                                           // 2 * pixel + channel quad of the slot, -1: outside the image / not an issuer
 #pragma unroll
   for (int i = 0; i < W2_NA; ++i) {
-    const int s = tid + i * 512;
-    a_pix[i] = -1; a_q[i] = 0;
-    if (s < W2_ASLOTS) {
+    const int s = tid + i * NTI;
+    a_pk[i] = -1;
+    if (issuer && s < W2_ASLOTS) {
       const int hx2 = s % WN_HW2, r1 = s / WN_HW2;
       const int hy = r1 % W2_HH, r2 = r1 / W2_HH;
       const int par = r2 & 1, qd = r2 >> 1;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + 2 * hx2 + par;
-      a_q[i] = qd;
-      if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) a_pix[i] = iy * P.w + ix;
+      if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) a_pk[i] = 2 * (iy * P.w + ix) + qd;
     }
   }
-  int b_off[W2_NB];
-#pragma unroll
-  for (int i = 0; i < W2_NB; ++i) {
-    const int s = tid + i * 512;                       // [pos][cout 64][quad]
-    const int qd = s & 1, co = (s >> 1) & 63, pos = s >> 7;
-    b_off[i] = (pos * P.cout + n0 + co) * P.cin_pad + 4 * qd;
-  }
+  // U slot s = tid + i * NTI of [pos][cout 64][quad]: pos = (tid >> 7) + i * NTI / 128
+  const unsigned b_off0 = (unsigned)((((tid & (NTI - 1)) >> 7) * P.cout + n0 + ((tid >> 1) & 63)) * P.cin_pad + 4 * (tid & 1)) * 4u;
+  const unsigned b_step = (unsigned)((NTI / 128) * P.cout * P.cin_pad) * 4u;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
   {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < W2_NA; ++i)
-      if (tid + i * 512 < W2_ASLOTS && a_pix[i] < 0)
-        for (int rs = 0; rs < W2_RING; ++rs) *reinterpret_cast<float4*>(wsm + rs * W2_STAGE + (tid + i * 512) * 16) = z;
+      if (issuer && tid + i * NTI < W2_ASLOTS && a_pk[i] < 0)
+        for (int rs = 0; rs < W2_RING; ++rs) *reinterpret_cast<float4*>(wsm + rs * W2_STAGE + (tid + i * NTI) * 16) = z;
   }
   int na_w = 0;
 #pragma unroll
-  for (int i = 0; i < W2_NA; ++i) na_w += (__ballot(a_pix[i] >= 0) != 0ull) ? 1 : 0;
-  const int n_issue = na_w + W2_NB;
+  for (int i = 0; i < W2_NA; ++i) na_w += (__ballot(a_pk[i] >= 0) != 0ull) ? 1 : 0;
+  const int n_issue = issuer ? na_w + W2_NB : 0;
 
   int nchunks = 0;
   for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / 8;
@@ -386,12 +393,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
     const unsigned la = lds0 + (unsigned)(f_slot * W2_STAGE);
     const float* sp = P.src[f_src] + (long long)img * P.img_stride[f_src] + f_c0;
     const unsigned pixb = (unsigned)P.ld[f_src] * 4u;
+    if (issuer) {
 #pragma unroll
-    for (int i = 0; i < W2_NA; ++i)
-      if (a_pix[i] >= 0) wn_glds16((unsigned)a_pix[i] * pixb + 16u * (unsigned)a_q[i], sp, la + i * 8192u);
-    const float* wp = P.weight + f_cpad + f_c0;
+      for (int i = 0; i < W2_NA; ++i)
+        if (a_pk[i] >= 0) wn_glds16((unsigned)(a_pk[i] >> 1) * pixb + 16u * (unsigned)(a_pk[i] & 1), sp, la + i * (NTI * 16u));
+      const float* wp = P.weight + f_cpad + f_c0;
+      unsigned bo = b_off0;
+      asm volatile("" : "+v"(bo));                       // opaque: eight hoisted offsets would not fit the register file
 #pragma unroll
-    for (int i = 0; i < W2_NB; ++i) wn_glds16((unsigned)b_off[i] * 4u, wp, la + (unsigned)W2_ABYTES + i * 8192u);
+      for (int i = 0; i < W2_NB; ++i) { wn_glds16(bo, wp, la + (unsigned)W2_ABYTES + i * (NTI * 16u)); bo += b_step; }
+    }
     ++f_chunk; f_c0 += 8;
     f_slot = f_slot == W2_RING - 1 ? 0 : f_slot + 1;
     if (f_c0 >= P.c[f_src] && f_src + 1 < P.nsrc) { f_cpad += P.c[f_src]; f_c0 = 0; ++f_src; }
@@ -673,13 +684,16 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
   static dev_once_t attr{0};
   if (dev_once_begin(attr)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(GPEMSR_ELAUNCH, "conv2d (Winograd form): cannot raise the dynamic LDS limit");
     dev_once_done(attr);
   }
   if (wide) {
     const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE) + 4096;     // + the partial sums' cross-wave exchange
-    hipLaunchKernelGGL(conv_wino2_f32_kernel, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
+    static const bool sym = getenv("GPEMSR_WINO_SYM") && atoi(getenv("GPEMSR_WINO_SYM")) != 0;      // A/B: all eight waves issue the DMA (the first form)
+    if (sym) hipLaunchKernelGGL(conv_wino2_f32_kernel<false>, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
+    else hipLaunchKernelGGL(conv_wino2_f32_kernel<true>, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
     return check_launch("conv_wino2_f32_kernel");
   }
   const size_t lds = (size_t)(WN_EBYTES > WN_RING * WN_STAGE ? WN_EBYTES : WN_RING * WN_STAGE);
