@@ -45,6 +45,7 @@ struct WinoParams {
   float* out; int out_ld;
   int tiles_x, tiles_y, tiles_n;
   int nblocks;
+  int tn_group;                   // wide kernel: cout blocks of one pixel tile that are neighbours in the launch order (divides tiles_n)
   float* gn_ws; int gn_parts;     // wide kernel: GroupNorm partial sums of (conv + bias) per (tile, channel): [n][gn_parts][cout][2] (conv_mfma.hip XEPI = 1)
   float* cos_ws;                  // wide kernel, cout == 64: patch-cosine partial sums against `residual` INSTEAD of storing (conv_mfma.hip XEPI = 2)
   int pixshuf, cq;                // wide kernel: store as PixelShuffle(2) (cout index = (2i + j) * cq + c, out is [n][2h][2w][cq])
@@ -349,11 +350,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
   // pixel tile fastest, cout block slowest: the workgroups that run together on an XCD read the SAME U slice (16 positions x 64 couts x cin:
   // 2 MB at 512 channels, it stays in the XCD's 4 MB L2) and different image tiles.  With the cout block fastest every workgroup of an XCD
   // streamed a different slice -- the whole 16.8 MB U tensor per pixel tile, 265 GB of fabric reads per step (profiles/r04a_fp32_pmc_summary.json)
+  // ... and `tn_group` (<= 4) cout blocks of one pixel tile run side by side: they share the tile's input chunks in L2, so the image is
+  // streamed tiles_n / tn_group times instead of tiles_n times (512 channels: 8 -> 2; the U chunks of the group, 4 x 32 KB, are shared by the
+  // ~8 pixel tiles in flight on the XCD).  Counters: profiles/r04_fp32_pmc_summary.json (289 GB read by this kernel with tn_group = 1)
   int t = bid;
+  const int tn_lo = t % P.tn_group; t /= P.tn_group;
   const int tx0 = t % P.tiles_x; t /= P.tiles_x;
   const int ty0 = t % P.tiles_y; t /= P.tiles_y;
   const int img = t % P.n; t /= P.n;
-  const int tn = t;
+  const int tn = t * P.tn_group + tn_lo;
   const int oy0 = ty0 * 8, ox0 = tx0 * 32, n0 = tn * 64;
 
   int a_pk[W2_NA];                                           // 2 * pixel + channel quad of the slot, -1: outside the image / not an issuer
@@ -681,6 +686,12 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (Winograd form): grid too large");
   P.nblocks = (int)nb;
+  {
+    static int grp = -1;
+    if (grp < 0) { const char* e = getenv("GPEMSR_WINO_TN_GROUP"); grp = e ? atoi(e) : 4; if (grp < 1) grp = 1; }
+    P.tn_group = 1;
+    for (int a = 4; a >= 2; a >>= 1) if (a <= grp && P.tiles_n % a == 0) { P.tn_group = a; break; }
+  }
   static dev_once_t attr{0};
   if (dev_once_begin(attr)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

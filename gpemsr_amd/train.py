@@ -311,13 +311,18 @@ class TrainEngine(Engine):
         for name in self.trainable:
             self._pack_one(name + ".weight", self.sd[name + ".weight"])
 
-    def enable_fast_refresh(self, flat_p: torch.Tensor):
-        """Every packed form of a trainable layer is a permutation of its master weights plus zero padding, so the per-step repack
-        (93 layers x ~10 small torch launches = 3.7 ms of host time per step, serial with the device) collapses into ONE gather
-        from the flat parameter buffer: the index map is found by packing index-valued tensors through the very same routines, and the
-        packed tensors become views of one flat buffer."""
+    def enable_fast_refresh(self, flat_p: torch.Tensor, verify: bool = True):
+        """Every packed form of a trainable layer is a permutation of its master weights times a per-layer constant (1, or the folded
+        C^-1/2 of an attention q projection) plus zero padding, so the per-step repack (93 layers x ~10 small torch launches in stage 3,
+        ~1,400 launches in stage 1: host time serial with the device) collapses into ONE gather from the flat parameter buffer.  The index
+        map is found by packing index-valued tensors through the very same routines -- as TWO planes (index + 1 = 4096 * hi + lo, both
+        exact in fp32 whatever constant multiplies them), so the map covers the 42.6 M parameters of the stage-1 generator (one fp32 plane
+        stops at 2^24) -- and the multiplier by packing ones.  The packed tensors become views of one flat buffer.  `verify`: the gathered
+        buffer is compared once with the layer-by-layer repack (a packing routine that SUMS weights would not be a permutation)."""
         base, n_flat = flat_p.data_ptr(), flat_p.numel()
+        assert n_flat < (1 << 31), "int32 gather indices"
         real, names = {}, sorted(self.trainable)
+        offs = {}
         for name in names:
             for leaf in ("weight", "bias"):
                 k = f"{name}.{leaf}"
@@ -326,34 +331,40 @@ class TrainEngine(Engine):
                     continue
                 off = (t.data_ptr() - base) // 4
                 assert 0 <= off and off + t.numel() <= n_flat, f"{k} is not a view of the flat parameter buffer"
-                assert off + t.numel() < (1 << 24), "index packing uses exact fp32 integers"
-                real[k] = t
-                self.sd[k] = (torch.arange(t.numel(), device=t.device, dtype=torch.float32) + float(off + 1)).view(t.shape)
-        try:
+                real[k], offs[k] = t, off
+
+        def packed_plane(plane: str) -> torch.Tensor:
+            """All packed slots (16-byte aligned each) after packing the index plane `plane` in place of the weights."""
+            for k, t in real.items():
+                i1 = torch.arange(t.numel(), device=t.device, dtype=torch.int64) + (offs[k] + 1)
+                v = (i1 & 4095) if plane == "lo" else ((i1 >> 12) if plane == "hi" else torch.ones_like(i1))
+                self.sd[k] = v.to(torch.float32).view(t.shape)
             for name in names:
                 self._pack_one(name + ".weight", self.sd[name + ".weight"])
-            slots = []
-            for name in names:
-                pc = self.pc.get(name)
-                if pc is not None:
-                    for attr in ("w", "b"):
-                        t = getattr(pc, attr, None)
-                        if t is not None:
-                            slots.append((pc, attr, t))
-                for leaf in ("weight", "bias"):
-                    if f"{name}.{leaf}" in self.par:
-                        slots.append((self.par, f"{name}.{leaf}", self.par[f"{name}.{leaf}"]))
-        finally:
-            self.sd.update(real)
+            return torch.cat([_pad4(t) for _, _, t in self._refresh_slots(names)])
+
         def _pad4(t):                                        # every view must stay 16-byte aligned (the kernels' vector loads)
             t = t.reshape(-1)
             return torch.cat([t, t.new_zeros((-t.numel()) % 4)])
-        idx = torch.cat([_pad4(t) for _, _, t in slots]).round().to(torch.int64)
-        self._rmask = (idx > 0).to(torch.float32)
-        self._ridx = (idx - 1).clamp_(min=0)
+        try:
+            one = packed_plane("one")
+            lo, hi = packed_plane("lo"), packed_plane("hi")
+        finally:
+            self.sd.update(real)
+        live = one != 0
+        safe = torch.where(live, one, torch.ones_like(one))
+        idx1 = (torch.round(hi / safe).to(torch.int64) << 12) + torch.round(lo / safe).to(torch.int64)
+        idx1 = torch.where(live, idx1, torch.zeros_like(idx1))
+        assert int(idx1.max()) <= n_flat and bool((idx1[live] > 0).all()), "index planes did not decode"
+        self._rmask = one.clone()                            # multiplier: 0 in the padding
+        self._ridx = (idx1 - 1).clamp_(min=0).to(torch.int32)
         self._rflat = flat_p
         self._rtmp = torch.empty_like(self._rmask)
         self._rpacked = torch.empty_like(self._rmask)
+        for name in names:                                   # the slots are re-created from the real weights, then re-pointed into the buffer
+            self._pack_one(name + ".weight", self.sd[name + ".weight"])
+        slots = self._refresh_slots(names)
+        want = torch.cat([_pad4(t) for _, _, t in slots]) if verify else None
         off = 0
         for obj, key, t in slots:
             view = self._rpacked[off:off + t.numel()].view(t.shape)
@@ -363,6 +374,23 @@ class TrainEngine(Engine):
                 setattr(obj, key, view)
             off += (t.numel() + 3) // 4 * 4
         self.refresh_weights()
+        if verify:
+            assert torch.equal(self._rpacked, want), "one-gather repack differs from the layer-by-layer repack"
+
+    def _refresh_slots(self, names):
+        """(owner, key, tensor) of every packed tensor the per-step repack rewrites, in a fixed order."""
+        slots = []
+        for name in names:
+            pc = self.pc.get(name)
+            if pc is not None:
+                for attr in ("w", "b"):
+                    t = getattr(pc, attr, None)
+                    if t is not None:
+                        slots.append((pc, attr, t))
+            for leaf in ("weight", "bias"):
+                if f"{name}.{leaf}" in self.par:
+                    slots.append((self.par, f"{name}.{leaf}", self.par[f"{name}.{leaf}"]))
+        return slots
 
     # -- recorded convolution ------------------------------------------------------------------------------------------
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -189,6 +191,8 @@ class Stage2Trainer(_TrainerState):
         sd = {k: v.detach() for k, v in model.state_dict().items()}
         self.eng = Stage2Engine(sd, device, model.scale, model.nframes, model.groups, model.nf, model._dec_nrb, names, gw, gb)
         self.gw, self.gb = gw, gb
+        if os.environ.get("GPEMSR_FAST_REFRESH", "1") != "0":     # the per-step repack as ONE gather from the flat buffer (TrainEngine.enable_fast_refresh)
+            self.eng.enable_fast_refresh(self.flat_p)
         self.step_count = 0
         o = self.opt
         self.lr = float(o.get("lr_G", 4e-4))

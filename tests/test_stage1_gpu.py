@@ -86,3 +86,47 @@ def test_two_generator_steps_match_the_reference_golden(golden_dir):
     tr.current_step = 40000                                             # the adversarial phase needs a discriminator (test_stage1_adv_gpu.py)
     with pytest.raises(RuntimeError, match="discriminator"):
         tr.forward_backward(imgs)
+
+
+def _fast_refresh_equals_layerwise(tr):
+    """TrainEngine.enable_fast_refresh (two index planes + multiplier, one gather) leaves exactly what the layer-by-layer repack leaves."""
+    eng = tr.eng
+    assert eng._ridx is not None and eng._ridx.dtype == torch.int32
+    assert int((eng._rmask != 0).sum()) >= tr.n_params
+    g = torch.Generator(device="cpu").manual_seed(5)
+    tr.flat_p.mul_(1.0 + 0.1 * torch.rand(tr.flat_p.numel(), generator=g).to(tr.flat_p.device))
+    eng.refresh_weights()
+    fast = {}
+    for name in sorted(eng.trainable):
+        pc = eng.pc.get(name)
+        if pc is not None:
+            fast[name + "@w"] = pc.w.clone()
+            if pc.b is not None:
+                fast[name + "@b"] = pc.b.clone()
+        for leaf in ("weight", "bias"):
+            if f"{name}.{leaf}" in eng.par:
+                fast[f"{name}.{leaf}@par"] = eng.par[f"{name}.{leaf}"].clone()
+    eng._ridx = None                                   # the layer-by-layer path (fresh tensors)
+    eng.refresh_weights()
+    n = 0
+    for name in sorted(eng.trainable):
+        pc = eng.pc.get(name)
+        if pc is not None:
+            assert torch.equal(fast[name + "@w"], pc.w), name
+            n += 1
+            if pc.b is not None:
+                assert torch.equal(fast[name + "@b"], pc.b), name
+        for leaf in ("weight", "bias"):
+            if f"{name}.{leaf}" in eng.par:
+                assert torch.equal(fast[f"{name}.{leaf}@par"], eng.par[f"{name}.{leaf}"]), name
+    return n
+
+
+def test_one_gather_repack_of_the_42M_parameter_generator(golden_dir):
+    """the stage-1 generator (42.6 M parameters, beyond the 2^24 exact integers of one fp32 index plane) repacks with ONE
+    gather per step; attention q projections carry their folded C^-1/2 through the multiplier plane."""
+    d = np.load(os.path.join(golden_dir, "stage1_gen.npz"))
+    tr, _, _ = _trainer(d, torch.device("cuda", 0))
+    assert tr.n_params > (1 << 24)
+    assert any(v != 1.0 for v in tr.eng.wscale.values())
+    assert _fast_refresh_equals_layerwise(tr) > 60

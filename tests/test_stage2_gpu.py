@@ -197,3 +197,46 @@ def test_x16_stage2_step_matches_reference_golden(golden_dir):
         errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
     print("x16 stage-2 gradient parity, worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:3], "median %.1e" % np.median(list(errs.values())))
     assert max(errs.values()) <= 2e-2 and np.median(list(errs.values())) <= 1e-3
+
+
+def _fast_refresh_equals_layerwise(tr):
+    """TrainEngine.enable_fast_refresh (two index planes + multiplier, one gather) leaves exactly what the layer-by-layer repack leaves."""
+    eng = tr.eng
+    assert eng._ridx is not None and eng._ridx.dtype == torch.int32
+    assert int((eng._rmask != 0).sum()) >= tr.n_params
+    g = torch.Generator(device="cpu").manual_seed(5)
+    tr.flat_p.mul_(1.0 + 0.1 * torch.rand(tr.flat_p.numel(), generator=g).to(tr.flat_p.device))
+    eng.refresh_weights()
+    fast = {}
+    for name in sorted(eng.trainable):
+        pc = eng.pc.get(name)
+        if pc is not None:
+            fast[name + "@w"] = pc.w.clone()
+            if pc.b is not None:
+                fast[name + "@b"] = pc.b.clone()
+        for leaf in ("weight", "bias"):
+            if f"{name}.{leaf}" in eng.par:
+                fast[f"{name}.{leaf}@par"] = eng.par[f"{name}.{leaf}"].clone()
+    eng._ridx = None                                   # the layer-by-layer path (fresh tensors)
+    eng.refresh_weights()
+    n = 0
+    for name in sorted(eng.trainable):
+        pc = eng.pc.get(name)
+        if pc is not None:
+            assert torch.equal(fast[name + "@w"], pc.w), name
+            n += 1
+            if pc.b is not None:
+                assert torch.equal(fast[name + "@b"], pc.b), name
+        for leaf in ("weight", "bias"):
+            if f"{name}.{leaf}" in eng.par:
+                assert torch.equal(fast[f"{name}.{leaf}@par"], eng.par[f"{name}.{leaf}"]), name
+    return n
+
+
+def test_one_gather_repack_of_the_indexer():
+    from gen_golden_stage2 import TRAIN_OPT
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.train_stage2 import Stage2Trainer
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    tr = Stage2Trainer(build_model(opt, load_prior_files=False).to(_dev()), TRAIN_OPT, _dev())
+    assert _fast_refresh_equals_layerwise(tr) > 30
