@@ -129,4 +129,4 @@ def test_one_gather_repack_of_the_42M_parameter_generator(golden_dir):
     tr, _, _ = _trainer(d, torch.device("cuda", 0))
     assert tr.n_params > (1 << 24)
     assert any(v != 1.0 for v in tr.eng.wscale.values())
-    assert _fast_refresh_equals_layerwise(tr) > 60
+    assert _fast_refresh_equals_layerwise(tr) > 40

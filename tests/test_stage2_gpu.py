@@ -239,4 +239,4 @@ def test_one_gather_repack_of_the_indexer():
     from gpemsr_amd.train_stage2 import Stage2Trainer
     opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
     tr = Stage2Trainer(build_model(opt, load_prior_files=False).to(_dev()), TRAIN_OPT, _dev())
-    assert _fast_refresh_equals_layerwise(tr) > 30
+    assert _fast_refresh_equals_layerwise(tr) >= 30
