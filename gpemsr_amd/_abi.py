@@ -22,6 +22,7 @@ SYMBOLS = [
     "gpemsr_groupnorm_stats", "gpemsr_groupnorm_apply", "gpemsr_softmax_rows", "gpemsr_softmax_rows_ld", "gpemsr_argmax_rows",
     "gpemsr_gather_rows", "gpemsr_bilinear", "gpemsr_avgpool2", "gpemsr_pool3s2_maxavg", "gpemsr_spynet_prep",
     "gpemsr_dcn_columns", "gpemsr_patch_cosine", "gpemsr_temporal_gate", "gpemsr_frame_mix_lrelu",
+    "gpemsr_png_gray8_size", "gpemsr_png_encode_workspace", "gpemsr_png_encode_gray8", "gpemsr_png_decode_gray8",
     "gpemsr_threeda_combine", "gpemsr_tensor2img_u8", "gpemsr_copy_channels", "gpemsr_copy_images",
     "gpemsr_gather_images", "gpemsr_maxpool2", "gpemsr_normalize3", "gpemsr_cx_channel_mean", "gpemsr_cx_center_normalize",
     "gpemsr_cx_rows", "gpemsr_cx_reduce",
@@ -125,6 +126,12 @@ def load():
     lib.gpemsr_frame_mix_lrelu.argtypes = [p, i64, i32, i32, p, p, p, p]
     lib.gpemsr_threeda_combine.argtypes = [p, p, p, p, p, i64, p, p]
     lib.gpemsr_tensor2img_u8.argtypes = [p, i64, p, p]
+    lib.gpemsr_png_gray8_size.argtypes = [i32, i32]
+    lib.gpemsr_png_gray8_size.restype = C.c_int64
+    lib.gpemsr_png_encode_workspace.argtypes = [i32, i32, i32]
+    lib.gpemsr_png_encode_workspace.restype = C.c_int64
+    lib.gpemsr_png_encode_gray8.argtypes = [p, i32, i32, i32, i64, i32, p, i64, p, i64, p]
+    lib.gpemsr_png_decode_gray8.argtypes = [p, p, i32, i32, i32, p, p, f32, p, p]
     lib.gpemsr_copy_channels.argtypes = [p, i32, p, i32, i64, i32, p]
     lib.gpemsr_copy_images.argtypes = [p, p, i64, i64, i32, i32, i32, p]
     lib.gpemsr_split_pack_rows.argtypes = [p, i32, i32, i32, i32, i64, p, p]

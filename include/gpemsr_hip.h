@@ -533,6 +533,25 @@ int gpemsr_sum_scaled(const float* x, int64_t count, float scale, int square, fl
 int gpemsr_instnorm_bwd_bwd(const float* x, const float* dy, const float* g, const float* mean_rstd, int n, int hw, int c, float* gx, float* gdy,
                             int accumulate_gx, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * PNG edges of the inference loop on the device.  Byte / integer kernels, csrc/png.hip.
+ * ------------------------------------------------------------------------- */
+/* R:output_GPEMSR.py:95 `cv2.imwrite(path, output)`: n 8-bit grayscale images (img + i*img_stride, rows row_stride bytes apart) -> n complete
+ * PNG files at out + i*out_stride, gpemsr_png_gray8_size(h, w) bytes each: signature, IHDR, ONE IDAT chunk whose zlib stream uses stored
+ * deflate blocks (filter type 0 on every scanline), IEND; Adler-32 and both CRC-32s computed on the device.  Any PNG reader decodes the
+ * same pixels cv2 would have written.  workspace: gpemsr_png_encode_workspace(n, h, w) bytes, 8-byte aligned. */
+int64_t gpemsr_png_gray8_size(int h, int w);
+int64_t gpemsr_png_encode_workspace(int n, int h, int w);
+int gpemsr_png_encode_gray8(const uint8_t* img, int n, int h, int w, int64_t img_stride, int row_stride, uint8_t* out, int64_t out_stride,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+/* R:data/util.py:75-88 `cv2.imread(path, IMREAD_UNCHANGED).astype(float32) / 255` for n non-interlaced 8-bit grayscale PNGs of one size:
+ * idat = the files' IDAT payloads back to back (image i: bytes offsets[i] .. offsets[i+1], a complete zlib stream; the host reads chunk
+ * lengths and IHDR, 50 bytes per file), raw = scratch of n*h*(w+1) bytes, out[n][h][w] = pixel / divisor (255; IEEE division, as numpy's).  One wave per image: lane 0
+ * inflates (stored, fixed and dynamic Huffman blocks; tables and the 32 KB window in LDS), all lanes check Adler-32 and undo the scanline filters.  status[i]: 0 ok, 1 bad zlib
+ * header, 2 bad block, 3 bad Huffman table, 4 bad symbol / distance, 5 size mismatch, 6 input exhausted, 7 Adler-32 mismatch, 8 bad filter, 9 wider than 16,384 pixels (two scanlines live in LDS). */
+int gpemsr_png_decode_gray8(const uint8_t* idat, const int64_t* offsets, int n, int h, int w, uint8_t* raw, float* out, float divisor,
+                            int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

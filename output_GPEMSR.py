@@ -12,7 +12,8 @@ as /root/reference/GPEMSR-CREMI/GPEMSR/output_GPEMSR.py:54-84,98-128), but the m
     goes through the per-slice half of the network once and the sliding windows share the cached features
     (bit-identical output, ~2.8x less work per slice); ``volume_block`` windows are processed per call;
   * ``tile_batch`` (option key) > 1 batches several 5-slice windows per forward call (without the cache);
-  * uint8 conversion runs on the device and PNG encoding/writing in a small thread pool, off the GPU's critical path;
+  * uint8 conversion, PNG decoding of the LR slices and PNG encoding of the outputs run on the device (csrc/png.hip; `png_on_device:
+    false`: host codec in a small thread pool); the files hold the same pixels as cv2.imwrite's, in stored deflate blocks;
   * with several ranks (torchrun), the volume is sharded along z over GPUs: contiguous output slices per rank, each rank reading
     its own LR slices plus a 2-slice halo (gpemsr_amd.dist.plan_volume_shard);
   * ``synthetic_weights_if_missing: true`` lets the script run without the authors'
@@ -175,44 +176,93 @@ def main():
     writers = ThreadPoolExecutor(max_workers=int(opt.get('writer_threads', 4) or 4))
     loaders = ThreadPoolExecutor(max_workers=1)
 
+    # PNG edges on the device (gpemsr_amd/png.py, csrc/png.hip; option `png_on_device: false` restores host decode / encode): the loader
+    # thread only reads file BYTES, the device inflates + unfilters + converts the 8-bit grayscale slices; the 8-bit outputs become complete
+    # PNG files in HBM (stored deflate blocks) and the writer threads copy bytes to disk -- no zlib on the host at 150+ images per second
+    # and GPU.  Files of another flavour (16-bit, colour, interlaced) are decoded on the host, as the reference does (cv2 / Pillow).
+    png_dev = opt.get('png_on_device', True) is not False
+    from gpemsr_amd import png as gpng
+
     def load_block(b0):
         b1 = min(hi, b0 + block)
+        files, win = index_windows(wpaths[b0:b1])
+        if png_dev:
+            blobs = []
+            for f in files:
+                with open(f, 'rb') as fh:
+                    blobs.append(fh.read())
+            dec = gpng.device_decodable(blobs)
+            if dec is not None:
+                return {"png": dec, "files": files, "win": win}
         if use_cache:
-            files, win = index_windows(wpaths[b0:b1])
-            return load_frames(files).pin_memory(), win
-        return torch.stack([load_frames(p) for p in wpaths[b0:b1]], dim=0).pin_memory(), None
+            return {"host": load_frames(files).pin_memory(), "win": win}
+        return {"host": torch.stack([load_frames(p) for p in wpaths[b0:b1]], dim=0).pin_memory(), "win": None}
+
+    def to_device(blk):
+        """-> (model input on the device, window matrix or None, decode status or None)"""
+        if "png" in blk:
+            h, w, payloads = blk["png"]
+            x, status = gpng.decode_gray8(payloads, h, w, device)                    # [files, 1, h, w] float32 / 255
+            if use_cache:
+                return x, blk["win"], (status, blk["files"])
+            return x[blk["win"].to(device).long()], None, (status, blk["files"])      # [windows, N, 1, h, w]
+        return blk["host"].to(device, non_blocking=True), blk["win"], None
+
+    def write_bytes(buf, path):
+        with open(path, 'wb') as fh:
+            fh.write(buf)
 
     pending = []
 
     def flush(item):
-        # the block's 8-bit images have landed in pinned host memory once its event has passed: hand them to the PNG writers
-        hostbuf, ev, c0, c1 = item
+        # the block's output has landed in pinned host memory once its event has passed: hand it to the writers
+        hostbuf, ev, c0, c1, status = item
         ev.synchronize()
+        if status is not None:
+            gpng.check_status(status[0], status[1])
         u8 = hostbuf.numpy()
         for j in range(c1 - c0):
-            pending.append(writers.submit(save_img, u8[j], osp.join(im_path_SR, '{}.png'.format(c0 + j))))
+            path = osp.join(im_path_SR, '{}.png'.format(c0 + j))
+            pending.append(writers.submit(write_bytes, u8[j].tobytes(), path) if png_dev else writers.submit(save_img, u8[j], path))
+
+    # the next block's upload + PNG decode run on a side stream while the current block's forward occupies the main one (the inflate is one
+    # lane per image: it needs 80 wave slots for a few milliseconds, not the machine)
+    side = torch.cuda.Stream(device=device)
+
+    def start_upload(blk):
+        with torch.cuda.stream(side):
+            x, win, status = to_device(blk)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return x, win, status, ev
 
     with torch.no_grad():
-        nxt = loaders.submit(load_block, lo) if lo < hi else None
+        cur = start_upload(load_block(lo)) if lo < hi else None
         inflight = None
         for b0 in range(lo, hi, block):
             b1 = min(hi, b0 + block)
-            host, win = nxt.result()
-            nxt = loaders.submit(load_block, b1) if b1 < hi else None       # decode the next block while the GPU works
+            x, win, status, ev_up = cur
+            torch.cuda.current_stream().wait_event(ev_up)
+            x.record_stream(torch.cuda.current_stream())
+            nxt = loaders.submit(load_block, b1) if b1 < hi else None       # read (host path: decode) the next block while the GPU works
             # the 8-bit image is written by the network's last kernel (conv_last + bilinear base + tensor2img): 1 B/pixel D2H
             if use_cache:
-                _, _, u8 = model.forward_volume(host.to(device, non_blocking=True), win, want_u8=True)
+                _, _, u8 = model.forward_volume(x, win, want_u8=True)
             else:
-                _, _, u8 = model(host.to(device, non_blocking=True), want_u8=True)
+                _, _, u8 = model(x, want_u8=True)
+            if png_dev:
+                u8 = gpng.encode_gray8(u8.reshape(-1, u8.shape[-2], u8.shape[-1]))      # [slices, file bytes]
             # asynchronous D2H into pinned memory; the host only waits for block k-1 AFTER block k has been enqueued, so the
             # device never idles between blocks (R:output_GPEMSR.py:88-95 moves every slice synchronously)
             hostbuf = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
             hostbuf.copy_(u8, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
+            if nxt is not None:
+                cur = start_upload(nxt.result())                           # enqueued behind nothing: overlaps with this block's forward
             if inflight is not None:
                 flush(inflight)
-            inflight = (hostbuf, ev, b0, b1)
+            inflight = (hostbuf, ev, b0, b1, status)
         if inflight is not None:
             flush(inflight)
     for f in pending:

@@ -527,9 +527,10 @@ def test_cli_volume_cache_writes_the_same_pngs(tmp_path):
     opt["pretrain_path"] = str(tmp_path / "missing.pth")
     opt["synthetic_weights_if_missing"] = True
     outs = {}
-    for mode, cache in (("vol", True), ("win", False)):
+    for mode, cache in (("vol", True), ("win", False), ("hostpng", True)):
         opt["save_path"] = str(tmp_path / mode)
         opt["volume_cache"] = cache
+        opt["png_on_device"] = mode != "hostpng"        # device inflate / stored-block encoder (csrc/png.hip) vs the host codec: same pixels
         opt["volume_block"] = 4                     # 7 windows -> two blocks: exercises the halo re-computation
         yml = tmp_path / f"{mode}.yml"
         yaml.safe_dump(opt, open(yml, "w"))
@@ -541,6 +542,9 @@ def test_cli_volume_cache_writes_the_same_pngs(tmp_path):
         assert outs[mode][0].shape == (128, 128) and outs[mode][0].dtype == np.uint8
     for k in range(n):
         assert np.array_equal(outs["vol"][k], outs["win"][k]), k
+        assert np.array_equal(outs["vol"][k], outs["hostpng"][k]), k
+    with open(tmp_path / "vol" / "0.png", "rb") as fh:              # the device encoder's file: one IDAT of stored blocks, 57 + 2 + 5 + h (w + 1) + 4 bytes
+        assert len(fh.read()) == 57 + 2 + 5 + 128 * 129 + 4
 
 
 def test_edge_shapes_empty_minimal_and_large_tile():

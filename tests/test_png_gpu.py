@@ -1,0 +1,120 @@
+"""PNG edges on the device (csrc/png.hip through the C ABI) against the oracle and against Pillow / zlib.
+Encode: byte-identical to oracle.png_oracle.encode_gray8_stored, readable by Pillow.  Decode: bit-identical to
+`np.array(Image.open(f)).astype(float32) / 255` (R:data/util.py:75-88 with cv2 replaced by the other libpng-compatible reader) for files
+with stored / fixed / dynamic deflate blocks, all five scanline filters, split IDAT chunks; corrupted streams are reported."""
+import io
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import png_oracle as po      # noqa: E402
+from test_png_cpu import _img      # noqa: E402
+
+Image = pytest.importorskip("PIL.Image")
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 1, 1), (3, 5, 7), (2, 128, 128), (1, 255, 257), (2, 1024, 1024), (1, 63, 1039), (1, 65534, 1)])
+def test_encode_matches_the_oracle_byte_for_byte(n, h, w):
+    from gpemsr_amd import png
+    imgs = np.stack([_img(h, w, 100 + 7 * i + h, "noise" if i % 2 == 0 else "smooth") for i in range(n)])
+    files = png.encode_gray8(torch.from_numpy(imgs).to(_dev()))
+    torch.cuda.synchronize()
+    assert files.shape == (n, png.png_size(h, w))
+    host = files.cpu().numpy()
+    for i in range(n):
+        want = po.encode_gray8_stored(imgs[i])
+        got = host[i].tobytes()
+        assert len(got) == len(want)
+        if got != want:
+            bad = next(k for k in range(len(want)) if got[k] != want[k])
+            raise AssertionError(f"image {i}: first difference at byte {bad} of {len(want)}: {got[bad]:#x} != {want[bad]:#x}")
+        assert np.array_equal(np.array(Image.open(io.BytesIO(got))), imgs[i])
+
+
+def test_encode_of_the_networks_uint8_output_round_trips():
+    """[n, 1, h, w] layout as forward(..., want_u8=True) returns it; decoding our own files on the device gives the pixels back."""
+    from gpemsr_amd import png
+    u8 = torch.from_numpy(np.stack([_img(96, 160, 3 + i) for i in range(4)])[:, None]).to(_dev())
+    files = png.encode_gray8(u8).cpu().numpy()
+    got = png.device_decodable([f.tobytes() for f in files])
+    assert got is not None and got[:2] == (96, 160)
+    x, status = png.decode_gray8(got[2], 96, 160, _dev())
+    torch.cuda.synchronize()
+    png.check_status(status)
+    assert np.array_equal(x.cpu().numpy(), u8.cpu().numpy().astype(np.float32) / 255.)      # numpy's IEEE division (torch's device division is not)
+
+
+def _files():
+    out = []
+    smooth, noise = _img(128, 128, 21, "smooth"), _img(128, 128, 22)
+    for img in (smooth, noise):
+        out.append(("stored", img, po.make_png(img, level=0)))
+        out.append(("fixed", img, po.make_png(img, types=(1,), strategy=zlib.Z_FIXED)))
+        out.append(("dynamic", img, po.make_png(img, types=(0, 1, 2, 3, 4))))
+        out.append(("paeth-split", img, po.make_png(img, types=(4,), level=9, idat_split=1000)))
+        for level in (1, 6, 9):
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="PNG", compress_level=level)
+            out.append((f"pillow-{level}", img, buf.getvalue()))
+    return out
+
+
+def test_decode_matches_numpy_bit_for_bit():
+    from gpemsr_amd import png
+    cases = _files()
+    got = png.device_decodable([c[2] for c in cases])
+    assert got is not None
+    h, w, payloads = got
+    x, status = png.decode_gray8(payloads, h, w, _dev())
+    torch.cuda.synchronize()
+    png.check_status(status, [c[0] for c in cases])
+    for i, (name, img, data) in enumerate(cases):
+        want = np.array(Image.open(io.BytesIO(data))).astype(np.float32) / 255.        # data/util.py:82 with the other libpng-compatible reader
+        assert np.array_equal(want, img.astype(np.float32) / 255.)
+        assert np.array_equal(x[i, 0].cpu().numpy(), want), name
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 2), (17, 1), (1, 300), (200, 333)])
+def test_decode_ragged_sizes(h, w):
+    from gpemsr_amd import png
+    img = _img(h, w, 40 + h, "smooth")
+    datas = [po.make_png(img, types=(t,)) for t in range(5)]
+    hh, ww, payloads = png.device_decodable(datas)
+    x, status = png.decode_gray8(payloads, hh, ww, _dev())
+    torch.cuda.synchronize()
+    png.check_status(status)
+    for i in range(5):
+        assert np.array_equal(x[i, 0].cpu().numpy(), img.astype(np.float32) / 255.)
+
+
+def test_decode_reports_corruption_and_other_flavours():
+    from gpemsr_amd import png
+    img = _img(64, 64, 9, "smooth")
+    good = po.make_png(img)
+    _, _, _, _, _, idat = po.parse(good)
+    broken = bytearray(idat); broken[len(broken) // 2] ^= 0x5A                 # a flipped byte inside the deflate stream
+    wrong_adler = bytearray(idat); wrong_adler[-1] ^= 1
+    truncated = idat[:len(idat) // 2]
+    x, status = png.decode_gray8([idat, bytes(broken), bytes(wrong_adler), truncated], 64, 64, _dev())
+    torch.cuda.synchronize()
+    st = status.cpu().tolist()
+    assert st[0] == 0 and np.array_equal(x[0, 0].cpu().numpy(), img.astype(np.float32) / 255.)
+    assert st[1] != 0 and st[2] == 7 and st[3] != 0
+    with pytest.raises(ValueError):
+        png.check_status(status)
+    rgb = io.BytesIO(); Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(rgb, format="PNG")
+    assert png.device_decodable([good, rgb.getvalue()]) is None                 # the caller reads those on the host, as the reference does
+    bad_crc = bytearray(good); bad_crc[40] ^= 1
+    with pytest.raises(ValueError):
+        png.parse_chunks(bytes(bad_crc))
