@@ -687,8 +687,9 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (Winograd form): grid too large");
   P.nblocks = (int)nb;
   {
-    static int grp = -1;
-    if (grp < 0) { const char* e = getenv("GPEMSR_WINO_TN_GROUP"); grp = e ? atoi(e) : 4; if (grp < 1) grp = 1; }
+    const char* e = getenv("GPEMSR_WINO_TN_GROUP");          // (read per launch: the tests switch it inside one process)
+    int grp = e ? atoi(e) : 4;
+    if (grp < 1) grp = 1;
     P.tn_group = 1;
     for (int a = 4; a >= 2; a >>= 1) if (a <= grp && P.tiles_n % a == 0) { P.tn_group = a; break; }
   }
@@ -702,7 +703,8 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
   }
   if (wide) {
     const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE) + 4096;     // + the partial sums' cross-wave exchange
-    static const bool sym = getenv("GPEMSR_WINO_SYM") && atoi(getenv("GPEMSR_WINO_SYM")) != 0;      // A/B: all eight waves issue the DMA (the first form)
+    const char* es = getenv("GPEMSR_WINO_SYM");
+    const bool sym = es && atoi(es) != 0;                    // A/B: all eight waves issue the DMA (the first form)
     if (sym) hipLaunchKernelGGL(conv_wino2_f32_kernel<false>, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
     else hipLaunchKernelGGL(conv_wino2_f32_kernel<true>, dim3(P.nblocks), dim3(512), lds2, reinterpret_cast<hipStream_t>(stream), P);
     return check_launch("conv_wino2_f32_kernel");

@@ -628,6 +628,25 @@ def test_groupnorm_statistics_from_the_fp32_conv_epilogue(n, cin, cout, k, h, w)
     _close(y1.nchw(), y0, tol=2e-6, what="GN from epilogue sums vs the statistics pass")
 
 
+@pytest.mark.parametrize("sym,group", [("1", "4"), ("0", "1"), ("0", "2"), ("1", "1")])
+def test_winograd_launch_variants_are_bit_identical(sym, group, monkeypatch):
+    """The A/B switches of the wide Winograd kernel -- GPEMSR_WINO_SYM (all eight waves issue the LDS-DMA vs one wave per SIMD) and
+    GPEMSR_WINO_TN_GROUP (cout blocks of a pixel tile that are neighbours in the launch order) -- change who loads and in which order the
+    workgroups run, never the arithmetic: results equal the default launch bit for bit (512 couts = 8 cout blocks, ragged tiles, 3 images)."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd
+    dev = _dev()
+    x = _rand(3, 128, 19, 45, seed=31)
+    wt = _rand(512, 128, 3, 3, seed=32, scale=1.0 / np.sqrt(128 * 9))
+    pc = pack_conv(wt, _rand(512, seed=33, scale=0.1), dev)
+    pc.wino = pack_winograd(wt, dev)
+    monkeypatch.delenv("GPEMSR_WINO_SYM", raising=False); monkeypatch.delenv("GPEMSR_WINO_TN_GROUP", raising=False)
+    want = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_RELU, winograd=True).nchw().clone()
+    monkeypatch.setenv("GPEMSR_WINO_SYM", sym); monkeypatch.setenv("GPEMSR_WINO_TN_GROUP", group)
+    got = ops.conv2d([_to_act(x, dev)], pc, ops.ACT_RELU, winograd=True).nchw()
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 37, 70), (1, 128, 256, 20, 36), (1, 512, 512, 16, 16), (3, 128, 128, 8, 32), (1, 64, 64, 1, 1)])
 def test_groupnorm_statistics_from_the_winograd_epilogue(n, cin, cout, h, w):
     """gpemsr_conv_desc.gn_partials with transposed = 3 (csrc/conv_wino.hip, wide kernel): the conv output equals the Winograd launch without
