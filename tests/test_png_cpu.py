@@ -51,3 +51,27 @@ def test_oracle_reads_pillow_files():
             buf = io.BytesIO()
             Image.fromarray(img).save(buf, format="PNG", compress_level=level)
             assert np.array_equal(po.decode_gray8(buf.getvalue()), img)
+
+
+def test_host_side_chunk_parser_and_routing():
+    """gpemsr_amd.png.parse_chunks / device_decodable (host code of the device decoder): IDAT payloads are concatenated across split chunks, CRCs
+    are verified, and only non-interlaced 8-bit grayscale files of one size are routed to the device -- everything else is read on the host,
+    as the reference does (R:data/util.py:75-88)."""
+    from gpemsr_amd import png
+    img = _img(24, 40, 3, "smooth")
+    whole, split = po.make_png(img), po.make_png(img, idat_split=50)
+    assert png.parse_chunks(whole)[:5] == (40, 24, 8, 0, 0)
+    assert png.parse_chunks(split)[5] == png.parse_chunks(whole)[5] == po.parse(whole)[5]
+    assert np.array_equal(po.unfilter_gray8(zlib.decompress(png.parse_chunks(split)[5]), 24, 40), img)
+    h, w, payloads = png.device_decodable([whole, split])
+    assert (h, w, len(payloads)) == (24, 40, 2)
+    buf = io.BytesIO(); Image.fromarray(img.astype(np.uint16) * 256).save(buf, format="PNG")            # 16-bit grayscale
+    assert png.device_decodable([whole, buf.getvalue()]) is None
+    buf = io.BytesIO(); Image.fromarray(np.stack([img] * 3, axis=-1)).save(buf, format="PNG")            # RGB
+    assert png.device_decodable([buf.getvalue()]) is None
+    assert png.device_decodable([whole, po.make_png(_img(24, 41, 4))]) is None                            # mixed sizes
+    bad = bytearray(whole); bad[-20] ^= 0xFF
+    with pytest.raises(ValueError):
+        png.parse_chunks(bytes(bad))
+    with pytest.raises(ValueError):
+        png.parse_chunks(b"not a png at all")
