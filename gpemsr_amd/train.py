@@ -467,6 +467,15 @@ class TrainEngine(Engine):
     def _wino_layer(self, name: str) -> bool:
         return bool(self.wino_train & 1) and name not in getattr(self, "trainable", ())
 
+    def sync_weights(self, live, force=()):
+        """Engine.sync_weights + the data-gradient packs: those of frozen layers are kept across steps (`_dpc_frozen`), so a parameter that
+        changed behind the engine's back (load_state_dict of a sub-module, the torch.autograd path) must drop them too."""
+        n = super().sync_weights(live, force)
+        if n:
+            self._dpc.clear()
+            self._dpc_frozen.clear()
+        return n
+
     def _conv_backward(self, srcs: List[Act], name: str, act: int, stride: int, y: Act, residual: Optional[Act], trainable: bool):
         pc = self.pc[name]
         wkey = name.split("@")[0]
