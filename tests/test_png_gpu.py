@@ -118,3 +118,31 @@ def test_decode_reports_corruption_and_other_flavours():
     bad_crc = bytearray(good); bad_crc[40] ^= 1
     with pytest.raises(ValueError):
         png.parse_chunks(bytes(bad_crc))
+
+
+def test_decode_differential_against_zlib_over_deflate_flavours():
+    """120 streams of one image size produced by zlib with every combination of level {0, 1, 4, 9}, strategy {default, filtered, huffman-only,
+    rle, fixed} and window {512 B, 4 KB, 32 KB}, on smooth, noisy and constant images with random filter types per row: the device inflater
+    must reproduce zlib's output (and so the pixels) for all of them."""
+    import struct
+    from gpemsr_amd import png
+    rng = np.random.default_rng(7)
+    h, w = 48, 200
+    imgs = [_img(h, w, 70, "smooth"), _img(h, w, 71), np.full((h, w), 131, np.uint8), (np.arange(h * w, dtype=np.int64).reshape(h, w) % 7 * 36).astype(np.uint8)]
+    payloads, want = [], []
+    for level in (0, 1, 4, 9):
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+            for wbits in (9, 12, 15):
+                for k in range(2):
+                    img = imgs[(len(payloads) + k) % len(imgs)]
+                    types = tuple(int(t) for t in rng.integers(0, 5, 5))
+                    co = zlib.compressobj(level, zlib.DEFLATED, wbits, int(rng.integers(1, 10)), strategy)
+                    z = co.compress(po.filter_gray8(img, types)) + co.flush()
+                    assert zlib.decompress(z) == po.filter_gray8(img, types)
+                    payloads.append(z); want.append(img)
+    x, status = png.decode_gray8(payloads, h, w, _dev())
+    torch.cuda.synchronize()
+    png.check_status(status)
+    got = x[:, 0].cpu().numpy()
+    for i, img in enumerate(want):
+        assert np.array_equal(got[i], img.astype(np.float32) / 255.), i
