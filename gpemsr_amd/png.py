@@ -33,13 +33,14 @@ def encode_gray8(u8: torch.Tensor) -> torch.Tensor:
     if u8.dim() == 4:
         assert u8.shape[1] == 1
         u8 = u8[:, 0]
-    u8 = u8.contiguous()
+    if u8.stride(2) != 1 or u8.stride(1) < u8.shape[2] or (u8.shape[0] > 1 and u8.stride(0) < 0):
+        u8 = u8.contiguous()                               # rows must be dense; row / image strides are passed through (crops of a larger buffer)
     n, h, w = u8.shape
     size = png_size(h, w)
     stride = (size + 15) // 16 * 16                       # every file starts 16-byte aligned (vector stores)
     out = torch.empty((n, stride), dtype=torch.uint8, device=u8.device)
     ws = torch.empty(int(lib.gpemsr_png_encode_workspace(n, h, w)) // 8 + 1, dtype=torch.int64, device=u8.device)
-    _abi.check(lib.gpemsr_png_encode_gray8(u8.data_ptr(), n, h, w, h * w, w, out.data_ptr(), stride, ws.data_ptr(), ws.numel() * 8,
+    _abi.check(lib.gpemsr_png_encode_gray8(u8.data_ptr(), n, h, w, u8.stride(0) if n > 1 else h * w, u8.stride(1), out.data_ptr(), stride, ws.data_ptr(), ws.numel() * 8,
                                            torch.cuda.current_stream().cuda_stream), "png_encode_gray8")
     return out[:, :size]
 

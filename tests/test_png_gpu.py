@@ -146,3 +146,16 @@ def test_decode_differential_against_zlib_over_deflate_flavours():
     got = x[:, 0].cpu().numpy()
     for i, img in enumerate(want):
         assert np.array_equal(got[i], img.astype(np.float32) / 255.), i
+
+
+def test_encode_crops_of_a_larger_buffer():
+    """Row and image strides of the source are honoured (a crop of a wider / taller buffer is encoded without a copy), including source
+    addresses that are not 4-byte aligned (the assemble kernel reads aligned dwords and funnel-shifts)."""
+    from gpemsr_amd import png
+    big = torch.from_numpy(np.stack([_img(150, 301, 60 + i) for i in range(3)])).to(_dev())
+    for (y0, x0, h, w) in ((0, 0, 150, 301), (7, 13, 100, 200), (1, 3, 64, 257), (20, 2, 33, 17)):
+        crop = big[:, y0:y0 + h, x0:x0 + w]
+        assert not crop.is_contiguous() or (h, w) == (150, 301)
+        files = png.encode_gray8(crop).cpu().numpy()
+        for i in range(3):
+            assert files[i].tobytes() == po.encode_gray8_stored(crop[i].cpu().numpy()), (y0, x0, h, w, i)
