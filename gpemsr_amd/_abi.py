@@ -23,6 +23,7 @@ SYMBOLS = [
     "gpemsr_gather_rows", "gpemsr_bilinear", "gpemsr_avgpool2", "gpemsr_pool3s2_maxavg", "gpemsr_spynet_prep",
     "gpemsr_dcn_columns", "gpemsr_patch_cosine", "gpemsr_temporal_gate", "gpemsr_frame_mix_lrelu",
     "gpemsr_png_gray8_size", "gpemsr_png_encode_workspace", "gpemsr_png_encode_gray8", "gpemsr_png_decode_gray8",
+    "gpemsr_png_huff_capacity", "gpemsr_png_huff_workspace", "gpemsr_png_encode_gray8_huff",
     "gpemsr_threeda_combine", "gpemsr_tensor2img_u8", "gpemsr_copy_channels", "gpemsr_copy_images",
     "gpemsr_gather_images", "gpemsr_maxpool2", "gpemsr_normalize3", "gpemsr_cx_channel_mean", "gpemsr_cx_center_normalize",
     "gpemsr_cx_rows", "gpemsr_cx_reduce",
@@ -132,6 +133,11 @@ def load():
     lib.gpemsr_png_encode_workspace.restype = C.c_int64
     lib.gpemsr_png_encode_gray8.argtypes = [p, i32, i32, i32, i64, i32, p, i64, p, i64, p]
     lib.gpemsr_png_decode_gray8.argtypes = [p, p, i32, i32, i32, p, p, f32, p, p]
+    lib.gpemsr_png_huff_capacity.argtypes = [i32, i32]
+    lib.gpemsr_png_huff_capacity.restype = C.c_int64
+    lib.gpemsr_png_huff_workspace.argtypes = [i32, i32, i32]
+    lib.gpemsr_png_huff_workspace.restype = C.c_int64
+    lib.gpemsr_png_encode_gray8_huff.argtypes = [p, i32, i32, i32, i64, i32, p, i64, p, p, i64, p]
     lib.gpemsr_copy_channels.argtypes = [p, i32, p, i32, i64, i32, p]
     lib.gpemsr_copy_images.argtypes = [p, p, i64, i64, i32, i32, i32, p]
     lib.gpemsr_split_pack_rows.argtypes = [p, i32, i32, i32, i32, i64, p, p]

@@ -11,16 +11,11 @@
 // DECODE  gpemsr_png_decode_gray8: the concatenated IDAT payloads of n non-interlaced 8-bit grayscale PNGs -> float32 [n][h][w] / 255.
 //   One lane per image inflates (stored / fixed / dynamic Huffman blocks, the LZ77 window is the output itself), verifies Adler-32 and
 //   undoes the five scanline filters; a second kernel converts.  Chunk parsing (lengths, IHDR fields) stays on the host: it touches 50 bytes.
-#include "common.h"
+#include "png_common.h"
 
 namespace gpemsr {
 namespace {
-
-constexpr uint32_t CRC_POLY = 0xEDB88320u;         // reflected CRC-32 (ISO 3309 / PNG)
-constexpr int ADLER_SEG = 4096;                    // raw bytes per Adler segment
-constexpr int CRC_SEG = 256;                       // message bytes per CRC segment (one lane each)
-constexpr uint32_t ADLER_MOD = 65521u;
-constexpr int STORED_MAX = 65535;                  // bytes per stored deflate block
+using namespace png;
 
 struct PngGeo {
   int n, h, w;
@@ -36,35 +31,6 @@ struct PngGeo {
   long long clen; int nseg, per;
   uint32_t x_seg, x_lvl[8], x_len;
 };
-
-__device__ __forceinline__ uint32_t crc_table_entry(uint32_t i) {
-  uint32_t c = i;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
-  return c;
-}
-
-// a(x) * b(x) mod P in the reflected representation (bit 31 = x^0)
-__host__ __device__ inline uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
-  uint32_t p = 0;
-  for (uint32_t m = 1u << 31; m != 0 && (a & (m | (m - 1))) != 0; m >>= 1) {      // stops once no term of a is left
-    if (a & m) p ^= b;
-    b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
-  }
-  return p;
-}
-// x^(8 n) mod P
-__host__ __device__ inline uint32_t gf2_x8n(unsigned long long n) {
-  uint32_t sq = 1u << 30;                          // x^1
-  sq = gf2_mulmod(sq, sq); sq = gf2_mulmod(sq, sq); sq = gf2_mulmod(sq, sq);      // x^8
-  uint32_t p = 1u << 31;                           // x^0
-  while (n) {
-    if (n & 1ull) p = gf2_mulmod(sq, p);
-    sq = gf2_mulmod(sq, sq);
-    n >>= 1;
-  }
-  return p;
-}
 
 // byte `o` of the file (checksum fields read as 0)
 __device__ __forceinline__ unsigned file_byte(const PngGeo& G, const uint8_t* img, long long o) {
@@ -174,12 +140,6 @@ __global__ __launch_bounds__(256) void png_adler_partial_kernel(PngGeo G, const 
     __syncthreads();
   }
   if (threadIdx.x == 0) { part[((long long)img * nseg + s) * 2] = sa[0]; part[((long long)img * nseg + s) * 2 + 1] = sb[0]; }
-}
-
-__device__ __forceinline__ uint32_t crc_raw_bytes(const uint32_t* tab, const uint8_t* p, int len) {      // initial value 0, no final inversion
-  uint32_t c = 0;
-  for (int i = 0; i < len; ++i) c = tab[(c ^ p[i]) & 255u] ^ (c >> 8);
-  return c;
 }
 
 // raw CRC-32 of every segment of the IDAT chunk's type + data (file offsets 37 .. 37 + clen) with the Adler-32 field still zero; segment j

@@ -45,6 +45,30 @@ def encode_gray8(u8: torch.Tensor) -> torch.Tensor:
     return out[:, :size]
 
 
+def encode_gray8_compressed(u8: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[n, h, w] uint8 on the device -> ([n, capacity] uint8, sizes [n] int64), both on the device: file i = row i[:sizes[i]].  The zlib stream
+    is one dynamic-Huffman block of literals (csrc/png_huff.hip): the files are about as small as zlib's for 8-bit EM slices, where LZ77
+    matches are rare."""
+    lib = _abi.load()
+    if not u8.is_cuda:
+        raise RuntimeError("gpemsr_amd.png: images must live on a cuda/HIP device (there is no CPU path)")
+    assert u8.dtype == torch.uint8
+    if u8.dim() == 4:
+        assert u8.shape[1] == 1
+        u8 = u8[:, 0]
+    if u8.stride(2) != 1 or u8.stride(1) < u8.shape[2] or (u8.shape[0] > 1 and u8.stride(0) < 0):
+        u8 = u8.contiguous()
+    n, h, w = u8.shape
+    cap = int(lib.gpemsr_png_huff_capacity(h, w))
+    out = torch.empty((n, cap), dtype=torch.uint8, device=u8.device)
+    sizes = torch.empty(n, dtype=torch.int64, device=u8.device)
+    ws = torch.empty(int(lib.gpemsr_png_huff_workspace(n, h, w)) // 8 + 2, dtype=torch.int64, device=u8.device)      # (torch allocations are 256-byte aligned)
+    _abi.check(lib.gpemsr_png_encode_gray8_huff(u8.data_ptr(), n, h, w, u8.stride(0) if n > 1 else h * w, u8.stride(1), out.data_ptr(), cap,
+                                                sizes.data_ptr(), ws.data_ptr(), ws.numel() * 8, torch.cuda.current_stream().cuda_stream),
+               "png_encode_gray8_huff")
+    return out, sizes
+
+
 def parse_chunks(data: bytes) -> Tuple[int, int, int, int, int, bytes]:
     """-> (width, height, bit depth, colour type, interlace, concatenated IDAT payload); chunk CRCs verified (host: 4 bytes per chunk)."""
     if data[:8] != _SIG:

@@ -544,6 +544,13 @@ int64_t gpemsr_png_gray8_size(int h, int w);
 int64_t gpemsr_png_encode_workspace(int n, int h, int w);
 int gpemsr_png_encode_gray8(const uint8_t* img, int n, int h, int w, int64_t img_stride, int row_stride, uint8_t* out, int64_t out_stride,
                             void* workspace, int64_t workspace_bytes, void* stream);
+/* The same files with a COMPRESSED zlib stream (csrc/png_huff.hip): one dynamic-Huffman deflate block of literals per image, scanline filter
+ * None or Sub (whichever has the lower order-0 entropy).  File sizes differ per image: sizes[i] bytes are valid at out + i*out_stride;
+ * out_stride >= gpemsr_png_huff_capacity(h, w) (a multiple of 16), out 16-byte aligned, workspace gpemsr_png_huff_workspace(n, h, w) bytes. */
+int64_t gpemsr_png_huff_capacity(int h, int w);
+int64_t gpemsr_png_huff_workspace(int n, int h, int w);
+int gpemsr_png_encode_gray8_huff(const uint8_t* img, int n, int h, int w, int64_t img_stride, int row_stride, uint8_t* out, int64_t out_stride,
+                                 int64_t* sizes, void* workspace, int64_t workspace_bytes, void* stream);
 /* R:data/util.py:75-88 `cv2.imread(path, IMREAD_UNCHANGED).astype(float32) / 255` for n non-interlaced 8-bit grayscale PNGs of one size:
  * idat = the files' IDAT payloads back to back (image i: bytes offsets[i] .. offsets[i+1], a complete zlib stream; the host reads chunk
  * lengths and IHDR, 50 bytes per file), raw = scratch of n*h*(w+1) bytes, out[n][h][w] = pixel / divisor (255; IEEE division, as numpy's).  One wave per image: lane 0

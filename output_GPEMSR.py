@@ -13,7 +13,7 @@ as /root/reference/GPEMSR-CREMI/GPEMSR/output_GPEMSR.py:54-84,98-128), but the m
     (bit-identical output, ~2.8x less work per slice); ``volume_block`` windows are processed per call;
   * ``tile_batch`` (option key) > 1 batches several 5-slice windows per forward call (without the cache);
   * uint8 conversion, PNG decoding of the LR slices and PNG encoding of the outputs run on the device (csrc/png.hip; `png_on_device:
-    false`: host codec in a small thread pool); the files hold the same pixels as cv2.imwrite's, in stored deflate blocks;
+    false`: host codec in a small thread pool); the files hold the same pixels as cv2.imwrite's, Huffman-compressed on the device (`png_compress: false`: stored deflate blocks);
   * with several ranks (torchrun), the volume is sharded along z over GPUs: contiguous output slices per rank, each rank reading
     its own LR slices plus a 2-slice halo (gpemsr_amd.dist.plan_volume_shard);
   * ``synthetic_weights_if_missing: true`` lets the script run without the authors'
@@ -181,6 +181,7 @@ def main():
     # PNG files in HBM (stored deflate blocks) and the writer threads copy bytes to disk -- no zlib on the host at 150+ images per second
     # and GPU.  Files of another flavour (16-bit, colour, interlaced) are decoded on the host, as the reference does (cv2 / Pillow).
     png_dev = opt.get('png_on_device', True) is not False
+    png_zip = opt.get('png_compress', True) is not False   # Huffman-compressed stream (files of zlib's size; `false`: stored blocks, 4x faster to make)
     from gpemsr_amd import png as gpng
 
     def load_block(b0):
@@ -216,14 +217,18 @@ def main():
 
     def flush(item):
         # the block's output has landed in pinned host memory once its event has passed: hand it to the writers
-        hostbuf, ev, c0, c1, status = item
+        hostbuf, ev, c0, c1, status, hostsizes = item
         ev.synchronize()
         if status is not None:
             gpng.check_status(status[0], status[1])
         u8 = hostbuf.numpy()
         for j in range(c1 - c0):
             path = osp.join(im_path_SR, '{}.png'.format(c0 + j))
-            pending.append(writers.submit(write_bytes, u8[j].tobytes(), path) if png_dev else writers.submit(save_img, u8[j], path))
+            if png_dev:
+                data = u8[j].tobytes() if hostsizes is None else u8[j, :int(hostsizes[j])].tobytes()
+                pending.append(writers.submit(write_bytes, data, path))
+            else:
+                pending.append(writers.submit(save_img, u8[j], path))
 
     # the next block's upload + PNG decode run on a side stream while the current block's forward occupies the main one (the inflate is one
     # lane per image: it needs 80 wave slots for a few milliseconds, not the machine)
@@ -250,7 +255,12 @@ def main():
                 _, _, u8 = model.forward_volume(x, win, want_u8=True)
             else:
                 _, _, u8 = model(x, want_u8=True)
-            if png_dev:
+            hostsizes = None
+            if png_dev and png_zip:
+                u8, fsz = gpng.encode_gray8_compressed(u8.reshape(-1, u8.shape[-2], u8.shape[-1]))      # [slices, capacity], sizes
+                hostsizes = torch.empty(fsz.shape, dtype=torch.int64, pin_memory=True)
+                hostsizes.copy_(fsz, non_blocking=True)
+            elif png_dev:
                 u8 = gpng.encode_gray8(u8.reshape(-1, u8.shape[-2], u8.shape[-1]))      # [slices, file bytes]
             # asynchronous D2H into pinned memory; the host only waits for block k-1 AFTER block k has been enqueued, so the
             # device never idles between blocks (R:output_GPEMSR.py:88-95 moves every slice synchronously)
@@ -262,7 +272,7 @@ def main():
                 cur = start_upload(nxt.result())                           # enqueued behind nothing: overlaps with this block's forward
             if inflight is not None:
                 flush(inflight)
-            inflight = (hostbuf, ev, b0, b1, status)
+            inflight = (hostbuf, ev, b0, b1, status, hostsizes)
         if inflight is not None:
             flush(inflight)
     for f in pending:

@@ -527,10 +527,11 @@ def test_cli_volume_cache_writes_the_same_pngs(tmp_path):
     opt["pretrain_path"] = str(tmp_path / "missing.pth")
     opt["synthetic_weights_if_missing"] = True
     outs = {}
-    for mode, cache in (("vol", True), ("win", False), ("hostpng", True)):
+    for mode, cache in (("vol", True), ("win", False), ("hostpng", True), ("zip", True)):
         opt["save_path"] = str(tmp_path / mode)
         opt["volume_cache"] = cache
         opt["png_on_device"] = mode != "hostpng"        # device inflate / stored-block encoder (csrc/png.hip) vs the host codec: same pixels
+        opt["png_compress"] = mode == "zip"             # Huffman-compressed stream (csrc/png_huff.hip; the CLI's default) vs stored blocks
         opt["volume_block"] = 4                     # 7 windows -> two blocks: exercises the halo re-computation
         yml = tmp_path / f"{mode}.yml"
         yaml.safe_dump(opt, open(yml, "w"))
@@ -543,6 +544,8 @@ def test_cli_volume_cache_writes_the_same_pngs(tmp_path):
     for k in range(n):
         assert np.array_equal(outs["vol"][k], outs["win"][k]), k
         assert np.array_equal(outs["vol"][k], outs["hostpng"][k]), k
+        assert np.array_equal(outs["vol"][k], outs["zip"][k]), k
+    assert os.path.getsize(tmp_path / "zip" / "0.png") < os.path.getsize(tmp_path / "vol" / "0.png")
     with open(tmp_path / "vol" / "0.png", "rb") as fh:              # the device encoder's file: one IDAT of stored blocks, 57 + 2 + 5 + h (w + 1) + 4 bytes
         assert len(fh.read()) == 57 + 2 + 5 + 128 * 129 + 4
 

@@ -159,3 +159,57 @@ def test_encode_crops_of_a_larger_buffer():
         files = png.encode_gray8(crop).cpu().numpy()
         for i in range(3):
             assert files[i].tobytes() == po.encode_gray8_stored(crop[i].cpu().numpy()), (y0, x0, h, w, i)
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 1, 1), (3, 5, 7), (2, 128, 128), (1, 255, 257), (2, 1024, 1024), (1, 63, 1039), (1, 4097, 1)])
+def test_compressed_encoder_writes_valid_small_pngs(n, h, w):
+    """gpemsr_png_encode_gray8_huff: every chunk CRC and the Adler-32 verify (oracle.parse / zlib), zlib inflates the stream to the scanlines
+    filtered with type 0 or 1 throughout, Pillow reads the pixels back, the device decoder reads them back, and the file is no larger than
+    1.01 x what zlib's Huffman-only strategy makes of the same scanlines (+ the stored-block size as the upper bound for noise)."""
+    from gpemsr_amd import png
+    kinds = ("smooth", "noise", "const")
+    imgs = []
+    for i in range(n):
+        k = kinds[i % 3]
+        imgs.append(np.full((h, w), 77, np.uint8) if k == "const" else _img(h, w, 300 + 11 * i + h, k))
+    imgs = np.stack(imgs)
+    files, sizes = png.encode_gray8_compressed(torch.from_numpy(imgs).to(_dev()))
+    torch.cuda.synchronize()
+    host, sz = files.cpu().numpy(), sizes.cpu().tolist()
+    blobs = []
+    for i in range(n):
+        data = host[i, :sz[i]].tobytes()
+        blobs.append(data)
+        pw, ph, depth, ctype, interlace, idat = po.parse(data)                 # chunk CRCs
+        assert (pw, ph, depth, ctype, interlace) == (w, h, 8, 0, 0)
+        raw = zlib.decompress(idat)                                            # Adler-32, stream validity
+        ft = raw[0]
+        assert ft in (0, 1) and raw == po.filter_gray8(imgs[i], (ft,))
+        assert np.array_equal(np.array(Image.open(io.BytesIO(data))), imgs[i])
+        co = zlib.compressobj(9, zlib.DEFLATED, 15, 9, zlib.Z_HUFFMAN_ONLY)
+        best = min(len(co.compress(po.filter_gray8(imgs[i], (f,))) + co.flush()) if f == ft else 1 << 60 for f in (0, 1))
+        assert len(idat) <= 1.01 * best + 160, (len(idat), best)
+        assert sz[i] <= png.png_size(h, w) + 1024            # uniform noise does not compress: 8 bits per symbol + the block header
+    dec = png.device_decodable(blobs)
+    assert dec is not None
+    x, status = png.decode_gray8(dec[2], h, w, _dev())
+    torch.cuda.synchronize()
+    png.check_status(status)
+    assert np.array_equal(x[:, 0].cpu().numpy(), imgs.astype(np.float32) / 255.)
+
+
+def test_compressed_encoder_length_limit():
+    """A Fibonacci-like histogram makes the unrestricted Huffman code deeper than 15 bits: the length-limiting rule (zlib's) must still give a
+    complete code that zlib accepts."""
+    from gpemsr_amd import png
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    vals = np.concatenate([np.full(c, 10 + i, np.uint8) for i, c in enumerate(fib)])
+    rng = np.random.default_rng(0); rng.shuffle(vals)
+    w = 257; h = len(vals) // w
+    img = vals[:h * w].reshape(h, w)
+    files, sizes = png.encode_gray8_compressed(torch.from_numpy(img[None]).to(_dev()))
+    data = files[0, :int(sizes[0])].cpu().numpy().tobytes()
+    assert np.array_equal(np.array(Image.open(io.BytesIO(data))), img)
+    assert np.array_equal(po.decode_gray8(data), img)
