@@ -508,6 +508,9 @@ def run_forward(args) -> int:
         if model_sd is not None:
             cpu_baseline = run_cpu_baseline(args, model_sd, x, out)
 
+    io_edges = None
+    if not args.stub and rank == 0 and world == 1 and not args.no_extras:
+        io_edges = measure_io_edges(out, dev)
     if rank == 0:
         cfg_name = {8: "BASELINE.json configs[1]" if args.precision == "fp32" else "BASELINE.json configs[2], one GPU's share",
                     16: "BASELINE.json configs[3], one GPU's share"}[s]
@@ -535,12 +538,37 @@ def run_forward(args) -> int:
             "ms_per_step_bf16": ((extras or {}).get("bf16") or {}).get("ms_per_step") if isinstance(extras, dict) else None,
             "kernels": (roofline or {}).get("kernels"),
             "algorithmic_bytes_per_step": (roofline or {}).get("algorithmic_bytes_per_step"),
+            "io_edges": io_edges,
             "extras": extras,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0
+
+
+def measure_io_edges(out, dev):
+    """SURVEY 8(f)3, outside the timed region: the step's HR tiles as 8-bit images -> complete PNG files on the device (csrc/png.hip, png_huff.hip):
+    tensor2img, then the stored-block and the Huffman-compressing encoder; bytes moved = image read by the assemble / histogram / pack and
+    checksum passes + file written and read once."""
+    import torch
+    from gpemsr_amd import ops, png
+    u8 = ops.tensor2img_u8(out.reshape(-1, out.shape[-2], out.shape[-1]))
+    n = u8.shape[0]
+    res = {"images": int(n), "image_shape": [int(u8.shape[-2]), int(u8.shape[-1])]}
+    for name, fn in (("stored", lambda: png.encode_gray8(u8)), ("huffman", lambda: png.encode_gray8_compressed(u8))):
+        for _ in range(2):
+            r = fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            r = fn()
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        nbytes = float(r.numel()) / n if name == "stored" else float(r[1].float().mean().item())
+        res[f"png_encode_{name}"] = {"ms_per_batch": round(ms, 4), "images_per_s": round(n / ms * 1e3, 0), "bytes_per_file": round(nbytes, 0)}
+    return res
 
 
 def main(argv=None) -> int:
