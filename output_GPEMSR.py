@@ -241,6 +241,10 @@ def main():
             ev.record(side)
         return x, win, status, ev
 
+    import time as _time
+    torch.cuda.synchronize()
+    t_loop = _time.perf_counter()
+    marks = []
     with torch.no_grad():
         cur = start_upload(load_block(lo)) if lo < hi else None
         inflight = None
@@ -257,7 +261,11 @@ def main():
                 _, _, u8 = model(x, want_u8=True)
             hostsizes = None
             if png_dev and png_zip:
-                u8, fsz = gpng.encode_gray8_compressed(u8.reshape(-1, u8.shape[-2], u8.shape[-1]))      # [slices, capacity], sizes
+                hh, ww = int(u8.shape[-2]), int(u8.shape[-1])
+                u8, fsz = gpng.encode_gray8_compressed(u8.reshape(-1, hh, ww))      # [slices, capacity], sizes
+                # an optimal prefix code is never longer than the 8-bit one by more than a bit per 256 symbols: the D2H copy stops there, not
+                # at the encoder's worst-case capacity (2 bytes per symbol)
+                u8 = u8[:, :min(u8.shape[1], gpng.png_size(hh, ww) + hh * (ww + 1) // 128 + 1024)]
                 hostsizes = torch.empty(fsz.shape, dtype=torch.int64, pin_memory=True)
                 hostsizes.copy_(fsz, non_blocking=True)
             elif png_dev:
@@ -272,12 +280,20 @@ def main():
                 cur = start_upload(nxt.result())                           # enqueued behind nothing: overlaps with this block's forward
             if inflight is not None:
                 flush(inflight)
+                marks.append((_time.perf_counter(), inflight[3]))           # (time, slices written so far): the loop is paced by the device
             inflight = (hostbuf, ev, b0, b1, status, hostsizes)
         if inflight is not None:
             flush(inflight)
     for f in pending:
         f.result()
     writers.shutdown(); loaders.shutdown()
+    if os.environ.get("GPEMSR_CLI_TIMING") and hi > lo:
+        dt = _time.perf_counter() - t_loop
+        steady = ""
+        if len(marks) >= 2:                                # without the first block (one-time costs: first launches, allocator growth)
+            (ta, sa), (tb, sb) = marks[0], (_time.perf_counter(), hi)
+            steady = f"; after the first block: {(sb - sa) / (tb - ta):.1f} slices/s"
+        print(f"[gpemsr_amd] loop: {hi - lo} slices in {dt:.3f} s = {(hi - lo) / dt:.1f} slices/s (files read -> files written){steady}", file=sys.stderr)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
