@@ -49,8 +49,19 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
-    if jobs:
-        check_flash_attention_object(os.path.join(LIBDIR, "attn_bf16.o"))
+    # the flash-attention object is checked whenever it is newer than the stamp of its last successful check (not only when something was
+    # compiled in THIS call: a failed check must not be forgotten by the next call); a rejected object and the library are removed
+    attn_obj, stamp = os.path.join(LIBDIR, "attn_bf16.o"), os.path.join(LIBDIR, "attn_bf16.checked")
+    if os.path.exists(attn_obj) and _stale(stamp, [attn_obj]):
+        try:
+            check_flash_attention_object(attn_obj)
+        except Exception:
+            for f in (attn_obj, LIB, stamp):
+                if os.path.exists(f):
+                    os.remove(f)
+            raise
+        with open(stamp, "w") as f:
+            f.write("flash_attn512_kernel: 768 / 768 AGPR accesses, no scratch\n")
     if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -30,6 +30,12 @@ namespace gpemsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// timing hooks of scripts/wino_probe.py exist only in a probe build (results are wrong on purpose with any of them set)
+#ifdef GPEMSR_WINO_PROBE
+#define WINO_DBG(P) ((P).dbg)
+#else
+#define WINO_DBG(P) 0
+#endif
 struct WinoParams {
   const float* src[GPEMSR_MAX_SRC];
   long long img_stride[GPEMSR_MAX_SRC];
@@ -49,7 +55,7 @@ struct WinoParams {
   float* gn_ws; int gn_parts;     // wide kernel: GroupNorm partial sums of (conv + bias) per (tile, channel): [n][gn_parts][cout][2] (conv_mfma.hip XEPI = 1)
   float* cos_ws;                  // wide kernel, cout == 64: patch-cosine partial sums against `residual` INSTEAD of storing (conv_mfma.hip XEPI = 2)
   int pixshuf, cq;                // wide kernel: store as PixelShuffle(2) (cout index = (2i + j) * cq + c, out is [n][2h][2w][cq])
-  int dbg;                        // timing experiments only (GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
+  int dbg;                        // timing experiments only, compiled in with -DGPEMSR_WINO_PROBE (scripts/wino_probe.py; GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
 };
 
 constexpr int WN_HH = 18, WN_HW2 = 17;                       // halo rows, halo columns per parity
@@ -465,9 +471,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
   // (a copy "cur = next" per stage was 48 vector moves per wave on the pipe the f32 MFMA shares)
   auto stage = [&](const int ck, float4 (&Uc)[4][2], float4 (&rc)[4], float4 (&Un)[4][2], float4 (&rn)[4]) {
     int issued = 0;
-    if (ck + 3 < nchunks && !(P.dbg & 4)) { issue_chunk(); issued = n_issue; }        // -> the slot of chunk ck (its fragments are in registers)
+    if (ck + 3 < nchunks && !(WINO_DBG(P) & 4)) { issue_chunk(); issued = n_issue; }        // -> the slot of chunk ck (its fragments are in registers)
     const char* sn = wsm + slot_n * W2_STAGE;
-    const bool more = ck + 1 < nchunks && !(P.dbg & 1);  // (wave-uniform)
+    const bool more = ck + 1 < nchunks && !(WINO_DBG(P) & 1);  // (wave-uniform)
     if (more) {                                          // next chunk's image rows and the U fragments of cout tile 0: under the first 16 MFMAs
       load_raw(sn, rn);
 #pragma unroll
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
     // chunk ck + 2 must have landed before the next stage reads it: only this stage's issues may stay in flight
     wn_wait_vmcnt(issued);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(P.dbg & 2)) __builtin_amdgcn_s_barrier();
+    if (!(WINO_DBG(P) & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     slot_n = slot_n == W2_RING - 1 ? 0 : slot_n + 1;
   };
@@ -681,7 +687,11 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
   P.pixshuf = d->pixel_shuffle; P.cq = d->cout / 4;
   P.cos_ws = d->cos_partials;
   P.gn_ws = d->gn_partials; P.gn_parts = cdiv(d->h, 8) * cdiv(d->w, 32);
+#ifdef GPEMSR_WINO_PROBE
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_WINO_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
+#else
+  P.dbg = 0;                       // the shipped library has no way to skip reads / barriers / DMA (each makes the results wrong on purpose)
+#endif
   P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, wide ? 8 : 16); P.tiles_n = d->cout / (wide ? 64 : 32);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (Winograd form): grid too large");

@@ -59,11 +59,16 @@ class FolderVolumes(torch.utils.data.Dataset):
             ls = g // s
             y = random.randint(0, max(0, lq.shape[1] - ls)); x = random.randint(0, max(0, lq.shape[2] - ls))
             lq, gt = lq[:, y:y + ls, x:x + ls], gt[y * s:y * s + g, x * s:x * s + g]
-            if self.opt.get("use_flip") and random.random() < 0.5:
+            # R:data/util.py:166-170 (`augment`): the vertical flip is gated on use_rot, not use_flip; a random number is drawn only
+            # when its flag is set (short-circuit `and`); order hflip, vflip, rot90
+            hflip = bool(self.opt.get("use_flip")) and random.random() < 0.5
+            vflip = bool(self.opt.get("use_rot")) and random.random() < 0.5
+            rot90 = bool(self.opt.get("use_rot")) and random.random() < 0.5
+            if hflip:
                 lq, gt = lq[:, :, ::-1], gt[:, ::-1]
-            if self.opt.get("use_flip") and random.random() < 0.5:
+            if vflip:
                 lq, gt = lq[:, ::-1, :], gt[::-1, :]
-            if self.opt.get("use_rot") and random.random() < 0.5:
+            if rot90:
                 lq, gt = lq.transpose(0, 2, 1), gt.T
         return {"LQ": torch.from_numpy(np.ascontiguousarray(lq)).float().unsqueeze(1), "GT": torch.from_numpy(np.ascontiguousarray(gt)).float().unsqueeze(0)}
 

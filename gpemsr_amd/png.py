@@ -78,8 +78,11 @@ def parse_chunks(data: bytes) -> Tuple[int, int, int, int, int, bytes]:
         (n,) = struct.unpack(">I", data[pos:pos + 4])
         kind = data[pos + 4:pos + 8]
         body = data[pos + 8:pos + 8 + n]
+        if pos + 12 + n > len(data):
+            raise ValueError(f"PNG chunk {kind!r}: truncated")
         (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
-        if crc != (zlib.crc32(kind + body) & 0xFFFFFFFF):
+        # critical chunks only: libpng (cv2, the reference's reader) merely warns about a bad CRC on an ancillary chunk and reads the file
+        if kind in (b"IHDR", b"IDAT") and crc != (zlib.crc32(kind + body) & 0xFFFFFFFF):
             raise ValueError(f"PNG chunk {kind!r}: CRC mismatch")
         if kind == b"IHDR":
             hdr = struct.unpack(">IIBBBBB", body)
@@ -95,10 +98,13 @@ def parse_chunks(data: bytes) -> Tuple[int, int, int, int, int, bytes]:
 
 
 def device_decodable(files: Sequence[bytes]) -> Optional[Tuple[int, int, List[bytes]]]:
-    """(h, w, IDAT payloads) when every file is a non-interlaced 8-bit grayscale PNG of one size, else None."""
+    """(h, w, IDAT payloads) when every file is a well-formed non-interlaced 8-bit grayscale PNG of one size, else None (host codec)."""
     payloads, hw = [], None
     for data in files:
-        w, h, depth, ctype, interlace, idat = parse_chunks(data)
+        try:
+            w, h, depth, ctype, interlace, idat = parse_chunks(data)
+        except (ValueError, struct.error, IndexError):
+            return None             # anything the chunk walk cannot take goes to the host codec, which reports (or reads) it as the reference does
         if (depth, ctype, interlace) != (8, 0, 0) or w > 16384 or (hw is not None and hw != (h, w)):      # (two scanlines live in LDS)
             return None
         hw = (h, w)

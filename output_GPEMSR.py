@@ -217,10 +217,15 @@ def main():
 
     def flush(item):
         # the block's output has landed in pinned host memory once its event has passed: hand it to the writers
-        hostbuf, ev, c0, c1, status, hostsizes = item
+        hostbuf, ev, c0, c1, status, hostsizes, devfull = item
         ev.synchronize()
         if status is not None:
             gpng.check_status(status[0], status[1])
+        if hostsizes is not None and int(hostsizes.max()) > hostbuf.shape[1]:
+            # the trimmed D2H copy assumed a near-optimal prefix code; the encoder limits code lengths with zlib's overflow rule, not
+            # package-merge, so the bound is not enforced anywhere: a block with a longer file is copied again at the encoder's full capacity
+            hostbuf = devfull.cpu()
+            assert int(hostsizes.max()) <= hostbuf.shape[1], "PNG encoder reported a file larger than its own capacity"
         u8 = hostbuf.numpy()
         for j in range(c1 - c0):
             path = osp.join(im_path_SR, '{}.png'.format(c0 + j))
@@ -259,10 +264,11 @@ def main():
                 _, _, u8 = model.forward_volume(x, win, want_u8=True)
             else:
                 _, _, u8 = model(x, want_u8=True)
-            hostsizes = None
+            hostsizes, devfull = None, None
             if png_dev and png_zip:
                 hh, ww = int(u8.shape[-2]), int(u8.shape[-1])
                 u8, fsz = gpng.encode_gray8_compressed(u8.reshape(-1, hh, ww))      # [slices, capacity], sizes
+                devfull = u8
                 # an optimal prefix code is never longer than the 8-bit one by more than a bit per 256 symbols: the D2H copy stops there, not
                 # at the encoder's worst-case capacity (2 bytes per symbol)
                 u8 = u8[:, :min(u8.shape[1], gpng.png_size(hh, ww) + hh * (ww + 1) // 128 + 1024)]
@@ -281,7 +287,7 @@ def main():
             if inflight is not None:
                 flush(inflight)
                 marks.append((_time.perf_counter(), inflight[3]))           # (time, slices written so far): the loop is paced by the device
-            inflight = (hostbuf, ev, b0, b1, status, hostsizes)
+            inflight = (hostbuf, ev, b0, b1, status, hostsizes, devfull)
         if inflight is not None:
             flush(inflight)
     for f in pending:

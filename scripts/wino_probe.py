@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the Winograd form of gpemsr_conv2d against the direct form on the fp32 path's layer shapes (GPEMSR_WINO_DBG variants are
-timing experiments: results are wrong on purpose).  python3 scripts/wino_probe.py"""
+timing experiments: results are wrong on purpose; the hooks exist only in a library whose conv_wino.hip was compiled with
+-DGPEMSR_WINO_PROBE -- the shipped build ignores the variable).  python3 scripts/wino_probe.py"""
 import os
 import sys
 
