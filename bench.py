@@ -59,6 +59,7 @@ def parse_args(argv=None):
                          "(fp32-grade); bf16op = fp32 activations, bf16 operands (round 1's bf16 mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-by-the-driver) measurements")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs of the default line (x16 forward in both precisions, training step)")
     ap.add_argument("--extras", type=str, default="bf16", help="comma list of precisions measured beside the official fp32 number")
     ap.add_argument("--cpu-lr", type=int, default=128, help="LR size of the CPU-oracle sample tile")
     ap.add_argument("--layer-report", type=str, default="", help="write a per-layer conv timing table to this file")
@@ -189,6 +190,28 @@ def timed_steps(step, steps: int, world: int, dev, sync):
     return dt, out
 
 
+PROFILED_STEPS = 3                  # steps of the second, event-carrying pass the kernel tables come from
+
+
+def measure_leg(step, args, world, dev, sync, stub=False):
+    """The OFFICIAL figure of a leg: exactly args.steps steps between barrier + synchronize pairs with NO per-launch events.  The kernel
+    tables (roofline, per-kernel rows, layer report) come from a SECOND pass of min(steps, PROFILED_STEPS) steps with HIP events around every
+    matrix-kernel launch (ops.LaunchProfiler; events on the launch stream).  Returns (dt, last output, profiler or None, profiled-pass seconds,
+    profiled steps)."""
+    dt, out = timed_steps(step, args.steps, world, dev, sync)
+    if stub:
+        return dt, out, None, dt, args.steps
+    from gpemsr_amd import ops
+    psteps = max(1, min(args.steps, PROFILED_STEPS))
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    try:
+        dtp, _ = timed_steps(step, psteps, world, dev, sync)
+    finally:
+        ops.PROFILER = None
+    return dt, out, prof, dtp, psteps
+
+
 def _family(summ, names):
     d = {"launches": 0, "ms": 0.0, "flops": 0.0, "executed": 0.0}
     for k in names:
@@ -202,23 +225,42 @@ def _tf(d):
     return d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
 
 
-PMC_ROUND = "r04"                   # profiles/<PMC_ROUND>_<precision>_pmc_summary.json: the counter summary taken on THIS tree
+PMC_ROUNDS = ("r05", "r04")         # profiles/<round>_<precision>_pmc_summary.json, newest first: the counter summary taken on THIS tree
 
 
-def pmc_traffic(tag: str, launches_per_step: int):
-    """HBM bytes per launch of the dominant kernel family from the rocprofv3 --pmc summary committed for THIS tree
-    (profiles/r04_<tag>_pmc_summary.json, scripts/pmc_round2.sh; separate passes, FETCH_SIZE x2 gfx950 correction).  The
-    summary records the family's launches per step; a mismatch means it was taken on another tree -> null."""
-    path = os.path.join(ROOT, "profiles", f"{PMC_ROUND}_{tag}_pmc_summary.json")
-    try:
-        doc = json.load(open(path))
-        fam = doc["dominant_family"]
-        if int(fam["launches_per_step"]) != int(launches_per_step):
-            return None, None
-        return round(fam["hbm_bytes_per_launch"]), {"file": os.path.relpath(path, ROOT),
-                                                     "hbm_bytes_per_step_all_kernels": doc.get("hbm_bytes_per_step_all_kernels")}
-    except Exception:
-        return None, None
+def _pmc_doc(tag: str):
+    for rnd in PMC_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}_pmc_summary.json")
+        try:
+            return json.load(open(path)), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def pmc_traffic(tag: str, kernel_name: str, launches_per_step: float, fam_launches_per_step: int):
+    """HBM bytes per launch from the rocprofv3 --pmc summary committed for THIS tree (scripts/pmc_round2.sh; separate passes, FETCH_SIZE x2
+    gfx950 correction): of the ONE dominant kernel (matched by base name + launches per step) and of the family.  A launch-count mismatch
+    means the summary was taken on another tree -> null."""
+    doc, path = _pmc_doc(tag)
+    if doc is None:
+        return None, None, None
+    src = {"file": path, "hbm_bytes_per_step_all_kernels": doc.get("hbm_bytes_per_step_all_kernels")}
+    fam = doc.get("dominant_family", {})
+    fam_traffic = round(fam["hbm_bytes_per_launch"]) if int(fam.get("launches_per_step", -1)) == int(fam_launches_per_step) else None
+    if fam_traffic is not None:
+        src["family_mfma_util_pmc"] = round(fam.get("mfma_util", 0.0), 4)
+    base = kernel_name.split("<")[0]
+    k_traffic = None
+    for nm, d in doc.get("per_kernel", {}).items():
+        if nm.split("<")[0] == base and abs(d.get("dispatches_per_step", -1) - launches_per_step) < 0.01:
+            k_traffic = round(1e9 * (d["hbm_read_GB_per_step"] + d["hbm_write_GB_per_step"]) / max(launches_per_step, 1e-9))
+            src["kernel_counter_name"] = nm
+            # SQ_VALU_MFMA_BUSY_CYCLES sums over 4 SIMDs x 256 CUs; GRBM_GUI_ACTIVE over 8 XCDs
+            if d.get("gui_active"):
+                src["kernel_mfma_util_pmc"] = round((d.get("mfma_busy_cycles", 0.0) / 1024.0) / (d["gui_active"] / 8.0), 4)
+            break
+    return k_traffic, fam_traffic, src
 
 
 FAMILIES = {
@@ -234,37 +276,63 @@ FAMILIES = {
 }
 
 
-def build_roofline(args, prof, dt, B, s, precision=None):
-    precision = precision or args.precision
+def _etf(d):
+    """EXECUTED TFLOP/s: the multiplies the matrix pipe really performed / the HIP-event time."""
+    return d["executed"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+
+
+def build_roofline(args, prof, dtp, psteps, B, s, precision):
+    """`roofline` = the ONE dominant kernel (most HIP-event time in the profiled pass): `achieved` / `frac` are EXECUTED matrix FLOPs per launch
+    / its average launch duration / the dtype's dense matrix peak -- always <= 1.  Where a kernel removes arithmetic (Winograd F(2x2,3x3):
+    16 of every 36 multiplies of the direct form), the ALGORITHMIC rate (direct-convolution FLOP count of SURVEY 8(d) / time) is stated
+    beside it as `effective_tflops` / `effective_frac` and may exceed the peak.  `family` = the same figures over every launch of the matrix
+    kernel family; `kernels` = the top instantiations one by one."""
     summ = prof.summary()
-    fam_names, kern, peak = FAMILIES[precision]
+    by_name = prof.summary(by_name=True)
+    fam_names, fam_desc, peak = FAMILIES[precision]
     fam = _family(summ, fam_names)
-    achieved = _tf(fam)
-    launches_per_step = fam["launches"] // max(args.steps, 1)
-    traffic, traffic_src = pmc_traffic(precision, launches_per_step)
+    steps = max(psteps, 1)
+    fam_lps = fam["launches"] // steps
+    # the dominant kernel: most time among the family's instantiations
+    dom_name, dom = max(((k, v) for k, v in by_name.items() if v["family"] in fam_names), key=lambda kv: kv[1]["ms"], default=("?", None))
+    if dom is None:
+        dom = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "executed": 0.0}
+    dom_lps = dom["launches"] / steps
+    k_traffic, fam_traffic, traffic_src = pmc_traffic(precision, dom_name, dom_lps, fam_lps)
+    nl = max(dom["launches"], 1)
     r = {
-        "bound": "mfma", "kernel": kern, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-        "algorithmic_gflop_per_launch": round(fam["flops"] / 1e9 / max(fam["launches"], 1), 2),
-        "launches_per_step": launches_per_step,
-        "avg_launch_us": round(1e3 * fam["ms"] / max(fam["launches"], 1), 2),
-        "algorithmic_gflop_per_tile_in_kernel": round(fam["flops"] / 1e9 / max(args.steps * B, 1), 1),
-        "essential_gflop_per_tile_survey": ESSENTIAL_GFLOP_PER_TILE[s],
-        "kernel_time_share_of_step": round(fam["ms"] * 1e-3 / dt, 3),
-        # `achieved` / `frac` count the ALGORITHMIC work (direct-convolution FLOPs).  Layers in the Winograd F(2x2,3x3) form
-        # execute 16/36 of their multiplies on the matrix pipe: what the pipe really did is stated beside it, so an algorithmic fraction
-        # above the executed one reads as arithmetic removed, not as work skipped
-        "executed_tflops": round(fam["executed"] / (fam["ms"] * 1e-3) / 1e12, 2) if fam["ms"] > 0 else 0.0,
-        "executed_frac": round(fam["executed"] / (fam["ms"] * 1e-3) / 1e12 / peak, 4) if fam["ms"] > 0 else 0.0,
-        "executed_over_algorithmic_flops": round(fam["executed"] / fam["flops"], 4) if fam["flops"] > 0 else 1.0,
-        "whole_path_tflops_essential": round(ESSENTIAL_GFLOP_PER_TILE[s] * B * args.steps / dt / 1e3, 2),
+        "bound": "mfma", "kernel": dom_name,
+        "achieved": round(_etf(dom), 2), "peak": peak, "unit": "TFLOP/s", "frac": round(_etf(dom) / peak, 4),
+        "achieved_is": "EXECUTED matrix FLOPs per launch / average launch duration (HIP events on the launch stream, second pass of "
+                       f"{steps} steps; the official `value` is timed in a pass without events)",
+        "traffic": k_traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x 2 + WRITE_SIZE)", "traffic_source": traffic_src,
+        "avg_launch_us": round(1e3 * dom["ms"] / nl, 2), "launches_per_step": round(dom_lps, 2),
+        "executed_gflop_per_launch": round(dom["executed"] / 1e9 / nl, 2),
+        "algorithmic_gflop_per_launch": round(dom["flops"] / 1e9 / nl, 2),
+        "algorithmic_bytes_per_launch": round(dom["bytes"] / nl),
+        "effective_tflops": round(_tf(dom), 2), "effective_frac": round(_tf(dom) / peak, 4),
+        "executed_over_algorithmic_flops": round(dom["executed"] / dom["flops"], 4) if dom["flops"] > 0 else 1.0,
+        "time_share_of_step": round(dom["ms"] * 1e-3 / dtp, 3),
+        "family": {
+            "kernels": fam_desc,
+            "achieved": round(_etf(fam), 2), "frac": round(_etf(fam) / peak, 4),
+            "effective_tflops": round(_tf(fam), 2), "effective_frac": round(_tf(fam) / peak, 4),
+            "executed_over_algorithmic_flops": round(fam["executed"] / fam["flops"], 4) if fam["flops"] > 0 else 1.0,
+            "launches_per_step": fam_lps, "avg_launch_us": round(1e3 * fam["ms"] / max(fam["launches"], 1), 2),
+            "algorithmic_gflop_per_launch": round(fam["flops"] / 1e9 / max(fam["launches"], 1), 2),
+            "traffic": fam_traffic,
+            "algorithmic_gflop_per_tile_in_kernel": round(fam["flops"] / 1e9 / max(steps * B, 1), 1),
+            "essential_gflop_per_tile_survey": ESSENTIAL_GFLOP_PER_TILE[s],
+            "time_share_of_step": round(fam["ms"] * 1e-3 / dtp, 3),
+        },
+        "whole_path_tflops_essential": round(ESSENTIAL_GFLOP_PER_TILE[s] * B * steps / dtp / 1e3, 2),
+        "profiled_pass_ms_per_step": round(1e3 * dtp / steps, 2),
     }
-    others = {k: {"tflops": round(_tf(v), 2), "launches_per_step": v["launches"] // max(args.steps, 1),
-                  "time_share_of_step": round(v["ms"] * 1e-3 / dt, 3)} for k, v in summ.items() if k not in fam_names}
+    others = {k: {"tflops": round(_tf(v), 2), "launches_per_step": v["launches"] // steps,
+                  "time_share_of_step": round(v["ms"] * 1e-3 / dtp, 3)} for k, v in summ.items() if k not in fam_names}
     if others:
         r["other_profiled_kernels"] = others
-    # what a reader needs to audit the family figure: algorithmic bytes beside the counter bytes, and the kernels one by one
-    steps = max(args.steps, 1)
+    # what a reader needs to audit the figures: algorithmic bytes beside the counter bytes, and the kernels one by one
     alg_bytes = sum(v["bytes"] for v in summ.values()) / steps
     r["algorithmic_bytes_per_step"] = round(alg_bytes)
     r["algorithmic_bytes_note"] = ("sum over every profiled launch (all convolution / product / fused-mask layers) of its unique inputs + outputs + weights "
@@ -277,15 +345,15 @@ def build_roofline(args, prof, dt, B, s, precision=None):
 
 
 def kernel_table(prof, steps: int, peak_tflops: float, top: int = 8):
-    """The `top` kernel instantiations of a leg by time: name, launches/step, ms/step, algorithmic GFLOP/step, achieved TFLOP/s and its
-    fraction of the leg's matrix peak, algorithmic GB/step and GB/s (HIP events on the launch stream, same data as `roofline`)."""
+    """The `top` kernel instantiations of a leg by time: name, launches/step, ms/step, EXECUTED TFLOP/s and its fraction of the leg's matrix
+    peak (`tflops`, `frac`), the algorithmic rate beside it (`effective_tflops`), algorithmic GB/step and GB/s (HIP events on the launch
+    stream, same data as `roofline`)."""
     rows = sorted(prof.summary(by_name=True).items(), key=lambda kv: -kv[1]["ms"])[:top]
     out = []
     for name, d in rows:
-        tf = _tf(d)
         out.append({"name": name, "family": d["family"], "launches_per_step": round(d["launches"] / steps, 2), "ms_per_step": round(d["ms"] / steps, 3),
-                    "algorithmic_gflop_per_step": round(d["flops"] / 1e9 / steps, 1), "tflops": round(tf, 1), "frac": round(tf / peak_tflops, 4),
-                    "executed_gflop_per_step": round(d["executed"] / 1e9 / steps, 1),
+                    "executed_gflop_per_step": round(d["executed"] / 1e9 / steps, 1), "tflops": round(_etf(d), 1), "frac": round(_etf(d) / peak_tflops, 4),
+                    "algorithmic_gflop_per_step": round(d["flops"] / 1e9 / steps, 1), "effective_tflops": round(_tf(d), 1),
                     "algorithmic_gb_per_step": round(d["bytes"] / 1e9 / steps, 3),
                     "algorithmic_gbps": round(d["bytes"] / 1e9 / (d["ms"] * 1e-3), 1) if d["ms"] > 0 else 0.0})
     return out
@@ -311,43 +379,83 @@ def _volume_bench(model, fr, win, steps):
     return (time.perf_counter() - tv) / steps
 
 
-def run_precision_leg(args, opt, x, rank, world, dev, mode, sync):
-    """One more precision of the SAME workload, measured the same way as the headline at the same N: every rank runs its
-    16 tiles, the step ends with the all-gather of the HR slabs, barrier + synchronize on both sides, max over ranks
-    (BASELINE configs[2] = "batch=128 tiles sharded over 8 MI355X, bf16 MFMA, RCCL all-gather of HR slabs" is this leg
-    at --gpus 8).  Returns (entry for `extras`, model, last output)."""
+def leg_entry(args, dt, steps, world, B, opix, roofline, phases=None):
+    e = {"value": round(world * B * opix / 1e6 * steps / dt, 3), "unit": "MP/s", "n_gpus": world,
+         "ms_per_step": round(1e3 * dt / steps, 2), "tiles_per_gpu": B, "scaling": "weak", "steps": steps,
+         "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the " +
+                         ("uint8 HR images [tiles,H,W] (tensor2img of SR, from the last kernel)" if args.gather == "u8" else "fp32 HR slabs [tiles,1,H,W]") +
+                         " at N > 1), synchronize + barrier; max over ranks; no per-launch events in this pass", "gather": args.gather,
+         "roofline": roofline}
+    if phases is not None:
+        e["rank_phases"] = phases
+    return e
+
+
+def run_precision_leg(args, opt, x, rank, world, dev, mode, sync, scale=None, steps=None, warmup=None):
+    """One more configuration of the forward, measured the same way as the headline at the same N: every rank runs its tiles, the step
+    ends with the all-gather of the HR slabs, barrier + synchronize on both sides, max over ranks (BASELINE configs[2] = "batch=128 tiles
+    sharded over 8 MI355X, bf16 MFMA, RCCL all-gather of HR slabs" is the bf16 leg at --gpus 8; configs[3] = the x16 legs).
+    Returns (entry, model, last output)."""
+    import copy
     import torch
     from gpemsr_amd import dist as gdist
-    B, s, lr = args.tiles, args.scale, args.lr
+    B, s = x.shape[0], (scale or args.scale)
+    largs = copy.copy(args)
+    largs.steps = steps or args.steps
     if args.stub:
-        m3, prof = _StubModel(), None
+        m3 = _StubModel()
     else:
-        from gpemsr_amd import ops
         from gpemsr_amd.config import build_model
         torch.cuda.empty_cache()
         m3 = build_model(opt, load_prior_files=False, precision=mode).eval().to(dev)
+    timing = [] if world > 1 else None
 
     def step3():
-        return gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True, gather_u8=args.gather == "u8")[0]
-    for _ in range(max(args.warmup, 2)):          # the allocator re-grows its pools after empty_cache(): keep that out of the timing
+        return gdist.forward_sharded(m3, x, rank, world, already_local=True, gather=True, gather_u8=args.gather == "u8", timing=timing)[0]
+    for _ in range(max(args.warmup if warmup is None else warmup, 2)):          # the allocator re-grows its pools after empty_cache(): keep that out of the timing
         step3()
-    if not args.stub:
-        prof = ops.LaunchProfiler()
-        ops.PROFILER = prof
-    d3, o3 = timed_steps(step3, args.steps, world, dev, sync)
-    if not args.stub:
-        ops.PROFILER = None
-        if args.layer_report and rank == 0:
-            write_layer_report(prof, args.layer_report + "." + mode)
+    if timing is not None:
+        timing.clear()
+    d3, o3, prof, dtp, psteps = measure_leg(step3, largs, world, dev, sync, stub=args.stub)
+    phases = gdist.step_phase_times(timing[:largs.steps], world, dev) if timing is not None else None
+    if prof is not None and args.layer_report and rank == 0:
+        write_layer_report(prof, args.layer_report + "." + mode + (f".x{s}" if s != args.scale else ""))
     assert o3.shape[0] == B * world
     opix = o3.shape[-1] * o3.shape[-2]
-    entry = {"value": round(world * B * opix / 1e6 * args.steps / d3, 3), "unit": "MP/s", "n_gpus": world,
-             "ms_per_step": round(1e3 * d3 / args.steps, 2), "tiles_per_gpu": B, "scaling": "weak",
-             "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the " +
-                             ("uint8 HR images [tiles,H,W] (tensor2img of SR, from the last kernel)" if args.gather == "u8" else "fp32 HR slabs [tiles,1,H,W]") +
-                             "), synchronize + barrier; max over ranks", "gather": args.gather,
-             "roofline": None if args.stub else build_roofline(args, prof, d3, B, s, precision=mode)}
-    return entry, m3, o3
+    roof = None if args.stub else build_roofline(largs, prof, dtp, psteps, B, s, precision=mode)
+    return leg_entry(args, d3, largs.steps, world, B, opix, roof, phases), m3, o3
+
+
+def compact_leg(entry):
+    """The few figures of a leg that ride at the top level of the line (and inside `roofline.legs`, which a driver that keeps only the
+    contract's keys still keeps): value, ms/step, the dominant kernel and its executed fraction, the family's."""
+    r = entry.get("roofline") or {}
+    return {"value": entry["value"], "unit": entry["unit"], "ms_per_step": entry["ms_per_step"], "steps": entry.get("steps"), "n_gpus": entry.get("n_gpus"),
+            "kernel": r.get("kernel"), "frac": r.get("frac"), "family_frac": (r.get("family") or {}).get("frac"),
+            "effective_frac": r.get("effective_frac")}
+
+
+def run_config_legs(args, rank, world, dev, sync):
+    """BASELINE configs[3] and configs[4] on the default line: 16x EMSR, 8 windows per GPU of 5x1x64x64 -> 1024^2
+    (R:option/output_GPEMSR_x16.yml) in fp32 and on the bf16 data path, and the stage-3 training step (batch 8 per GPU of 32^2 -> 256^2
+    crops, R:train_stage3.py:343-366).  Fewer steps than the headline (the whole default command has to stay within minutes)."""
+    import torch
+    from gpemsr_amd.config import load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    legs = {}
+    steps, warm = max(1, min(args.steps, 10)), 2
+    opt16 = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x16.yml"))
+    x16 = synth_lr_tiles(8, 5, 64, 64, seed=1600 + rank, kind="uniform").to(dev)
+    for mode in ("bf16", "fp32"):
+        e, m, o = run_precision_leg(args, opt16, x16, rank, world, dev, mode, sync, scale=16, steps=steps, warmup=warm)
+        e["config"] = f"16x EMSR stage-3 forward, 8 windows per GPU of 5x1x64x64 -> 1024x1024, {mode} (BASELINE.json configs[3], one GPU's share)"
+        legs["x16_" + mode] = e
+        del m, o
+        torch.cuda.empty_cache()
+    import bench_train
+    legs["train"] = bench_train.train_leg(ROOT, 8, rank, world, dev, steps=steps, warmup=warm)
+    torch.cuda.empty_cache()
+    return legs
 
 
 def run_extras(args, model, opt, x, out, dt, dev, rank=0, world=1, sync=None):
@@ -456,13 +564,16 @@ def run_forward(args) -> int:
     B, s, lr = args.tiles, args.scale, args.lr
     if args.stub and os.environ.get("GPEMSR_BENCH_TEST_HANG_RANK") == str(rank):
         time.sleep(3600)                    # launcher self-test: this rank never arrives (tests/test_bench_launcher_cpu.py)
+    if world > 1 and args.backend != "gloo":
+        # a silent gloo fall-back on a multi-GPU box would read as bad scaling: RCCL ("nccl" on ROCm) unless gloo was asked for explicitly
+        assert torch.distributed.get_backend() == "nccl", f"N > 1 runs over RCCL; got backend {torch.distributed.get_backend()!r} (pass --backend gloo for a rehearsal)"
     if args.stub:
         dev = torch.device("cpu")
         sync = lambda: None                                                        # noqa: E731
         model = _StubModel()
         x = torch.rand(B, 5, 1, lr, lr, generator=torch.Generator().manual_seed(1000 + rank))
+        opt = None
     else:
-        from gpemsr_amd import ops
         from gpemsr_amd.config import build_model, load_options
         from gpemsr_amd.synth import synth_lr_tiles
         assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU path)"
@@ -474,20 +585,19 @@ def run_forward(args) -> int:
         opt = load_options(os.path.join(ROOT, "option", f"output_GPEMSR_x{s}.yml"))
         model = build_model(opt, load_prior_files=False, precision=args.precision).eval().to(dev)
         x = synth_lr_tiles(B, 5, lr, lr, seed=1000 + rank, kind="uniform").to(dev)     # resident in HBM before timing
+    timing = [] if world > 1 else None
 
     def step():
-        out, _ = gdist.forward_sharded(model, x, rank, world, already_local=True, gather=True, gather_u8=args.gather == "u8")
+        out, _ = gdist.forward_sharded(model, x, rank, world, already_local=True, gather=True, gather_u8=args.gather == "u8", timing=timing)
         return out
 
     for _ in range(args.warmup):
         step()
-    prof = None
-    if not args.stub:
-        prof = ops.LaunchProfiler()
-        ops.PROFILER = prof
-    dt, out = timed_steps(step, args.steps, world, dev, sync)
-    if not args.stub:
-        ops.PROFILER = None
+    if timing is not None:
+        timing.clear()
+    # the official number: K steps with NO per-launch events; the tables: a second, profiled pass (measure_leg)
+    dt, out, prof, dtp, psteps = measure_leg(step, args, world, dev, sync, stub=args.stub)
+    rank_phases = gdist.step_phase_times(timing[:args.steps], world, dev) if timing is not None else None
     assert out.shape[0] == B * world
     rccl_world = torch.distributed.get_world_size() if world > 1 else 1           # the group the all-gathers above ran on
     dist_backend = torch.distributed.get_backend() if world > 1 else None         # "nccl" = RCCL on ROCm; "gloo" in rehearsals / self-tests
@@ -495,16 +605,19 @@ def run_forward(args) -> int:
     opix = out.shape[-1] * out.shape[-2]
     mp_per_step = world * B * opix / 1e6
     value = mp_per_step * args.steps / dt
-    roofline, extras, cpu_baseline = None, None, None
+    roofline, extras, cpu_baseline, legs = None, None, None, None
     if args.stub and not args.no_extras:
         extras = run_extras(args, model, None, x, out, dt, dev, rank, world, sync)
     if not args.stub:
-        roofline = build_roofline(args, prof, dt, B, s)
+        roofline = build_roofline(args, prof, dtp, psteps, B, s, args.precision)
         if args.layer_report and rank == 0:
             write_layer_report(prof, args.layer_report)
         model_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
         if not args.no_extras:
             extras = run_extras(args, model, opt, x, out, dt, dev, rank, world, sync)
+        del model
+        if not args.no_extras and not args.no_config_legs and s == 8 and args.precision == "fp32" and args.gather == "f32":
+            legs = run_config_legs(args, rank, world, dev, sync)
         if model_sd is not None:
             cpu_baseline = run_cpu_baseline(args, model_sd, x, out)
 
@@ -517,12 +630,19 @@ def run_forward(args) -> int:
         dtype = {"fp32": "f32", "bf16": "bf16 (bf16 activations in HBM, bf16 MFMA, fp32 accumulate; indexer logits at fp32 precision = 3 bf16 products of hi+lo operands, argmax on fp32 logits)",
                  "bf16x3": "bf16x3 (fp32 activations; convs as 3 split hi+lo bf16 MFMA products, fp32 accumulate)",
                  "bf16op": "bf16 operands rounded in the kernel (fp32 activations in HBM), fp32 accumulate"}[args.precision]
+        bf = ((extras or {}).get("bf16") or {}) if isinstance(extras, dict) else {}
+        compact = {k: (compact_leg(v) if k != "train" else v) for k, v in (legs or {}).items()}
+        if bf:
+            compact["x8_bf16"] = compact_leg(bf)
+        if roofline is not None and compact:
+            roofline["legs"] = compact          # inside the contract's `roofline` object: survives a driver that drops unknown top-level keys
         line = {
             "metric": "output megapixels/sec, 8x EMSR 128->1024 tiles" if s == 8 else "output megapixels/sec, 16x EMSR 64->1024 tiles",
             "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "rccl_world": rccl_world, "dist_backend": dist_backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the " +
-                            ("uint8 HR images" if args.gather == "u8" else "fp32 HR slabs") + " at N > 1), synchronize + barrier; max over ranks",
+                            ("uint8 HR images" if args.gather == "u8" else "fp32 HR slabs") + " at N > 1), synchronize + barrier; max over ranks; "
+                            "no per-launch events in this pass (the roofline tables come from a second pass)",
             "gather": args.gather,
             "vs_baseline": None, "dtype": "stub" if args.stub else dtype, "data": "synthetic",
             "config": {"workload": ("launcher self-test (stub model, CPU, gloo)" if args.stub else
@@ -532,10 +652,14 @@ def run_forward(args) -> int:
                        "weights": "deterministic synthetic init (reference checkpoints are not redistributable)",
                        "parallelism": f"tiles sharded over {world} GPU(s), one process per GPU, RCCL all-gather of HR slabs" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
-            # the bf16 leg's own blocks at the TOP level (a driver that keeps only the top-level keys keeps them): BASELINE configs[2]
-            "roofline_bf16": ((extras or {}).get("bf16") or {}).get("roofline") if isinstance(extras, dict) else None,
-            "value_bf16": ((extras or {}).get("bf16") or {}).get("value") if isinstance(extras, dict) else None,
-            "ms_per_step_bf16": ((extras or {}).get("bf16") or {}).get("ms_per_step") if isinstance(extras, dict) else None,
+            "rank_phases": rank_phases,
+            # the other BASELINE configurations at the TOP level: configs[2] (bf16 leg), configs[3] (x16, both precisions), configs[4] (training step)
+            "roofline_bf16": bf.get("roofline"),
+            "value_bf16": bf.get("value"), "ms_per_step_bf16": bf.get("ms_per_step"),
+            "value_x16_fp32": ((legs or {}).get("x16_fp32") or {}).get("value"), "ms_per_step_x16_fp32": ((legs or {}).get("x16_fp32") or {}).get("ms_per_step"),
+            "value_x16_bf16": ((legs or {}).get("x16_bf16") or {}).get("value"), "ms_per_step_x16_bf16": ((legs or {}).get("x16_bf16") or {}).get("ms_per_step"),
+            "value_train": ((legs or {}).get("train") or {}).get("value"), "ms_per_step_train": ((legs or {}).get("train") or {}).get("ms_per_step"),
+            "legs": legs,
             "kernels": (roofline or {}).get("kernels"),
             "algorithmic_bytes_per_step": (roofline or {}).get("algorithmic_bytes_per_step"),
             "io_edges": io_edges,

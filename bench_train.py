@@ -17,6 +17,71 @@ TRAIN_OPT = dict(lr_G=4e-4, beta1=0.9, beta2=0.99, lr_scheme="CosineAnnealingLR_
                  ref_loss_factor=0.001)                     # option/train_stage3_x8.yml:90-108
 
 
+def train_leg(root: str, scale: int, rank: int, world: int, dev, steps: int = 10, warmup: int = 2, batch: int = 8, lr: int = 32,
+              precision: str = "fp32") -> dict:
+    """BASELINE configs[4] as a compact leg of the default `python bench.py` line: the stage-3 training step (R:train_stage3.py:343-366:
+    forward, L1 + 0.001 x contextual(VGG relu3_4) loss, backward, gradient all-reduce at N > 1, Adam), batch `batch` per GPU of 5x1xlrxlr crops.
+    Timed like every leg (K steps between barrier + synchronize pairs, no per-launch events, max over ranks); the executed fraction of the
+    f32 matrix peak comes from a second pass with HIP events around every convolution / weight-gradient launch."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.config import build_model, load_options
+    from gpemsr_amd.synth import synth_lr_tiles
+    from gpemsr_amd.train import Stage3Trainer
+    opt = load_options(os.path.join(root, "option", f"output_GPEMSR_x{scale}.yml"))
+    model = build_model(opt, load_prior_files=False, precision=precision).to(dev)
+    trainer = Stage3Trainer(model, TRAIN_OPT, dev, world=world)
+    LR = synth_lr_tiles(batch, 5, lr, lr, seed=2000 + rank, kind="smooth").to(dev)
+    GT = torch.rand(batch, 1, lr * scale, lr * scale, generator=torch.Generator().manual_seed(3000 + rank)).to(dev)
+    for _ in range(warmup):
+        trainer.step(LR, GT)
+
+    def timed_pass(k):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            o_ = trainer.step(LR, GT)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        d_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d_], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            d_ = float(tt.item())
+        return d_, o_
+    dt, o = timed_pass(steps)
+    psteps = max(1, min(steps, 3))
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    try:
+        dtp, _ = timed_pass(psteps)
+    finally:
+        ops.PROFILER = None
+    summ = prof.summary()
+    fam = [summ[k] for k in ("conv_mfma", "conv_wgrad") if k in summ]
+    ms = sum(v["ms"] for v in fam)
+    ex = sum(v["executed"] for v in fam)
+    fl = sum(v["flops"] for v in fam)
+    by_name = {k: v for k, v in prof.summary(by_name=True).items() if v["family"] in ("conv_mfma", "conv_wgrad")}
+    dom_name, dom = max(by_name.items(), key=lambda kv: kv[1]["ms"]) if by_name else ("?", {"ms": 0.0, "executed": 0.0, "launches": 0})
+    etf = lambda d_: d_["executed"] / (d_["ms"] * 1e-3) / 1e12 if d_["ms"] > 0 else 0.0      # noqa: E731
+    res = {"value": round(world * batch * steps / dt, 3), "unit": "training samples/s", "ms_per_step": round(1e3 * dt / steps, 2), "steps": steps,
+           "n_gpus": world, "batch_per_gpu": batch, "dtype": "f32" if precision == "fp32" else precision,
+           "config": f"{scale}x EMSR stage-3 training step, batch {batch}/GPU of 5x1x{lr}x{lr} -> {lr * scale}^2 crops (BASELINE.json configs[4]; the reference's "
+                     "step has no discriminator)",
+           "kernel": dom_name, "frac": round(etf(dom) / PEAK_F32_MATRIX_TFLOPS, 4),
+           "kernel_avg_launch_us": round(1e3 * dom["ms"] / max(dom["launches"], 1), 2),
+           "family_frac": round((ex / (ms * 1e-3) / 1e12 if ms > 0 else 0.0) / PEAK_F32_MATRIX_TFLOPS, 4),
+           "effective_frac": round((fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0) / PEAK_F32_MATRIX_TFLOPS, 4),
+           "family": "f32 MFMA convolution family of the step: forward + data gradients (conv_mfma) and weight gradients (conv_wgrad)",
+           "family_time_share_of_step": round(ms * 1e-3 / dtp, 3), "profiled_pass_ms_per_step": round(1e3 * dtp / psteps, 2),
+           "losses_last_step": {"rec": float(o["rec_loss"].item()), "ref": float(o["ref_loss"].item())}}
+    del trainer, model
+    return res
+
+
 def run(args, root: str, effective_cores):
     from gpemsr_amd import dist as gdist, ops
     from gpemsr_amd.config import build_model, load_options

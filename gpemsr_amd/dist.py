@@ -81,28 +81,70 @@ def all_gather_ragged(local: torch.Tensor, total: int, rank: int, world: int) ->
     return torch.cat([g[r, : hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
+class _Mark:
+    """A point in time on the stream the step runs on: a HIP event on the current stream (GPU), the host clock otherwise."""
+
+    def __init__(self, cuda: bool):
+        self.cuda = cuda
+        if cuda:
+            self.ev = torch.cuda.Event(enable_timing=True)
+            self.ev.record()
+        else:
+            import time
+            self.t = time.perf_counter()
+
+    def ms_until(self, other: "_Mark") -> float:
+        return self.ev.elapsed_time(other.ev) if self.cuda else 1e3 * (other.t - self.t)
+
+
 def forward_sharded(model, x_all_or_local: torch.Tensor, rank: int, world: int, already_local: bool = False,
-                    gather: bool = True, gather_u8: bool = False):
+                    gather: bool = True, gather_u8: bool = False, timing: list = None):
     """Run the stage-3 forward on this rank's tiles and (optionally) all-gather the SR slabs.
     x: [B,N,1,H,W]; returns (out_all [B,1,sH,sW] on every rank, ref_img_local).
     gather_u8: exchange the 8-bit image the network's last kernel writes (``model(x, want_u8=True)``, the reference's tensor2img of
     SR: what output_GPEMSR.py saves) instead of the fp32 slab -- 1 MiB instead of 4 MiB per 1024^2 tile over xGMI; the first return
-    value is then uint8 [B, sH, sW]."""
+    value is then uint8 [B, sH, sW].
+    timing: a list that receives one (start, after forward, after all-gather) triple of `_Mark`s per call (`step_phase_times`); the
+    collective's mark sits on the launch stream, which waits for RCCL's stream before anything after it runs."""
     B = x_all_or_local.shape[0] * (world if already_local else 1)
     if already_local:
         x = x_all_or_local
     else:
         lo, hi = shard_range(B, rank, world)
         x = x_all_or_local[lo:hi]
+    cuda = x.is_cuda
+    m0 = _Mark(cuda) if timing is not None else None
     if gather_u8:
         _, ref, out = model(x, want_u8=True)
     else:
         out, ref = model(x)
-    if not gather or world == 1:
-        return out, ref
-    if B % world == 0:
-        return all_gather_slabs(out, world), ref
-    return all_gather_ragged(out, B, rank, world), ref
+    m1 = _Mark(cuda) if timing is not None else None
+    if gather and world > 1:
+        out = all_gather_slabs(out, world) if B % world == 0 else all_gather_ragged(out, B, rank, world)
+    if timing is not None:
+        timing.append((m0, m1, _Mark(cuda)))
+    return out, ref
+
+
+def step_phase_times(timing: list, world: int, device) -> dict:
+    """Per-rank mean forward / all-gather milliseconds of the recorded steps and their max / min over ranks, so that an N-GPU line says
+    whether a step is long because one rank's forward is slow (a slow device, a straggler) or because the exchange is."""
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    n = max(len(timing), 1)
+    fwd = sum(a.ms_until(b) for a, b, _ in timing) / n
+    gat = sum(b.ms_until(c) for _, b, c in timing) / n
+    mine = torch.tensor([fwd, gat], dtype=torch.float64, device=device)
+    if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = torch.stack(allr).cpu()
+    else:
+        rows = mine.cpu().view(1, 2)
+    f, g = rows[:, 0], rows[:, 1]
+    return {"forward_ms_per_rank": [round(float(v), 3) for v in f], "gather_ms_per_rank": [round(float(v), 3) for v in g],
+            "forward_ms_max": round(float(f.max()), 3), "forward_ms_min": round(float(f.min()), 3),
+            "gather_ms_max": round(float(g.max()), 3), "gather_ms_min": round(float(g.min()), 3), "steps_recorded": len(timing)}
 
 
 def average_gradients(flat_grad: torch.Tensor, world: int) -> torch.Tensor:

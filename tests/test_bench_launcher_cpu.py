@@ -29,6 +29,21 @@ def test_plain_invocation_spawns_two_ranks():
     leg = d["extras"]["bf16"]
     assert leg["n_gpus"] == 2 and leg["value"] > 0 and leg["ms_per_step"] > 0 and leg["tiles_per_gpu"] == 3
     assert "all-gather" in leg["timed_region"]
+    # at N > 1 every leg says where a step's time went, rank by rank: forward and all-gather separately, max / min over ranks
+    for ph in (d["rank_phases"], leg["rank_phases"]):
+        assert len(ph["forward_ms_per_rank"]) == 2 and len(ph["gather_ms_per_rank"]) == 2 and ph["steps_recorded"] == 2
+        assert ph["forward_ms_max"] >= ph["forward_ms_min"] > 0 and ph["gather_ms_max"] >= ph["gather_ms_min"] > 0
+    assert "no per-launch events" in d["timed_region"]
+
+
+def test_a_silent_gloo_fallback_is_refused():
+    """Without `--backend gloo` an N > 1 run must be on RCCL ("nccl"): on this GPU-less container torch.distributed would pick gloo by
+    itself, which on an 8-GPU box would read as bad scaling -- the rank asserts instead."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GPEMSR_BENCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub", "--tiles", "2", "--lr", "16", "--steps", "1", "--warmup", "0", "--gpus", "2",
+                        "--rank-timeout", "120"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_single_rank_runs_in_process():
@@ -77,6 +92,7 @@ def test_eight_ranks_rehearsal_gloo():
     assert d["n_gpus"] == 8 and d["rccl_world"] == 8 and d["dist_backend"] == "gloo" and d["config"]["global_tiles"] == 24
     assert d["gather"] == "f32" and "fp32 HR slabs" in d["timed_region"]
     assert d["extras"]["bf16"]["n_gpus"] == 8 and d["extras"]["bf16"]["gather"] == "f32"
+    assert len(d["rank_phases"]["forward_ms_per_rank"]) == 8 and d["rank_phases"]["gather_ms_max"] > 0
 
 
 def test_uint8_gather_option_two_ranks():
