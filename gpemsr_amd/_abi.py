@@ -38,7 +38,7 @@ SYMBOLS = [
     # bf16 data path
     "gpemsr_conv2d_bf16", "gpemsr_conv2d_bf16_gn_parts", "gpemsr_conv2d_bf16_axf_ok", "gpemsr_groupnorm_scale_shift", "gpemsr_pack_rows_bf16_ex", "gpemsr_flash_attention_bf16", "gpemsr_maxpool2_bf16", "gpemsr_im2col4", "gpemsr_col2im4", "gpemsr_lrelu_slope", "gpemsr_lrelu_slope_bwd", "gpemsr_sum_scaled", "gpemsr_instnorm_bwd_bwd", "gpemsr_groupnorm_stats_bf16", "gpemsr_groupnorm_finish", "gpemsr_groupnorm_apply_bf16",
     "gpemsr_softmax_rows_bf16", "gpemsr_gather_rows_bf16", "gpemsr_pack_rows_bf16", "gpemsr_cast_f32_bf16", "gpemsr_cast_bf16_f32",
-    "gpemsr_bilinear_bf16", "gpemsr_pool3s2_maxavg_bf16", "gpemsr_spynet_prep_bf16", "gpemsr_dcn_columns_bf16", "gpemsr_patch_cosine_bf16",
+    "gpemsr_bilinear_bf16", "gpemsr_pool3s2_maxavg_bf16", "gpemsr_spynet_prep_bf16", "gpemsr_dcn_columns_bf16", "gpemsr_dcn_conv_bf16", "gpemsr_patch_cosine_bf16",
     "gpemsr_temporal_gate_bf16", "gpemsr_frame_mix_lrelu_bf16", "gpemsr_threeda_combine_bf16", "gpemsr_copy_channels_bf16",
     "gpemsr_copy_channels_f32_bf16", "gpemsr_conv2d_stem1_bf16", "gpemsr_conv2d_direct_bf16", "gpemsr_vgg_mask_bf16",
     "gpemsr_conv_c64_cout1_bf16", "gpemsr_upconv_out_c64_bf16", "gpemsr_conv7_c16_cout2_bf16", "gpemsr_conv_c64_cout1_f32", "gpemsr_upconv_out_c64_f32", "gpemsr_vq_codebook_loss", "gpemsr_conv7_c16_cout2_f32", "gpemsr_split_f32_bf16x2", "gpemsr_conv2d_gn_parts", "gpemsr_patch_cosine_finish",
@@ -205,6 +205,7 @@ def load():
     lib.gpemsr_pool3s2_maxavg_bf16.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p]
     lib.gpemsr_spynet_prep_bf16.argtypes = [p, p, p, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), p, p, p]
     lib.gpemsr_dcn_columns_bf16.argtypes = [p, i32, i32, i32, i32, i32, p, i32, i32, p, p]
+    lib.gpemsr_dcn_conv_bf16.argtypes = [p, i32, i32, i32, i32, p, i32, p, p, i32, p, i32, p]
     lib.gpemsr_patch_cosine_bf16.argtypes = [p, p, i32, i32, i32, i32, p, p]
     lib.gpemsr_temporal_gate_bf16.argtypes = [p, p, p, i32, i32, i32, i32, p, p]
     lib.gpemsr_frame_mix_lrelu_bf16.argtypes = [p, i64, i32, i32, p, p, p, p]

@@ -29,7 +29,7 @@ import torch
 
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
-from .packing import (pack_conv, pack_conv_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3, pack_rowpair7,
+from .packing import (pack_conv, pack_conv_bf16, pack_dcn_rows_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3, pack_rowpair7,
                       pack_vgg_first, pack_cout1_taps, pack_winograd, pack_conv7_c32_cout16, pack_conv7_c8_cout32, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
@@ -91,6 +91,7 @@ class Engine:
         self.winograd = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD", "1") != "0"
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
+        self.fuse_dcn = os.environ.get("GPEMSR_FUSE_DCN", "1") != "0"     # bf16 path: DCN sampling + contraction in one kernel (gpemsr_dcn_conv_bf16)
         self.split = precision in ("bf16x3", "bf16op")
         self._forced_flow = None
         self.o = ops            # operator namespace; the training engine swaps in a recording proxy (gpemsr_amd/train.py)
@@ -173,6 +174,8 @@ class Engine:
             self.pc[name] = pack_dcn(w, b, dev)
             if self.bf16:       # 1x1 over the tap-major column tensor [9*cin]
                 self.pc[name].wb = pack_conv_bf16(w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1, 1, 1), dev)
+                if tuple(w.shape) == (64, 64, 3, 3):
+                    self.pc[name].wrows = pack_dcn_rows_bf16(w, dev)       # sampling + contraction in one kernel (csrc/dcn_bf16.hip)
         elif w.dim() == 4 and (name.startswith("reffea_L") or name.endswith(".upblock")):
             self.pc[name] = pack_convT(w, b, dev)
             if self.split and w.shape[0] % 16 == 0:
@@ -617,6 +620,9 @@ class Engine:
 
     def dcn(self, x: Act, feat: Act, name: str, act: int) -> Act:
         om = self.conv(feat, name + ".conv_offset", force_mfma=True, out_f32=self.bf16)    # sampling coordinates stay fp32
+        if self.bf16 and self.fuse_dcn and self.o is ops and ops.dcn_conv_ok(x, om, self.pc[name], self.groups):
+            # deformable sampling and the 64 x 576 contraction in one kernel: the column tensor stays in LDS (csrc/dcn_bf16.hip)
+            return ops.dcn_conv_bf16(x, om, self.pc[name], act, tag=name)
         col = self.o.dcn_columns(x, om, self.groups)
         return self.conv(col, name, act)
 

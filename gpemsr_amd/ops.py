@@ -216,6 +216,7 @@ class PackedConv:
     w7c16: Optional[torch.Tensor] = None   # bf16 data path, 32 -> 16 7x7: 16x16x32 MFMA fragments (packing.pack_conv7_c32_cout16)
     wino: Optional[torch.Tensor] = None    # fp32, 3x3 stride 1: Winograd F(2x2,3x3) weights U[16][cout][cin] (packing.pack_winograd; descriptor.transposed = 3)
     wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
+    wrows: Optional[torch.Tensor] = None   # bf16 data path, DCN 64 -> 64: plain rows [cout][9 taps][64 channels] bf16 (packing.pack_dcn_rows_bf16; csrc/dcn_bf16.hip)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
                                            # the profiler's flop count uses this, so split products are not credited as extra work
 
@@ -571,6 +572,33 @@ def dcn_columns(x: Act, om: Act, groups: int) -> Act:
     _abi.check(_abi.load().gpemsr_dcn_columns(x.ptr, x.n, x.h, x.w, x.c, x.ld, om.ptr, om.ld, groups, col.ptr, _stream()),
                "dcn_columns")
     return col
+
+
+def dcn_conv_ok(x: Act, om: Act, pc: "PackedConv", groups: int) -> bool:
+    """True when gpemsr_dcn_conv_bf16 (deformable sampling + contraction in one kernel) takes this layer."""
+    return (x.bf16 and not om.bf16 and pc.wrows is not None and x.c == 64 and pc.cout == 64 and groups == 8 and om.c >= 216 and x.ld % 8 == 0
+            and x.ptr % 16 == 0 and (om.n, om.h, om.w) == (x.n, x.h, x.w))
+
+
+def dcn_conv_bf16(x: Act, om: Act, pc: "PackedConv", act: int = ACT_NONE, out: Optional[Act] = None, tag: str = "") -> Act:
+    """DCNv2 after its conv_offset (basicsr DCNv2Pack -> torchvision deform_conv2d; R:model/GPEMSR.py:79-94) on the bf16 path: x bf16
+    [n][h][w][64], om fp32 [n][h][w][216] (offsets | mask logits) -> bf16 [n][h][w][64]; the column tensor stays in LDS."""
+    _require_gpu(x, om)
+    assert dcn_conv_ok(x, om, pc, 8)
+    if out is None:
+        out = new_act(x.n, x.h, x.w, 64, device=x.buf.device, bf16=True)
+    assert out.bf16 and (out.n, out.h, out.w, out.c) == (x.n, x.h, x.w, 64) and out.ld % 8 == 0 and out.ptr % 16 == 0
+    lib = _abi.load()
+
+    def _go():
+        _abi.check(lib.gpemsr_dcn_conv_bf16(x.ptr, x.n, x.h, x.w, x.ld, om.ptr, om.ld, pc.wrows.data_ptr(), pc.b.data_ptr() if pc.b is not None else None, act,
+                                            out.ptr, out.ld, _stream()), "dcn_conv_bf16")
+    if PROFILER is not None:
+        px = float(x.n * x.h * x.w)
+        PROFILER.run("conv_bf16", tag, 2.0 * px * 64 * 576, _go, name="dcn_fused16_kernel", nbytes=px * (2.0 * 64 + 4.0 * 216 + 2.0 * 64) + 2.0 * 64 * 576)
+    else:
+        _go()
+    return out
 
 
 def patch_cosine(a: Act, b: Act) -> Act:

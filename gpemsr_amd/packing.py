@@ -111,6 +111,13 @@ def pack_dcn(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
                       1, cout, (kh * kw * cin,), 32)
 
 
+def pack_dcn_rows_bf16(w: torch.Tensor, device) -> torch.Tensor:
+    """DCN weight [cout][cin][3][3] as plain bf16 rows [cout][tap][cin] -- the K order of the column rows gpemsr_dcn_conv_bf16 builds in LDS
+    (tap-major, channel fastest: the same order as the stand-alone column tensor of gpemsr_dcn_columns_bf16)."""
+    cout, cin, kh, kw = w.shape
+    return w.detach().to(torch.float32).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin).to(torch.bfloat16).contiguous().to(device)
+
+
 def pack_vgg_first(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
     """vgg conv1_1 applied to a 1-channel image expanded to 3 identical channels
     (model/GPEMSR.py:386,390) == a 1->64 conv with the weights summed over Cin."""

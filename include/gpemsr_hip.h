@@ -249,6 +249,14 @@ int gpemsr_spynet_prep_bf16(const float* ref, const float* supp, const float* fl
                             const float* mean3, const float* std3, float* up_flow, void* inp16, void* stream);
 int gpemsr_dcn_columns_bf16(const void* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
                             void* col, void* stream);
+/* Modulated deformable convolution in ONE kernel (csrc/dcn_bf16.hip): the deformable sampling of gpemsr_dcn_columns_bf16 into LDS and the
+ * 64 x (9 x 64) contraction on the matrix cores from there -- the column tensor never exists in HBM.  Replaces basicsr DCNv2Pack.forward ->
+ * torchvision.ops.deform_conv2d (R:model/GPEMSR.py:79-94 call sites :115,122,131,138) after its conv_offset convolution, for 64 -> 64
+ * channels, 8 deformable groups, 3x3, stride 1, pad 1.  x [n][h][w][x_ld >= 64] bf16; om [n][h][w][om_ld >= 216] fp32 = the raw conv_offset
+ * output (144 offsets: group g, tap k -> dy = om[18g+2k], dx = om[18g+2k+1]; 72 mask logits om[144+9g+k], sigmoid applied here);
+ * weight_rows [64 couts][9 taps][64 channels] bf16; bias[64] fp32 or NULL; act: none / ReLU / LeakyReLU; out [n][h][w][out_ld >= 64] bf16. */
+int gpemsr_dcn_conv_bf16(const void* x, int n, int h, int w, int x_ld, const float* om, int om_ld, const void* weight_rows,
+                         const float* bias, int act, void* out, int out_ld, void* stream);
 int gpemsr_patch_cosine_bf16(const void* a, const void* b, int n, int h, int w, int c, float* out, void* stream);
 int gpemsr_temporal_gate_bf16(const void* aligned, const void* emb, const void* emb_ref, int b, int t, int hw, int c,
                               void* af, void* stream);

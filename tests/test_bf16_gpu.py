@@ -486,6 +486,38 @@ def test_stem_direct_and_dcn_bf16():
     _close(c16.nchw(), c32.nchw(), BF, "dcn columns")
 
 
+@pytest.mark.parametrize("geom", [(2, 12, 16, 64, 0, 0), (3, 8, 8, 64, 2, 2.0), (1, 7, 9, 72, 1, 12.0), (5, 32, 32, 64, 0, 1.0)])
+def test_dcn_sampling_and_contraction_in_one_kernel(geom):
+    """gpemsr_dcn_conv_bf16 (csrc/dcn_bf16.hip): deformable sampling into LDS + the 64 x 576 contraction == the oracle's restatement of
+    basicsr DCNv2Pack -> torchvision deform_conv2d (R:model/GPEMSR.py:79-94) on the bf16-rounded features and weights, and == the
+    two-kernel form (gpemsr_dcn_columns_bf16 + the 1x1 product) it replaces.  Ragged pixel counts (7 x 9 = 63 per image), a strided
+    source, offsets far outside the image, all three activations."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv_bf16, pack_dcn, pack_dcn_rows_bf16
+    from oracle import gpemsr_oracle as orc
+    n, h, w, ld, act, big = geom
+    dev = _dev()
+    x = _r(_rand(n, 64, h, w, seed=300 + h))
+    om = _rand(n, 216, h, w, seed=301 + h, scale=2.0)
+    if big:
+        om[:, :144] *= big                                  # sampling points up to +-24 pixels away: the out-of-image rule
+    wt = _r(_rand(64, 64, 3, 3, seed=302, scale=0.05)); b = _rand(64, seed=303, scale=0.1)
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    want = _apply_act(orc.deform_conv2d_v2(x, torch.cat((o1, o2), 1), torch.sigmoid(m), wt, b), act)
+    pc = pack_dcn(wt, b, dev)
+    pc.wb = pack_conv_bf16(wt.permute(0, 2, 3, 1).reshape(64, -1, 1, 1), dev)
+    pc.wrows = pack_dcn_rows_bf16(wt, dev)
+    xa, oma = _act16(x, dev, ld=ld), _act32(om, dev)
+    assert ops.dcn_conv_ok(xa, oma, pc, 8)
+    got = ops.dcn_conv_bf16(xa, oma, pc, act)
+    assert got.bf16
+    _close(got.nchw(), want, 1.5 * BF, "fused DCN vs deform_conv2d semantics")
+    two = ops.conv2d([ops.dcn_columns(xa, oma, 8)], pc, act, precision="bf16")
+    _close(got.nchw(), two.nchw(), 1.5 * BF, "fused DCN vs columns + product")
+    got2 = ops.dcn_conv_bf16(xa, oma, pc, act)               # bit-stable run to run (no atomics, fixed order)
+    assert torch.equal(got.buf, got2.buf)
+
+
 def test_spynet_prep_bf16_matches_fp32_kernel():
     from gpemsr_amd import ops
     dev = _dev()
