@@ -47,26 +47,43 @@ __global__ __launch_bounds__(512, 1) void dcn_fused16_kernel(DcnParams P) {
   const unsigned cl_lds = xlds_addr(cl), wl_lds = xlds_addr(wl);
   const int li = lane & 31, lh = lane >> 5;
 
+  // item i of this thread in a tile: e = tid + 512 i -> pixel e / 72, tap (e % 72) / 8, group e % 8 (lanes of a wave share one or two pixels)
+  // The gather is a chain of two dependent round trips (offsets / mask logits, then the four corner rows they point at) and one workgroup
+  // per CU has only 8 waves to hide them: the offsets of the NEXT tile are requested while this tile is gathered and multiplied (first
+  // version, offsets loaded per batch: 1.13 ms per 128^2 level against 1.51 ms for columns + product; the HBM floor is ~0.3 ms).  Corner rows of
+  // two batches in flight at once (double-buffered) need 96 + 24 registers beside the 27 offsets and spill: one batch at a time.
+  float omv[9][3];
+  auto load_om = [&](int tile) {
+    const long long p0 = (long long)tile * 64;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int e = tid + i * 512, pl = e / 72, r = e % 72, k = r >> 3, g = r & 7;
+      long long pix = p0 + pl;
+      pix = pix < P.npix ? pix : P.npix - 1;
+      const float* o = P.om + pix * P.om_ld;
+      omv[i][0] = o[g * 18 + 2 * k]; omv[i][1] = o[g * 18 + 2 * k + 1]; omv[i][2] = o[144 + g * 9 + k];
+    }
+  };
+  if ((int)blockIdx.x < P.ntiles) load_om(blockIdx.x);
+
   for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
     const long long p0 = (long long)tile * 64;
     // ---- (1) deformable gather -> column rows in LDS: three batches of three items per thread ----
-#pragma unroll 1
-    for (int b = 0; b < 3; ++b) {
-      uint4 v[3][4];
-      float wq[3][4], mk[3];
-      int dst[3];
+    uint4 v[1][3][4];
+    float wq[1][3][4], mk[1][3];
+    auto fetch = [&](const int b) {
+      constexpr int sl = 0;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const int e = tid + (3 * b + i) * 512;    // item: pixel-major, then tap, then group (lanes of a wave share one or two pixels)
+        const int it = 3 * b + i;
+        const int e = tid + it * 512;
         const int pl = e / 72, r = e % 72, k = r >> 3, g = r & 7;
-        dst[i] = pl * (DCN_ROW * 2) + (k * 64 + g * 8) * 2;
         long long pix = p0 + pl;
         const bool live = pix < P.npix;
         pix = live ? pix : P.npix - 1;
         const int img = (int)(pix / hw), rem = (int)(pix % hw), yq = rem / P.w, xq = rem % P.w;
-        const float* o = P.om + pix * P.om_ld;
-        const float dy = o[g * 18 + 2 * k], dx = o[g * 18 + 2 * k + 1], ml = o[144 + g * 9 + k];
-        const float m = 1.f / (1.f + expf(-ml));
+        const float dy = omv[it][0], dx = omv[it][1], ml = omv[it][2];
+        mk[sl][i] = 1.f / (1.f + expf(-ml));
         const float py = (float)(yq - 1 + k / 3) + dy, px = (float)(xq - 1 + k % 3) + dx;
         const bool inside = live && py > -1.f && py < fh && px > -1.f && px < fw;
         const float fy = floorf(py), fx = floorf(px);
@@ -79,28 +96,40 @@ __global__ __launch_bounds__(512, 1) void dcn_fused16_kernel(DcnParams P) {
         for (int q = 0; q < 4; ++q) {
           const bool ok = inside && ys[q] >= 0 && ys[q] <= P.h - 1 && xs[q] >= 0 && xs[q] <= P.w - 1;
           const int yc = min(max(ys[q], 0), P.h - 1), xc = min(max(xs[q], 0), P.w - 1);
-          v[i][q] = *reinterpret_cast<const uint4*>(xb + (long long)(yc * P.w + xc) * P.x_ld);
-          wq[i][q] = ok ? wts[q] : 0.f;
+          v[sl][i][q] = *reinterpret_cast<const uint4*>(xb + (long long)(yc * P.w + xc) * P.x_ld);
+          wq[sl][i][q] = ok ? wts[q] : 0.f;
         }
-        mk[i] = m;
       }
+    };
+    auto combine = [&](const int b) {
+      constexpr int sl = 0;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
+        const int e = tid + (3 * b + i) * 512;
+        const int pl = e / 72, r = e % 72, k = r >> 3, g = r & 7;
         unsigned o4[4];
 #pragma unroll
         for (int z = 0; z < 4; ++z) {
-          const unsigned u0 = z == 0 ? v[i][0].x : (z == 1 ? v[i][0].y : (z == 2 ? v[i][0].z : v[i][0].w));
-          const unsigned u1 = z == 0 ? v[i][1].x : (z == 1 ? v[i][1].y : (z == 2 ? v[i][1].z : v[i][1].w));
-          const unsigned u2 = z == 0 ? v[i][2].x : (z == 1 ? v[i][2].y : (z == 2 ? v[i][2].z : v[i][2].w));
-          const unsigned u3 = z == 0 ? v[i][3].x : (z == 1 ? v[i][3].y : (z == 2 ? v[i][3].z : v[i][3].w));
+          const unsigned u0 = z == 0 ? v[sl][i][0].x : (z == 1 ? v[sl][i][0].y : (z == 2 ? v[sl][i][0].z : v[sl][i][0].w));
+          const unsigned u1 = z == 0 ? v[sl][i][1].x : (z == 1 ? v[sl][i][1].y : (z == 2 ? v[sl][i][1].z : v[sl][i][1].w));
+          const unsigned u2 = z == 0 ? v[sl][i][2].x : (z == 1 ? v[sl][i][2].y : (z == 2 ? v[sl][i][2].z : v[sl][i][2].w));
+          const unsigned u3 = z == 0 ? v[sl][i][3].x : (z == 1 ? v[sl][i][3].y : (z == 2 ? v[sl][i][3].z : v[sl][i][3].w));
           // the same sums in the same order as the stand-alone column kernel: ((w0 a + w1 b) + w2 c) + w3 d, then the mask
-          float lo = wq[i][0] * xbf_lo(u0); lo += wq[i][1] * xbf_lo(u1); lo += wq[i][2] * xbf_lo(u2); lo += wq[i][3] * xbf_lo(u3);
-          float hi = wq[i][0] * xbf_hi(u0); hi += wq[i][1] * xbf_hi(u1); hi += wq[i][2] * xbf_hi(u2); hi += wq[i][3] * xbf_hi(u3);
-          o4[z] = xcvt_pk_bf16(lo * mk[i], hi * mk[i]);
+          float lo = wq[sl][i][0] * xbf_lo(u0); lo += wq[sl][i][1] * xbf_lo(u1); lo += wq[sl][i][2] * xbf_lo(u2); lo += wq[sl][i][3] * xbf_lo(u3);
+          float hi = wq[sl][i][0] * xbf_hi(u0); hi += wq[sl][i][1] * xbf_hi(u1); hi += wq[sl][i][2] * xbf_hi(u2); hi += wq[sl][i][3] * xbf_hi(u3);
+          o4[z] = xcvt_pk_bf16(lo * mk[sl][i], hi * mk[sl][i]);
         }
-        *reinterpret_cast<uint4*>(cl + dst[i]) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        *reinterpret_cast<uint4*>(cl + pl * (DCN_ROW * 2) + (k * 64 + g * 8) * 2) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
       }
-    }
+    };
+    fetch(0);
+    combine(0);
+    fetch(1);
+    combine(1);
+    fetch(2);
+    // every offset of this tile has been consumed: request the next tile's now (they land under the rest of this tile)
+    if (tile + (int)gridDim.x < P.ntiles) load_om(tile + gridDim.x);
+    combine(2);
     __syncthreads();
     // ---- (2) contraction: wave (mt, nt) = 32 pixels x 32 couts over K = 576 ----
     if (wave < 4) {

@@ -716,6 +716,81 @@ def test_argmax_in_the_logits_gemm_epilogue(n, h, w, cout):
     assert float((ref == got).float().mean()) > 0.999               # (torch's CUDA argmax may break ties differently)
 
 
+GEMM_DIRECT_CASES = [
+    # (n, cins, cout, h, w, act, residual bf16, out_f32, kpack)      -- gemm_bf16.hip: cout % 256 == 0, 64-channel chunks, an even number >= 4 of them
+    (2, (512,), 512, 8, 16, 0, True, False, False),          # one ragged 128-row tile per image and cout block
+    (3, (512,), 512, 24, 24, 1, False, False, False),        # 576 rows: two full tiles + a ragged one, several tiles per workgroup stream
+    (1, (256,), 256, 20, 13, 2, False, True, False),         # four chunks (the minimum), fp32 result, LeakyReLU
+    (2, (512,), 1024, 16, 16, 0, False, False, True),        # B-operand ("kpack") store, four cout blocks
+    (1, (512, 512, 512), 1024, 17, 19, 0, False, True, False),   # three sources (the three-product logits GEMM's shape), 24 chunks
+    (70, (512,), 512, 32, 32, 0, True, False, False),        # 560 tiles on 256 workgroups: the chunk stream crosses tiles, images and cout blocks
+]
+
+
+@pytest.mark.parametrize("case", GEMM_DIRECT_CASES)
+def test_matrix_products_with_activations_straight_into_registers(case):
+    """gemm_direct_bf16_kernel (csrc/gemm_bf16.hip; R:model/blocks.py:61-83 q / k / v / proj_out, R:model/indexer.py:89-100): against torch on the
+    bf16-rounded operands, and bit-for-bit against nothing -- but the ring kernel (variant 14) must agree to the same tolerance, and the
+    library must really have picked the new kernel for the default variant."""
+    import ctypes as C
+    from gpemsr_amd import _abi, ops
+    n, cins, cout, h, w, act, use_res, out_f32, kpack = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _r(_rand(n, cin, h, w, seed=11))
+    wt = _r(_rand(cout, cin, 1, 1, seed=12, scale=1.0 / np.sqrt(cin)))
+    b = _rand(cout, seed=13, scale=0.1)
+    want = _apply_act(F.conv2d(x, wt, b), act)
+    res = _r(_rand(n, cout, h, w, seed=14)) if use_res else None
+    if res is not None:
+        want = want + res
+    srcs, o = [], 0
+    for i, c in enumerate(cins):
+        srcs.append(_act16(x[:, o:o + c], dev, ld=c + (8 if i == 0 else 0), off=8 if i == 0 else 0))
+        o += c
+    pc = _pc(wt, b, dev, cins)
+    r_act = None if res is None else _act16(res, dev)
+    # the instantiation the library picks for this descriptor
+    d = _abi.ConvDesc16()
+    d.n, d.h, d.w, d.nsrc = n, h, w, len(srcs)
+    for i, s_ in enumerate(srcs):
+        d.src[i].ptr, d.src[i].ld, d.src[i].c = s_.ptr, s_.ld, s_.c
+        d.src_image_stride[i] = -1
+    d.cout, d.ksize, d.stride, d.weight, d.out, d.out_ld, d.out_f32, d.kpack = cout, 1, 1, pc.wb.data_ptr(), srcs[0].ptr, cout, int(out_f32), int(kpack)
+    buf = C.create_string_buffer(160)
+    assert _abi.load().gpemsr_conv2d_bf16_kernel_name(C.byref(d), buf, 160) == 0 and buf.value.decode().startswith("gemm_direct_bf16_kernel"), buf.value
+    kw = dict(residual=r_act, precision="bf16", out_f32=out_f32, kpack=kpack, force_mfma=True)
+    got = ops.conv2d(srcs, pc, act, **kw)
+    ring = ops.conv2d(srcs, pc, act, variant=14, **kw)
+    if kpack:       # [n][cout/8][pixels][8]
+        unpack = lambda t: t.float().permute(0, 1, 3, 2).reshape(n, cout, h, w)      # noqa: E731
+        _close(unpack(got), want, BF, str(case))
+        _close(unpack(got), unpack(ring), BF, "new kernel vs ring kernel")
+    else:
+        assert got.bf16 == (not out_f32)
+        _close(got.nchw(), want, 1e-4 if out_f32 else BF, str(case))
+        _close(got.nchw(), ring.nchw(), 1e-4 if out_f32 else BF, "new kernel vs ring kernel")
+    again = ops.conv2d(srcs, pc, act, **kw)                   # bit-stable run to run (screens the DMA / barrier discipline for races)
+    assert torch.equal(got if kpack else got.buf, again if kpack else again.buf)
+
+
+def test_per_image_weights_on_the_direct_product_kernel():
+    """v^T = W_v . hn^T of the NonLocalBlock at C = 512 (R:model/blocks.py:72-80): the A operand is ONE weight matrix shared by all images
+    (src_image_stride 0), the B operand a per-image activation in the kpack layout (weight_image_stride), the result again kpack."""
+    from gpemsr_amd import ops
+    dev = _dev()
+    n, h, w, c = 3, 16, 32, 512
+    T = h * w
+    hn = _r(_rand(n, c, h, w, seed=21))
+    wv = _r(_rand(c, c, 1, 1, seed=22, scale=1.0 / np.sqrt(c)))
+    hn_a = _act16(hn, dev)
+    hnp = ops.pack_rows_bf16(hn_a)
+    wa = ops.Act(wv.reshape(c, c).to(torch.bfloat16).to(dev).contiguous().view(-1), n, 1, c, c, c, 0)
+    vtp = ops.conv2d([wa], ops.PackedConv(None, None, 1, T, (c,), 32, wb=hnp), 0, weight_image_stride=T * c, src_image_stride=[0], kpack=True, precision="bf16")
+    v_ref = F.conv2d(hn, wv).permute(0, 2, 3, 1).reshape(n, T, c)
+    _close(vtp.float().permute(0, 2, 1, 3).reshape(n, c, T), v_ref.transpose(1, 2), BF, "v^T kpack, C = 512")
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 16, 32), (3, 37, 70), (1, 5, 5), (20, 64, 96)])
 def test_conv7_c8_cout32_four_taps_per_mfma(n, h, w):
     """SpyNet's 8 -> 32 7x7 stems (basicsr BasicModule's first convolution, R:model/GPEMSR.py:67,99) with four taps per
