@@ -1386,8 +1386,8 @@ int plan_x(const gpemsr_conv16_desc* d, XParams& P, XPlan& L) {
       else if (var != 1 && BN == 64) { TH = 16; WM = 8; WN = 1; NL = 4; }   // 512 px x 64 columns
       // 64-channel sources (an even number >= 4 of chunks), couts in blocks of 256: activations straight into registers, only the weights
       // through LDS (gemm_bf16.hip) -- 256 px x 256 columns on 8 waves.  variant 14 / GPEMSR_GEMM_DIRECT=0 keep the ring kernel (A/B).
-      static int gd_env = -1;
-      if (gd_env < 0) { const char* e = getenv("GPEMSR_GEMM_DIRECT"); gd_env = (e && e[0] == '0') ? 0 : 1; }
+      const char* gd_e = getenv("GPEMSR_GEMM_DIRECT");     // (read per launch: A/B runs switch it inside one process)
+      const bool gd_env = !(gd_e && gd_e[0] == '0');
       if (ck64 && gd_env && var == 0 && d->cout % 256 == 0 && nchunk_total >= 4 && nchunk_total % 2 == 0 && !d->pixmul && !d->gn_partials && !L.axf &&
           bias_bytes <= 16 * 1024) {
         L.gdirect = true; BN = 256; TH = 8; WM = 8; WN = 1; NL = 0;
