@@ -30,7 +30,7 @@ namespace gpemsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// timing hooks of scripts/wino_probe.py exist only in a probe build (results are wrong on purpose with any of them set)
+// timing hooks of scripts/attic/wino_probe.py exist only in a probe build (results are wrong on purpose with any of them set)
 #ifdef GPEMSR_WINO_PROBE
 #define WINO_DBG(P) ((P).dbg)
 #else
@@ -55,7 +55,7 @@ struct WinoParams {
   float* gn_ws; int gn_parts;     // wide kernel: GroupNorm partial sums of (conv + bias) per (tile, channel): [n][gn_parts][cout][2] (conv_mfma.hip XEPI = 1)
   float* cos_ws;                  // wide kernel, cout == 64: patch-cosine partial sums against `residual` INSTEAD of storing (conv_mfma.hip XEPI = 2)
   int pixshuf, cq;                // wide kernel: store as PixelShuffle(2) (cout index = (2i + j) * cq + c, out is [n][2h][2w][cq])
-  int dbg;                        // timing experiments only, compiled in with -DGPEMSR_WINO_PROBE (scripts/wino_probe.py; GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
+  int dbg;                        // timing experiments only, compiled in with -DGPEMSR_WINO_PROBE (scripts/attic/wino_probe.py; GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
 };
 
 constexpr int WN_HH = 18, WN_HW2 = 17;                       // halo rows, halo columns per parity

@@ -23,7 +23,7 @@
 namespace gpemsr {
 
 #ifdef GPVGG_STAMP
-// diagnostic build (scripts/vgg_stamp_probe.py): cycles per bucket of every wave of the first 256 workgroups, summed over the workgroup's life
+// diagnostic build (scripts/attic/vgg_stamp_probe.py): cycles per bucket of every wave of the first 256 workgroups, summed over the workgroup's life
 __device__ unsigned long long g_vstamps[256 * 16 * 8];
 #define VSEG_DECL unsigned long long vs_t = __builtin_amdgcn_s_memtime(), vs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define VSEG(k) do { const unsigned long long vs_n = __builtin_amdgcn_s_memtime(); vs_acc[k] += vs_n - vs_t; vs_t = vs_n; } while (0)
@@ -393,7 +393,7 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         if (which == 0 || P.hr2) {
           // (the second image already up-sampled by gpemsr_bilinear, `scale` == 1: the on-the-fly resampling below -- 36 loads and
           // ~250 vector operations per halo pixel group -- kept the producer waves busy for 10k cycles per LR item, in-kernel stamps:
-          // scripts/vgg_stamp_probe.py; the up-sampled image costs 0.34 GB of traffic per step)
+          // scripts/attic/vgg_stamp_probe.py; the up-sampled image costs 0.34 GB of traffic per step)
           const float* im = which == 0 ? rimg : P.lr + (long long)img * P.H * P.W;
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp) raw[gi][tp] = im[(long long)yc[tp / 3] * P.W + xc[tp % 3]];      // clamped address, masked at use

@@ -7,12 +7,12 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gpemsr_amd.config import build_model, load_options  # noqa: E402
 from gpemsr_amd.synth import synth_lr_tiles  # noqa: E402
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 opt = load_options(os.path.join(root, "option", "output_GPEMSR_x8.yml"))
 dev = torch.device("cuda", 0)
 x = synth_lr_tiles(16, 5, 128, 128, seed=1, kind="smooth").to(dev)

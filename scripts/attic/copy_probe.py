@@ -2,12 +2,12 @@
 """Which Python lines of the bf16 forward issue device copies / fills through torch (they show up as __amd_rocclr_copyBuffer and
 FillFunctor launches between the library's kernels)?  One profiled forward, aten::copy_ / fill_ / zero_ grouped by caller line."""
 import os, sys, collections, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gpemsr_amd.config import build_model, load_options
 from gpemsr_amd.synth import synth_lr_tiles
 
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 opt = load_options(os.path.join(root, "option", "output_GPEMSR_x8.yml"))
 model = build_model(opt, load_prior_files=False, precision=prec).eval().to(torch.device("cuda", 0))

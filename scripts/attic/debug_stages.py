@@ -1,6 +1,6 @@
 """Dev helper (GPU box): stage-by-stage HIP vs CPU-oracle comparison."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from gpemsr_amd.config import build_model, load_options

@@ -2,7 +2,7 @@
 """GPU box: one training step against tests/golden/train_x8.npz with a per-tensor gradient error listing."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from gen_golden_train import TRAIN_OPT, projection
 from gpemsr_amd.config import build_model, load_options

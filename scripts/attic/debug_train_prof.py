@@ -1,5 +1,5 @@
 import os, sys, cProfile, pstats, torch, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from train_constants import TRAIN_OPT
 from gpemsr_amd.config import build_model, load_options

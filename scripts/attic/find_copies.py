@@ -2,7 +2,7 @@
 """GPU box: which Python lines launch device-to-device copies (aten::copy_ and friends) during one bf16 forward of 16 windows."""
 import collections, os, sys, traceback
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from gpemsr_amd.config import build_model, load_options
 from gpemsr_amd.synth import synth_lr_tiles

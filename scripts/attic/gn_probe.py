@@ -2,7 +2,7 @@
 """Times gpemsr_groupnorm_apply_bf16 (+ its statistics pass) on the two largest GroupNorm tensors of the 8x forward at batch 16."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gpemsr_amd import ops
 dev = torch.device("cuda", 0)
 for (n, h, w, c) in ((80, 512, 512, 64), (80, 256, 256, 128), (80, 64, 64, 512)):

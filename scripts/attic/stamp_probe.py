@@ -1,7 +1,7 @@
 """Dev helper (GPU box, GPEMSR_LIB_PATH = a -DGP_STAMP build): per-block s_memtime stamps of conv_mfma_kernel
 (entry, main loop start, epilogue start, exit) -> median phase durations in 100 MHz ticks (10 ns)."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from gpemsr_amd import ops, _abi
 from gpemsr_amd.packing import pack_conv, pack_convT

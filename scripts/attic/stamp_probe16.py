@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gpemsr_amd import _abi, ops  # noqa: E402
 from gpemsr_amd.packing import pack_conv, pack_conv_bf16, pack_convT, pack_convT_bf16  # noqa: E402
 

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gpemsr_amd import _abi, ops  # noqa: E402
 from gpemsr_amd.ops import ACT_NONE, ACT_RELU  # noqa: E402
 from gpemsr_amd.packing import pack_conv, pack_conv_bf16  # noqa: E402

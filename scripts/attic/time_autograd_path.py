@@ -2,7 +2,7 @@
 """GPU box: ms/step of the zero-change torch.autograd path (reference statements + torch Adam) next to Stage3Trainer, batch 8."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bench_train import TRAIN_OPT
 from gpemsr_amd.config import build_model, load_options

@@ -5,7 +5,7 @@ vgg_mask2_kernel spend their cycles (s_memtime buckets per wave, summed over the
   multipliers (waves 0-7): 0 conv1_2 MFMA loop | 1 feature / patch-sum epilogue | 2 barrier wait | 3 other"""
 import ctypes as C, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gpemsr_amd import _abi, ops
 from gpemsr_amd.packing import pack_conv_bf16
 dev = torch.device("cuda", 0)
