@@ -22,6 +22,7 @@ namespace gpemsr {
 struct DcnParams {
   const unsigned short* x; const float* om; const unsigned short* wrows; const float* bias; unsigned short* out;
   long long npix; int h, w, x_ld, om_ld, out_ld, act, ntiles;
+  unsigned mg_hw, mg_w;                        // floor((2^32 - 1) / (h w)), floor((2^32 - 1) / w): pixel index -> (image, y, x) by mulhi (xdivmod)
 };
 
 constexpr int DCN_ROW = 576 + 8;                 // bf16 elements per LDS row (1,168 B = 292 dwords: conflict-free 16-byte fragment reads)
@@ -60,8 +61,8 @@ __global__ __launch_bounds__(512, 1) void dcn_fused16_kernel(DcnParams P) {
       const int e = tid + i * 512, pl = e / 72, r = e % 72, k = r >> 3, g = r & 7;
       long long pix = p0 + pl;
       pix = pix < P.npix ? pix : P.npix - 1;
-      const float* o = P.om + pix * P.om_ld;
-      omv[i][0] = o[g * 18 + 2 * k]; omv[i][1] = o[g * 18 + 2 * k + 1]; omv[i][2] = o[144 + g * 9 + k];
+      const float* o = P.om + pix * P.om_ld + (g * 18 + 2 * k);
+      omv[i][0] = o[0]; omv[i][1] = o[1]; omv[i][2] = o[144 - 9 * g - k];      // (144 + 9 g + k) - (18 g + 2 k)
     }
   };
   if ((int)blockIdx.x < P.ntiles) load_om(blockIdx.x);
@@ -78,27 +79,31 @@ __global__ __launch_bounds__(512, 1) void dcn_fused16_kernel(DcnParams P) {
         const int it = 3 * b + i;
         const int e = tid + it * 512;
         const int pl = e / 72, r = e % 72, k = r >> 3, g = r & 7;
-        long long pix = p0 + pl;
-        const bool live = pix < P.npix;
-        pix = live ? pix : P.npix - 1;
-        const int img = (int)(pix / hw), rem = (int)(pix % hw), yq = rem / P.w, xq = rem % P.w;
+        // (image, y, x) of the pixel by reciprocal multiplication: the compiler's 64-bit division is ~150 vector instructions, and the gather
+        // is VALU-bound (72 items per pixel); the host guarantees n h w < 2^31
+        int pix = (int)p0 + pl;
+        const bool live = (long long)pix < P.npix;
+        pix = live ? pix : (int)P.npix - 1;
+        int img, rem, yq, xq;
+        xdivmod(pix, hw, P.mg_hw, img, rem);
+        xdivmod(rem, P.w, P.mg_w, yq, xq);
         const float dy = omv[it][0], dx = omv[it][1], ml = omv[it][2];
-        mk[sl][i] = 1.f / (1.f + expf(-ml));
+        mk[sl][i] = __builtin_amdgcn_rcpf(1.f + __expf(-ml));          // sigmoid: v_exp_f32 + v_rcp_f32 (~1e-7 relative; the result is rounded to bf16)
         const float py = (float)(yq - 1 + k / 3) + dy, px = (float)(xq - 1 + k % 3) + dx;
         const bool inside = live && py > -1.f && py < fh && px > -1.f && px < fw;
         const float fy = floorf(py), fx = floorf(px);
         const float ly = py - fy, lx = px - fx;
         const int y0 = (int)fmaxf(fminf(fy, fh), -2.f), x0 = (int)fmaxf(fminf(fx, fw), -2.f);
         const float wts[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
-        const int ys[4] = {y0, y0, y0 + 1, y0 + 1}, xs[4] = {x0, x0 + 1, x0, x0 + 1};
-        const unsigned short* xb = P.x + (long long)img * hw * P.x_ld + g * 8;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool ok = inside && ys[q] >= 0 && ys[q] <= P.h - 1 && xs[q] >= 0 && xs[q] <= P.w - 1;
-          const int yc = min(max(ys[q], 0), P.h - 1), xc = min(max(xs[q], 0), P.w - 1);
-          v[sl][i][q] = *reinterpret_cast<const uint4*>(xb + (long long)(yc * P.w + xc) * P.x_ld);
-          wq[sl][i][q] = ok ? wts[q] : 0.f;
-        }
+        const char* xb = reinterpret_cast<const char*>(P.x) + ((size_t)(unsigned)(img * hw) * (unsigned)P.x_ld + (unsigned)(g * 8)) * 2u;
+        const int yc0 = min(max(y0, 0), P.h - 1), yc1 = min(max(y0 + 1, 0), P.h - 1), xc0 = min(max(x0, 0), P.w - 1), xc1 = min(max(x0 + 1, 0), P.w - 1);
+        const bool oky0 = y0 >= 0 && y0 <= P.h - 1, oky1 = y0 + 1 >= 0 && y0 + 1 <= P.h - 1, okx0 = x0 >= 0 && x0 <= P.w - 1, okx1 = x0 + 1 >= 0 && x0 + 1 <= P.w - 1;
+        const unsigned pb = (unsigned)P.x_ld * 2u;                           // (host: h w x_ld 2 < 2^32 per image)
+        const unsigned r0 = (unsigned)(yc0 * P.w) * pb, r1 = (unsigned)(yc1 * P.w) * pb, c0 = (unsigned)xc0 * pb, c1 = (unsigned)xc1 * pb;
+        v[sl][i][0] = *reinterpret_cast<const uint4*>(xb + (r0 + c0)); v[sl][i][1] = *reinterpret_cast<const uint4*>(xb + (r0 + c1));
+        v[sl][i][2] = *reinterpret_cast<const uint4*>(xb + (r1 + c0)); v[sl][i][3] = *reinterpret_cast<const uint4*>(xb + (r1 + c1));
+        wq[sl][i][0] = (inside && oky0 && okx0) ? wts[0] : 0.f; wq[sl][i][1] = (inside && oky0 && okx1) ? wts[1] : 0.f;
+        wq[sl][i][2] = (inside && oky1 && okx0) ? wts[2] : 0.f; wq[sl][i][3] = (inside && oky1 && okx1) ? wts[3] : 0.f;
       }
     };
     auto combine = [&](const int b) {
@@ -175,7 +180,7 @@ extern "C" int gpemsr_dcn_conv_bf16(const void* x, int n, int h, int w, int x_ld
   GP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)weight_rows & 15) == 0, "dcn_conv_bf16: 16-byte alignment of x / out / weight rows");
   GP_REQUIRE(act == GPEMSR_ACT_NONE || act == GPEMSR_ACT_RELU || act == GPEMSR_ACT_LRELU, "dcn_conv_bf16: activation none / ReLU / LeakyReLU");
   const long long npix = (long long)n * h * w;
-  GP_REQUIRE(npix * (long long)(om_ld > x_ld ? om_ld : x_ld) < (1ll << 40) && (npix + 63) / 64 < (1ll << 31), "dcn_conv_bf16: tensor too large");
+  GP_REQUIRE(npix + 64 < (1ll << 31) && (long long)h * w * x_ld * 2 < (1ll << 32) && (long long)n * h * w * x_ld < (1ll << 32), "dcn_conv_bf16: tensor too large for 32-bit pixel offsets");
   static dev_once_t once{0};
   if (dev_once_begin(once)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_fused16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DCN_LDS) != hipSuccess)
@@ -186,6 +191,7 @@ extern "C" int gpemsr_dcn_conv_bf16(const void* x, int n, int h, int w, int x_ld
   P.x = reinterpret_cast<const unsigned short*>(x); P.om = om; P.wrows = reinterpret_cast<const unsigned short*>(weight_rows); P.bias = bias;
   P.out = reinterpret_cast<unsigned short*>(out);
   P.npix = npix; P.h = h; P.w = w; P.x_ld = x_ld; P.om_ld = om_ld; P.out_ld = out_ld; P.act = act; P.ntiles = (int)((npix + 63) / 64);
+  P.mg_hw = 0xFFFFFFFFu / (unsigned)(h * w); P.mg_w = 0xFFFFFFFFu / (unsigned)w;
   const int cus = device_cus();
   const int grid = P.ntiles < cus ? P.ntiles : cus;
   hipLaunchKernelGGL(dcn_fused16_kernel, dim3(grid), dim3(512), DCN_LDS, reinterpret_cast<hipStream_t>(stream), P);

@@ -78,9 +78,15 @@ class Engine:
         # "bf16" (default): everything on the bf16 data path, logits GEMM as three products (always).
         self.indexer_precision = indexer_precision or "bf16"
         self._hp_mode, self._hp_n = None, 0
-        if self.bf16 and self.indexer_precision != "bf16":
+        # "fp32:all": the WHOLE indexer (R:model/indexer.py:63-102) on the exact-fp32 kernels -- a second, indexer-only Engine over the same
+        # weights picks the code indices, the rest of the path stays bf16 (the setting with ~100 % code agreement; cost: the fp32 indexer)
+        self._idx_engine = None
+        if self.bf16 and self.indexer_precision == "fp32:all":
+            sub = {k: v for k, v in sd.items() if k.startswith("refmodel.indexer.")}
+            self._idx_engine = Engine(sub, device, scale, nframes, groups, nf, dec_num_res_blocks, frame_chunk, tile_chunk, precision="fp32")
+        elif self.bf16 and self.indexer_precision != "bf16":
             mode, _, cnt = self.indexer_precision.partition(":")
-            assert mode in ("bf16x3", "fp32") and (cnt == "" or cnt.isdigit()), f"indexer_precision {indexer_precision!r}: bf16 | bf16x3:N | fp32:N"
+            assert mode in ("bf16x3", "fp32") and (cnt == "" or cnt.isdigit()), f"indexer_precision {indexer_precision!r}: bf16 | bf16x3:N | fp32:N | fp32:all"
             self._hp_mode, self._hp_n = mode, int(cnt or 1)
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
         self.flash_attn = os.environ.get("GPEMSR_FLASH_ATTN", "1") != "0"   # bf16 path: NonLocalBlock products + softmax as one kernel (C = 512, T % 128 == 0)
@@ -134,6 +140,8 @@ class Engine:
         ``force`` (weights written by a HIP kernel through the raw pointer, which torch's counters cannot see) is repacked.
         The reference re-reads its Parameters on every forward (R:train_stage3.py:197-312 validates between optimizer
         steps); a packed copy must therefore never outlive the weights it was made from."""
+        if getattr(self, "_idx_engine", None) is not None:
+            self._idx_engine.sync_weights({k: v for k, v in live.items() if k.startswith("refmodel.indexer.")}, [k for k in force if k.startswith("refmodel.indexer.")])
         sig = self._signature(live)
         changed = {k for k in sig if sig[k] != self._sig.get(k)} | {k for k in force if k in live}
         if not changed:
@@ -468,7 +476,14 @@ class Engine:
         ln, lh_, lw_ = xf.n, (xf.h // 2 if s == 8 else xf.h), (xf.w // 2 if s == 8 else xf.w)     # latent grid (R:model/indexer.py:78-79: x8 halves once)
         fused = (self.bf16 and self.fuse_argmax and forced_idx is None and trace is None and ("refmodel.indexer.embedding@x3") in self.pc
                  and self.o is ops)
-        if fused:
+        if self._idx_engine is not None and forced_idx is None:
+            logits = self._idx_engine.indexer_logits(xf)           # the whole indexer at exact fp32 (`indexer_precision: fp32:all`)
+            idx = self.o.argmax_rows(logits)
+            if trace is not None:
+                trace.setdefault("logits", []).append(logits.torch().clone())
+                trace.setdefault("code_idx", []).append(idx.clone())
+            del logits
+        elif fused:
             idx = self.indexer_logits(xf, argmax=True)             # arg-max in the logits GEMM's epilogue: no [cells][1024] tensor
         else:
             logits = self.indexer_logits(xf)
