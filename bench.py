@@ -674,7 +674,7 @@ def run_forward(args) -> int:
 def measure_io_edges(out, dev):
     """SURVEY 8(f)3, outside the timed region: the step's HR tiles as 8-bit images -> complete PNG files on the device (csrc/png.hip, png_huff.hip):
     tensor2img, then the stored-block and the Huffman-compressing encoder; bytes moved = image read by the assemble / histogram / pack and
-    checksum passes + file written and read once."""
+    checksum passes + file written and read once (DESIGN_HISTORY.md §3.12)."""
     import torch
     from gpemsr_amd import ops, png
     u8 = ops.tensor2img_u8(out.reshape(-1, out.shape[-2], out.shape[-1]))

@@ -225,7 +225,7 @@ def run(args, root: str, effective_cores):
         extras = {"fp32_winograd_frozen": extras_w, "bf16x3_frozen_forward": {
             "value": round(B * args.steps / d3, 3), "unit": "samples/s", "ms_per_step": round(1e3 * d3 / args.steps, 2),
             "dtype": "frozen sub-networks' forward convolutions: fp32 operands split hi+lo bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate "
-                     "(fp32-grade, DESIGN 3.3); trainable layers, data and weight gradients: f32 MFMA",
+                     "(fp32-grade, DESIGN_HISTORY.md §3.3); trainable layers, data and weight gradients: f32 MFMA",
             "losses_last_step": {"rec": float(o3["rec_loss"].item()), "ref": float(o3["ref_loss"].item())},
             "speedup_vs_fp32_step": round((dt / args.steps) / (d3 / args.steps), 3)}}
         # ... and with the frozen sub-networks that carry no gradient (VQGAN prior, VGG mask, SpyNet) on the bf16 DATA PATH of the

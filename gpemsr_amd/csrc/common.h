@@ -50,5 +50,7 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // gpemsr_conv_desc.transposed == 3: the Winograd F(2x2, 3x3) form (conv_wino.hip); name_buf != NULL: write the kernel's name, launch nothing
 int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap, int* parts_only = nullptr);
+// gpemsr_conv_desc.transposed == 4: the 1-D Winograd F(2, 7) form of a 7x7 stride-1 convolution (conv7_wino.hip)
+int conv2d_winograd7(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap);
 
 }  // namespace gpemsr

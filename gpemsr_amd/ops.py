@@ -216,6 +216,7 @@ class PackedConv:
     w7c16: Optional[torch.Tensor] = None   # bf16 data path, 32 -> 16 7x7: 16x16x32 MFMA fragments (packing.pack_conv7_c32_cout16)
     wino: Optional[torch.Tensor] = None    # fp32, 3x3 stride 1: Winograd F(2x2,3x3) weights U[16][cout][cin] (packing.pack_winograd; descriptor.transposed = 3)
     wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
+    wino7: Optional[torch.Tensor] = None   # fp32, 7x7 stride 1: 1-D Winograd F(2, 7) weights U[cin/8][7][8][2][cout][4] (packing.pack_winograd7; descriptor.transposed = 4)
     wrows: Optional[torch.Tensor] = None   # bf16 data path, DCN 64 -> 64: plain rows [cout][9 taps][64 channels] bf16 (packing.pack_dcn_rows_bf16; csrc/dcn_bf16.hip)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
                                            # the profiler's flop count uses this, so split products are not credited as extra work
@@ -294,6 +295,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
                            _u8_fused=_u8_fused, **kw16)
     gn_stats = bool(kw16.pop("gn_stats", False))          # fp32 too: GroupNorm partial sums from the epilogue (gpemsr_conv_desc.gn_partials)
     winograd = bool(kw16.pop("winograd", False))          # fp32: the Winograd F(2x2,3x3) form where the layer qualifies (winograd_ok)
+    direct7 = bool(kw16.pop("direct7", False))            # fp32: keep the direct form of a 7x7 layer that has F(2, 7) weights packed (A/B, tests)
     cos_with = kw16.pop("cos_with", None)                  # fp32: patch cosine of the result against this tensor, result not stored
     if cos_with is not None:
         return _conv2d_cosine(srcs, pc, act, cos_with, tag, winograd=winograd)
@@ -424,6 +426,10 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             and pixmul is None and weight_image_stride == 0 and src_image_stride is None and out.ld % 4 == 0 and out.ptr % 16 == 0
             and (residual is None or (residual.ld % 4 == 0 and residual.ptr % 16 == 0))):
         d.transposed, d.weight = 2, pc.wpair7.data_ptr()       # row-pair form: both halves of the 32-row matrix tile do useful work
+    if (pc.wino7 is not None and not direct7 and precision == "fp32" and winograd7_ok(srcs, pc, stride, out, residual, pixmul) and weight_image_stride == 0
+            and src_image_stride is None and not d.gn_partials):
+        d.transposed, d.weight = 4, pc.wino7.data_ptr()         # 8 multiplies per output pair and filter row instead of 14 (csrc/conv7_wino.hip)
+        executed = flops * 8.0 / 14.0
     if PROFILER is not None:
         nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32", n, h, w, tuple((s_.c, s_.ld % 4, s_.ptr % 16) for s_ in srcs), pc.cout, k, stride, int(d.transposed),
                                                              int(pc.pixel_shuffle), bool(d.gn_partials), out.ld % 4, residual is not None))
@@ -433,6 +439,17 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     else:
         _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
     return out
+
+
+def winograd7_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
+    """Layers the F(2, 7) row form of gpemsr_conv2d takes: 7x7, stride 1, ONE fp32 source of c % 8 == 0 channels with 16-byte aligned rows,
+    cout % 32 == 0, plain store, images at least 64 pixels wide (the tile is 4 x 64 pixels); `pc.wino7` packed."""
+    if pc.wino7 is None or pc.ksize != 7 or stride != 1 or pc.transposed or pc.pixel_shuffle or pc.cout % 32 != 0 or len(srcs) != 1:
+        return False
+    s_ = srcs[0]
+    if s_.bf16 or s_.c % 8 != 0 or s_.ld % 4 != 0 or s_.ptr % 16 != 0 or s_.w < 64 or residual is not None or pixmul is not None:
+        return False
+    return out is None or not out.bf16
 
 
 def winograd_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None) -> bool:

@@ -111,6 +111,31 @@ def pack_dcn(w: torch.Tensor, b: torch.Tensor, device) -> PackedConv:
                       1, cout, (kh * kw * cin,), 32)
 
 
+# 1-D Winograd F(2, 7), interpolation points 0, +-1, +-2, +-1/2, infinity:  [y0, y1] = A^T [ (G g) (.) (B^T d) ],  d = 8 inputs, g = 7 taps.
+# G evaluates the filter polynomial at the points (last row: leading coefficient); B^T and A^T are hard-coded in csrc/conv7_wino.hip
+# (B^T = C^-T of the 8 x 8 Vandermonde matrix, A^T = [1 1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 -1/2 1]); tests/test_host_cpu.py re-derives all
+# three and checks the identity in float64.
+WINO7_POINTS = (0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5)
+WINO7_G = torch.tensor([[p ** k for k in range(7)] for p in WINO7_POINTS] + [[0.0] * 6 + [1.0]], dtype=torch.float64)
+WINO7_AT = torch.tensor([[1.0] * 7 + [0.0], list(WINO7_POINTS) + [1.0]], dtype=torch.float64)
+
+
+def wino7_bt() -> torch.Tensor:
+    """B^T [8][8] of F(2, 7) for WINO7_POINTS: the transpose of the inverse of the evaluation matrix of degree-7 polynomials."""
+    C = torch.tensor([[p ** k for k in range(8)] for p in WINO7_POINTS] + [[0.0] * 7 + [1.0]], dtype=torch.float64)
+    return torch.linalg.inv(C).T.contiguous()
+
+
+def pack_winograd7(w: torch.Tensor, device) -> torch.Tensor:
+    """Weights of a 7x7 stride-1 convolution [cout][cin][7][7] (cin % 8 == 0) in the F(2, 7) row form of gpemsr_conv2d (descriptor.transposed
+    = 4): U[cin/8][ky][nu][quad][cout][4] fp32 with U[nu] = sum_kx G[nu][kx] w[ky][kx], folded in float64."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 7 and kw == 7 and cin % 8 == 0
+    u = torch.einsum("pk,ocyk->ocyp", WINO7_G, w.detach().to(torch.float64).cpu())           # [cout][cin][ky][nu]
+    u = u.reshape(cout, cin // 8, 2, 4, 7, 8).permute(1, 4, 5, 2, 0, 3)                          # [chunk][ky][nu][quad][cout][4]
+    return u.to(torch.float32).contiguous().to(device)
+
+
 def pack_dcn_rows_bf16(w: torch.Tensor, device) -> torch.Tensor:
     """DCN weight [cout][cin][3][3] as plain bf16 rows [cout][tap][cin] -- the K order of the column rows gpemsr_dcn_conv_bf16 builds in LDS
     (tap-major, channel fastest: the same order as the stand-alone column tensor of gpemsr_dcn_columns_bf16)."""

@@ -8,7 +8,7 @@
 with the forward of gpemsr_amd/engine.py, a recorded tape of that forward for the backward, Adam on one flat parameter
 buffer and (world > 1) one RCCL all-reduce of the flat gradient buffer (what DistributedDataParallel does, :141).
 
-How the backward is built:
+How the backward is built (DESIGN_HISTORY.md §3.6):
   * The engine issues every operator through ``self.o``; in training that is ``TapeOps``, which runs the same HIP kernel
     and, if an input depends on a trainable parameter, appends a closure that launches the operator's gradient kernels.
     Gradients live in a zero-initialised buffer per allocation (``Act.grad()``); every gradient kernel ACCUMULATES, which
@@ -234,7 +234,7 @@ class TrainEngine(Engine):
         # reference's distance) for a step 7 % shorter (profiles/r04_winograd_training_sweep.log).
         self.wino_train = int(os.environ.get("GPEMSR_WINO_TRAIN", str(int(wino_train))))
         self.fuse_tail_f32 = False                             # training keeps the layered decoder tail / VALU 64 -> 1 convs: the tape's
-        #                                                        backward kernels were validated against exactly that forward
+        #                                                        backward kernels were validated against exactly that forward (DESIGN_HISTORY.md §3.6)
         # precision "bf16": the FROZEN sub-networks whose inputs carry no gradient -- the VQGAN prior (indexer, codebook, decoder), the
         # VGG relu1_2 mask and SpyNet: about two thirds of the step's convolution time -- run on the bf16 DATA PATH of the inference
         # engine (bf16 activations in HBM, fused kernels, flash attention); everything that is trained or differentiated through
@@ -755,7 +755,7 @@ class Stage3Trainer(_TrainerState):
         self.model, self.dev, self.world = model, device, world
         assert all(p.is_cuda for p in model.parameters()), "move the model to the device first (model.to(device))"
         # model.precision "fp32" (default, exact) or "bf16x3": the FORWARD convolutions (incl. the frozen prior / VGG, about two
-        # thirds of the step) run on the split-bf16 kernel (fp32-grade); data / weight gradients stay on the f32 pipe
+        # thirds of the step) run on the split-bf16 kernel (fp32-grade, DESIGN_HISTORY.md §3.3); data / weight gradients stay on the f32 pipe
         assert model.precision in ("fp32", "bf16x3", "bf16"), "training supports precision fp32, bf16x3 or bf16 (bf16 data path for the frozen sub-networks)"
         self.opt = dict(opt_train)
         self.band_width = band_width

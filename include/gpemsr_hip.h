@@ -80,7 +80,12 @@ typedef struct {
                                       3 = WINOGRAD F(2x2, 3x3) form of a 3x3 stride-1 convolution (same result to fp32 rounding, 16/36 of
                                       the multiplies; csrc/conv_wino.hip): every source c % 8 == 0, cout % 32 == 0, no pixel_shuffle /
                                       gn_partials / cos_partials; weight = U[16 positions][cout][cin] = G g G^T
-                                      (gpemsr_amd/packing.py::pack_winograd) */
+                                      (gpemsr_amd/packing.py::pack_winograd).
+                                      4 = 1-D WINOGRAD F(2, 7) form of a 7x7 stride-1 convolution along the image rows (SpyNet's 32 -> 64 and
+                                      64 -> 32 layers, basicsr spynet_arch.BasicModule via R:model/GPEMSR.py:67,98-100; same result to fp32
+                                      rounding, 8/14 of the multiplies; csrc/conv7_wino.hip): ONE source with c % 8 == 0, cout % 32 == 0, no
+                                      residual / pixmul / pixel_shuffle / gn_partials / cos_partials; weight = U[cin/8][7 ky][8 nu][2][cout][4]
+                                      = G g per filter row (gpemsr_amd/packing.py::pack_winograd7) */
   const float* weight;             /* packed [tap][cout][cin_pad], tap = ky*k+kx, cin fastest, cin padded per source to 8
                                       (k>=3) or 32 (k=1).  transposed: [tap = 2*dy+dx][n' = (co/32)*128 + q*32 + co%32][cin_pad],
                                       q = 2*py+px, the phase-stacked 2x2-tap form (gpemsr_amd/packing.py::pack_convT) */

@@ -378,3 +378,48 @@ def test_volume_window_table_matches_the_reference_script():
     from gpemsr_amd.dist import volume_window_rows
     rows = volume_window_rows(7)
     assert rows == [[0, 0, 0, 1, 2], [0, 0, 1, 2, 3], [0, 1, 2, 3, 4], [1, 2, 3, 4, 5], [2, 3, 4, 5, 6], [3, 4, 5, 6, 6], [4, 5, 6, 6, 6]]
+
+
+def test_winograd_f27_transforms_are_an_exact_identity():
+    """The 1-D Winograd F(2, 7) form of the fp32 SpyNet 7x7 layers (csrc/conv7_wino.hip, packing.pack_winograd7): with G (host, float64) and the
+    B^T / A^T constants the kernel hard-codes, [y0, y1] = A^T [(G g) (.) (B^T d)] is the correlation of 8 inputs with 7 taps -- in float64 to
+    1e-12; and a whole 7x7 convolution assembled from the packed U tensor (chunk / filter-row / position / quad layout) equals F.conv2d."""
+    import torch
+    import torch.nn.functional as F
+    from gpemsr_amd.packing import WINO7_AT, WINO7_G, pack_winograd7, wino7_bt
+    bt = wino7_bt()
+    # the constants of conv7_wino.hip, row by row
+    kernel_bt = torch.tensor([
+        [1, 0, -21 / 4, 0, 21 / 4, 0, -1, 0],
+        [0, -2 / 9, -2 / 9, 17 / 18, 17 / 18, -2 / 9, -2 / 9, 0],
+        [0, 2 / 9, -2 / 9, -17 / 18, 17 / 18, 2 / 9, -2 / 9, 0],
+        [0, 1 / 180, 1 / 360, -1 / 36, -1 / 72, 1 / 45, 1 / 90, 0],
+        [0, -1 / 180, 1 / 360, 1 / 36, -1 / 72, -1 / 45, 1 / 90, 0],
+        [0, 64 / 45, 128 / 45, -16 / 9, -32 / 9, 16 / 45, 32 / 45, 0],
+        [0, -64 / 45, 128 / 45, 16 / 9, -32 / 9, -16 / 45, 32 / 45, 0],
+        [0, -1, 0, 21 / 4, 0, -21 / 4, 0, 1]], dtype=torch.float64)
+    assert float((bt - kernel_bt).abs().max()) < 1e-12
+    g = torch.Generator().manual_seed(5)
+    d = torch.rand(8, generator=g, dtype=torch.float64) - 0.5
+    taps = torch.rand(7, generator=g, dtype=torch.float64) - 0.5
+    y = WINO7_AT @ ((WINO7_G @ taps) * (kernel_bt @ d))
+    want = torch.stack([(d[0:7] * taps).sum(), (d[1:8] * taps).sum()])
+    assert float((y - want).abs().max()) < 1e-12
+    # whole layer through the packed tensor: U[chunk][ky][nu][quad][cout][4]
+    cin, cout, h, w = 16, 32, 6, 12
+    x = torch.rand(1, cin, h, w, generator=g, dtype=torch.float64) - 0.5
+    wt = torch.rand(cout, cin, 7, 7, generator=g, dtype=torch.float64) - 0.5
+    U = pack_winograd7(wt, "cpu").double()                                # (rounded to fp32 on the way: 1e-7)
+    assert tuple(U.shape) == (cin // 8, 7, 8, 2, cout, 4)
+    Uc = U.permute(1, 2, 4, 0, 3, 5).reshape(7, 8, cout, cin)             # [ky][nu][cout][cin]
+    xp = F.pad(x, (3, 3, 3, 3))[0]                                         # [cin][h+6][w+6]
+    out = torch.zeros(cout, h, w, dtype=torch.float64)
+    for yy in range(h):
+        for j in range(w // 2):
+            M = torch.zeros(8, cout, dtype=torch.float64)
+            for ky in range(7):
+                V = torch.einsum("pi,ci->pc", kernel_bt, xp[:, yy + ky, 2 * j:2 * j + 8])       # [nu][cin]
+                M += torch.einsum("pc,poc->po", V, Uc[ky])
+            out[:, yy, 2 * j:2 * j + 2] = (WINO7_AT @ M).T
+    ref = F.conv2d(x, wt, None, 1, 3)[0]
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6

@@ -603,6 +603,32 @@ def test_conv7_cout16_row_pair_form(n, cin, h, w, res):
     _close(got.nchw(), plain, tol=2e-6, what="row-pair 7x7 vs the plain kernel")
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,act", [(2, 32, 64, 16, 64, 1), (1, 64, 32, 37, 130, 1), (3, 32, 32, 8, 64, 0), (1, 8, 96, 5, 70, 2), (2, 64, 64, 64, 128, 1),
+                                                (1, 32, 64, 3, 200, 1)])
+def test_conv7_winograd_row_form(n, cin, cout, h, w, act):
+    """gpemsr_conv2d with descriptor.transposed = 4 (csrc/conv7_wino.hip, packing.pack_winograd7): Conv2d(cin -> cout, 7x7, pad 3) + bias +
+    activation in the 1-D Winograd F(2, 7) form (SpyNet's 32 -> 64 / 64 -> 32 layers, basicsr BasicModule via R:model/GPEMSR.py:67,98-100)
+    == the float64 convolution to 2e-5 of the result and the direct fp32 kernel to the same; ragged heights (not a multiple of the 4-row
+    tile) and widths (not a multiple of 64), both cout forms (32 and 64 per workgroup), one / eight chunks, run-to-run bit-stable."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd7
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=900 + h)
+    wt = _rand(cout, cin, 7, 7, seed=901, scale=1.0 / (7 * cin ** 0.5)); b = _rand(cout, seed=902)
+    pc = pack_conv(wt, b, dev)
+    pc.wino7 = pack_winograd7(wt, dev)
+    xa = _to_act(x, dev)
+    assert ops.winograd7_ok([xa], pc)
+    direct = ops.conv2d([xa], pc, act, direct7=True).nchw().clone()
+    got = ops.conv2d([xa], pc, act)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 3)
+    want = {0: want, 1: torch.relu(want), 2: F.leaky_relu(want, 0.1)}[act]
+    _close(got.nchw(), want.float(), tol=2e-5, what="F(2,7) row form vs fp64")
+    _close(got.nchw(), direct, tol=2e-5, what="F(2,7) row form vs the direct kernel")
+    again = ops.conv2d([xa], pc, act)
+    assert torch.equal(got.buf, again.buf)
+
+
 @pytest.mark.parametrize("n,cin,cout,k,h,w", [(2, 64, 64, 3, 37, 70), (1, 128, 256, 3, 20, 36), (3, 64, 512, 1, 16, 16), (1, 32, 128, 3, 64, 64), (2, 64, 32, 3, 9, 50)])
 def test_groupnorm_statistics_from_the_fp32_conv_epilogue(n, cin, cout, k, h, w):
     """gpemsr_conv_desc.gn_partials: the conv output is unchanged (bit for bit) and groupnorm_relu on it -- now finish + apply, no

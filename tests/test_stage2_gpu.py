@@ -147,7 +147,7 @@ def test_two_stage2_steps_match_reference_golden(golden_dir):
             continue
         errs[k] = max(abs(g.norm().item() - want[0]), abs((g * projection(k, g.numel())).sum().item() - want[2])) / want[0]
     print("stage-2 gradient parity, worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:4], "median %.1e" % np.median(list(errs.values())))
-    assert max(errs.values()) <= 2e-2 and np.median(list(errs.values())) <= 1e-3       # ReLU kinks, as in stage 3
+    assert max(errs.values()) <= 2e-2 and np.median(list(errs.values())) <= 1e-3       # ReLU kinks, as in stage 3 (DESIGN_HISTORY.md §3.6)
     for k in FULL:
         base, leaf = ("refmodel." + k).rsplit(".", 1)
         g = (tr.gw if leaf == "weight" else tr.gb)[base].detach().cpu().reshape(d["grad__" + k].shape)

@@ -28,7 +28,7 @@ def test_schedulers_match_reference(golden_dir):
 def test_oracle_autograd_matches_reference_golden(golden_dir):
     """The CPU restatement (forward + stage3_losses) under torch autograd against the reference's training step: losses and
     the gradient statistics of all trainable tensors.  Tolerances as in tests/test_train_gpu.py (the gradient is piecewise:
-    kinks move single elements when rounding differs)."""
+    kinks move single elements when rounding differs, DESIGN_HISTORY.md §3.6)."""
     import yaml
     from train_constants import TRAIN_OPT, projection
     from gpemsr_amd.arch import param_specs

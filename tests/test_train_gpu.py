@@ -12,7 +12,7 @@ Three layers of evidence:
 Tolerance of (3): the code indices and SpyNet flows of the frozen sub-networks are teacher-forced.  What remains is the
 conditioning of the gradient itself: LeakyReLU/ReLU kinks, max-pool arg-maxes and the floor() of the deformable sampling
 make it piecewise -- perturbing the weights by 1e-7 (relative) moves some POD-side gradient tensors by 2e-3 in the CPU
-oracle itself, and ONE flipped sign in a 4x4x64 map of the ThreeDA attention pyramid moves that
+oracle itself (DESIGN_HISTORY.md §3.6), and ONE flipped sign in a 4x4x64 map of the ThreeDA attention pyramid moves that
 branch's tensors by 1/sqrt(2048) = 2e-2.  So the reconstruction trunk and upsampler (large maps, no amplification) are held
 to 1e-3, every other tensor to 6e-2 with the median below 3e-3 and the 90th percentile below 1.5e-2, and the kernels are
 pinned by (1) and (2) at 1e-5 .. 5e-5."""
