@@ -603,7 +603,7 @@ def test_conv7_cout16_row_pair_form(n, cin, h, w, res):
     _close(got.nchw(), plain, tol=2e-6, what="row-pair 7x7 vs the plain kernel")
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w,act", [(2, 32, 64, 16, 64, 1), (1, 64, 32, 37, 130, 1), (3, 32, 32, 8, 64, 0), (1, 8, 96, 5, 70, 2), (2, 64, 64, 64, 128, 1),
+@pytest.mark.parametrize("n,cin,cout,h,w,act", [(2, 32, 64, 16, 64, 1), (1, 64, 32, 37, 130, 1), (3, 32, 32, 8, 64, 0), (1, 8, 64, 5, 70, 2), (4, 8, 32, 64, 64, 1), (2, 64, 64, 64, 128, 1),
                                                 (1, 32, 64, 3, 200, 1)])
 def test_conv7_winograd_row_form(n, cin, cout, h, w, act):
     """gpemsr_conv2d with descriptor.transposed = 4 (csrc/conv7_wino.hip, packing.pack_winograd7): Conv2d(cin -> cout, 7x7, pad 3) + bias +
