@@ -10,7 +10,8 @@
 //
 //   * workgroup = 8 waves, output tile 4 rows x 64 pixels (32 pairs = one MFMA row tile) x 32 NT couts; wave (yw = w & 3, vh = w >> 2)
 //     owns output row yw and the positions nu = 4 vh .. 4 vh + 3: 4 NT accumulator tiles;
-//   * per chunk of 8 input channels: (T) all threads transform the 10 raw halo rows into V[row][nu][quad][pair] in LDS -- the transform of an
+//   * per chunk of 8 input channels: (T) all threads transform the 10 raw halo rows into V[row][nu][quad][pair] in LDS (rows 8 and 9 cut
+//     into position pairs so that every thread has work in both rounds) -- the transform of an
 //     input row is shared by the 7 filter rows and all couts that use it (30 vector operations per 8 outputs and channel: rows 1/2, 3/4, 5/6
 //     of B^T are even +- odd parts); (M) seven steps ky = 0..6: wave yw multiplies V[yw + ky] with the weight slab U[ky] -- one float4 of V
 //     and one of U per four MFMAs;
@@ -162,36 +163,57 @@ __global__ __launch_bounds__(512, 1) void conv7_wino_f32_kernel(W7Params P) {
   const unsigned u_frag = (unsigned)(W7_U_OFF + (((4 * vh) * 2 + lh) * CO + li) * 16);
 
   for (int c = 0; c < nchunks; ++c) {
-    // ---- (T) input transform of chunk c: item (row, quad, pair); threads 0-127 take rows 8 and 9 as a second item ----
+    // ---- (T) input transform of chunk c.  Round 1: item (row 0..7, quad, pair) per thread, all eight positions.  Round 2: rows 8 and 9 are
+    // only 128 items -- each is cut into four position pairs (0,7), (1,2), (3,4), (5,6) so that all 512 threads work (a second full round
+    // for a quarter of the threads cost as much as the first) ----
     {
       const char* rawb = wsm + W7_RAW_OFF + (c & 1) * W7_RAW_BYTES;
       const int j = tid & 31, q = (tid >> 5) & 1;
-#pragma unroll 1
-      for (int it = 0; it < 2; ++it) {
-        const int row = (tid >> 6) + 8 * it;
-        if (row >= W7_ROWS) break;
-        float4 d[8];
+      auto load8 = [&](int row, float4 (&d)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           d[i] = *reinterpret_cast<const float4*>(rawb + ((((q * 2 + (i & 1)) * W7_ROWS + row) * W7_C2) + j + (i >> 1)) * 16);
-        char* vb = wsm + ((row * 8 * 2 + q) * 32 + j) * 16;          // + nu * (2 * 32 * 16)
-        // B^T d  (points 0, +-1, +-2, +-1/2, infinity; rows 1/2, 3/4, 5/6 = even part +- odd part)
-        const float4 v0 = W7_F4(-, w7_fma(5.25f, W7_F4(-, d[4], d[2]), d[0]), d[6]);
-        const float4 v7 = W7_F4(-, w7_fma(5.25f, W7_F4(-, d[3], d[5]), d[7]), d[1]);
-        const float4 e1 = w7_fma(17.f / 18.f, d[4], w7_mul(-2.f / 9.f, W7_F4(+, d[2], d[6])));
-        const float4 o1 = w7_fma(17.f / 18.f, d[3], w7_mul(-2.f / 9.f, W7_F4(+, d[1], d[5])));
-        const float4 e3 = w7_fma(1.f / 360.f, d[2], w7_fma(-1.f / 72.f, d[4], w7_mul(1.f / 90.f, d[6])));
-        const float4 o3 = w7_fma(1.f / 180.f, d[1], w7_fma(-1.f / 36.f, d[3], w7_mul(1.f / 45.f, d[5])));
-        const float4 e5 = w7_fma(128.f / 45.f, d[2], w7_fma(-32.f / 9.f, d[4], w7_mul(32.f / 45.f, d[6])));
-        const float4 o5 = w7_fma(64.f / 45.f, d[1], w7_fma(-16.f / 9.f, d[3], w7_mul(16.f / 45.f, d[5])));
-        *reinterpret_cast<float4*>(vb + 0 * 1024) = v0;
-        *reinterpret_cast<float4*>(vb + 1 * 1024) = W7_F4(+, e1, o1);
-        *reinterpret_cast<float4*>(vb + 2 * 1024) = W7_F4(-, e1, o1);
-        *reinterpret_cast<float4*>(vb + 3 * 1024) = W7_F4(+, e3, o3);
-        *reinterpret_cast<float4*>(vb + 4 * 1024) = W7_F4(-, e3, o3);
-        *reinterpret_cast<float4*>(vb + 5 * 1024) = W7_F4(+, e5, o5);
-        *reinterpret_cast<float4*>(vb + 6 * 1024) = W7_F4(-, e5, o5);
-        *reinterpret_cast<float4*>(vb + 7 * 1024) = v7;
+      };
+      // B^T d  (points 0, +-1, +-2, +-1/2, infinity; rows 1/2, 3/4, 5/6 = even part +- odd part); sel: -1 all, else the pair 0..3
+      auto transform = [&](const float4 (&d)[8], char* vb, const int sel) {
+        if (sel < 0 || sel == 0) {
+          *reinterpret_cast<float4*>(vb + 0 * 1024) = W7_F4(-, w7_fma(5.25f, W7_F4(-, d[4], d[2]), d[0]), d[6]);
+          *reinterpret_cast<float4*>(vb + 7 * 1024) = W7_F4(-, w7_fma(5.25f, W7_F4(-, d[3], d[5]), d[7]), d[1]);
+        }
+        if (sel < 0 || sel == 1) {
+          const float4 e1 = w7_fma(17.f / 18.f, d[4], w7_mul(-2.f / 9.f, W7_F4(+, d[2], d[6])));
+          const float4 o1 = w7_fma(17.f / 18.f, d[3], w7_mul(-2.f / 9.f, W7_F4(+, d[1], d[5])));
+          *reinterpret_cast<float4*>(vb + 1 * 1024) = W7_F4(+, e1, o1);
+          *reinterpret_cast<float4*>(vb + 2 * 1024) = W7_F4(-, e1, o1);
+        }
+        if (sel < 0 || sel == 2) {
+          const float4 e3 = w7_fma(1.f / 360.f, d[2], w7_fma(-1.f / 72.f, d[4], w7_mul(1.f / 90.f, d[6])));
+          const float4 o3 = w7_fma(1.f / 180.f, d[1], w7_fma(-1.f / 36.f, d[3], w7_mul(1.f / 45.f, d[5])));
+          *reinterpret_cast<float4*>(vb + 3 * 1024) = W7_F4(+, e3, o3);
+          *reinterpret_cast<float4*>(vb + 4 * 1024) = W7_F4(-, e3, o3);
+        }
+        if (sel < 0 || sel == 3) {
+          const float4 e5 = w7_fma(128.f / 45.f, d[2], w7_fma(-32.f / 9.f, d[4], w7_mul(32.f / 45.f, d[6])));
+          const float4 o5 = w7_fma(64.f / 45.f, d[1], w7_fma(-16.f / 9.f, d[3], w7_mul(16.f / 45.f, d[5])));
+          *reinterpret_cast<float4*>(vb + 5 * 1024) = W7_F4(+, e5, o5);
+          *reinterpret_cast<float4*>(vb + 6 * 1024) = W7_F4(-, e5, o5);
+        }
+      };
+      {
+        const int row = tid >> 6;                              // 0..7
+        float4 d[8];
+        load8(row, d);
+        transform(d, wsm + ((row * 8 * 2 + q) * 32 + j) * 16, -1);
+      }
+      {
+        const int row = 8 + ((tid >> 6) & 1), sub = wave >> 1;  // (wave-uniform)
+        float4 d[8];
+        load8(row, d);
+        char* vb = wsm + ((row * 8 * 2 + q) * 32 + j) * 16;
+        if (sub == 0) transform(d, vb, 0);
+        else if (sub == 1) transform(d, vb, 1);
+        else if (sub == 2) transform(d, vb, 2);
+        else transform(d, vb, 3);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

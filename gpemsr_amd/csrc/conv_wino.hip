@@ -23,74 +23,9 @@
 //
 // Replaces gpemsr_conv2d's direct form for the 3x3 stride-1 layers of R:model/GPEMSR.py:323-456 whose sources are multiples of 8
 // channels and whose cout is a multiple of 32 (descriptor.transposed = 3; weight = packing.pack_winograd).
-#include "common.h"
-#include <stdlib.h>
+#include "conv_wino.h"
 
 namespace gpemsr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// timing hooks of scripts/attic/wino_probe.py exist only in a probe build (results are wrong on purpose with any of them set)
-#ifdef GPEMSR_WINO_PROBE
-#define WINO_DBG(P) ((P).dbg)
-#else
-#define WINO_DBG(P) 0
-#endif
-struct WinoParams {
-  const float* src[GPEMSR_MAX_SRC];
-  long long img_stride[GPEMSR_MAX_SRC];
-  int ld[GPEMSR_MAX_SRC];
-  int c[GPEMSR_MAX_SRC];
-  int nsrc;
-  int n, h, w;
-  int cin_pad, cout;
-  const float* weight;            // U [16][cout][cin_pad]
-  const float* bias; int act;
-  const float* residual; int res_ld;
-  const float* pixmul;
-  float* out; int out_ld;
-  int tiles_x, tiles_y, tiles_n;
-  int nblocks;
-  int tn_group;                   // wide kernel: cout blocks of one pixel tile that are neighbours in the launch order (divides tiles_n)
-  float* gn_ws; int gn_parts;     // wide kernel: GroupNorm partial sums of (conv + bias) per (tile, channel): [n][gn_parts][cout][2] (conv_mfma.hip XEPI = 1)
-  float* cos_ws;                  // wide kernel, cout == 64: patch-cosine partial sums against `residual` INSTEAD of storing (conv_mfma.hip XEPI = 2)
-  int pixshuf, cq;                // wide kernel: store as PixelShuffle(2) (cout index = (2i + j) * cq + c, out is [n][2h][2w][cq])
-  int dbg;                        // timing experiments only, compiled in with -DGPEMSR_WINO_PROBE (scripts/attic/wino_probe.py; GPEMSR_WINO_DBG): 1 no fragment reads, 2 no barriers, 4 no DMA after the prologue
-};
-
-constexpr int WN_HH = 18, WN_HW2 = 17;                       // halo rows, halo columns per parity
-constexpr int WN_ASLOTS = 2 * 2 * WN_HH * WN_HW2;            // 1224 16-byte slots: [quad][parity][row][col / 2]
-constexpr int WN_ABYTES = WN_ASLOTS * 16;                    // 19,584
-constexpr int WN_BSLOTS = 16 * 32 * 2;                       // [pos][cout][quad]
-constexpr int WN_BBYTES = WN_BSLOTS * 16;                    // 16,384
-constexpr int WN_STAGE = WN_ABYTES + WN_BBYTES;              // 35,968
-constexpr int WN_RING = 4;
-constexpr int WN_NA = (WN_ASLOTS + 511) / 512;               // 3 slots per thread
-constexpr int WN_NB = WN_BSLOTS / 512;                       // 2
-constexpr int WN_EPIX = 36;                                  // floats per (tile) row of the exchange buffer: 32 couts + 4 (bank spread)
-constexpr int WN_EBYTES = 4 * 2 * 128 * WN_EPIX * 4;         // 147,456
-
-__device__ __forceinline__ void wn_glds16(unsigned voff, const void* base, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
-}
-__device__ __forceinline__ void wn_wait_vmcnt(int n) {
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-  }
-}
 
 __global__ __launch_bounds__(512, 2) void conv_wino_f32_kernel(WinoParams P) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];
@@ -323,15 +258,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f32_kernel(WinoParams P) {
 // three; ALL fragments of chunk c + 1 (the row-combined image rows and the eight U fragments) are read during stage c, so chunk c's
 // slot is free at the top of stage c and receives chunk c + 3.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int W2_HH = 10;
-constexpr int W2_ASLOTS = 2 * 2 * W2_HH * WN_HW2;            // 680
-constexpr int W2_ABYTES = W2_ASLOTS * 16;                    // 10,880
-constexpr int W2_BSLOTS = 16 * 64 * 2;                       // 2048
-constexpr int W2_BBYTES = W2_BSLOTS * 16;                    // 32,768
-constexpr int W2_STAGE = W2_ABYTES + W2_BBYTES;              // 43,648
-constexpr int W2_RING = 3;
-constexpr int W2_EPIX = 68;
-constexpr int W2_EBYTES = 4 * 2 * 64 * W2_EPIX * 4;          // 139,264
 
 // ASYM: only waves 0-3 (one per SIMD) issue the LDS-DMA of a stage, twice as many instructions each; waves 4-7 go straight to their
 // MFMAs.  The DMA intake of a CU is ~27 B/clk whoever issues (43 KB per stage = ~1,600 of the stage's 4,096 matrix clocks) and an issuing wave
@@ -680,7 +606,12 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
   static int force1 = -1;
   if (force1 < 0) { const char* e = getenv("GPEMSR_WINO_FORM"); force1 = (e && e[0] == '1') ? 1 : 0; }      // A/B: the 32-cout kernel everywhere
   const bool wide = d->cout % 64 == 0 && (!force1 || d->pixel_shuffle || d->cos_partials || d->gn_partials);      // 64 couts per workgroup: one vector operation per MFMA instead of two
-  if (name_buf) { snprintf(name_buf, (size_t)name_cap, wide ? "conv_wino2_f32_kernel" : "conv_wino_f32_kernel"); return GPEMSR_OK; }
+  // 64-cout form with a chunk count = 2 (mod 3), even, >= 8 (64-channel layers: 8; 256 channels: 32): the persistent kernel overlaps the next
+  // tile's first chunks with the last two stages and the epilogue of the current one (conv_wino_p.hip).  GPEMSR_WINO_PERSIST=0: one tile per workgroup.
+  const char* pe = getenv("GPEMSR_WINO_PERSIST");             // (read per launch: A/B runs switch it inside one process)
+  const int nch = cin / 8;
+  const bool persist = wide && !(pe && pe[0] == '0') && nch >= 8 && nch % 3 == 2 && nch % 2 == 0;
+  if (name_buf) { snprintf(name_buf, (size_t)name_cap, wide ? (persist ? "conv_wino2p_f32_kernel" : "conv_wino2_f32_kernel") : "conv_wino_f32_kernel"); return GPEMSR_OK; }
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cin_pad = cin; P.cout = d->cout;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;
   P.out = d->out; P.out_ld = d->out_ld;
@@ -703,6 +634,8 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
     P.tn_group = 1;
     for (int a = 4; a >= 2; a >>= 1) if (a <= grp && P.tiles_n % a == 0) { P.tn_group = a; break; }
   }
+  P.mg_g = 0xFFFFFFFFu / (unsigned)P.tn_group; P.mg_x = 0xFFFFFFFFu / (unsigned)P.tiles_x; P.mg_y = 0xFFFFFFFFu / (unsigned)P.tiles_y;
+  P.mg_n = 0xFFFFFFFFu / (unsigned)d->n;
   static dev_once_t attr{0};
   if (dev_once_begin(attr)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -711,6 +644,7 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
       return fail(GPEMSR_ELAUNCH, "conv2d (Winograd form): cannot raise the dynamic LDS limit");
     dev_once_done(attr);
   }
+  if (persist) return launch_wino2_persistent(P, reinterpret_cast<hipStream_t>(stream));
   if (wide) {
     const size_t lds2 = (size_t)(W2_EBYTES > W2_RING * W2_STAGE ? W2_EBYTES : W2_RING * W2_STAGE) + 4096;     // + the partial sums' cross-wave exchange
     const char* es = getenv("GPEMSR_WINO_SYM");

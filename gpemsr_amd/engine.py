@@ -95,7 +95,8 @@ class Engine:
         # weights of a trainable layer are not a permutation of its master weights, so the one-gather repack cannot refresh them).
         # GPEMSR_WINOGRAD=0: the direct form everywhere.
         self.winograd = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD", "1") != "0"
-        # exact-fp32 path: 7x7 stride-1 layers with cin % 8 == 0 and cout % 32 == 0 (SpyNet 8 -> 32, 32 -> 64, 64 -> 32) in the 1-D Winograd
+        # exact-fp32 path: 7x7 stride-1 layers with cin >= 32 (% 8 == 0) and cout % 32 == 0 (SpyNet 32 -> 64, 64 -> 32; the one-chunk 8 -> 32 stems measured
+        # no faster: 4.9 vs 5.0 ms, GPEMSR_WINOGRAD7_MIN_CIN=8 enables them) in the 1-D Winograd
         # F(2, 7) row form (8 instead of 14 multiplies per output pair and filter row, fp32 arithmetic; csrc/conv7_wino.hip).  GPEMSR_WINOGRAD7=0: direct form.
         self.winograd7 = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD7", "1") != "0"
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
@@ -224,7 +225,7 @@ class Engine:
                     and all(c % 8 == 0 for c in self.pc[name].splits)):
                 self.pc[name].wino = pack_winograd(w, dev, pixel_shuffle=name in ps)      # Winograd form of the 3x3 stride-1 layers (fp32 path)
             if (self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1
-                    and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "8"))):
+                    and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32"))):
                 self.pc[name].wino7 = pack_winograd7(w, dev)          # 1-D Winograd F(2, 7) form of SpyNet's 32 <-> 64 7x7 layers (fp32 path)
             if self.bf16 and tuple(w.shape) == (1, 64, 3, 3):
                 self.pc[name].wtap = pack_cout1_taps(w, dev)            # 64 -> 1 on the matrix cores (csrc/tap_sum.hip)

@@ -673,6 +673,56 @@ def test_winograd_launch_variants_are_bit_identical(sym, group, monkeypatch):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("n,cins,cout,h,w,mode", [(3, (64,), 64, 37, 70, "res"), (40, (64,), 64, 64, 96, "plain"), (2, (64, 128, 64), 128, 19, 45, "plain"),
+                                                  (6, (64,), 256, 40, 64, "ps"), (9, (64,), 64, 48, 64, "gn"), (5, (64,), 64, 32, 64, "cos")])
+def test_persistent_winograd_kernel_equals_the_one_tile_kernel(n, cins, cout, h, w, mode, monkeypatch):
+    """conv_wino2p_f32_kernel (csrc/conv_wino_p.hip: workgroups walk tiles, the next tile's first chunks land under the current tile's last two
+    stages and its epilogue; chunk counts = 2 mod 3, i.e. the 64- and 256-channel layers) against conv_wino2_f32_kernel (GPEMSR_WINO_PERSIST=0):
+    bit for bit -- same arithmetic, only who waits for what changes -- for the plain / residual + multiplier / PixelShuffle stores, the
+    GroupNorm partial sums and the patch-cosine sums; more tiles than workgroups (40 x 8 x 3 = 960), ragged tiles, three sources."""
+    import ctypes as C
+    from gpemsr_amd import _abi, ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd
+    dev = _dev()
+    cin = sum(cins)
+    x = _rand(n, cin, h, w, seed=41)
+    wt = _rand(cout, cin, 3, 3, seed=42, scale=1.0 / np.sqrt(cin * 9)); b = _rand(cout, seed=43, scale=0.1)
+    ps = mode == "ps"
+    pc = pack_conv(wt, b, dev, cins, pixel_shuffle=ps)
+    pc.wino = pack_winograd(wt, dev, pixel_shuffle=ps)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(_to_act(x[:, o:o + c], dev)); o += c
+    kw = {}
+    if mode == "res":
+        kw = dict(residual=_to_act(_rand(n, cout, h, w, seed=44), dev), pixmul=ops.Act((_rand(n, 1, h, w, seed=45).abs() + 0.5).reshape(-1).to(dev), n, h, w, 1, 1, 0))
+    elif mode == "gn":
+        kw = dict(gn_stats=True)
+    elif mode == "cos":
+        kw = dict(cos_with=_to_act(_rand(n, cout, h, w, seed=46).abs(), dev))
+
+    def run():
+        r = ops.conv2d(srcs, pc, ops.ACT_NONE if mode == "gn" else ops.ACT_RELU, winograd=True, **kw)
+        extra = r.gn[0].clone() if mode == "gn" else None
+        return r.nchw().clone(), extra
+    monkeypatch.setenv("GPEMSR_WINO_PERSIST", "0")
+    want, want_gn = run()
+    monkeypatch.delenv("GPEMSR_WINO_PERSIST")
+    got, got_gn = run()
+    assert torch.equal(got, want), float((got - want).abs().max())
+    if mode == "gn":
+        assert torch.equal(got_gn, want_gn)
+    # ... and the library really picked the persistent kernel for this descriptor
+    d = _abi.ConvDesc()
+    d.n, d.h, d.w, d.nsrc = n, h, w, len(srcs)
+    for i, s_ in enumerate(srcs):
+        d.src[i].ptr, d.src[i].ld, d.src[i].c = s_.ptr, s_.ld, s_.c
+        d.src_image_stride[i] = -1
+    d.cout, d.ksize, d.stride, d.transposed, d.weight, d.out, d.out_ld = cout, 3, 1, 3, pc.wino.data_ptr(), srcs[0].ptr, cout
+    buf = C.create_string_buffer(160)
+    assert _abi.load().gpemsr_conv2d_kernel_name(C.byref(d), buf, 160) == 0 and buf.value.decode() == "conv_wino2p_f32_kernel", buf.value
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 37, 70), (1, 128, 256, 20, 36), (1, 512, 512, 16, 16), (3, 128, 128, 8, 32), (1, 64, 64, 1, 1)])
 def test_groupnorm_statistics_from_the_winograd_epilogue(n, cin, cout, h, w):
     """gpemsr_conv_desc.gn_partials with transposed = 3 (csrc/conv_wino.hip, wide kernel): the conv output equals the Winograd launch without
