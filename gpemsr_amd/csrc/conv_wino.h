@@ -22,7 +22,7 @@ struct WinoParams {
   int nsrc;
   int n, h, w;
   int cin_pad, cout;
-  const float* weight;            // U [16][cout][cin_pad]
+  const float* weight;            // U [cin_pad / 8][16][cout][8]  (packing.pack_winograd)
   const float* bias; int act;
   const float* residual; int res_ld;
   const float* pixmul;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f32_kernel(WinoParams P) {
   for (int i = 0; i < WN_NB; ++i) {
     const int s = tid + i * 512;                       // [pos][cout][quad]
     const int qd = s & 1, co = (s >> 1) & 31, pos = s >> 6;
-    b_off[i] = (pos * P.cout + n0 + co) * P.cin_pad + 4 * qd;
+    b_off[i] = (pos * P.cout + n0 + co) * 8 + 4 * qd;            // inside one chunk's [position][cout][8] block of U
   }
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f32_kernel(WinoParams P) {
 #pragma unroll
     for (int i = 0; i < WN_NA; ++i)
       if (a_pix[i] >= 0) wn_glds16((unsigned)a_pix[i] * pixb + 16u * (unsigned)a_q[i], sp, la + i * 8192u);
-    const float* wp = P.weight + f_cpad + f_c0;
+    const float* wp = P.weight + (long long)(f_cpad + f_c0) * (16 * P.cout);      // chunk (f_cpad + f_c0) / 8 of U[cin / 8][16][cout][8]
 #pragma unroll
     for (int i = 0; i < WN_NB; ++i) wn_glds16((unsigned)b_off[i] * 4u, wp, la + (unsigned)WN_ABYTES + i * 8192u);
     ++f_chunk; f_c0 += 8;
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
     }
   }
   // U slot s = tid + i * NTI of [pos][cout 64][quad]: pos = (tid >> 7) + i * NTI / 128
-  const unsigned b_off0 = (unsigned)((((tid & (NTI - 1)) >> 7) * P.cout + n0 + ((tid >> 1) & 63)) * P.cin_pad + 4 * (tid & 1)) * 4u;
-  const unsigned b_step = (unsigned)((NTI / 128) * P.cout * P.cin_pad) * 4u;
+  const unsigned b_off0 = (unsigned)((((tid & (NTI - 1)) >> 7) * P.cout + n0 + ((tid >> 1) & 63)) * 8 + 4 * (tid & 1)) * 4u;
+  const unsigned b_step = (unsigned)((NTI / 128) * P.cout * 8) * 4u;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
   {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2_f32_kernel(WinoParams P) {
 #pragma unroll
       for (int i = 0; i < W2_NA; ++i)
         if (a_pk[i] >= 0) wn_glds16((unsigned)(a_pk[i] >> 1) * pixb + 16u * (unsigned)(a_pk[i] & 1), sp, la + i * (NTI * 16u));
-      const float* wp = P.weight + f_cpad + f_c0;
+      const float* wp = P.weight + (long long)(f_cpad + f_c0) * (16 * P.cout);      // chunk (f_cpad + f_c0) / 8 of U[cin / 8][16][cout][8]
       unsigned bo = b_off0;
       asm volatile("" : "+v"(bo));                       // opaque: eight hoisted offsets would not fit the register file
 #pragma unroll
@@ -606,11 +606,15 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
   static int force1 = -1;
   if (force1 < 0) { const char* e = getenv("GPEMSR_WINO_FORM"); force1 = (e && e[0] == '1') ? 1 : 0; }      // A/B: the 32-cout kernel everywhere
   const bool wide = d->cout % 64 == 0 && (!force1 || d->pixel_shuffle || d->cos_partials || d->gn_partials);      // 64 couts per workgroup: one vector operation per MFMA instead of two
-  // 64-cout form with a chunk count = 2 (mod 3), even, >= 8 (64-channel layers: 8; 256 channels: 32): the persistent kernel overlaps the next
-  // tile's first chunks with the last two stages and the epilogue of the current one (conv_wino_p.hip).  GPEMSR_WINO_PERSIST=0: one tile per workgroup.
+  // 64-cout form, 64 input channels (8 chunks; the kernel takes any even chunk count = 2 mod 3): the persistent kernel overlaps the next tile's
+  // first chunks with the last two stages and the epilogue of the current one (conv_wino_p.hip).  Measured per layer on one box
+  // (profiles/r05_winograd_persistent_layers.log): 64-channel layers +1-2 % (VGG relu1_2 76.8 -> 75.5 ms), 256-channel layers (32 chunks)
+  // 2 % SLOWER (its position-by-position MFMA order), so only the 8-chunk layers take it.  GPEMSR_WINO_PERSIST=0: one tile per workgroup;
+  // =2: every eligible chunk count.
   const char* pe = getenv("GPEMSR_WINO_PERSIST");             // (read per launch: A/B runs switch it inside one process)
   const int nch = cin / 8;
-  const bool persist = wide && !(pe && pe[0] == '0') && nch >= 8 && nch % 3 == 2 && nch % 2 == 0;
+  const int pmode = pe ? atoi(pe) : 1;
+  const bool persist = wide && pmode != 0 && nch >= 8 && nch % 3 == 2 && nch % 2 == 0 && (nch == 8 || pmode == 2);
   if (name_buf) { snprintf(name_buf, (size_t)name_cap, wide ? (persist ? "conv_wino2p_f32_kernel" : "conv_wino2_f32_kernel") : "conv_wino_f32_kernel"); return GPEMSR_OK; }
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cin_pad = cin; P.cout = d->cout;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2p_f32_kernel(WinoParams P) {
   for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / 8;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
-  const unsigned b_step = (unsigned)((NTI / 128) * P.cout * P.cin_pad) * 4u;
+  const unsigned b_step = (unsigned)((NTI / 128) * P.cout * 8) * 4u;
 
   // ---- issue state: the tile whose chunks are being issued (the current one, or the next one during the last two stages) ----
   int a_pk[W2_NA];                                             // 2 * pixel + channel quad of the slot, -1: outside the image / not an issuer
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2p_f32_kernel(WinoParams P) {
     }
     n_issue = issuer ? na_w + W2_NB : 0;
     i_img = g.img;
-    b_off0 = (unsigned)((((tq & (NTI - 1)) >> 7) * P.cout + n0 + ((tq >> 1) & 63)) * P.cin_pad + 4 * (tq & 1)) * 4u;
+    b_off0 = (unsigned)((((tq & (NTI - 1)) >> 7) * P.cout + n0 + ((tq >> 1) & 63)) * 8 + 4 * (tq & 1)) * 4u;
     f_src = 0; f_c0 = 0; f_cpad = 0; f_slot = 0;
   };
   auto issue_chunk = [&]() {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino2p_f32_kernel(WinoParams P) {
         else if (tid + i * NTI < W2_ASLOTS)                  // zero padding of THIS tile (the slot may hold another tile's pixels)
           *reinterpret_cast<float4*>(wsm + f_slot * W2_STAGE + (tid + i * NTI) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      const float* wp = P.weight + f_cpad + f_c0;
+      const float* wp = P.weight + (long long)(f_cpad + f_c0) * (16 * P.cout);      // chunk (f_cpad + f_c0) / 8 of U[cin / 8][16][cout][8]
       unsigned bo = b_off0;
       asm volatile("" : "+v"(bo));                       // opaque: eight hoisted offsets would not fit the register file
 #pragma unroll

@@ -51,7 +51,7 @@ def pack_conv(w: torch.Tensor, b: Optional[torch.Tensor], device, splits: Option
 
 def pack_winograd(w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch.Tensor:
     """Conv2d(3x3) weight OIHW fp32 -> U = G g G^T for the Winograd F(2x2, 3x3) form of gpemsr_conv2d (descriptor.transposed = 3;
-    csrc/conv_wino.hip): [position p = 4 xi + nu][cout][cin] fp32, computed in float64 (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]).
+    csrc/conv_wino.hip): [cin / 8][position p = 4 xi + nu][cout][8] fp32, computed in float64 (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]).
     Concat sources need no padding here: the form requires every source to be a multiple of 8 channels."""
     cout, cin, kh, kw = w.shape
     assert kh == 3 and kw == 3
@@ -61,7 +61,10 @@ def pack_winograd(w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch
         cq = cout // 4
         g = g[torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)]
     U = torch.einsum("xa,ocab,yb->xyoc", G, g, G)                      # [xi][nu][cout][cin]
-    return U.reshape(16, cout, cin).to(torch.float32).contiguous().to(device)
+    # staged order [cin / 8][position][cout][8]: the 64 (32) couts of a workgroup's block are 2 KB (1 KB) of CONSECUTIVE memory per position and
+    # chunk, so every LDS-DMA instruction reads whole cache lines (round 4's [position][cout][cin] made each lane fetch an isolated 32-byte piece
+    # of a line whose other 96 bytes belonged to later chunks)
+    return U.reshape(16, cout, cin // 8, 8).permute(2, 0, 1, 3).to(torch.float32).contiguous().to(device)
 
 
 def pack_rowpair7(w: torch.Tensor, device) -> torch.Tensor:

@@ -79,8 +79,8 @@ typedef struct {
                                       (0 for ky' = 0) (gpemsr_amd/packing.py::pack_rowpair7); cout stays 16, out is h x w.
                                       3 = WINOGRAD F(2x2, 3x3) form of a 3x3 stride-1 convolution (same result to fp32 rounding, 16/36 of
                                       the multiplies; csrc/conv_wino.hip): every source c % 8 == 0, cout % 32 == 0, no pixel_shuffle /
-                                      gn_partials / cos_partials; weight = U[16 positions][cout][cin] = G g G^T
-                                      (gpemsr_amd/packing.py::pack_winograd).
+                                      gn_partials / cos_partials; weight = U[cin / 8][16 positions][cout][8] = G g G^T in the order the
+                                      kernel stages it (gpemsr_amd/packing.py::pack_winograd).
                                       4 = 1-D WINOGRAD F(2, 7) form of a 7x7 stride-1 convolution along the image rows (SpyNet's 32 -> 64 and
                                       64 -> 32 layers, basicsr spynet_arch.BasicModule via R:model/GPEMSR.py:67,98-100; same result to fp32
                                       rounding, 8/14 of the multiplies; csrc/conv7_wino.hip): ONE source with c % 8 == 0, cout % 32 == 0, no
