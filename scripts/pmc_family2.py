@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Fold rocprofv3 --pmc passes (one directory per counter set) of ONE bench.py command into the summary bench.py reads for
-`roofline.traffic` (profiles/r04_<precision>_pmc_summary.json):
+`roofline.traffic` (profiles/r05_<precision>_pmc_summary.json):
     python3 scripts/pmc_family2.py <dir with pass_*/> <out.json> <precision> <forward passes in the profiled command> "<note>"
 FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md, HBM section: 128-B requests
 tallied at 64 B).  Infinity-cache hits are counted as traffic by these counters, so the figures are an upper bound of DRAM bytes."""
 import collections, csv, glob, json, sys
 
 root, out_path, precision, passes, note = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
-FAMILY = {"fp32": ("conv_mfma_kernel", "conv_wino"), "bf16": ("conv_bf16_kernel", "conv64_resident", "convt64_resident", "conv7_c32_cout16", "conv7_c8_cout32", "vgg_mask", "flash_attn512")}[precision]
+FAMILY = {"fp32": ("conv_mfma_kernel", "conv_wino", "conv7_wino"),
+          "bf16": ("conv_bf16_kernel", "conv64_resident", "convt64_resident", "conv7_c32_cout16", "conv7_c8_cout32", "vgg_mask", "flash_attn512", "gemm_direct_bf16", "dcn_fused16")}[precision]
 per = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
