@@ -776,6 +776,9 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only,
   if (d->transposed == 3) {          // Winograd F(2x2, 3x3) form of a 3x3 stride-1 convolution (conv_wino.hip)
     return conv2d_winograd(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0, parts_only);
   }
+  if (d->transposed == 5) {          // Winograd F(4x4, 3x3) form of a 3x3 stride-1 convolution with many input channels (conv_wino4.hip)
+    return conv2d_winograd4(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0, parts_only);
+  }
   if (d->transposed == 4) {          // 1-D Winograd F(2, 7) form of a 7x7 stride-1 convolution (conv7_wino.hip)
     GP_REQUIRE(parts_only == nullptr, "conv2d (F(2,7) form): no GroupNorm partial sums");
     return conv2d_winograd7(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0);

@@ -30,7 +30,7 @@ import torch
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
 from .packing import (pack_conv, pack_conv_bf16, pack_dcn_rows_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3, pack_rowpair7,
-                      pack_vgg_first, pack_cout1_taps, pack_winograd, pack_winograd7, pack_conv7_c32_cout16, pack_conv7_c8_cout32, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
+                      pack_vgg_first, pack_cout1_taps, pack_winograd, pack_winograd4, pack_winograd7, pack_conv7_c32_cout16, pack_conv7_c8_cout32, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -99,6 +99,12 @@ class Engine:
         # no faster: 4.9 vs 5.0 ms, GPEMSR_WINOGRAD7_MIN_CIN=8 enables them) in the 1-D Winograd
         # F(2, 7) row form (8 instead of 14 multiplies per output pair and filter row, fp32 arithmetic; csrc/conv7_wino.hip).  GPEMSR_WINOGRAD7=0: direct form.
         self.winograd7 = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD7", "1") != "0"
+        # exact-fp32 path: 3x3 stride-1 layers with >= GPEMSR_WINOGRAD4_MIN_CIN (128) input channels and cout % 64 == 0 in the F(4x4,3x3) form (36
+        # instead of 144 multiplies per 4x4 outputs; ~2e-5 of the result at 512 channels; csrc/conv_wino4.hip).  GPEMSR_WINOGRAD4 = "decoder"
+        # (default): every such layer EXCEPT the indexer's, whose arg-max decides codebook entries and keeps the tighter F(2x2) rounding;
+        # "all": the indexer too; "0": F(2x2) everywhere.
+        self.winograd4 = os.environ.get("GPEMSR_WINOGRAD4", "0") if self.winograd else "0"
+        assert self.winograd4 in ("0", "decoder", "all"), f"GPEMSR_WINOGRAD4={self.winograd4!r}: 0 | decoder | all"
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.fuse_dcn = os.environ.get("GPEMSR_FUSE_DCN", "1") != "0"     # bf16 path: DCN sampling + contraction in one kernel (gpemsr_dcn_conv_bf16)
@@ -224,6 +230,9 @@ class Engine:
             if (self.winograd and self._wino_layer(name) and kk == 3 and w.shape[0] % 32 == 0 and (name not in ps or w.shape[0] % 64 == 0)
                     and all(c % 8 == 0 for c in self.pc[name].splits)):
                 self.pc[name].wino = pack_winograd(w, dev, pixel_shuffle=name in ps)      # Winograd form of the 3x3 stride-1 layers (fp32 path)
+                if (self.winograd4 != "0" and name not in ps and w.shape[0] % 64 == 0 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "128"))
+                        and (self.winograd4 == "all" or not name.startswith("refmodel.indexer."))):
+                    self.pc[name].wino4 = pack_winograd4(w, dev)                           # F(4x4,3x3) form of the many-channel layers
             if (self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1
                     and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32"))):
                 self.pc[name].wino7 = pack_winograd7(w, dev)          # 1-D Winograd F(2, 7) form of SpyNet's 32 <-> 64 7x7 layers (fp32 path)

@@ -216,6 +216,7 @@ class PackedConv:
     w7c16: Optional[torch.Tensor] = None   # bf16 data path, 32 -> 16 7x7: 16x16x32 MFMA fragments (packing.pack_conv7_c32_cout16)
     wino: Optional[torch.Tensor] = None    # fp32, 3x3 stride 1: Winograd F(2x2,3x3) weights U[16][cout][cin] (packing.pack_winograd; descriptor.transposed = 3)
     wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
+    wino4: Optional[torch.Tensor] = None   # fp32, 3x3 stride 1, >= 128 input channels: Winograd F(4x4,3x3) weights U[cin/8][36][2][cout][4] (packing.pack_winograd4; descriptor.transposed = 5)
     wino7: Optional[torch.Tensor] = None   # fp32, 7x7 stride 1: 1-D Winograd F(2, 7) weights U[cin/8][7][8][2][cout][4] (packing.pack_winograd7; descriptor.transposed = 4)
     wrows: Optional[torch.Tensor] = None   # bf16 data path, DCN 64 -> 64: plain rows [cout][9 taps][64 channels] bf16 (packing.pack_dcn_rows_bf16; csrc/dcn_bf16.hip)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
@@ -412,6 +413,9 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     if winograd and precision == "fp32" and winograd_ok(srcs, pc, stride, out, residual) and weight_image_stride == 0 and src_image_stride is None:
         d.transposed, d.weight = 3, pc.wino.data_ptr()          # 16 multiplies per 2x2 outputs instead of 36 (csrc/conv_wino.hip)
         executed = flops * 16.0 / 36.0
+        if winograd4_ok(srcs, pc, residual, pixmul):
+            d.transposed, d.weight = 5, pc.wino4.data_ptr()     # 36 multiplies per 4x4 outputs instead of 144 (csrc/conv_wino4.hip)
+            executed = flops * 36.0 / 144.0
     if (gn_stats and precision == "fp32" and act == ACT_NONE and residual is None and pixmul is None and not pc.transposed and not pc.pixel_shuffle
             and pc.cout % 4 == 0 and out.ld % 4 == 0 and out.ptr % 16 == 0 and (pc.b is None or pc.b.data_ptr() % 16 == 0)
             # the partial-sum epilogue exists only in the LDS-DMA instantiations (conv_mfma.hip: GP_REQUIRE(dma && BN >= 32)): sources it
@@ -439,6 +443,14 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     else:
         _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d")
     return out
+
+
+def winograd4_ok(srcs, pc: "PackedConv", residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
+    """Layers (among those winograd_ok accepts) the F(4x4, 3x3) form takes: `pc.wino4` packed (the engine packs it for layers of >= 128 input
+    channels), cout % 64 == 0, plain store, images of at least 16 x 32 pixels (one tile)."""
+    if pc.wino4 is None or pc.cout % 64 != 0 or pc.pixel_shuffle or residual is not None or pixmul is not None:
+        return False
+    return srcs[0].h >= 16 and srcs[0].w >= 32
 
 
 def winograd7_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:

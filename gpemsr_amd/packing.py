@@ -67,6 +67,25 @@ def pack_winograd(w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch
     return U.reshape(16, cout, cin // 8, 8).permute(2, 0, 1, 3).to(torch.float32).contiguous().to(device)
 
 
+# Winograd F(4x4, 3x3) with the points 0, +-1, +-2, infinity (Lavin & Gray's scaling: an integer B^T, the fractions in G) -- csrc/conv_wino4.hip
+WINO4_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                        [0, 0, 1]], dtype=torch.float64)
+WINO4_BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                         [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+WINO4_AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+
+
+def pack_winograd4(w: torch.Tensor, device) -> torch.Tensor:
+    """Conv2d(3x3) weight OIHW fp32 (cin % 8 == 0) -> U = G g G^T for the Winograd F(4x4, 3x3) form of gpemsr_conv2d (descriptor.transposed
+    = 5; csrc/conv_wino4.hip): [cin / 8][position p = 6 xi + nu][quad][cout][4] fp32, folded in float64.  A wave's fragment of one position
+    (32 couts x one quad) is 512 consecutive bytes: the kernel reads it straight into registers."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cin % 8 == 0
+    U = torch.einsum("xa,ocab,yb->xyoc", WINO4_G, w.detach().to(torch.float64).cpu(), WINO4_G)   # [xi][nu][cout][cin]
+    U = U.reshape(36, cout, cin // 8, 2, 4).permute(2, 0, 3, 1, 4)                                    # [chunk][p][quad][cout][4]
+    return U.to(torch.float32).contiguous().to(device)
+
+
 def pack_rowpair7(w: torch.Tensor, device) -> torch.Tensor:
     """Conv2d(cin -> 16, 7x7, stride 1, pad 3) fp32 weight -> the ROW-PAIR form of gpemsr_conv2d (descriptor.transposed = 2):
     out(2i, x) = sum_{ky'=0..6} in(2i-3+ky') W[ky'] and out(2i+1, x) = sum_{ky'=1..7} in(2i-3+ky') W[ky'-1] share the 8-row window of
