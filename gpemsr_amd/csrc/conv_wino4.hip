@@ -16,7 +16,7 @@
 //   * NO weights in LDS: a position is multiplied by exactly one wave, so its U rows go global -> registers (U is packed
 //     [cin / 8][36][quad][cout][4]: a wave's fragment is 512 consecutive bytes per quad), one chunk ahead, into the registers the
 //     previous chunk's fragments have just left; the raw halo image goes global -> registers -> LDS one chunk ahead too.  There is no LDS-DMA
-//     in this kernel, so every wait is the compiler's own and exact;
+//     in this kernel and no branch around a load, so every wait is the compiler's own and exact;
 //   * per chunk: (T1) the row transform B^T along x of the 18 x 34 halo image into X[row][nu][quad][block column] (576 items of one channel
 //     pair), (T2) the column transform into V[xi][nu][quad][block] (768 items: every thread one), (M) 24 MFMAs per wave from V and the
 //     register-held U; three barriers.  Pair-sized items keep the transform's transient registers at 24 beside the 96 accumulators;
@@ -33,6 +33,13 @@
 namespace gpemsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// timing experiments only (scripts/build_wino_probe_lib.sh compiles variants with -DW4_SKIP=mask; results are wrong on purpose):
+// 1 no T1, 2 no T2, 4 no MFMAs, 8 no U loads after the prologue, 16 no image loads after the prologue.  Compile-time: a run-time branch around a
+// load would make the compiler's vmcnt counts conservative and change what is being timed.
+#ifndef W4_SKIP
+#define W4_SKIP 0
+#endif
 
 struct W4Params {
   const float* src[GPEMSR_MAX_SRC];
@@ -51,14 +58,16 @@ struct W4Params {
 constexpr int W4_NT = 768;                                               // threads
 constexpr int W4_RAW_SLOTS = 2 * 4 * 18 * 9;                             // [quad][col & 3][row 18][col >> 2 (9)] = 1296 16-byte slots
 constexpr int W4_RAW_BYTES = W4_RAW_SLOTS * 16;                          // 20,736
-constexpr int W4_X_BYTES = 18 * 6 * 2 * 8 * 16;                          // X[row][nu][quad][block column]: 27,648
+constexpr int W4_XROW = 6 * 2 * 8 * 16 + 32;                             // X row stride: 1,536 + 32 bytes -- the four block rows a T2 wave reads (4 rows apart)
+                                                                         // then fall on alternating 128-byte bank halves instead of one (4-way conflict)
+constexpr int W4_X_BYTES = 18 * W4_XROW;                                 // X[row][nu][quad][block column]: 28,224
 constexpr int W4_V_BYTES = 36 * 2 * 32 * 16;                             // V[p][quad][block]: 36,864
 constexpr int W4_X_OFF = 2 * W4_RAW_BYTES, W4_V_OFF = W4_X_OFF + W4_X_BYTES;
-constexpr int W4_MAIN = W4_V_OFF + W4_V_BYTES;                           // 105,984
+constexpr int W4_MAIN = W4_V_OFF + W4_V_BYTES;                           // 106,560
 constexpr int W4_EPIX = 20;                                              // floats per (position, block) row of the exchange buffer: 16 couts + 4
 constexpr int W4_E_BYTES = 36 * 32 * W4_EPIX * 4;                        // 92,160 (overlays raw / X / V)
 constexpr int W4_RED_OFF = W4_MAIN;                                      // GroupNorm sums [32 blocks][64 couts][2]: 16,384
-constexpr int W4_LDS = W4_RED_OFF + 16384;                               // 122,368
+constexpr int W4_LDS = W4_RED_OFF + 16384;                               // 122,944
 
 // B^T of F(4, 3) (integer form): one 6-vector, component-wise on a channel pair
 __device__ __forceinline__ void w4_bt(const float2 (&d)[6], float2 (&t)[6]) {
@@ -106,7 +115,12 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / 8;
 
   // ---- raw halo image: two 16-byte slots per thread, slot s = tid + 768 i of [quad][col & 3][row][col >> 2]; pixel index or -1 ----
-  //      global -> LDS by DMA (no registers beside the 96 accumulators); a slot outside the image is zeroed by a plain store instead
+  //      global -> registers at the start of a chunk's MFMA phase -> LDS at its end (the phase is >= 4,600 matrix clocks per SIMD: longer than an
+  //      HBM round trip).  Every lane loads in every chunk -- a slot outside the image reads pixel 0 and is zeroed on its way to LDS, the last
+  //      chunk re-reads itself -- so no branch surrounds a load and the compiler's vmcnt counts are exact: the waits for the U fragments
+  //      leave the two younger image loads in flight.  (A first version fetched the image by LDS-DMA at the top of the chunk: the DMA is
+  //      invisible to those counts, the fragment waits became vmcnt(0) and every chunk stalled for the image's round trip -- 8.0 k instead
+  //      of 5.4 k clocks per chunk.)
   int r_pix[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -120,22 +134,28 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
       if (col < 34 && iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) r_pix[i] = iy * P.w + ix;
     }
   }
-  const unsigned r_q0 = tid >= W4_RAW_SLOTS / 2 ? 16u : 0u;   // byte offset of slot 0's quad (slot 1 = tid + 768 is always quad 1)
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm + (unsigned)wave * 1024u);
-  int f_src = 0, f_c0 = 0;                                    // source cursor of the chunk whose raw image is issued next
-  auto issue_raw = [&](int buf) {
+  const int r_q0 = tid >= W4_RAW_SLOTS / 2 ? 4 : 0;           // channel offset of slot 0's quad (slot 1 = tid + 768 is always quad 1)
+  int f_src = 0, f_c0 = 0;                                    // source cursor of the chunk whose raw image is loaded next
+  auto load_raw = [&](float4 (&rr)[2]) {
     const float* sp = P.src[f_src] + (long long)img * P.img_stride[f_src] + f_c0;
-    const unsigned pixb = (unsigned)P.ld[f_src] * 4u;
-    const unsigned la = lds0 + (unsigned)(buf * W4_RAW_BYTES);
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r_pix[0] >= 0) wn_glds16((unsigned)r_pix[0] * pixb + r_q0, sp, la);
-    else *reinterpret_cast<float4*>(wsm + buf * W4_RAW_BYTES + tid * 16) = zero;
-    if (tid + W4_NT < W4_RAW_SLOTS) {
-      if (r_pix[1] >= 0) wn_glds16((unsigned)r_pix[1] * pixb + 16u, sp, la + W4_NT * 16u);
-      else *reinterpret_cast<float4*>(wsm + buf * W4_RAW_BYTES + (tid + W4_NT) * 16) = zero;
-    }
+    const int ldp = P.ld[f_src];
+    rr[0] = *reinterpret_cast<const float4*>(sp + (long long)max(r_pix[0], 0) * ldp + r_q0);
+    rr[1] = *reinterpret_cast<const float4*>(sp + (long long)max(r_pix[1], 0) * ldp + 4);
+    asm volatile("" ::: "memory");                            // the image loads stay OLDER than the U loads that follow (vmcnt is in order)
     f_c0 += 8;
-    if (f_c0 >= P.c[f_src] && f_src + 1 < P.nsrc) { f_c0 = 0; ++f_src; }
+    if (f_c0 >= P.c[f_src]) {
+      if (f_src + 1 < P.nsrc) { f_c0 = 0; ++f_src; } else f_c0 -= 8;
+    }
+  };
+  auto store_raw = [&](int buf, const float4 (&rr)[2]) {      // (the zeroing is a bit mask: a select of two float4 made the compiler go through scratch)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = ~(r_pix[i] >> 31);
+      asm volatile("" : "+v"(m) :: "memory");                 // the masking (= the wait for the image loads) stays BEHIND the U loads of this chunk
+      const float4 v = make_float4(__int_as_float(__float_as_int(rr[i].x) & m), __int_as_float(__float_as_int(rr[i].y) & m),
+                                   __int_as_float(__float_as_int(rr[i].z) & m), __int_as_float(__float_as_int(rr[i].w) & m));
+      if (i == 0 || tid + W4_NT < W4_RAW_SLOTS) *reinterpret_cast<float4*>(wsm + buf * W4_RAW_BYTES + (tid + i * W4_NT) * 16) = v;
+    }
   };
   // ---- U fragments of this wave's three positions: lane (li = cout, lh = quad), [chunk][p][quad][cout][4] ----
   const float* u_lane = P.weight + ((long long)(3 * wave * 2 + lh) * P.cout + n0 + li) * 4;
@@ -155,21 +175,20 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
       for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
 
   // ---- prologue: raw image and U fragments of chunk 0 ----
-  float4 U[3][2];
-  issue_raw(0);
+  float4 U[3][2], rr[2];
+  load_raw(rr);
 #pragma unroll
   for (int j = 0; j < 3; ++j) load_u(0, j, U[j]);
-  wn_wait_vmcnt(0);
+  store_raw(0, rr);
   __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
-    const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U: no branch around the loads)
-    if (c + 1 < nchunks) issue_raw((c + 1) & 1);             // raw image of chunk c + 1: that buffer was last read by T1 of chunk c - 1
+    const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U and image: no branch around the loads)
     int tl = tid;                                            // opaque copy: the item addresses are recomputed per chunk (a few integer operations)
     asm volatile("" : "+v"(tl));                             // rather than hoisted out of the loop into registers the accumulators need
     const int hb = (tl & 1) * 8, t_bc = (tl >> 1) & 7;       // transform items: one channel PAIR of a quad (8 bytes) -- all 12 waves take part
     // ---- (T1) row transform along x: item (row, quad, block column, pair) ----
-    if (wave < 9) {
+    if (wave < 9 && !(W4_SKIP & 1)) {
       const int q = (tl >> 4) & 1, row = tl >> 5;
       const char* rb = wsm + (c & 1) * W4_RAW_BYTES + hb;
       float2 d[6], tt[6];
@@ -177,24 +196,26 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
       for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(rb + ((((q * 4 + (i & 3)) * 18 + row) * 9) + t_bc + (i >> 2)) * 16);
       w4_bt(d, tt);
 #pragma unroll
-      for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<float2*>(wsm + W4_X_OFF + hb + ((((row * 6 + nu) * 2 + q) * 8) + t_bc) * 16) = tt[nu];
+      for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<float2*>(wsm + W4_X_OFF + hb + row * W4_XROW + (((nu * 2 + q) * 8) + t_bc) * 16) = tt[nu];
     }
     __syncthreads();
     // ---- (T2) column transform along y: item (nu, quad, block row, block column, pair); (nu, quad) is wave-uniform ----
-    {
+    if (!(W4_SKIP & 2)) {
       const int br = (tl >> 4) & 3, q = wave & 1, nu = wave >> 1;
       float2 d[6], tt[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(wsm + W4_X_OFF + hb + (((((4 * br + i) * 6 + nu) * 2 + q) * 8) + t_bc) * 16);
+      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(wsm + W4_X_OFF + hb + (4 * br + i) * W4_XROW + (((nu * 2 + q) * 8) + t_bc) * 16);
       w4_bt(d, tt);
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) *reinterpret_cast<float2*>(wsm + W4_V_OFF + hb + ((((xi * 6 + nu) * 2 + q) * 32) + br * 8 + t_bc) * 16) = tt[xi];
     }
     __syncthreads();
-    // ---- (M) this wave's three positions; the next chunk's U fragments follow each position into its registers ----
+    // ---- (M) this wave's three positions; the next chunk's raw image and U fragments are fetched underneath ----
+    if (!(W4_SKIP & 16)) load_raw(rr);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float4 vf = *reinterpret_cast<const float4*>(wsm + W4_V_OFF + (3 * wave + j) * 1024 + (tl & 63) * 16);   // [p][lh][li]
+      if (!(W4_SKIP & 4))
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, U[j][nt].x, acc[j][nt], 0, 0, 0);
@@ -202,11 +223,9 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
         acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, U[j][nt].z, acc[j][nt], 0, 0, 0);
         acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, U[j][nt].w, acc[j][nt], 0, 0, 0);
       }
-      load_u(cn, j, U[j]);
+      if (!(W4_SKIP & 8)) load_u(cn, j, U[j]);
     }
-    // the raw-image DMA of this chunk is older than the six U loads just issued: vmcnt is in order, "at most six outstanding" means it landed
-    // (the compiler does not see the DMA in its own counts: its waits for U fragments are then stricter than needed, never weaker)
-    wn_wait_vmcnt(6);
+    store_raw((c + 1) & 1, rr);                              // (waits for the two image loads only: the six U loads behind them stay in flight)
     __syncthreads();                                         // V may be rewritten; the next raw image is visible
   }
 
@@ -288,7 +307,8 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
                (reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) == 0, "conv2d (F(4x4,3x3) form): source %d needs c %% 8 == 0, 16-byte aligned rows", s);
     P.src[s] = d->src[s].ptr; P.ld[s] = d->src[s].ld; P.c[s] = d->src[s].c;
     P.img_stride[s] = d->src_image_stride[s] < 0 ? (long long)d->h * d->w * d->src[s].ld : d->src_image_stride[s];
-    GP_REQUIRE(P.img_stride[s] % 4 == 0, "conv2d (F(4x4,3x3) form): source %d misaligned", s);
+    GP_REQUIRE(P.img_stride[s] % 4 == 0 && (long long)d->h * d->w * d->src[s].ld * 4 < (1ll << 32),
+               "conv2d (F(4x4,3x3) form): source %d misaligned, or an image beyond the 32-bit byte offsets of the LDS-DMA", s);
     cin += d->src[s].c;
   }
   GP_REQUIRE((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->out) & 3) == 0 && (long long)d->h * d->w < (1ll << 31),

@@ -423,3 +423,45 @@ def test_winograd_f27_transforms_are_an_exact_identity():
             out[:, yy, 2 * j:2 * j + 2] = (WINO7_AT @ M).T
     ref = F.conv2d(x, wt, None, 1, 3)[0]
     assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
+def test_winograd_f4x4_transforms_are_an_exact_identity():
+    """The Winograd F(4x4, 3x3) form of the many-channel fp32 layers (csrc/conv_wino4.hip, packing.pack_winograd4): with G (host, float64), the
+    integer B^T the kernel evaluates as sums (w4_bt) and A^T (w4_at), Y = A^T [(G g G^T) (.) (B^T d B)] A is the 4x4 block of the pad-1
+    correlation of a 6x6 patch with 3x3 taps -- in float64 to 1e-12; the kernel's factored sums equal the matrices; and a whole layer
+    assembled from the packed U tensor (chunk / position / quad layout) equals F.conv2d."""
+    import torch
+    import torch.nn.functional as F
+    from gpemsr_amd.packing import WINO4_AT, WINO4_BT, WINO4_G, pack_winograd4
+    g = torch.Generator().manual_seed(9)
+    d = torch.rand(6, 6, generator=g, dtype=torch.float64) - 0.5
+    taps = torch.rand(3, 3, generator=g, dtype=torch.float64) - 0.5
+    y = WINO4_AT @ ((WINO4_G @ taps @ WINO4_G.T) * (WINO4_BT @ d @ WINO4_BT.T)) @ WINO4_AT.T
+    want = F.conv2d(d[None, None], taps[None, None])[0, 0]
+    assert float((y - want).abs().max()) < 1e-12
+
+    def kernel_bt(v):       # w4_bt of conv_wino4.hip, operation by operation
+        a, b, c, e = v[4] - 4 * v[2], v[3] - 4 * v[1], v[4] - v[2], v[3] - v[1]
+        return torch.stack([4 * v[0] + (-5 * v[2] + v[4]), a + b, a - b, 2 * e + c, -2 * e + c, 4 * v[1] + (-5 * v[3] + v[5])])
+
+    def kernel_at(m):       # w4_at
+        s12, d12, s34, d34 = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4]
+        return torch.stack([(m[0] + s12) + s34, 2 * d34 + d12, 4 * s34 + s12, 8 * d34 + d12 + m[5]])
+    v = torch.rand(6, generator=g, dtype=torch.float64)
+    assert float((kernel_bt(v) - WINO4_BT @ v).abs().max()) < 1e-12 and float((kernel_at(v) - WINO4_AT @ v).abs().max()) < 1e-12
+    # whole layer through the packed tensor: U[chunk][p = 6 xi + nu][quad][cout][4]
+    cin, cout, h, w = 16, 64, 8, 12
+    x = torch.rand(1, cin, h, w, generator=g, dtype=torch.float64) - 0.5
+    wt = torch.rand(cout, cin, 3, 3, generator=g, dtype=torch.float64) - 0.5
+    U = pack_winograd4(wt, "cpu").double()                                 # (rounded to fp32 on the way: 1e-7)
+    assert tuple(U.shape) == (cin // 8, 36, 2, cout, 4)
+    Uc = U.permute(1, 3, 0, 2, 4).reshape(6, 6, cout, cin)                 # [xi][nu][cout][cin]
+    xp = F.pad(x, (1, 1, 1, 1))[0]
+    out = torch.zeros(cout, h, w, dtype=torch.float64)
+    for by in range(h // 4):
+        for bx in range(w // 4):
+            V = torch.einsum("xi,cij,yj->xyc", WINO4_BT, xp[:, 4 * by:4 * by + 6, 4 * bx:4 * bx + 6], WINO4_BT)
+            M = torch.einsum("xyc,xyoc->xyo", V, Uc)
+            out[:, 4 * by:4 * by + 4, 4 * bx:4 * bx + 4] = torch.einsum("ix,xyo,jy->oij", WINO4_AT, M, WINO4_AT)
+    ref = F.conv2d(x, wt, None, 1, 1)[0]
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6

@@ -845,6 +845,68 @@ def test_conv2d_winograd_form(case):
     assert torch.equal(out.buf, again.buf), "not bit-stable run to run"
 
 
+WINO4_CASES = [
+    # (n, cins, cout, h, w, act)
+    (1, (128,), 64, 16, 32, 0),                 # exactly one 16 x 32 tile, 16 chunks
+    (2, (128,), 128, 37, 70, 1),                # ragged tiles both ways, odd sizes (blocks across the right / bottom edge)
+    (1, (512,), 512, 32, 64, 0),                # the VQGAN 512-channel layers: 64 chunks, 8 cout blocks
+    (2, (64, 128, 64), 64, 17, 33, 2),          # concat of three sources
+    (3, (256,), 128, 48, 40, 0),                # several images x tiles x cout blocks
+    (1, (8,), 64, 20, 36, 0),                   # ONE chunk (prologue only)
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_conv2d_winograd_f4x4_form(case):
+    """gpemsr_conv_desc.transposed = 5: the Winograd F(4x4, 3x3) form of the many-channel 3x3 stride-1 layers (csrc/conv_wino4.hip) against
+    torch in float64 (tolerance 6e-5 of the result's scale: the transforms' constants reach 8, fp32 throughout; F(2x2) sits at 2e-5), against
+    the direct kernel, sources / output embedded in wider buffers, the GroupNorm partial sums of its epilogue against the statistics pass,
+    and run-to-run bit-stable."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd, pack_winograd4
+    n, cins, cout, h, w, act = case
+    dev = _dev()
+    cin = sum(cins)
+    x = _rand(n, cin, h, w, seed=31)
+    wt = _rand(cout, cin, 3, 3, seed=32, scale=1.0 / np.sqrt(cin * 9))
+    b = _rand(cout, seed=33, scale=0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    if act == 1:
+        want = F.relu(want)
+    elif act == 2:
+        want = F.leaky_relu(want, 0.1)
+    srcs, o = [], 0
+    for i, c in enumerate(cins):
+        srcs.append(_to_act(x[:, o:o + c], dev, ld=c + (8 if i == 0 else 0), off=8 if i == 0 else 0))
+        o += c
+    pc = pack_conv(wt, b, dev, cins)
+    pc.wino = pack_winograd(wt, dev)
+    pc.wino4 = pack_winograd4(wt, dev)
+    assert ops.winograd_ok(srcs, pc) and ops.winograd4_ok(srcs, pc)
+    out = _to_act(torch.zeros(n, cout, h, w), dev, ld=cout + 12, off=4)
+    got = ops.conv2d(srcs, pc, act, out=out, winograd=True)
+    _close(got.nchw(), want, 6e-5, f"winograd F(4x4) {case}")
+    assert float((out.buf.view(n, h, w, cout + 12)[..., :4] - 7.0).abs().max()) == 0.0       # neighbours of the slice untouched
+    direct = ops.conv2d(srcs, pc, act)
+    _close(got.nchw(), direct.nchw(), 6e-5, "winograd F(4x4) vs direct")
+    again = _to_act(torch.zeros(n, cout, h, w), dev, ld=cout + 12, off=4)
+    ops.conv2d(srcs, pc, act, out=again, winograd=True)
+    assert torch.equal(out.buf, again.buf), "not bit-stable run to run"
+    if act == 0 and cout % 32 == 0:
+        g = (1.0 + 0.2 * _rand(cout, seed=34)).to(dev); be = (0.2 * _rand(cout, seed=35)).to(dev)
+        plain = ops.conv2d(srcs, pc, ops.ACT_NONE, winograd=True)
+        y0 = ops.groupnorm_relu(plain, g, be, True).nchw().clone()
+        st = ops.conv2d(srcs, pc, ops.ACT_NONE, gn_stats=True, winograd=True)
+        assert st.gn is not None and st.gn[1] == -(-h // 16) * -(-w // 32)
+        assert torch.equal(st.nchw(), plain.nchw())
+        sums = st.gn[0].clone()
+        y1 = ops.groupnorm_relu(st, g, be, True)
+        wantg = torch.relu(F.group_norm(F.conv2d(x.double(), wt.double(), b.double(), 1, 1), 32, g.double().cpu(), be.double().cpu(), 1e-6))
+        _close(y1.nchw(), wantg.float(), tol=6e-5, what="GN from the F(4x4) epilogue sums vs fp64")
+        _close(y1.nchw(), y0, tol=2e-6, what="GN from the F(4x4) epilogue sums vs the statistics pass")
+        assert torch.equal(ops.conv2d(srcs, pc, ops.ACT_NONE, gn_stats=True, winograd=True).gn[0], sums), "partial sums not bit-stable"
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 16, 32), (1, 13, 21)])
 def test_conv2d_winograd_form_pixel_shuffle(n, h, w):
     """upconv1-3 (R:model/GPEMSR.py:304-316,442-448: conv 64 -> 256 + PixelShuffle(2) + LeakyReLU) in the Winograd form: the store map
