@@ -15,11 +15,13 @@
 //     wave w owns the positions p = 3 w .. 3 w + 2 (p = 6 xi + nu): 3 x 2 accumulator tiles = 96 registers;
 //   * NO weights in LDS: a position is multiplied by exactly one wave, so its U rows go global -> registers (U is packed
 //     [cin / 8][36][quad][cout][4]: a wave's fragment is 512 consecutive bytes per quad), one chunk ahead, into the registers the
-//     previous chunk's fragments have just left; the raw halo image goes global -> registers -> LDS one chunk ahead too.  There is no LDS-DMA
-//     in this kernel and no branch around a load, so every wait is the compiler's own and exact;
-//   * per chunk: (T1) the row transform B^T along x of the 18 x 34 halo image into X[row][nu][quad][block column] (576 items of one channel
-//     pair), (T2) the column transform into V[xi][nu][quad][block] (768 items: every thread one), (M) 24 MFMAs per wave from V and the
-//     register-held U; three barriers.  Pair-sized items keep the transform's transient registers at 24 beside the 96 accumulators;
+//     previous chunk's fragments have just left; the raw halo image goes global -> LDS by DMA three chunks ahead (ring of three);
+//   * software pipeline over chunks: while a wave multiplies chunk c (24 MFMAs from V[c & 1] and the register-held U) it also does its share of
+//     the transforms of chunk c + 1 -- (T1) the row transform B^T along x of the 18 x 34 halo image into X[row][nu][quad][block column] (576
+//     items of one channel pair) under positions 0-1, barrier, (T2) the column transform into V[(c + 1) & 1][xi][nu][quad][block] (768 items)
+//     under position 2, barrier.  Measured before the pipeline (phases one after the other, three barriers; profiles/r05_wino4_phase_probe_v1.log,
+//     512 -> 512 at 80 x 64^2): 5.06 ms = 0.78 fixed + 2.9 MFMA + 0.7 transforms + 0.65 loads -- nothing overlapped.  Pair-sized items keep the
+//     transform's transient registers at 24 beside the 96 accumulators;
 //   * raw image in LDS as [quad][column mod 4][row][column / 4]: the six columns an item reads for consecutive block columns are consecutive
 //     16-byte slots (a pixel-major image would be read at a 64-byte stride);
 //   * epilogue: the 36 sums of every (block, cout) meet through LDS in four passes of 16 couts (92 KB each), A^T . A in registers (10 + 10
@@ -58,16 +60,20 @@ struct W4Params {
 constexpr int W4_NT = 768;                                               // threads
 constexpr int W4_RAW_SLOTS = 2 * 4 * 18 * 9;                             // [quad][col & 3][row 18][col >> 2 (9)] = 1296 16-byte slots
 constexpr int W4_RAW_BYTES = W4_RAW_SLOTS * 16;                          // 20,736
-constexpr int W4_XROW = 6 * 2 * 8 * 16 + 32;                             // X row stride: 1,536 + 32 bytes -- the four block rows a T2 wave reads (4 rows apart)
-                                                                         // then fall on alternating 128-byte bank halves instead of one (4-way conflict)
-constexpr int W4_X_BYTES = 18 * W4_XROW;                                 // X[row][nu][quad][block column]: 28,224
-constexpr int W4_V_BYTES = 36 * 2 * 32 * 16;                             // V[p][quad][block]: 36,864
-constexpr int W4_X_OFF = 2 * W4_RAW_BYTES, W4_V_OFF = W4_X_OFF + W4_X_BYTES;
-constexpr int W4_MAIN = W4_V_OFF + W4_V_BYTES;                           // 106,560
+constexpr int W4_X_BYTES = 18 * 6 * 2 * 8 * 16;                          // X[row][nu][quad][block column]: 27,648 (128-byte halves swapped on odd row groups, see w4_xoff)
+constexpr int W4_V_BYTES = 36 * 2 * 32 * 16;                             // V[p][quad][block]: 36,864, two buffers
+constexpr int W4_X_OFF = 3 * W4_RAW_BYTES, W4_V_OFF = W4_X_OFF + W4_X_BYTES;
+constexpr int W4_LDS = W4_V_OFF + 2 * W4_V_BYTES;                        // 163,584 of 163,840
 constexpr int W4_EPIX = 20;                                              // floats per (position, block) row of the exchange buffer: 16 couts + 4
-constexpr int W4_E_BYTES = 36 * 32 * W4_EPIX * 4;                        // 92,160 (overlays raw / X / V)
-constexpr int W4_RED_OFF = W4_MAIN;                                      // GroupNorm sums [32 blocks][64 couts][2]: 16,384
-constexpr int W4_LDS = W4_RED_OFF + 16384;                               // 122,944
+constexpr int W4_E_BYTES = 36 * 32 * W4_EPIX * 4;                        // 92,160 (overlays the raw images / X after the main loop)
+constexpr int W4_RED_OFF = W4_E_BYTES;                                   // GroupNorm sums [32 blocks][64 couts][2]: 16,384 (overlays too)
+static_assert(W4_RED_OFF + 16384 <= W4_LDS && W4_LDS <= 160 * 1024, "LDS map");
+
+// X[row][nu][quad][block column] byte offset of a channel pair.  The four block rows a T2 wave reads are 4 rows = 6,144 bytes apart -- the same 32
+// banks, a 4-way conflict; swapping the two 128-byte halves (the quad bit) on every other group of four rows puts them on alternating halves.
+__device__ __forceinline__ int w4_xoff(int row, int nu, int q, int bc, int hb) {
+  return (row * 1536 + (((nu * 2 + q) * 8) + bc) * 16 + hb) ^ (((row >> 2) & 1) << 7);
+}
 
 // B^T of F(4, 3) (integer form): one 6-vector, component-wise on a channel pair
 __device__ __forceinline__ void w4_bt(const float2 (&d)[6], float2 (&t)[6]) {
@@ -115,55 +121,53 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   for (int s = 0; s < P.nsrc; ++s) nchunks += P.c[s] / 8;
 
   // ---- raw halo image: two 16-byte slots per thread, slot s = tid + 768 i of [quad][col & 3][row][col >> 2]; pixel index or -1 ----
-  //      global -> registers at the start of a chunk's MFMA phase -> LDS at its end (the phase is >= 4,600 matrix clocks per SIMD: longer than an
-  //      HBM round trip).  Every lane loads in every chunk -- a slot outside the image reads pixel 0 and is zeroed on its way to LDS, the last
-  //      chunk re-reads itself -- so no branch surrounds a load and the compiler's vmcnt counts are exact: the waits for the U fragments
-  //      leave the two younger image loads in flight.  (A first version fetched the image by LDS-DMA at the top of the chunk: the DMA is
-  //      invisible to those counts, the fragment waits became vmcnt(0) and every chunk stalled for the image's round trip -- 8.0 k instead
-  //      of 5.4 k clocks per chunk.)
-  int r_pix[2];
+  //      global -> LDS by DMA, three chunks ahead, into a ring of three images (no registers beside the accumulators; a slot outside the image
+  //      is zeroed by a plain store).  The DMA is inline asm, invisible to the compiler's vmcnt counts (vmcnt is in order): it is issued AFTER
+  //      the last wait for this chunk's U fragments and BEFORE the load of the next chunk's last fragment, so the compiler's own wait for that
+  //      fragment -- one iteration later, ahead of the barrier that publishes the image -- is also the wait for the DMA, and no compiler wait
+  //      ever sits between the issue and that point with the DMA as its youngest entry.
+  unsigned r_off[2];                                          // byte offset of the slot's 16 bytes in the CURRENT source's image, or ~0u outside the image
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int s = tid + i * W4_NT;
-    r_pix[i] = -1;
+    r_off[i] = ~0u;
     if (s < W4_RAW_SLOTS) {
       const int c4 = s % 9, r1 = s / 9;
-      const int row = r1 % 18, ph = (r1 / 18) & 3;
-      const int col = 4 * c4 + ph;
+      const int row = r1 % 18, r2 = r1 / 18;
+      const int col = 4 * c4 + (r2 & 3);
       const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
-      if (col < 34 && iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) r_pix[i] = iy * P.w + ix;
+      if (col < 34 && iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) r_off[i] = (unsigned)(iy * P.w + ix) * ((unsigned)P.ld[0] * 4u) + 16u * (unsigned)(r2 >> 2);
     }
   }
-  const int r_q0 = tid >= W4_RAW_SLOTS / 2 ? 4 : 0;           // channel offset of slot 0's quad (slot 1 = tid + 768 is always quad 1)
-  int f_src = 0, f_c0 = 0;                                    // source cursor of the chunk whose raw image is loaded next
-  auto load_raw = [&](float4 (&rr)[2]) {
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm + (unsigned)wave * 1024u);
+  int f_src = 0, f_c0 = 0;                                    // source cursor of the chunk whose raw image is issued next
+  auto issue_raw = [&](int buf) {
     const float* sp = P.src[f_src] + (long long)img * P.img_stride[f_src] + f_c0;
-    const int ldp = P.ld[f_src];
-    rr[0] = *reinterpret_cast<const float4*>(sp + (long long)max(r_pix[0], 0) * ldp + r_q0);
-    rr[1] = *reinterpret_cast<const float4*>(sp + (long long)max(r_pix[1], 0) * ldp + 4);
-    asm volatile("" ::: "memory");                            // the image loads stay OLDER than the U loads that follow (vmcnt is in order)
+    const unsigned la = lds0 + (unsigned)(buf * W4_RAW_BYTES);
+    float z = 0.f;
+    asm volatile("" : "+v"(z));                               // (a transient zero: four of them would otherwise be kept across the loop)
+    const float4 zero = make_float4(z, z, z, z);
+    if (r_off[0] != ~0u) wn_glds16(r_off[0], sp, la);
+    else *reinterpret_cast<float4*>(wsm + buf * W4_RAW_BYTES + tid * 16) = zero;
+    if (tid + W4_NT < W4_RAW_SLOTS) {
+      if (r_off[1] != ~0u) wn_glds16(r_off[1], sp, la + W4_NT * 16u);
+      else *reinterpret_cast<float4*>(wsm + buf * W4_RAW_BYTES + (tid + W4_NT) * 16) = zero;
+    }
     f_c0 += 8;
-    if (f_c0 >= P.c[f_src]) {
-      if (f_src + 1 < P.nsrc) { f_c0 = 0; ++f_src; } else f_c0 -= 8;
-    }
-  };
-  auto store_raw = [&](int buf, const float4 (&rr)[2]) {      // (the zeroing is a bit mask: a select of two float4 made the compiler go through scratch)
+    if (f_c0 >= P.c[f_src] && f_src + 1 < P.nsrc) {           // next source: rescale the pixel part of the offsets to its row pitch (rare: <= 3 times per tile)
+      const unsigned pb0 = (unsigned)P.ld[f_src] * 4u, pb1 = (unsigned)P.ld[f_src + 1] * 4u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int m = ~(r_pix[i] >> 31);
-      asm volatile("" : "+v"(m) :: "memory");                 // the masking (= the wait for the image loads) stays BEHIND the U loads of this chunk
-      const float4 v = make_float4(__int_as_float(__float_as_int(rr[i].x) & m), __int_as_float(__float_as_int(rr[i].y) & m),
-                                   __int_as_float(__float_as_int(rr[i].z) & m), __int_as_float(__float_as_int(rr[i].w) & m));
-      if (i == 0 || tid + W4_NT < W4_RAW_SLOTS) *reinterpret_cast<float4*>(wsm + buf * W4_RAW_BYTES + (tid + i * W4_NT) * 16) = v;
+      for (int i = 0; i < 2; ++i)
+        if (r_off[i] != ~0u) { const unsigned qo = r_off[i] & 16u; r_off[i] = (r_off[i] - qo) / pb0 * pb1 + qo; }
+      f_c0 = 0; ++f_src;
     }
   };
-  // ---- U fragments of this wave's three positions: lane (li = cout, lh = quad), [chunk][p][quad][cout][4] ----
-  const float* u_lane = P.weight + ((long long)(3 * wave * 2 + lh) * P.cout + n0 + li) * 4;
-  const long long u_chunk = (long long)36 * 2 * P.cout * 4;
+  // ---- U fragments of this wave's three positions: lane (li = cout, lh = quad), [chunk][p][quad][cout][4]: a uniform base + ONE per-lane offset ----
+  const unsigned u_off = (unsigned)(lh * P.cout + li) * 4u;                       // floats
   auto load_u = [&](int chunk, int j, float4 (&U)[2]) {
-    const float* up = u_lane + (long long)chunk * u_chunk + (long long)j * (2 * P.cout * 4);
-    U[0] = *reinterpret_cast<const float4*>(up);
-    U[1] = *reinterpret_cast<const float4*>(up + 32 * 4);
+    const float* ub = P.weight + ((long long)(chunk * 36 + 3 * wave + j) * 2 * P.cout + n0) * 4;     // wave-uniform
+    U[0] = *reinterpret_cast<const float4*>(ub + u_off);
+    U[1] = *reinterpret_cast<const float4*>(ub + u_off + 32 * 4);
   };
 
   f32x16 acc[3][2];
@@ -174,59 +178,103 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
 
-  // ---- prologue: raw image and U fragments of chunk 0 ----
-  float4 U[3][2], rr[2];
-  load_raw(rr);
+  // transform items: one channel PAIR of a quad (8 bytes).  (T1) row transform along x, item (row, quad, block column, pair), waves 0-8;
+  // (T2) column transform along y, item (nu, quad, block row, block column, pair), (nu, quad) wave-uniform, every thread one item.
+  // One base address per access group, everything else an instruction offset: every vector-ALU instruction in this loop is paid for in matrix
+  // time (the f32 MFMA runs on the vector FMA units -- transforms placed in the "shadow" of other waves' MFMAs hid nothing, 5.02 vs 5.06 ms).
+  const int it_hb = (tid & 1) * 8, it_bc = (tid >> 1) & 7;
+  int a_t1l, a_t1s, a_t2l, a_t2s;
+  {
+    const int q = (tid >> 4) & 1, row = tid >> 5;                                  // T1 item
+    a_t1l = it_hb + ((q * 4 * 18 + row) * 9 + it_bc) * 16;                         // + ((i & 3) * 162 + (i >> 2)) * 16 + raw image
+    a_t1s = W4_X_OFF + w4_xoff(row, 0, q, it_bc, it_hb);                           // + nu * 256
+    const int br = (tid >> 4) & 3, q2 = wave & 1, nu = wave >> 1;                  // T2 item
+    a_t2l = W4_X_OFF + w4_xoff(4 * br, nu, q2, it_bc, it_hb);                      // + i * 1536, i < 4; rows 4 br + 4, + 5: the other 128-byte half
+    a_t2s = W4_V_OFF + it_hb + (((nu * 2 + q2) * 32) + br * 8 + it_bc) * 16;       // + xi * 6144 + V buffer
+  }
+  auto t1_load = [&](int buf, float2 (&d)[6]) {
+    const char* rb = wsm + a_t1l + buf * W4_RAW_BYTES;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(rb + ((i & 3) * 162 + (i >> 2)) * 16);
+  };
+  auto t1_store = [&](const float2 (&d)[6]) {
+    float2 tt[6];
+    w4_bt(d, tt);
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<float2*>(wsm + a_t1s + nu * 256) = tt[nu];
+  };
+  auto t2_load = [&](float2 (&d)[6]) {
+    const char* xa = wsm + a_t2l;
+    const char* xb = wsm + (a_t2l ^ 128);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>((i < 4 ? xa : xb) + i * 1536);
+  };
+  auto t2_store = [&](int vbuf, const float2 (&d)[6]) {
+    float2 tt[6];
+    w4_bt(d, tt);
+    char* vp = wsm + a_t2s + vbuf * W4_V_BYTES;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) *reinterpret_cast<float2*>(vp + xi * 6144) = tt[xi];
+  };
+
+  // ---- prologue: raw images of chunks 0-2, U fragments of chunk 0, V of chunk 0 ----
+  float4 U[3][2];
+  issue_raw(0);
+  if (nchunks > 1) issue_raw(1);
+  if (nchunks > 2) issue_raw(2);
 #pragma unroll
   for (int j = 0; j < 3; ++j) load_u(0, j, U[j]);
-  store_raw(0, rr);
+  wn_wait_vmcnt(0);
   __syncthreads();
+  {
+    float2 d[6];
+    if (wave < 9) { t1_load(0, d); t1_store(d); }
+    __syncthreads();
+    t2_load(d); t2_store(0, d);
+    __syncthreads();
+  }
 
+  // ---- main loop: iteration c multiplies chunk c (V[c & 1], U in registers) and transforms chunk c + 1 (raw image (c + 1) % 3 -> X ->
+  //      V[(c + 1) & 1]), fetches the U fragments of chunk c + 1 and starts the DMA of raw image c + 3.  Two barriers per chunk.
+  const int a_v = W4_V_OFF + (3 * wave) * 1024 + lane * 16;  // V[.][p][lh][li]
+  int rb1 = 1;                                               // ring slot of raw image c + 1; image c + 3 goes to the slot of image c = (rb1 + 2) % 3
   for (int c = 0; c < nchunks; ++c) {
-    const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U and image: no branch around the loads)
-    int tl = tid;                                            // opaque copy: the item addresses are recomputed per chunk (a few integer operations)
-    asm volatile("" : "+v"(tl));                             // rather than hoisted out of the loop into registers the accumulators need
-    const int hb = (tl & 1) * 8, t_bc = (tl >> 1) & 7;       // transform items: one channel PAIR of a quad (8 bytes) -- all 12 waves take part
-    // ---- (T1) row transform along x: item (row, quad, block column, pair) ----
-    if (wave < 9 && !(W4_SKIP & 1)) {
-      const int q = (tl >> 4) & 1, row = tl >> 5;
-      const char* rb = wsm + (c & 1) * W4_RAW_BYTES + hb;
-      float2 d[6], tt[6];
+    const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U: no branch around the loads)
+    const bool more = c + 1 < nchunks;
+    const char* vb = wsm + a_v + (c & 1) * W4_V_BYTES;
+    auto mma = [&](int j, int nt, const float4& vf, int k0, int k1) {
+      if (W4_SKIP & 4) return;
+      const float v[4] = {vf.x, vf.y, vf.z, vf.w};
+      const float u[4] = {U[j][nt].x, U[j][nt].y, U[j][nt].z, U[j][nt].w};
 #pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(rb + ((((q * 4 + (i & 3)) * 18 + row) * 9) + t_bc + (i >> 2)) * 16);
-      w4_bt(d, tt);
-#pragma unroll
-      for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<float2*>(wsm + W4_X_OFF + hb + row * W4_XROW + (((nu * 2 + q) * 8) + t_bc) * 16) = tt[nu];
-    }
+      for (int k = k0; k < k1; ++k) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[j][nt], 0, 0, 0);
+    };
+    float2 d[6];
+    // ---- phase A: positions 0 and 1, T1 of the next chunk between them ----
+    const bool do_t1 = more && wave < 9 && !(W4_SKIP & 1);
+    float4 vf = *reinterpret_cast<const float4*>(vb);
+    if (do_t1) t1_load(rb1, d);
+    mma(0, 0, vf, 0, 4); mma(0, 1, vf, 0, 4);
+    if (!(W4_SKIP & 8)) load_u(cn, 0, U[0]);
+    if (do_t1) t1_store(d);
+    vf = *reinterpret_cast<const float4*>(vb + 1024);
+    mma(1, 0, vf, 0, 4); mma(1, 1, vf, 0, 4);
+    if (!(W4_SKIP & 8)) load_u(cn, 1, U[1]);
     __syncthreads();
-    // ---- (T2) column transform along y: item (nu, quad, block row, block column, pair); (nu, quad) is wave-uniform ----
-    if (!(W4_SKIP & 2)) {
-      const int br = (tl >> 4) & 3, q = wave & 1, nu = wave >> 1;
-      float2 d[6], tt[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(wsm + W4_X_OFF + hb + (4 * br + i) * W4_XROW + (((nu * 2 + q) * 8) + t_bc) * 16);
-      w4_bt(d, tt);
-#pragma unroll
-      for (int xi = 0; xi < 6; ++xi) *reinterpret_cast<float2*>(wsm + W4_V_OFF + hb + ((((xi * 6 + nu) * 2 + q) * 32) + br * 8 + t_bc) * 16) = tt[xi];
-    }
+    // ---- phase B: position 2 and T2 of the next chunk; the DMA of raw image c + 3 behind the last wait for this chunk's U ----
+    const bool do_t2 = more && !(W4_SKIP & 2);
+    vf = *reinterpret_cast<const float4*>(vb + 2048);
+    if (do_t2) t2_load(d);
+    mma(2, 0, vf, 0, 2); mma(2, 1, vf, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 3 < nchunks && !(W4_SKIP & 16)) issue_raw(rb1 == 0 ? 2 : rb1 - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_t2) t2_store((c + 1) & 1, d);
+    mma(2, 0, vf, 2, 4); mma(2, 1, vf, 2, 4);
+    asm volatile("" ::: "memory");
+    if (!(W4_SKIP & 8)) load_u(cn, 2, U[2]);                 // (younger than the DMA: the compiler's wait for it next iteration covers the DMA)
+    rb1 = rb1 == 2 ? 0 : rb1 + 1;
     __syncthreads();
-    // ---- (M) this wave's three positions; the next chunk's raw image and U fragments are fetched underneath ----
-    if (!(W4_SKIP & 16)) load_raw(rr);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float4 vf = *reinterpret_cast<const float4*>(wsm + W4_V_OFF + (3 * wave + j) * 1024 + (tl & 63) * 16);   // [p][lh][li]
-      if (!(W4_SKIP & 4))
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, U[j][nt].x, acc[j][nt], 0, 0, 0);
-        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, U[j][nt].y, acc[j][nt], 0, 0, 0);
-        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, U[j][nt].z, acc[j][nt], 0, 0, 0);
-        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, U[j][nt].w, acc[j][nt], 0, 0, 0);
-      }
-      if (!(W4_SKIP & 8)) load_u(cn, j, U[j]);
-    }
-    store_raw((c + 1) & 1, rr);                              // (waits for the two image loads only: the six U loads behind them stay in flight)
-    __syncthreads();                                         // V may be rewritten; the next raw image is visible
   }
 
   // ---- epilogue: four passes of 16 couts through the exchange buffer ----
@@ -307,8 +355,8 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
                (reinterpret_cast<uintptr_t>(d->src[s].ptr) & 15) == 0, "conv2d (F(4x4,3x3) form): source %d needs c %% 8 == 0, 16-byte aligned rows", s);
     P.src[s] = d->src[s].ptr; P.ld[s] = d->src[s].ld; P.c[s] = d->src[s].c;
     P.img_stride[s] = d->src_image_stride[s] < 0 ? (long long)d->h * d->w * d->src[s].ld : d->src_image_stride[s];
-    GP_REQUIRE(P.img_stride[s] % 4 == 0 && (long long)d->h * d->w * d->src[s].ld * 4 < (1ll << 32),
-               "conv2d (F(4x4,3x3) form): source %d misaligned, or an image beyond the 32-bit byte offsets of the LDS-DMA", s);
+    GP_REQUIRE(P.img_stride[s] % 4 == 0 && (long long)d->h * d->w * d->src[s].ld * 4 < (1ll << 32) && (long long)d->h * d->w < (1 << 24) && d->src[s].ld < (1 << 22),
+               "conv2d (F(4x4,3x3) form): source %d misaligned, or an image beyond the 32-bit byte offsets (24-bit pixel index) of the LDS-DMA", s);
     cin += d->src[s].c;
   }
   GP_REQUIRE((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->out) & 3) == 0 && (long long)d->h * d->w < (1ll << 31),

@@ -100,10 +100,11 @@ class Engine:
         # F(2, 7) row form (8 instead of 14 multiplies per output pair and filter row, fp32 arithmetic; csrc/conv7_wino.hip).  GPEMSR_WINOGRAD7=0: direct form.
         self.winograd7 = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD7", "1") != "0"
         # exact-fp32 path: 3x3 stride-1 layers with >= GPEMSR_WINOGRAD4_MIN_CIN (128) input channels and cout % 64 == 0 in the F(4x4,3x3) form (36
-        # instead of 144 multiplies per 4x4 outputs; ~2e-5 of the result at 512 channels; csrc/conv_wino4.hip).  GPEMSR_WINOGRAD4 = "decoder"
-        # (default): every such layer EXCEPT the indexer's, whose arg-max decides codebook entries and keeps the tighter F(2x2) rounding;
-        # "all": the indexer too; "0": F(2x2) everywhere.
-        self.winograd4 = os.environ.get("GPEMSR_WINOGRAD4", "0") if self.winograd else "0"
+        # instead of 144 multiplies per 4x4 outputs; logits of the full-size golden tile within 2.9e-6 of the reference's, every code equal;
+        # csrc/conv_wino4.hip; 64-channel layers measured slower than on F(2x2): 8 chunks do not amortise a tile's fixed cost).
+        # GPEMSR_WINOGRAD4 = "all" (default): every such layer; "decoder": all but the indexer's (its arg-max decides codebook entries:
+        # this keeps the tighter F(2x2) rounding there, at +17 ms per step); "0": F(2x2) everywhere.
+        self.winograd4 = os.environ.get("GPEMSR_WINOGRAD4", "all") if self.winograd else "0"
         assert self.winograd4 in ("0", "decoder", "all"), f"GPEMSR_WINOGRAD4={self.winograd4!r}: 0 | decoder | all"
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
@@ -290,6 +291,9 @@ class Engine:
         if self.winograd and kw["precision"] == "fp32" and pc.wino is not None \
                 and self.wino_geometry_ok(srcs if isinstance(srcs, Act) else srcs[0], pc.cout):
             kw.setdefault("winograd", True)
+            x0 = srcs if isinstance(srcs, Act) else srcs[0]
+            if pc.wino4 is not None and 3 * x0.h * x0.w < 2 * (-(-x0.h // 16) * 16) * (-(-x0.w // 32) * 32):
+                kw.setdefault("winograd4", False)            # a map that fills < 2/3 of the F(4x4) kernel's 16 x 32 tiles stays on F(2x2) (8 x 32 tiles)
         return self.o.conv2d(srcs, pc, act, tag=name, **kw)
 
     def resblocks_nobn(self, x: Act, prefix: str, pixmul: Optional[Act] = None) -> Act:

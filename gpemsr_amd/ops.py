@@ -296,6 +296,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
                            _u8_fused=_u8_fused, **kw16)
     gn_stats = bool(kw16.pop("gn_stats", False))          # fp32 too: GroupNorm partial sums from the epilogue (gpemsr_conv_desc.gn_partials)
     winograd = bool(kw16.pop("winograd", False))          # fp32: the Winograd F(2x2,3x3) form where the layer qualifies (winograd_ok)
+    winograd4 = bool(kw16.pop("winograd4", True))         # ... and the F(4x4,3x3) form where `pc.wino4` is packed (winograd4_ok)
     direct7 = bool(kw16.pop("direct7", False))            # fp32: keep the direct form of a 7x7 layer that has F(2, 7) weights packed (A/B, tests)
     cos_with = kw16.pop("cos_with", None)                  # fp32: patch cosine of the result against this tensor, result not stored
     if cos_with is not None:
@@ -413,7 +414,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     if winograd and precision == "fp32" and winograd_ok(srcs, pc, stride, out, residual) and weight_image_stride == 0 and src_image_stride is None:
         d.transposed, d.weight = 3, pc.wino.data_ptr()          # 16 multiplies per 2x2 outputs instead of 36 (csrc/conv_wino.hip)
         executed = flops * 16.0 / 36.0
-        if winograd4_ok(srcs, pc, residual, pixmul):
+        if winograd4 and winograd4_ok(srcs, pc, residual, pixmul):
             d.transposed, d.weight = 5, pc.wino4.data_ptr()     # 36 multiplies per 4x4 outputs instead of 144 (csrc/conv_wino4.hip)
             executed = flops * 36.0 / 144.0
     if (gn_stats and precision == "fp32" and act == ACT_NONE and residual is None and pixmul is None and not pc.transposed and not pc.pixel_shuffle
@@ -447,10 +448,8 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
 
 def winograd4_ok(srcs, pc: "PackedConv", residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
     """Layers (among those winograd_ok accepts) the F(4x4, 3x3) form takes: `pc.wino4` packed (the engine packs it for layers of >= 128 input
-    channels), cout % 64 == 0, plain store, images of at least 16 x 32 pixels (one tile)."""
-    if pc.wino4 is None or pc.cout % 64 != 0 or pc.pixel_shuffle or residual is not None or pixmul is not None:
-        return False
-    return srcs[0].h >= 16 and srcs[0].w >= 32
+    channels), cout % 64 == 0, plain store.  (Whether a small map is worth its 16 x 32 pixel tiles is the caller's call: `winograd4=False`.)"""
+    return not (pc.wino4 is None or pc.cout % 64 != 0 or pc.pixel_shuffle or residual is not None or pixmul is not None)
 
 
 def winograd7_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:

@@ -853,6 +853,9 @@ WINO4_CASES = [
     (2, (64, 128, 64), 64, 17, 33, 2),          # concat of three sources
     (3, (256,), 128, 48, 40, 0),                # several images x tiles x cout blocks
     (1, (8,), 64, 20, 36, 0),                   # ONE chunk (prologue only)
+    (1, (16,), 64, 16, 32, 0),                  # two chunks (no image DMA inside the loop)
+    (2, (24,), 64, 21, 40, 1),                  # three chunks (the ring of three raw images filled by the prologue)
+    (1, (32,), 128, 33, 65, 0),                 # four chunks: the first DMA issued inside the loop
 ]
 
 
