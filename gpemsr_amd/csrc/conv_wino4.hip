@@ -31,6 +31,7 @@
 // multiples of 8 channels (>= 128 in all), cout % 64 == 0, no residual / multiplier / PixelShuffle.
 #include "common.h"
 #include "conv_wino.h"
+#include <type_traits>
 
 namespace gpemsr {
 
@@ -54,6 +55,10 @@ struct W4Params {
   const float* bias; int act;
   float* out; int out_ld;
   float* gn_ws; int gn_parts;     // GroupNorm partial sums of (conv + bias): [n][gn_parts = tiles per image][cout][2]
+  const float* residual; int res_ld;   // W4_RES: added after the activation; W4_COS: the operand map `a` of the patch cosine
+  const float* pixmul;            // W4_MUL: one multiplier per pixel, after the residual
+  int cq;                         // W4_PS: cout / 4 (PixelShuffle(2): cout block q = ch / cq goes to sub-pixel (q >> 1, q & 1) of a 2h x 2w image)
+  float* cos_ws;                  // W4_COS: [n][h / 4 strips][w / 16 patch columns][4] sums of a.b, a.a, b.b (b = act(conv + bias)), nothing stored
   int tiles_x, tiles_y, tiles_n, nblocks;
 };
 
@@ -100,6 +105,10 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
   y[3] = fmaf(8.f, d34, d12) + m[5];
 }
 
+// epilogue modes (compile-time: the item loop stays branch-free)
+constexpr int W4_RES = 1, W4_MUL = 2, W4_PS = 4, W4_COS = 8;
+
+template <int MODE>
 __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -277,59 +286,121 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     __syncthreads();
   }
 
-  // ---- epilogue: four passes of 16 couts through the exchange buffer ----
+  // ---- epilogue: four passes of 16 couts through the exchange buffer (fully unrolled: static accumulator indices, nothing in scratch -- a
+  //      scratch reload waits on vmcnt, i.e. for every output store before it) ----
   float* E = reinterpret_cast<float*>(wsm);
   float* red = reinterpret_cast<float*>(wsm + W4_RED_OFF);
-  float* out_img = P.out + (long long)img * P.h * P.w * P.out_ld;
   const int act = P.act;
-#pragma unroll 1
+  const bool inside = oy0 + 16 <= P.h && ox0 + 32 <= P.w;     // (uniform) the whole tile is image: no per-pixel tests
+  const int e_cc = tid & 15, e_b = tid >> 4;                   // item of a pass: (cout of the pass, block), threads 0-511
+  const int e_br = e_b >> 3, e_bc = e_b & 7;
+  // addresses = a UNIFORM base (tile, pass, pixel of the block: scalar registers) + ONE per-lane 32-bit element offset per tensor: sixteen
+  // 64-bit per-lane addresses per tensor went to scratch beside the accumulators (and a scratch reload waits on vmcnt, i.e. on the stores)
+  const long long t_pix = ((long long)img * P.h + oy0) * P.w + ox0;                        // first pixel of the tile
+  float* t_out = (MODE & W4_PS) ? P.out + (((long long)img * 2 * P.h + 2 * oy0) * (2 * P.w) + 2 * ox0) * P.out_ld : P.out + t_pix * P.out_ld + n0;
+  const float* t_res = (MODE & (W4_RES | W4_COS)) ? P.residual + t_pix * P.res_ld + n0 : nullptr;
+  const float* t_mul = (MODE & W4_MUL) ? P.pixmul + t_pix : nullptr;
+  // (BYTE offsets added to a char pointer: "uniform pointer + zero-extended 32-bit register" is the pattern of the scalar-base addressing mode)
+  const unsigned e_ooff = 4u * ((MODE & W4_PS) ? (unsigned)((8 * e_br * (2 * P.w) + 8 * e_bc) * P.out_ld + e_cc)
+                                               : (unsigned)((4 * e_br * P.w + 4 * e_bc) * P.out_ld + e_cc));
+  const unsigned e_roff = 4u * (unsigned)((4 * e_br * P.w + 4 * e_bc) * P.res_ld + e_cc);
+  const unsigned e_moff = 4u * (unsigned)(4 * e_br * P.w + 4 * e_bc);
+  float e_bias[4];                                             // all four passes' biases up front: a load inside a pass would wait (vmcnt) for the
+#pragma unroll                                                 // previous pass's stores
+  for (int k = 0; k < 4; ++k) e_bias[k] = P.bias && tid < 512 ? P.bias[n0 + 16 * k + e_cc] : 0.f;
+  const float slope = act == GPEMSR_ACT_LRELU ? 0.1f : 1.f;   // branch-free activation (NONE / RELU / LRELU only, checked on the host)
+  const bool relu = act == GPEMSR_ACT_RELU;
+  float cab = 0.f, caa = 0.f, cbb = 0.f;                       // W4_COS: this thread's sums over its block and the four passes
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int nt = k >> 1, half = k & 1;
     if ((li >> 4) == half) {
+      float* ew = E + ((3 * wave) * 32 + 4 * lh) * W4_EPIX + (li & 15);
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // block of this register
-          const float v = nt == 0 ? acc[j][0][r] : acc[j][1][r];
-          E[((3 * wave + j) * 32 + row) * W4_EPIX + (li & 15)] = v;
-        }
+        for (int r = 0; r < 16; ++r) ew[(j * 32 + (r & 3) + 8 * (r >> 2)) * W4_EPIX] = acc[j][nt][r];   // register r = block (r & 3) + 8 (r >> 2) + 4 lh
     }
     __syncthreads();
     if (tid < 512) {
-      const int cc = tid & 15, b = tid >> 4;                  // (cout of this pass, block)
-      const int br = b >> 3, bc = b & 7;
-      const int co = n0 + nt * 32 + 16 * half + cc;
-      const float bias = P.bias ? P.bias[co] : 0.f;
-      float z[6][4];                                          // A^T over xi for every nu: z[nu][i]
-#pragma unroll
-      for (int nu = 0; nu < 6; ++nu) {
-        float m[6];
-#pragma unroll
-        for (int xi = 0; xi < 6; ++xi) m[xi] = E[((xi * 6 + nu) * 32 + b) * W4_EPIX + cc];
-        w4_at(m, z[nu]);
-      }
+      const int cq = nt * 32 + 16 * half;                     // first cout of this pass within the block
+      const float bias = e_bias[k];
+      const float* er = E + e_b * W4_EPIX + e_cc;
       float gs = 0.f, gq = 0.f;
+      auto rows = [&](auto guarded) {
+        constexpr bool G = decltype(guarded)::value;
+        // (the lane offsets are made opaque before every access: otherwise "base + offset" is formed once as a 64-bit per-lane pointer and every
+        //  access becomes that pointer + a uniform step -- sixteen register pairs per tensor instead of one register and scalar bases)
+        unsigned oo = e_ooff, ro = e_roff, mo = e_moff;
+        // residual / cosine operand: one row of four pixels at a time, requested one row ahead (all sixteen up front did not fit beside the
+        // accumulators: scratch, whose reloads wait on vmcnt, i.e. on the stores)
+        auto load_row = [&](int i, float (&r)[4]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float m[6] = {z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i]};
-        float y[4];
-        w4_at(m, y);
-        const int oy = oy0 + 4 * br + i;
+          for (int jx = 0; jx < 4; ++jx) {
+            r[jx] = 0.f;
+            if (!G || (oy0 + 4 * e_br + i < P.h && ox0 + 4 * e_bc + jx < P.w)) { asm volatile("" : "+v"(ro)); r[jx] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t_res + ((long long)i * P.w + jx) * P.res_ld + cq) + ro); }
+          }
+        };
+        float rv[4], rn[4];
+        if (MODE & (W4_RES | W4_COS)) load_row(0, rv);
+        float z[6][4];                                        // A^T over xi for every nu: z[nu][i]
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-          const int ox = ox0 + 4 * bc + jx;
-          if (oy < P.h && ox < P.w) {
-            float v = y[jx] + bias;
-            gs += v; gq = fmaf(v, v, gq);
-            v = apply_act(v, act);
-            out_img[((long long)oy * P.w + ox) * P.out_ld + co] = v;
+        for (int nu = 0; nu < 6; ++nu) {
+          float m[6];
+#pragma unroll
+          for (int xi = 0; xi < 6; ++xi) m[xi] = er[((xi * 6 + nu) * 32) * W4_EPIX];
+          w4_at(m, z[nu]);
+        }
+        float* op = t_out + cq;                               // uniform; + the row / column step below; [e_ooff] per lane
+        if (MODE & W4_PS) {                                    // channels n0 + cq .. + 15 of the permuted cout order lie in ONE sub-pixel q = ch / (cout / 4)
+          const int ch0 = n0 + cq, q = ch0 / P.cq;
+          op = t_out + ((long long)(q >> 1) * (2 * P.w) + (q & 1)) * P.out_ld + (ch0 - q * P.cq);
+        }
+        const long long o_row = (MODE & W4_PS) ? (long long)4 * P.w * P.out_ld : (long long)P.w * P.out_ld;   // one input row down
+        const int o_col = (MODE & W4_PS) ? 2 * P.out_ld : P.out_ld;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                          // A^T over nu, bias, statistics, activation, (residual, multiplier,) store -- row by row
+          const float m[6] = {z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i]};
+          float y[4];
+          w4_at(m, y);
+          if ((MODE & (W4_RES | W4_COS)) && i < 3) load_row(i + 1, rn);
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) {
+            const float v = y[jx] + bias;
+            if (!G || (oy0 + 4 * e_br + i < P.h && ox0 + 4 * e_bc + jx < P.w)) {
+              gs += v; gq = fmaf(v, v, gq);
+              float t = relu ? fmaxf(v, 0.f) : (v > 0.f ? v : slope * v);
+              if (MODE & W4_COS) {
+                cab = fmaf(rv[jx], t, cab); caa = fmaf(rv[jx], rv[jx], caa); cbb = fmaf(t, t, cbb);
+              } else {
+                if (MODE & W4_RES) t += rv[jx];
+                if (MODE & W4_MUL) { asm volatile("" : "+v"(mo)); t *= *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t_mul + (long long)i * P.w + jx) + mo); }
+                asm volatile("" : "+v"(oo));
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(op + jx * o_col) + oo) = t;
+              }
+            }
+          }
+          op += o_row;
+          if (MODE & (W4_RES | W4_COS)) {
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) rv[jx] = rn[jx];
           }
         }
-      }
-      if (P.gn_ws) { red[(b * 64 + nt * 32 + 16 * half + cc) * 2] = gs; red[(b * 64 + nt * 32 + 16 * half + cc) * 2 + 1] = gq; }
+      };
+      if (inside) rows(std::false_type{}); else rows(std::true_type{});
+      if (P.gn_ws) { red[(e_b * 64 + cq + e_cc) * 2] = gs; red[(e_b * 64 + cq + e_cc) * 2 + 1] = gq; }
     }
     __syncthreads();
+  }
+  if (MODE & W4_COS) {
+    // R:model/GPEMSR.py:387-395 without the second relu1_2 map in memory: one record per 4-row strip and 16-pixel patch column (the layout of
+    // the direct kernel's XEPI = 2 epilogue, four strips make a patch: gpemsr_patch_cosine_finish).  Waves 0-7 hold the items of blocks
+    // 4 w .. 4 w + 3 = strip w / 2, patch column w & 1 of this tile: per-thread sums in pass order, then one xor tree per wave -- bit-stable.
+    for (int o = 1; o < 64; o <<= 1) { cab += __shfl_xor(cab, o); caa += __shfl_xor(caa, o); cbb += __shfl_xor(cbb, o); }
+    if (wave < 8 && lane == 0) {
+      float* rec = P.cos_ws + ((((long long)img * (P.tiles_y * 4) + ty0 * 4 + (wave >> 1)) * (P.tiles_x * 2)) + tx0 * 2 + (wave & 1)) * 4;
+      rec[0] = cab; rec[1] = caa; rec[2] = cbb;
+    }
   }
   if (P.gn_ws && tid < 64) {                                   // per (tile, channel): the 32 blocks in fixed order
     float s = 0.f, q = 0.f;
@@ -341,13 +412,41 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
 }
 
 // descriptor.transposed == 5: called from gpemsr_conv2d (conv_mfma.hip); parts_only != NULL: only report the GroupNorm records per image
+template <int MODE>
+static int launch_wino4(const W4Params& P, hipStream_t st) {
+  static dev_once_t done{0};
+  if (dev_once_begin(done)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)
+      return fail(GPEMSR_ELAUNCH, "conv2d (F(4x4,3x3) form): cannot raise the dynamic LDS limit to %d bytes", W4_LDS);
+    dev_once_done(done);
+  }
+  hipLaunchKernelGGL(conv_wino4_f32_kernel<MODE>, dim3(P.nblocks), dim3(W4_NT), W4_LDS, st, P);
+  return check_launch("conv_wino4_f32_kernel");
+}
+
+// descriptor.transposed == 5: called from gpemsr_conv2d (conv_mfma.hip); parts_only != NULL: only report the GroupNorm records per image
 int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap, int* parts_only) {
   GP_REQUIRE(d->ksize == 3 && d->stride == 1 && d->weight_image_stride == 0, "conv2d (F(4x4,3x3) form): 3x3, stride 1, one weight set");
-  GP_REQUIRE(!d->residual && !d->pixmul && !d->pixel_shuffle && !d->cos_partials, "conv2d (F(4x4,3x3) form): plain store only");
   GP_REQUIRE(d->cout % 64 == 0, "conv2d (F(4x4,3x3) form): cout %% 64 == 0 (got %d)", d->cout);
-  if (d->gn_partials || parts_only) GP_REQUIRE(d->act == GPEMSR_ACT_NONE, "conv2d (F(4x4,3x3) form): GroupNorm partial sums need act NONE");
+  GP_REQUIRE(d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU, "conv2d (F(4x4,3x3) form): act NONE / RELU / LRELU (got %d)", d->act);
+  int mode = 0;
+  if (d->cos_partials) {
+    GP_REQUIRE(d->cout == 64 && d->h % 16 == 0 && d->w % 32 == 0 && d->residual && !d->pixel_shuffle && !d->pixmul && !d->gn_partials && !parts_only,
+               "conv2d (F(4x4,3x3) form): the patch-cosine epilogue needs cout == 64, h %% 16 == 0, w %% 32 == 0, the operand map in `residual`");
+    mode = W4_COS;
+  } else if (d->pixel_shuffle) {
+    GP_REQUIRE(!d->residual && !d->pixmul && !d->gn_partials && !parts_only && d->cout % 256 == 0, "conv2d (F(4x4,3x3) form): PixelShuffle needs cout %% 256 == 0, plain store");
+    mode = W4_PS;
+  } else {
+    GP_REQUIRE(!d->pixmul || d->residual, "conv2d (F(4x4,3x3) form): a pixel multiplier comes with a residual");
+    mode = (d->residual ? W4_RES : 0) | (d->pixmul ? W4_MUL : 0);
+  }
+  if (d->gn_partials || parts_only) GP_REQUIRE(d->act == GPEMSR_ACT_NONE && mode == 0, "conv2d (F(4x4,3x3) form): GroupNorm partial sums need act NONE, plain store");
   if (parts_only) { *parts_only = cdiv(d->h, 16) * cdiv(d->w, 32); return GPEMSR_OK; }
-  if (name_buf) { snprintf(name_buf, (size_t)name_cap, "conv_wino4_f32_kernel"); return GPEMSR_OK; }
+  if (name_buf) {
+    snprintf(name_buf, (size_t)name_cap, "conv_wino4_f32_kernel<%s>", mode == W4_COS ? "COS" : mode == W4_PS ? "PS" : mode == 3 ? "RES,MUL" : mode == 1 ? "RES" : "PLAIN");
+    return GPEMSR_OK;
+  }
   W4Params P{};
   int cin = 0;
   for (int s = 0; s < d->nsrc; ++s) {
@@ -364,18 +463,19 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cout = d->cout;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.out = d->out; P.out_ld = d->out_ld;
   P.gn_ws = d->gn_partials; P.gn_parts = cdiv(d->h, 16) * cdiv(d->w, 32);
+  P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul; P.cq = d->cout / 4; P.cos_ws = d->cos_partials;
   P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, 16); P.tiles_n = d->cout / 64;
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (F(4x4,3x3) form): grid too large");
   P.nblocks = (int)nb;
-  static dev_once_t done{0};
-  if (dev_once_begin(done)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS) != hipSuccess)
-      return fail(GPEMSR_ELAUNCH, "conv2d (F(4x4,3x3) form): cannot raise the dynamic LDS limit to %d bytes", W4_LDS);
-    dev_once_done(done);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (mode) {
+    case 0: return launch_wino4<0>(P, st);
+    case W4_RES: return launch_wino4<W4_RES>(P, st);
+    case W4_RES | W4_MUL: return launch_wino4<W4_RES | W4_MUL>(P, st);
+    case W4_PS: return launch_wino4<W4_PS>(P, st);
+    default: return launch_wino4<W4_COS>(P, st);
   }
-  hipLaunchKernelGGL(conv_wino4_f32_kernel, dim3(P.nblocks), dim3(W4_NT), W4_LDS, reinterpret_cast<hipStream_t>(stream), P);
-  return check_launch("conv_wino4_f32_kernel");
 }
 
 }  // namespace gpemsr

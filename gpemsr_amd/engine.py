@@ -231,9 +231,9 @@ class Engine:
             if (self.winograd and self._wino_layer(name) and kk == 3 and w.shape[0] % 32 == 0 and (name not in ps or w.shape[0] % 64 == 0)
                     and all(c % 8 == 0 for c in self.pc[name].splits)):
                 self.pc[name].wino = pack_winograd(w, dev, pixel_shuffle=name in ps)      # Winograd form of the 3x3 stride-1 layers (fp32 path)
-                if (self.winograd4 != "0" and name not in ps and w.shape[0] % 64 == 0 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "128"))
+                if (self.winograd4 != "0" and w.shape[0] % (256 if name in ps else 64) == 0 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "64"))
                         and (self.winograd4 == "all" or not name.startswith("refmodel.indexer."))):
-                    self.pc[name].wino4 = pack_winograd4(w, dev)                           # F(4x4,3x3) form of the many-channel layers
+                    self.pc[name].wino4 = pack_winograd4(w, dev, pixel_shuffle=name in ps)     # F(4x4,3x3) form
             if (self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1
                     and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32"))):
                 self.pc[name].wino7 = pack_winograd7(w, dev)          # 1-D Winograd F(2, 7) form of SpyNet's 32 <-> 64 7x7 layers (fp32 path)

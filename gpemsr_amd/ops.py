@@ -216,7 +216,7 @@ class PackedConv:
     w7c16: Optional[torch.Tensor] = None   # bf16 data path, 32 -> 16 7x7: 16x16x32 MFMA fragments (packing.pack_conv7_c32_cout16)
     wino: Optional[torch.Tensor] = None    # fp32, 3x3 stride 1: Winograd F(2x2,3x3) weights U[16][cout][cin] (packing.pack_winograd; descriptor.transposed = 3)
     wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
-    wino4: Optional[torch.Tensor] = None   # fp32, 3x3 stride 1, >= 128 input channels: Winograd F(4x4,3x3) weights U[cin/8][36][2][cout][4] (packing.pack_winograd4; descriptor.transposed = 5)
+    wino4: Optional[torch.Tensor] = None   # fp32, 3x3 stride 1, >= 64 input channels: Winograd F(4x4,3x3) weights U[cin/8][36][2][cout][4] (packing.pack_winograd4; descriptor.transposed = 5)
     wino7: Optional[torch.Tensor] = None   # fp32, 7x7 stride 1: 1-D Winograd F(2, 7) weights U[cin/8][7][8][2][cout][4] (packing.pack_winograd7; descriptor.transposed = 4)
     wrows: Optional[torch.Tensor] = None   # bf16 data path, DCN 64 -> 64: plain rows [cout][9 taps][64 channels] bf16 (packing.pack_dcn_rows_bf16; csrc/dcn_bf16.hip)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
@@ -246,7 +246,7 @@ def conv_cosine_ok(src: "Act", pc: "PackedConv") -> bool:
             and src.h % 16 == 0 and src.w % 32 == 0 and src.ld % 4 == 0 and src.ptr % 16 == 0 and len(pc.splits) == 1 and src.c % 8 == 0)
 
 
-def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str, winograd: bool = False) -> "Act":
+def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str, winograd: bool = False, winograd4: bool = True) -> "Act":
     """act(conv(src)) is NOT stored: its 16x16-patch cosine against `a` (R:model/GPEMSR.py:387-395) comes from partial sums formed in the
     convolution's epilogue (gpemsr_conv_desc.cos_partials) + gpemsr_patch_cosine_finish -> [n, h/16, w/16, 1]."""
     lib = _abi.load()
@@ -270,6 +270,9 @@ def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str, winogra
     if winograd and pc.wino is not None and pc.cout == 64 and s0.c % 8 == 0 and h % 16 == 0 and w % 32 == 0:
         d.transposed, d.weight = 3, pc.wino.data_ptr()          # the Winograd form leaves the same records (csrc/conv_wino.hip)
         executed = flops * 16.0 / 36.0
+        if winograd4 and pc.wino4 is not None and act in (ACT_NONE, ACT_RELU, ACT_LRELU):
+            d.transposed, d.weight = 5, pc.wino4.data_ptr()     # ... and so does the F(4x4) form (csrc/conv_wino4.hip)
+            executed = flops * 36.0 / 144.0
     if PROFILER is not None:
         nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32cos", n, h, w, s0.c, pc.cout, int(d.transposed)))
         nb = 4.0 * (n * h * w * (s0.c + pc.cout) + pc.cout * pc.cin * 9)          # source + the operand map read; the result is not stored
@@ -300,7 +303,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     direct7 = bool(kw16.pop("direct7", False))            # fp32: keep the direct form of a 7x7 layer that has F(2, 7) weights packed (A/B, tests)
     cos_with = kw16.pop("cos_with", None)                  # fp32: patch cosine of the result against this tensor, result not stored
     if cos_with is not None:
-        return _conv2d_cosine(srcs, pc, act, cos_with, tag, winograd=winograd)
+        return _conv2d_cosine(srcs, pc, act, cos_with, tag, winograd=winograd, winograd4=winograd4)
     assert not kw16 or not any(kw16.values()), f"{sorted(kw16)} are options of the bf16 data path"
     s0 = srcs[0]
     n, h, w = s0.n, s0.h, s0.w
@@ -414,7 +417,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     if winograd and precision == "fp32" and winograd_ok(srcs, pc, stride, out, residual) and weight_image_stride == 0 and src_image_stride is None:
         d.transposed, d.weight = 3, pc.wino.data_ptr()          # 16 multiplies per 2x2 outputs instead of 36 (csrc/conv_wino.hip)
         executed = flops * 16.0 / 36.0
-        if winograd4 and winograd4_ok(srcs, pc, residual, pixmul):
+        if winograd4 and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and winograd4_ok(srcs, pc, residual, pixmul):
             d.transposed, d.weight = 5, pc.wino4.data_ptr()     # 36 multiplies per 4x4 outputs instead of 144 (csrc/conv_wino4.hip)
             executed = flops * 36.0 / 144.0
     if (gn_stats and precision == "fp32" and act == ACT_NONE and residual is None and pixmul is None and not pc.transposed and not pc.pixel_shuffle
@@ -447,9 +450,12 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
 
 
 def winograd4_ok(srcs, pc: "PackedConv", residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
-    """Layers (among those winograd_ok accepts) the F(4x4, 3x3) form takes: `pc.wino4` packed (the engine packs it for layers of >= 128 input
-    channels), cout % 64 == 0, plain store.  (Whether a small map is worth its 16 x 32 pixel tiles is the caller's call: `winograd4=False`.)"""
-    return not (pc.wino4 is None or pc.cout % 64 != 0 or pc.pixel_shuffle or residual is not None or pixmul is not None)
+    """Layers (among those winograd_ok accepts) the F(4x4, 3x3) form takes: `pc.wino4` packed (the engine packs it for layers of >= 64 input
+    channels), cout % 64 == 0; plain store, + residual (+ pixel multiplier), or PixelShuffle (cout % 256 == 0, nothing else).  (Whether a small
+    map is worth its 16 x 32 pixel tiles is the caller's call: `winograd4=False`.)"""
+    if pc.wino4 is None or pc.cout % 64 != 0 or (pixmul is not None and residual is None):
+        return False
+    return not pc.pixel_shuffle or (pc.cout % 256 == 0 and residual is None and pixmul is None)
 
 
 def winograd7_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:

@@ -75,13 +75,17 @@ WINO4_BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -
 WINO4_AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
 
 
-def pack_winograd4(w: torch.Tensor, device) -> torch.Tensor:
+def pack_winograd4(w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch.Tensor:
     """Conv2d(3x3) weight OIHW fp32 (cin % 8 == 0) -> U = G g G^T for the Winograd F(4x4, 3x3) form of gpemsr_conv2d (descriptor.transposed
     = 5; csrc/conv_wino4.hip): [cin / 8][position p = 6 xi + nu][quad][cout][4] fp32, folded in float64.  A wave's fragment of one position
     (32 couts x one quad) is 512 consecutive bytes: the kernel reads it straight into registers."""
     cout, cin, kh, kw = w.shape
     assert kh == 3 and kw == 3 and cin % 8 == 0
-    U = torch.einsum("xa,ocab,yb->xyoc", WINO4_G, w.detach().to(torch.float64).cpu(), WINO4_G)   # [xi][nu][cout][cin]
+    g = w.detach().to(torch.float64).cpu()
+    if pixel_shuffle:                                                    # the same row permutation as pack_conv: (2i + j) * C/4 + c
+        cq = cout // 4
+        g = g[torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)]
+    U = torch.einsum("xa,ocab,yb->xyoc", WINO4_G, g, WINO4_G)                                     # [xi][nu][cout][cin]
     U = U.reshape(36, cout, cin // 8, 2, 4).permute(2, 0, 3, 1, 4)                                    # [chunk][p][quad][cout][4]
     return U.to(torch.float32).contiguous().to(device)
 

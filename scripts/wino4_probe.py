@@ -27,7 +27,10 @@ def timed(fn, reps=3):
     return s.elapsed_time(e) / reps
 
 
-for (n, cin, cout, h, w) in ((80, 512, 512, 64, 64), (80, 256, 256, 128, 128), (16, 128, 128, 256, 256), (16, 192, 64, 512, 512)):
+SHAPES = ((80, 512, 512, 64, 64), (80, 256, 256, 128, 128), (16, 128, 128, 256, 256), (16, 192, 64, 512, 512))
+if "--c64" in sys.argv:                                   # the 64-channel layers (8 chunks per tile): where a tile's fixed cost shows
+    SHAPES = ((16, 64, 64, 1024, 1024), (80, 64, 64, 128, 128))
+for (n, cin, cout, h, w) in SHAPES:
     wt = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5
     pc = pack_conv(wt, torch.rand(cout), dev)
     pc.wino = pack_winograd(wt, dev)

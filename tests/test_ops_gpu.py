@@ -787,6 +787,13 @@ def test_patch_cosine_from_the_conv_epilogue(n, h, w):
     assert torch.equal(aa.nchw(), a_before)
     _close(gw.nchw(), want.float(), tol=1e-5, what="Winograd epilogue patch cosine vs fp64")
     assert torch.equal(gw.buf, ops.conv2d([ta], pc, ops.ACT_RELU, cos_with=aa, winograd=True).buf), "not bit-stable"
+    # ... and from the F(4x4) form's (csrc/conv_wino4.hip, W4_COS)
+    from gpemsr_amd.packing import pack_winograd4
+    pc.wino4 = pack_winograd4(wt, dev)
+    g4 = ops.conv2d([ta], pc, ops.ACT_RELU, cos_with=aa, winograd=True)
+    assert torch.equal(aa.nchw(), a_before) and not torch.equal(g4.buf, gw.buf)          # (another summation order: the F(4x4) kernel ran)
+    _close(g4.nchw(), want.float(), tol=2e-5, what="F(4x4) epilogue patch cosine vs fp64")
+    assert torch.equal(g4.buf, ops.conv2d([ta], pc, ops.ACT_RELU, cos_with=aa, winograd=True).buf), "not bit-stable"
 
 
 WINO_CASES = [
@@ -846,16 +853,18 @@ def test_conv2d_winograd_form(case):
 
 
 WINO4_CASES = [
-    # (n, cins, cout, h, w, act)
-    (1, (128,), 64, 16, 32, 0),                 # exactly one 16 x 32 tile, 16 chunks
-    (2, (128,), 128, 37, 70, 1),                # ragged tiles both ways, odd sizes (blocks across the right / bottom edge)
-    (1, (512,), 512, 32, 64, 0),                # the VQGAN 512-channel layers: 64 chunks, 8 cout blocks
-    (2, (64, 128, 64), 64, 17, 33, 2),          # concat of three sources
-    (3, (256,), 128, 48, 40, 0),                # several images x tiles x cout blocks
-    (1, (8,), 64, 20, 36, 0),                   # ONE chunk (prologue only)
-    (1, (16,), 64, 16, 32, 0),                  # two chunks (no image DMA inside the loop)
-    (2, (24,), 64, 21, 40, 1),                  # three chunks (the ring of three raw images filled by the prologue)
-    (1, (32,), 128, 33, 65, 0),                 # four chunks: the first DMA issued inside the loop
+    # (n, cins, cout, h, w, act, residual, pixmul)
+    (1, (128,), 64, 16, 32, 0, False, False),   # exactly one 16 x 32 tile, 16 chunks
+    (2, (128,), 128, 37, 70, 1, False, False),  # ragged tiles both ways, odd sizes (blocks across the right / bottom edge)
+    (1, (512,), 512, 32, 64, 0, False, False),  # the VQGAN 512-channel layers: 64 chunks, 8 cout blocks
+    (2, (64, 128, 64), 64, 17, 33, 2, False, False),   # concat of three sources
+    (3, (256,), 128, 48, 40, 0, False, False),  # several images x tiles x cout blocks
+    (1, (8,), 64, 20, 36, 0, False, False),     # ONE chunk (prologue only)
+    (1, (16,), 64, 16, 32, 0, False, False),    # two chunks (no image DMA inside the loop)
+    (2, (24,), 64, 21, 40, 1, False, False),    # three chunks (the ring of three raw images filled by the prologue)
+    (1, (32,), 128, 33, 65, 0, False, False),   # four chunks: the first DMA issued inside the loop
+    (2, (64,), 64, 32, 64, 0, True, False),     # ResidualBlockNoBN conv2: + residual, whole tiles
+    (3, (64,), 64, 37, 70, 2, True, True),      # + residual and the per-pixel multiplier (MPF mask), ragged tiles
 ]
 
 
@@ -867,7 +876,7 @@ def test_conv2d_winograd_f4x4_form(case):
     and run-to-run bit-stable."""
     from gpemsr_amd import ops
     from gpemsr_amd.packing import pack_conv, pack_winograd, pack_winograd4
-    n, cins, cout, h, w, act = case
+    n, cins, cout, h, w, act, use_res, use_mul = case
     dev = _dev()
     cin = sum(cins)
     x = _rand(n, cin, h, w, seed=31)
@@ -885,17 +894,27 @@ def test_conv2d_winograd_f4x4_form(case):
     pc = pack_conv(wt, b, dev, cins)
     pc.wino = pack_winograd(wt, dev)
     pc.wino4 = pack_winograd4(wt, dev)
-    assert ops.winograd_ok(srcs, pc) and ops.winograd4_ok(srcs, pc)
+    res = _rand(n, cout, h, w, seed=36) if use_res else None
+    mul = _rand(n, 1, h, w, seed=37).abs() + 0.5 if use_mul else None
+    if res is not None:
+        want = want + res.double()
+    if mul is not None:
+        want = want * mul.double()
+    r_act = None if res is None else _to_act(res, dev, ld=cout + 4, off=4)
+    m_act = None if mul is None else ops.Act(mul.reshape(-1).to(dev), n, h, w, 1, 1, 0)
+    assert ops.winograd_ok(srcs, pc, residual=r_act) and ops.winograd4_ok(srcs, pc, r_act, m_act)
     out = _to_act(torch.zeros(n, cout, h, w), dev, ld=cout + 12, off=4)
-    got = ops.conv2d(srcs, pc, act, out=out, winograd=True)
+    got = ops.conv2d(srcs, pc, act, residual=r_act, pixmul=m_act, out=out, winograd=True)
     _close(got.nchw(), want, 6e-5, f"winograd F(4x4) {case}")
     assert float((out.buf.view(n, h, w, cout + 12)[..., :4] - 7.0).abs().max()) == 0.0       # neighbours of the slice untouched
-    direct = ops.conv2d(srcs, pc, act)
+    direct = ops.conv2d(srcs, pc, act, residual=r_act, pixmul=m_act)
     _close(got.nchw(), direct.nchw(), 6e-5, "winograd F(4x4) vs direct")
+    f2 = ops.conv2d(srcs, pc, act, residual=r_act, pixmul=m_act, winograd=True, winograd4=False)
+    assert not torch.equal(f2.nchw(), got.nchw()), "the F(4x4) kernel did not run"
     again = _to_act(torch.zeros(n, cout, h, w), dev, ld=cout + 12, off=4)
-    ops.conv2d(srcs, pc, act, out=again, winograd=True)
+    ops.conv2d(srcs, pc, act, residual=r_act, pixmul=m_act, out=again, winograd=True)
     assert torch.equal(out.buf, again.buf), "not bit-stable run to run"
-    if act == 0 and cout % 32 == 0:
+    if act == 0 and cout % 32 == 0 and not use_res:
         g = (1.0 + 0.2 * _rand(cout, seed=34)).to(dev); be = (0.2 * _rand(cout, seed=35)).to(dev)
         plain = ops.conv2d(srcs, pc, ops.ACT_NONE, winograd=True)
         y0 = ops.groupnorm_relu(plain, g, be, True).nchw().clone()
@@ -929,3 +948,9 @@ def test_conv2d_winograd_form_pixel_shuffle(n, h, w):
     assert (got.n, got.h, got.w, got.c) == (n, 2 * h, 2 * w, 64)
     _close(got.nchw(), want, 2e-5, "winograd + pixel shuffle")
     _close(got.nchw(), ops.conv2d([xa], pc, 2).nchw(), 2e-5, "vs direct")
+    from gpemsr_amd.packing import pack_winograd4
+    pc.wino4 = pack_winograd4(wt, dev, pixel_shuffle=True)              # upconv1-3 on the F(4x4) form (csrc/conv_wino4.hip, W4_PS)
+    assert ops.winograd4_ok([xa], pc)
+    g4 = ops.conv2d([xa], pc, 2, winograd=True)
+    assert (g4.n, g4.h, g4.w, g4.c) == (n, 2 * h, 2 * w, 64) and not torch.equal(g4.nchw(), got.nchw())
+    _close(g4.nchw(), want, 6e-5, "winograd F(4x4) + pixel shuffle")
