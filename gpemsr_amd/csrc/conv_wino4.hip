@@ -22,7 +22,7 @@
 //     under position 2, barrier.  Measured before the pipeline (phases one after the other, three barriers; profiles/r05_wino4_phase_probe_v1.log,
 //     512 -> 512 at 80 x 64^2): 5.06 ms = 0.78 fixed + 2.9 MFMA + 0.7 transforms + 0.65 loads -- nothing overlapped.  Pair-sized items keep the
 //     transform's transient registers at 24 beside the 96 accumulators;
-//   * raw image in LDS as [quad][column mod 4][row][column / 4]: the six columns an item reads for consecutive block columns are consecutive
+//   * raw image in LDS as [column mod 4][row][column / 4][quad]: the six columns an item reads for consecutive block columns are consecutive
 //     16-byte slots (a pixel-major image would be read at a 64-byte stride);
 //   * epilogue: the 36 sums of every (block, cout) meet through LDS in four passes of 16 couts (92 KB each), A^T . A in registers (10 + 10
 //     additions per row / column pass), bias, GroupNorm partial sums (conv + bias, per tile and channel, fixed order), activation, store.
@@ -63,7 +63,7 @@ struct W4Params {
 };
 
 constexpr int W4_NT = 768;                                               // threads
-constexpr int W4_RAW_SLOTS = 2 * 4 * 18 * 9;                             // [quad][col & 3][row 18][col >> 2 (9)] = 1296 16-byte slots
+constexpr int W4_RAW_SLOTS = 4 * 18 * 9 * 2;                             // [col & 3][row 18][col >> 2 (9)][quad] = 1296 16-byte slots
 constexpr int W4_RAW_BYTES = W4_RAW_SLOTS * 16;                          // 20,736
 constexpr int W4_X_BYTES = 18 * 6 * 2 * 8 * 16;                          // X[row][nu][quad][block column]: 27,648 (128-byte halves swapped on odd row groups, see w4_xoff)
 constexpr int W4_V_BYTES = 36 * 2 * 32 * 16;                             // V[p][quad][block]: 36,864, two buffers
@@ -141,11 +141,12 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     const int s = tid + i * W4_NT;
     r_off[i] = ~0u;
     if (s < W4_RAW_SLOTS) {
-      const int c4 = s % 9, r1 = s / 9;
-      const int row = r1 % 18, r2 = r1 / 18;
-      const int col = 4 * c4 + (r2 & 3);
+      const int q = s & 1, p1 = s >> 1;                       // quad innermost: neighbouring lanes fetch the two halves of one pixel's 32 bytes --
+      const int c4 = p1 % 9, r1 = p1 / 9;                     // a DMA instruction touches 32 cache lines, not 64
+      const int row = r1 % 18, ph = r1 / 18;
+      const int col = 4 * c4 + ph;
       const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
-      if (col < 34 && iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) r_off[i] = (unsigned)(iy * P.w + ix) * ((unsigned)P.ld[0] * 4u) + 16u * (unsigned)(r2 >> 2);
+      if (col < 34 && iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) r_off[i] = (unsigned)(iy * P.w + ix) * ((unsigned)P.ld[0] * 4u) + 16u * (unsigned)q;
     }
   }
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm + (unsigned)wave * 1024u);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
       const unsigned pb0 = (unsigned)P.ld[f_src] * 4u, pb1 = (unsigned)P.ld[f_src + 1] * 4u;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        if (r_off[i] != ~0u) { const unsigned qo = r_off[i] & 16u; r_off[i] = (r_off[i] - qo) / pb0 * pb1 + qo; }
+        if (r_off[i] != ~0u) { const unsigned qo = 16u * (unsigned)(tid & 1); r_off[i] = (r_off[i] - qo) / pb0 * pb1 + qo; }   // (slot parity = quad)
       f_c0 = 0; ++f_src;
     }
   };
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   int a_t1l, a_t1s, a_t2l, a_t2s;
   {
     const int q = (tid >> 4) & 1, row = tid >> 5;                                  // T1 item
-    a_t1l = it_hb + ((q * 4 * 18 + row) * 9 + it_bc) * 16;                         // + ((i & 3) * 162 + (i >> 2)) * 16 + raw image
+    a_t1l = it_hb + ((row * 9 + it_bc) * 2 + q) * 16;                              // + ((i & 3) * 162 + (i >> 2)) * 32 + raw image
     a_t1s = W4_X_OFF + w4_xoff(row, 0, q, it_bc, it_hb);                           // + nu * 256
     const int br = (tid >> 4) & 3, q2 = wave & 1, nu = wave >> 1;                  // T2 item
     a_t2l = W4_X_OFF + w4_xoff(4 * br, nu, q2, it_bc, it_hb);                      // + i * 1536, i < 4; rows 4 br + 4, + 5: the other 128-byte half
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   auto t1_load = [&](int buf, float2 (&d)[6]) {
     const char* rb = wsm + a_t1l + buf * W4_RAW_BYTES;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(rb + ((i & 3) * 162 + (i >> 2)) * 16);
+    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(rb + ((i & 3) * 162 + (i >> 2)) * 32);
   };
   auto t1_store = [&](const float2 (&d)[6]) {
     float2 tt[6];
@@ -275,11 +276,21 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     vf = *reinterpret_cast<const float4*>(vb + 2048);
     if (do_t2) t2_load(d);
     mma(2, 0, vf, 0, 2); mma(2, 1, vf, 0, 2);
+    // The DMA goes out behind the last wait for this chunk's U and ahead of the load of U[2] -- at a different point of that window in each
+    // of a SIMD's three waves (role = wave / 4): 21 gather instructions of 32 cache lines each, issued by all twelve waves at the same program
+    // point, fill the address queue and hold every wave (in-order issue: its MFMAs too) until they drain.
+    const bool dma = c + 3 < nchunks && !(W4_SKIP & 16);
+    const int role = wave >> 2, rbi = rb1 == 0 ? 2 : rb1 - 1;
     __builtin_amdgcn_sched_barrier(0);
-    if (c + 3 < nchunks && !(W4_SKIP & 16)) issue_raw(rb1 == 0 ? 2 : rb1 - 1);
+    if (dma && role == 0) issue_raw(rbi);
     __builtin_amdgcn_sched_barrier(0);
     if (do_t2) t2_store((c + 1) & 1, d);
+    __builtin_amdgcn_sched_barrier(0);
+    if (dma && role == 1) issue_raw(rbi);
+    __builtin_amdgcn_sched_barrier(0);
     mma(2, 0, vf, 2, 4); mma(2, 1, vf, 2, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (dma && role == 2) issue_raw(rbi);
     asm volatile("" ::: "memory");
     if (!(W4_SKIP & 8)) load_u(cn, 2, U[2]);                 // (younger than the DMA: the compiler's wait for it next iteration covers the DMA)
     rb1 = rb1 == 2 ? 0 : rb1 + 1;

@@ -889,7 +889,7 @@ def test_conv2d_winograd_f4x4_form(case):
         want = F.leaky_relu(want, 0.1)
     srcs, o = [], 0
     for i, c in enumerate(cins):
-        srcs.append(_to_act(x[:, o:o + c], dev, ld=c + (8 if i == 0 else 0), off=8 if i == 0 else 0))
+        srcs.append(_to_act(x[:, o:o + c], dev, ld=c + (8 if i == 0 else 4 if i == 1 else 0), off=8 if i == 0 else 0))   # (row pitches = 0 and 4 mod 8 floats)
         o += c
     pc = pack_conv(wt, b, dev, cins)
     pc.wino = pack_winograd(wt, dev)
