@@ -38,7 +38,8 @@ namespace gpemsr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // timing experiments only (scripts/build_wino_probe_lib.sh compiles variants with -DW4_SKIP=mask; results are wrong on purpose):
-// 1 no T1, 2 no T2, 4 no MFMAs, 8 no U loads after the prologue, 16 no image loads after the prologue.  Compile-time: a run-time branch around a
+// 1 no T1, 2 no T2, 4 no MFMAs, 8 no U loads after the prologue, 16 no image loads after the prologue, 32 no output stores, 64 no epilogue passes,
+// 128 one chunk only (prologue + epilogue).  Compile-time: a run-time branch around a
 // load would make the compiler's vmcnt counts conservative and change what is being timed.
 #ifndef W4_SKIP
 #define W4_SKIP 0
@@ -107,7 +108,7 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 }
 
 // epilogue modes (compile-time: the item loop stays branch-free)
-constexpr int W4_RES = 1, W4_MUL = 2, W4_PS = 4, W4_COS = 8;
+constexpr int W4_RES = 1, W4_MUL = 2, W4_PS = 4, W4_COS = 8, W4_ACT = 16, W4_GN = 32;   // W4_ACT: RELU / LRELU (else none); W4_GN: GroupNorm sums
 
 template <int MODE>
 __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   //      V[(c + 1) & 1]), fetches the U fragments of chunk c + 1 and starts the DMA of raw image c + 3.  Two barriers per chunk.
   const int a_v = W4_V_OFF + (3 * wave) * 1024 + lane * 16;  // V[.][p][lh][li]
   int rb1 = 1;                                               // ring slot of raw image c + 1; image c + 3 goes to the slot of image c = (rb1 + 2) % 3
+  if (W4_SKIP & 128) nchunks = 1;
   for (int c = 0; c < nchunks; ++c) {
     const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U: no branch around the loads)
     const bool more = c + 1 < nchunks;
@@ -321,11 +323,12 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   float e_bias[4];                                             // all four passes' biases up front: a load inside a pass would wait (vmcnt) for the
 #pragma unroll                                                 // previous pass's stores
   for (int k = 0; k < 4; ++k) e_bias[k] = P.bias && tid < 512 ? P.bias[n0 + 16 * k + e_cc] : 0.f;
-  const float slope = act == GPEMSR_ACT_LRELU ? 0.1f : 1.f;   // branch-free activation (NONE / RELU / LRELU only, checked on the host)
-  const bool relu = act == GPEMSR_ACT_RELU;
+  // activation as arithmetic, max(v, slope v) + 0 with slope 0 / 0.1 for RELU / LRELU (checked on the host; the + 0 turns RELU's -0 into
+  // +0): written as a select, the compiler built control flow around every store -- 1,200 instructions and 150 branches per item and pass
+  const float slope = act == GPEMSR_ACT_LRELU ? 0.1f : 0.f;   // (W4_ACT instantiations only)
   float cab = 0.f, caa = 0.f, cbb = 0.f;                       // W4_COS: this thread's sums over its block and the four passes
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < ((W4_SKIP & 64) ? 0 : 4); ++k) {
     const int nt = k >> 1, half = k & 1;
     if ((li >> 4) == half) {
       float* ew = E + ((3 * wave) * 32 + 4 * lh) * W4_EPIX + (li & 15);
@@ -364,6 +367,9 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
           for (int xi = 0; xi < 6; ++xi) m[xi] = er[((xi * 6 + nu) * 32) * W4_EPIX];
           w4_at(m, z[nu]);
         }
+        // the bias rides the second transform: A^T e_1 = (1, 1, 1, 1), so b added to z[1][i] is b added to the four outputs of row i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[1][i] += bias;
         float* op = t_out + cq;                               // uniform; + the row / column step below; [e_ooff] per lane
         if (MODE & W4_PS) {                                    // channels n0 + cq .. + 15 of the permuted cout order lie in ONE sub-pixel q = ch / (cout / 4)
           const int ch0 = n0 + cq, q = ch0 / P.cq;
@@ -379,17 +385,17 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
           if ((MODE & (W4_RES | W4_COS)) && i < 3) load_row(i + 1, rn);
 #pragma unroll
           for (int jx = 0; jx < 4; ++jx) {
-            const float v = y[jx] + bias;
+            const float v = y[jx];
             if (!G || (oy0 + 4 * e_br + i < P.h && ox0 + 4 * e_bc + jx < P.w)) {
-              gs += v; gq = fmaf(v, v, gq);
-              float t = relu ? fmaxf(v, 0.f) : (v > 0.f ? v : slope * v);
+              if (MODE & W4_GN) { gs += v; gq = fmaf(v, v, gq); }
+              float t = (MODE & W4_ACT) ? fmaxf(v, slope * v) + 0.f : v;
               if (MODE & W4_COS) {
                 cab = fmaf(rv[jx], t, cab); caa = fmaf(rv[jx], rv[jx], caa); cbb = fmaf(t, t, cbb);
               } else {
                 if (MODE & W4_RES) t += rv[jx];
                 if (MODE & W4_MUL) { asm volatile("" : "+v"(mo)); t *= *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t_mul + (long long)i * P.w + jx) + mo); }
                 asm volatile("" : "+v"(oo));
-                *reinterpret_cast<float*>(reinterpret_cast<char*>(op + jx * o_col) + oo) = t;
+                if (!(W4_SKIP & 32) || t == 12345.678f) *reinterpret_cast<float*>(reinterpret_cast<char*>(op + jx * o_col) + oo) = t;
               }
             }
           }
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
         }
       };
       if (inside) rows(std::false_type{}); else rows(std::true_type{});
-      if (P.gn_ws) { red[(e_b * 64 + cq + e_cc) * 2] = gs; red[(e_b * 64 + cq + e_cc) * 2 + 1] = gq; }
+      if (MODE & W4_GN) { red[(e_b * 64 + cq + e_cc) * 2] = gs; red[(e_b * 64 + cq + e_cc) * 2 + 1] = gq; }
     }
     __syncthreads();
   }
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
       rec[0] = cab; rec[1] = caa; rec[2] = cbb;
     }
   }
-  if (P.gn_ws && tid < 64) {                                   // per (tile, channel): the 32 blocks in fixed order
+  if ((MODE & W4_GN) && tid < 64) {                                   // per (tile, channel): the 32 blocks in fixed order
     float s = 0.f, q = 0.f;
     for (int b = 0; b < 32; ++b) { s += red[(b * 64 + tid) * 2]; q += red[(b * 64 + tid) * 2 + 1]; }
     const int part = ty0 * P.tiles_x + tx0;
@@ -457,7 +463,8 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
   if (d->gn_partials || parts_only) GP_REQUIRE(d->act == GPEMSR_ACT_NONE && mode == 0, "conv2d (F(4x4,3x3) form): GroupNorm partial sums need act NONE, plain store");
   if (parts_only) { *parts_only = cdiv(d->h, 16) * cdiv(d->w, 32); return GPEMSR_OK; }
   if (name_buf) {
-    snprintf(name_buf, (size_t)name_cap, "conv_wino4_f32_kernel<%s>", mode == W4_COS ? "COS" : mode == W4_PS ? "PS" : mode == 3 ? "RES,MUL" : mode == 1 ? "RES" : "PLAIN");
+    snprintf(name_buf, (size_t)name_cap, "conv_wino4_f32_kernel<%s%s%s>", mode == W4_COS ? "COS" : mode == W4_PS ? "PS" : mode == 3 ? "RES,MUL" : mode == 1 ? "RES" : "PLAIN",
+             d->act != GPEMSR_ACT_NONE ? ",ACT" : "", d->gn_partials ? ",GN" : "");
     return GPEMSR_OK;
   }
   W4Params P{};
@@ -483,12 +490,14 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
   P.nblocks = (int)nb;
   { const char* e = getenv("GPEMSR_WINO4_ORDER"); P.cout_fast = e ? atoi(e) : 1; }   // same time either way (profiles/r05_ab_wino4_order.log); 1 reads the input from HBM once
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  switch (mode) {
-    case 0: return launch_wino4<0>(P, st);
-    case W4_RES: return launch_wino4<W4_RES>(P, st);
-    case W4_RES | W4_MUL: return launch_wino4<W4_RES | W4_MUL>(P, st);
-    case W4_PS: return launch_wino4<W4_PS>(P, st);
-    default: return launch_wino4<W4_COS>(P, st);
+  const int full = mode | (d->act != GPEMSR_ACT_NONE ? W4_ACT : 0) | (d->gn_partials ? W4_GN : 0);
+  switch (full) {
+#define W4_CASE(M) case M: return launch_wino4<M>(P, st)
+    W4_CASE(0); W4_CASE(W4_ACT); W4_CASE(W4_GN);
+    W4_CASE(W4_RES); W4_CASE(W4_RES | W4_ACT); W4_CASE(W4_RES | W4_MUL); W4_CASE(W4_RES | W4_MUL | W4_ACT);
+    W4_CASE(W4_PS); W4_CASE(W4_PS | W4_ACT); W4_CASE(W4_COS); W4_CASE(W4_COS | W4_ACT);
+#undef W4_CASE
+    default: return fail(GPEMSR_EINVAL, "conv2d (F(4x4,3x3) form): no instantiation for epilogue mode %d", full);
   }
 }
 
