@@ -24,8 +24,10 @@
 //     transform's transient registers at 24 beside the 96 accumulators;
 //   * raw image in LDS as [column mod 4][row][column / 4][quad]: the six columns an item reads for consecutive block columns are consecutive
 //     16-byte slots (a pixel-major image would be read at a 64-byte stride);
-//   * epilogue: the 36 sums of every (block, cout) meet through LDS in four passes of 16 couts (92 KB each), A^T . A in registers (10 + 10
-//     additions per row / column pass), bias, GroupNorm partial sums (conv + bias, per tile and channel, fixed order), activation, store.
+//   * epilogue: the 36 sums of every (block, cout) meet through LDS in four passes of 16 couts, two 72 KB exchange buffers (pass k + 1 is
+//     written while pass k is transformed: one barrier per pass), A^T . A in registers (10 + 10 additions per row / column pass), bias,
+//     GroupNorm partial sums (conv + bias, per tile and channel, fixed order), activation, residual / multiplier / PixelShuffle store or
+//     patch-cosine sums.
 //
 // Replaces gpemsr_conv2d's direct form (descriptor.transposed = 5; weight = packing.pack_winograd4) for 3x3 stride-1 layers whose sources are
 // multiples of 8 channels (>= 128 in all), cout % 64 == 0, no residual / multiplier / PixelShuffle.
@@ -70,11 +72,13 @@ constexpr int W4_RAW_BYTES = W4_RAW_SLOTS * 16;                          // 20,7
 constexpr int W4_X_BYTES = 18 * 6 * 2 * 8 * 16;                          // X[row][nu][quad][block column]: 27,648 (128-byte halves swapped on odd row groups, see w4_xoff)
 constexpr int W4_V_BYTES = 36 * 2 * 32 * 16;                             // V[p][quad][block]: 36,864, two buffers
 constexpr int W4_X_OFF = 3 * W4_RAW_BYTES, W4_V_OFF = W4_X_OFF + W4_X_BYTES;
-constexpr int W4_LDS = W4_V_OFF + 2 * W4_V_BYTES;                        // 163,584 of 163,840
-constexpr int W4_EPIX = 20;                                              // floats per (position, block) row of the exchange buffer: 16 couts + 4
-constexpr int W4_E_BYTES = 36 * 32 * W4_EPIX * 4;                        // 92,160 (overlays the raw images / X after the main loop)
-constexpr int W4_RED_OFF = W4_E_BYTES;                                   // GroupNorm sums [32 blocks][64 couts][2]: 16,384 (overlays too)
-static_assert(W4_RED_OFF + 16384 <= W4_LDS && W4_LDS <= 160 * 1024, "LDS map");
+constexpr int W4_MAIN_LDS = W4_V_OFF + 2 * W4_V_BYTES;                   // 163,584: the main loop's map
+constexpr int W4_EPIX = 16;                                              // floats per (position, block) row of an exchange buffer: the 16 couts of a pass (an item
+                                                                         // wave reads 4 blocks x 64 bytes = 256 consecutive bytes: conflict-free without padding)
+constexpr int W4_E_BYTES = 36 * 32 * W4_EPIX * 4;                        // 73,728; TWO buffers (pass k + 1 is written while pass k is transformed), over the main map
+constexpr int W4_RED_OFF = 2 * W4_E_BYTES;                               // GroupNorm sums [32 blocks][64 couts][2]: 16,384
+constexpr int W4_LDS = W4_RED_OFF + 16384;                               // 163,840 = all of the CU's LDS
+static_assert(W4_MAIN_LDS <= W4_LDS && W4_LDS <= 160 * 1024, "LDS map");
 
 // X[row][nu][quad][block column] byte offset of a channel pair.  The four block rows a T2 wave reads are 4 rows = 6,144 bytes apart -- the same 32
 // banks, a 4-way conflict; swapping the two 128-byte halves (the quad bit) on every other group of four rows puts them on alternating halves.
@@ -327,21 +331,26 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   // +0): written as a select, the compiler built control flow around every store -- 1,200 instructions and 150 branches per item and pass
   const float slope = act == GPEMSR_ACT_LRELU ? 0.1f : 0.f;   // (W4_ACT instantiations only)
   float cab = 0.f, caa = 0.f, cbb = 0.f;                       // W4_COS: this thread's sums over its block and the four passes
-#pragma unroll
-  for (int k = 0; k < ((W4_SKIP & 64) ? 0 : 4); ++k) {
+  auto e_write = [&](int k) {                                  // this wave's three positions x 32 blocks x the 16 couts of pass k -> E[k & 1]
     const int nt = k >> 1, half = k & 1;
     if ((li >> 4) == half) {
-      float* ew = E + ((3 * wave) * 32 + 4 * lh) * W4_EPIX + (li & 15);
+      float* ew = E + (k & 1) * (W4_E_BYTES / 4) + ((3 * wave) * 32 + 4 * lh) * W4_EPIX + (li & 15);
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ew[(j * 32 + (r & 3) + 8 * (r >> 2)) * W4_EPIX] = acc[j][nt][r];   // register r = block (r & 3) + 8 (r >> 2) + 4 lh
+        for (int r = 0; r < 16; ++r) ew[(j * 32 + (r & 3) + 8 * (r >> 2)) * W4_EPIX] = nt == 0 ? acc[j][0][r] : acc[j][1][r];   // register r = block (r & 3) + 8 (r >> 2) + 4 lh
     }
-    __syncthreads();
+  };
+  if (!(W4_SKIP & 64)) e_write(0);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < ((W4_SKIP & 64) ? 0 : 4); ++k) {
+    const int nt = k >> 1, half = k & 1;
+    if (k < 3) e_write(k + 1);                                 // (the buffer pass k - 1 was read from: every reader passed the barrier below)
     if (tid < 512) {
       const int cq = nt * 32 + 16 * half;                     // first cout of this pass within the block
       const float bias = e_bias[k];
-      const float* er = E + e_b * W4_EPIX + e_cc;
+      const float* er = E + (k & 1) * (W4_E_BYTES / 4) + e_b * W4_EPIX + e_cc;
       float gs = 0.f, gq = 0.f;
       auto rows = [&](auto guarded) {
         constexpr bool G = decltype(guarded)::value;
