@@ -1,4 +1,4 @@
-// Winograd F(4x4, 3x3) form of the 3x3 stride-1 convolution on the exact-fp32 matrix pipe, for layers with MANY input channels.
+// Winograd F(4x4, 3x3) form of the 3x3 stride-1 convolution on the exact-fp32 matrix pipe (layers with >= 64 input channels, cout % 64 == 0).
 //
 // F(2x2, 3x3) (conv_wino.hip) does 16 multiplies per 2x2 outputs = 4 per output; F(4x4, 3x3) does 36 per 4x4 outputs = 2.25 per output
 // (direct: 9): executed MFMA FLOPs = 1/4 of the algorithmic ones.
@@ -7,9 +7,11 @@
 // the host in float64).  Thirty-six independent GEMMs  M_p[block][cout] = sum_cin V_p[block][cin] U_p[cin][cout]  on 1/16 of the pixels.  All
 // arithmetic is fp32; simulated and measured error ~2e-5 of the result at 512 channels (F(2x2): ~5e-6; direct: 3e-6; the path's bar: 1e-3).
 //
-// The price is transform work per MULTIPLY four times that of F(2x2) and an exchange of 36 x 32 x 64 sums per tile in the epilogue, so this
-// kernel is for the layers where a tile's main loop is long: >= 16 chunks of 8 input channels (the 128-512-channel layers of the VQGAN prior and
-// the first prior-fusion convolutions, R:model/blocks.py:5-29, R:model/GPEMSR.py:255-262); 64-channel layers keep F(2x2).
+// The price is transform work per MULTIPLY four times that of F(2x2) and an exchange of 36 x 32 x 64 sums per tile in the epilogue -- and on
+// this chip v_mfma_f32_32x32x2_f32 runs on the vector FMA units, so every vector instruction (transforms, addresses, the epilogue's A^T . A) is
+// paid in matrix time, overlapped or not.  It pays most where a tile's main loop is long (the 128-512-channel layers of the VQGAN prior and the
+// prior-fusion convolutions, R:model/blocks.py:5-29, R:model/GPEMSR.py:255-262: 6.7 -> 4.4 ms at 512 channels) and still on the 64-channel
+// layers (8 chunks per tile: 7.2 -> 4.9 ms on a 1024^2 map) once the epilogue was free of scratch and control flow.
 //
 //   * workgroup = 12 waves (three per SIMD, 168 registers), output tile 16 x 32 pixels = 32 blocks of 4x4 (one MFMA row tile) x 64 couts;
 //     wave w owns the positions p = 3 w .. 3 w + 2 (p = 6 xi + nu): 3 x 2 accumulator tiles = 96 registers;
@@ -30,7 +32,8 @@
 //     patch-cosine sums.
 //
 // Replaces gpemsr_conv2d's direct form (descriptor.transposed = 5; weight = packing.pack_winograd4) for 3x3 stride-1 layers whose sources are
-// multiples of 8 channels (>= 128 in all), cout % 64 == 0, no residual / multiplier / PixelShuffle.
+// multiples of 8 channels, cout % 64 == 0, activation NONE / RELU / LRELU; epilogue flavours: plain (+ GroupNorm sums), + residual (+ pixel
+// multiplier), PixelShuffle(2) (cout % 256 == 0), patch-cosine sums against `residual` instead of a store (cout == 64).
 #include "common.h"
 #include "conv_wino.h"
 #include <type_traits>
