@@ -86,11 +86,13 @@ typedef struct {
                                       rounding, 8/14 of the multiplies; csrc/conv7_wino.hip): ONE source with c % 8 == 0, cout % 32 == 0, no
                                       residual / pixmul / pixel_shuffle / gn_partials / cos_partials; weight = U[cin/8][7 ky][8 nu][2][cout][4]
                                       = G g per filter row (gpemsr_amd/packing.py::pack_winograd7).
-                                      5 = WINOGRAD F(4x4, 3x3) form of a 3x3 stride-1 convolution for layers with many input channels (the
-                                      VQGAN prior's 128-512-channel convolutions, R:model/blocks.py:5-29; same result to fp32 rounding --
-                                      ~2e-5 of the result's scale at 512 channels --, 36/144 of the multiplies; csrc/conv_wino4.hip): every
-                                      source c % 8 == 0, cout % 64 == 0, no residual / pixmul / pixel_shuffle / cos_partials, gn_partials
-                                      allowed; weight = U[cin/8][36 positions][2][cout][4] = G g G^T (gpemsr_amd/packing.py::pack_winograd4) */
+                                      5 = WINOGRAD F(4x4, 3x3) form of a 3x3 stride-1 convolution (same result to fp32 rounding -- ~2e-5 of
+                                      the result's scale at 512 channels --, 36/144 of the multiplies; csrc/conv_wino4.hip; the VQGAN prior's
+                                      128-512-channel convolutions, R:model/blocks.py:5-29, and the 64-channel fusion / reconstruction /
+                                      VGG layers): every source c % 8 == 0, cout % 64 == 0, act NONE / RELU / LRELU; epilogues: plain store
+                                      (+ gn_partials), residual (+ pixmul), pixel_shuffle (cout % 256 == 0, alone), cos_partials (cout == 64,
+                                      h % 16 == 0, w % 32 == 0, operand map in `residual`); weight = U[cin/8][36 positions][2][cout][4] = G g G^T
+                                      (gpemsr_amd/packing.py::pack_winograd4) */
   const float* weight;             /* packed [tap][cout][cin_pad], tap = ky*k+kx, cin fastest, cin padded per source to 8
                                       (k>=3) or 32 (k=1).  transposed: [tap = 2*dy+dx][n' = (co/32)*128 + q*32 + co%32][cin_pad],
                                       q = 2*py+px, the phase-stacked 2x2-tap form (gpemsr_amd/packing.py::pack_convT) */
