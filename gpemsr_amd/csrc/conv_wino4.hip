@@ -66,7 +66,7 @@ struct W4Params {
   int cq;                         // W4_PS: cout / 4 (PixelShuffle(2): cout block q = ch / cq goes to sub-pixel (q >> 1, q & 1) of a 2h x 2w image)
   float* cos_ws;                  // W4_COS: [n][h / 4 strips][w / 16 patch columns][4] sums of a.b, a.a, b.b (b = act(conv + bias)), nothing stored
   int tiles_x, tiles_y, tiles_n, nblocks;
-  int cout_fast;                  // launch order: 1 = cout block fastest (GPEMSR_WINO4_ORDER)
+  int cgroup;                     // launch order: cout blocks side by side per pixel tile (divides tiles_n; GPEMSR_WINO4_CGROUP)
 };
 
 constexpr int W4_NT = 768;                                               // threads
@@ -128,12 +128,15 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     const int nwg = P.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   }
-  int t = bid, tn = 0;
-  if (P.cout_fast) { tn = t % P.tiles_n; t /= P.tiles_n; }   // the cout blocks of one pixel tile side by side: the input tile is fetched from HBM once
+  // Launch order [cout-block group][pixel tile][cout block within the group]: an XCD's 32 resident workgroups are 32 / g pixel tiles x g cout
+  // blocks.  Per round they pull g U slices and 32 / g halo tiles through the XCD's L2 (neither fits: 4 MB): g = all blocks re-streams the whole
+  // U every round, g = 1 fetches every input tile once per cout block; measured fetch per 512 -> 512 launch: g = 1: 6.7 GB, 2: 5.1, 4: 5.8, 8: 9.6 (algorithmic 1.4; host: W4Params::cgroup, default 2).
+  int t = bid;
+  const int tn_lo = t % P.cgroup; t /= P.cgroup;
   const int tx0 = t % P.tiles_x; t /= P.tiles_x;
   const int ty0 = t % P.tiles_y; t /= P.tiles_y;
   const int img = t % P.n; t /= P.n;
-  if (!P.cout_fast) tn = t;                                   // cout block slowest: the workgroups running together read ONE U slice
+  const int tn = t * P.cgroup + tn_lo;
   const int oy0 = ty0 * 16, ox0 = tx0 * 32, n0 = tn * 64;
 
   int nchunks = 0;
@@ -500,7 +503,13 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (F(4x4,3x3) form): grid too large");
   P.nblocks = (int)nb;
-  { const char* e = getenv("GPEMSR_WINO4_ORDER"); P.cout_fast = e ? atoi(e) : 1; }   // same time either way (profiles/r05_ab_wino4_order.log); 1 reads the input from HBM once
+  {   // same time for every grouping (profiles/r05_ab_wino4_order.log); the L2-miss bytes differ (profiles/r05_wino4_cgroup_counters.log)
+    const char* e = getenv("GPEMSR_WINO4_CGROUP");
+    int g = e ? atoi(e) : 2;
+    if (g < 1) g = 1;
+    while (P.tiles_n % g) --g;
+    P.cgroup = g;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int full = mode | (d->act != GPEMSR_ACT_NONE ? W4_ACT : 0) | (d->gn_partials ? W4_GN : 0);
   switch (full) {
