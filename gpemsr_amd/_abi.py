@@ -62,6 +62,7 @@ class ConvDesc(C.Structure):
         ("pixmul", C.c_void_p), ("pixel_shuffle", C.c_int32),
         ("out", C.c_void_p), ("out_ld", C.c_int32),
         ("gn_partials", C.c_void_p), ("cos_partials", C.c_void_p),
+        ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_relu", C.c_int32),
     ]
 
 

@@ -776,6 +776,7 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only,
   if (d->transposed == 3) {          // Winograd F(2x2, 3x3) form of a 3x3 stride-1 convolution (conv_wino.hip)
     return conv2d_winograd(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0, parts_only);
   }
+  GP_REQUIRE(d->a_scale == nullptr || d->transposed == 5, "conv2d: a_scale / a_shift (folded source GroupNorm) exist in the F(4x4,3x3) form only");
   if (d->transposed == 5) {          // Winograd F(4x4, 3x3) form of a 3x3 stride-1 convolution with many input channels (conv_wino4.hip)
     return conv2d_winograd4(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0, parts_only);
   }
@@ -967,4 +968,4 @@ extern "C" int gpemsr_debug_read_stamps(unsigned long long* host, int nblocks) {
 #endif
 
 // The Python binding (gpemsr_amd/_abi.py) mirrors this struct field by field.
-static_assert(sizeof(gpemsr_conv_desc) == 224, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");
+static_assert(sizeof(gpemsr_conv_desc) == 248, "gpemsr_conv_desc layout changed: update gpemsr_amd/_abi.py");

@@ -64,6 +64,7 @@ struct W4Params {
   const float* residual; int res_ld;   // W4_RES: added after the activation; W4_COS: the operand map `a` of the patch cosine
   const float* pixmul;            // W4_MUL: one multiplier per pixel, after the residual
   int cq;                         // W4_PS: cout / 4 (PixelShuffle(2): cout block q = ch / cq goes to sub-pixel (q >> 1, q & 1) of a 2h x 2w image)
+  const float* a_scale; const float* a_shift;   // W4_AFF: [n][cin] tables (gpemsr_groupnorm_scale_shift)
   float* cos_ws;                  // W4_COS: [n][h / 4 strips][w / 16 patch columns][4] sums of a.b, a.a, b.b (b = act(conv + bias)), nothing stored
   int tiles_x, tiles_y, tiles_n, nblocks;
   int cgroup;                     // launch order: cout blocks side by side per pixel tile (divides tiles_n; GPEMSR_WINO4_CGROUP)
@@ -116,6 +117,7 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 
 // epilogue modes (compile-time: the item loop stays branch-free)
 constexpr int W4_RES = 1, W4_MUL = 2, W4_PS = 4, W4_COS = 8, W4_ACT = 16, W4_GN = 32;   // W4_ACT: RELU / LRELU (else none); W4_GN: GroupNorm sums
+constexpr int W4_AFF = 64;   // the (single) source is read as relu(scale[n][c] x + shift[n][c]): the producer's GroupNorm + ReLU folded into T1
 
 template <int MODE>
 __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
@@ -220,7 +222,37 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const float2*>(rb + ((i & 3) * 162 + (i >> 2)) * 32);
   };
-  auto t1_store = [&](const float2 (&d)[6]) {
+  // W4_AFF: this thread's channel pair of chunk c is channels 8 c + t1_ch, + 1 of the image; its scale / shift pair is requested one chunk
+  // ahead (right after the previous one was used: older than this iteration's DMA, so waiting for it never forces the DMA).  Slots outside
+  // the image must stay zero (relu(shift) is not): on edge tiles the six columns and the row of the item are tested.
+  const int t1_ch = 4 * ((tid >> 4) & 1) + 2 * (tid & 1);
+  const float* aff_s = (MODE & W4_AFF) ? P.a_scale + (long long)img * P.c[0] + t1_ch : nullptr;
+  const float* aff_h = (MODE & W4_AFF) ? P.a_shift + (long long)img * P.c[0] + t1_ch : nullptr;
+  float2 aff_sc = make_float2(1.f, 1.f), aff_sh = make_float2(0.f, 0.f);
+  auto aff_load = [&](int chunk) {
+    if (MODE & W4_AFF) { aff_sc = *reinterpret_cast<const float2*>(aff_s + 8 * chunk); aff_sh = *reinterpret_cast<const float2*>(aff_h + 8 * chunk); }
+  };
+  unsigned t1_ok = 0x7fu;                                      // bits 0-5: column i inside the image, bit 6: the row
+  if (MODE & W4_AFF) {
+    const int row = tid >> 5, bc = (tid >> 1) & 7;
+    const int iy = oy0 - 1 + row;
+    t1_ok = (iy >= 0 && iy < P.h) ? 0x40u : 0u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const int ix = ox0 - 1 + 4 * bc + i; if (ix >= 0 && ix < P.w) t1_ok |= 1u << i; }
+  }
+  const bool t1_edge = !(oy0 >= 1 && oy0 + 17 <= P.h && ox0 >= 1 && ox0 + 33 <= P.w);    // (uniform) the halo leaves the image
+  auto t1_store = [&](float2 (&d)[6]) {
+    if (MODE & W4_AFF) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        d[i].x = fmaxf(fmaf(d[i].x, aff_sc.x, aff_sh.x), 0.f); d[i].y = fmaxf(fmaf(d[i].y, aff_sc.y, aff_sh.y), 0.f);
+      }
+      if (t1_edge) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          if (!((t1_ok >> 6) & (t1_ok >> i) & 1u)) d[i] = make_float2(0.f, 0.f);
+      }
+    }
     float2 tt[6];
     w4_bt(d, tt);
 #pragma unroll
@@ -251,7 +283,9 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   __syncthreads();
   {
     float2 d[6];
+    aff_load(0);
     if (wave < 9) { t1_load(0, d); t1_store(d); }
+    aff_load(nchunks > 1 ? 1 : 0);
     __syncthreads();
     t2_load(d); t2_store(0, d);
     __syncthreads();
@@ -281,6 +315,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     mma(0, 0, vf, 0, 4); mma(0, 1, vf, 0, 4);
     if (!(W4_SKIP & 8)) load_u(cn, 0, U[0]);
     if (do_t1) t1_store(d);
+    if (MODE & W4_AFF) aff_load(c + 2 < nchunks ? c + 2 : c);     // (clamped: no branch around a load)
     vf = *reinterpret_cast<const float4*>(vb + 1024);
     mma(1, 0, vf, 0, 4); mma(1, 1, vf, 0, 4);
     if (!(W4_SKIP & 8)) load_u(cn, 1, U[1]);
@@ -476,10 +511,13 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
     mode = (d->residual ? W4_RES : 0) | (d->pixmul ? W4_MUL : 0);
   }
   if (d->gn_partials || parts_only) GP_REQUIRE(d->act == GPEMSR_ACT_NONE && mode == 0, "conv2d (F(4x4,3x3) form): GroupNorm partial sums need act NONE, plain store");
+  if (d->a_scale) GP_REQUIRE(d->a_shift && d->a_relu && d->nsrc == 1 && mode == 0 && d->act == GPEMSR_ACT_NONE && (reinterpret_cast<uintptr_t>(d->a_scale) & 7) == 0 &&
+                             (reinterpret_cast<uintptr_t>(d->a_shift) & 7) == 0,
+                             "conv2d (F(4x4,3x3) form): the folded source GroupNorm + ReLU needs one source, act NONE, plain store, 8-byte aligned tables");
   if (parts_only) { *parts_only = cdiv(d->h, 16) * cdiv(d->w, 32); return GPEMSR_OK; }
   if (name_buf) {
     snprintf(name_buf, (size_t)name_cap, "conv_wino4_f32_kernel<%s%s%s>", mode == W4_COS ? "COS" : mode == W4_PS ? "PS" : mode == 3 ? "RES,MUL" : mode == 1 ? "RES" : "PLAIN",
-             d->act != GPEMSR_ACT_NONE ? ",ACT" : "", d->gn_partials ? ",GN" : "");
+             d->act != GPEMSR_ACT_NONE ? ",ACT" : "", d->gn_partials ? (d->a_scale ? ",GN,AFF" : ",GN") : (d->a_scale ? ",AFF" : ""));
     return GPEMSR_OK;
   }
   W4Params P{};
@@ -499,6 +537,7 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.out = d->out; P.out_ld = d->out_ld;
   P.gn_ws = d->gn_partials; P.gn_parts = cdiv(d->h, 16) * cdiv(d->w, 32);
   P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul; P.cq = d->cout / 4; P.cos_ws = d->cos_partials;
+  P.a_scale = d->a_scale; P.a_shift = d->a_shift;
   P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, 16); P.tiles_n = d->cout / 64;
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (F(4x4,3x3) form): grid too large");
@@ -511,10 +550,10 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
     P.cgroup = g;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int full = mode | (d->act != GPEMSR_ACT_NONE ? W4_ACT : 0) | (d->gn_partials ? W4_GN : 0);
+  const int full = mode | (d->act != GPEMSR_ACT_NONE ? W4_ACT : 0) | (d->gn_partials ? W4_GN : 0) | (d->a_scale ? W4_AFF : 0);
   switch (full) {
 #define W4_CASE(M) case M: return launch_wino4<M>(P, st)
-    W4_CASE(0); W4_CASE(W4_ACT); W4_CASE(W4_GN);
+    W4_CASE(0); W4_CASE(W4_ACT); W4_CASE(W4_GN); W4_CASE(W4_GN | W4_AFF); W4_CASE(W4_AFF);
     W4_CASE(W4_RES); W4_CASE(W4_RES | W4_ACT); W4_CASE(W4_RES | W4_MUL); W4_CASE(W4_RES | W4_MUL | W4_ACT);
     W4_CASE(W4_PS); W4_CASE(W4_PS | W4_ACT); W4_CASE(W4_COS); W4_CASE(W4_COS | W4_ACT);
 #undef W4_CASE

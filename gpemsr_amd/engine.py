@@ -89,6 +89,7 @@ class Engine:
             assert mode in ("bf16x3", "fp32") and (cnt == "" or cnt.isdigit()), f"indexer_precision {indexer_precision!r}: bf16 | bf16x3:N | fp32:N | fp32:all"
             self._hp_mode, self._hp_n = mode, int(cnt or 1)
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
+        self.fold_gn32 = os.environ.get("GPEMSR_FOLD_GN32", "1") != "0"  # fp32 path: the same, in the input transform of the F(4x4) Winograd form
         self.flash_attn = os.environ.get("GPEMSR_FLASH_ATTN", "1") != "0"   # bf16 path: NonLocalBlock products + softmax as one kernel (C = 512, T % 128 == 0)
         # exact-fp32 path: 3x3 stride-1 layers in the Winograd F(2x2,3x3) form (16 instead of 36 multiplies per 2x2 outputs, fp32 arithmetic,
         # ~1e-6 of the result; csrc/conv_wino.hip).  The training engines use it for their FROZEN layers only (`_wino_layer`: the transformed
@@ -285,6 +286,11 @@ class Engine:
         th = 8 if cout % 64 == 0 else 16
         return 3 * x.h * x.w >= 2 * (-(-x.h // th) * th) * (-(-x.w // 32) * 32)
 
+    def _wino4_runs(self, x: Act, pc) -> bool:
+        """Will `conv(x, <layer of pc>)` take the F(4x4) Winograd form?  (the decisions of `conv` below)"""
+        return (self.winograd and pc.wino is not None and pc.wino4 is not None and self.wino_geometry_ok(x, pc.cout)
+                and 3 * x.h * x.w >= 2 * (-(-x.h // 16) * 16) * (-(-x.w // 32) * 32))
+
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
         kw.setdefault("precision", self.precision)
         pc = self.pc[name]
@@ -321,7 +327,12 @@ class Engine:
             # pass over the stored tensor (0.55 ms per 2.7 GB) is cheaper than the sums in the epilogue (+0.9 ms); A/B -1.1 ms per step
             epi = False
         t = self.conv(x, p + ".block.0", gn_stats=epi)
-        if self.bf16 and self.fold_gn and self.o.conv_affine_source_ok(t, self.pc[p + ".block.3"]):
+        pc3 = self.pc[p + ".block.3"]
+        if (not self.bf16 and self.precision == "fp32" and self.fold_gn32 and self._wino4_runs(t, pc3) and self.o.conv_affine_source_ok32(t, pc3)):
+            # exact-fp32 path: the same fold in the input transform of the F(4x4) Winograd form (csrc/conv_wino4.hip, W4_AFF)
+            sc, sh = self.o.groupnorm_scale_shift(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"])
+            u = self.conv(t, p + ".block.3", gn_stats=epi, a_affine=(sc, sh, True))
+        elif self.bf16 and self.fold_gn and self.o.conv_affine_source_ok(t, self.pc[p + ".block.3"]):
             # the first Normalize + ReLU of the block is applied by the second convolution while it stages its source: the normalised
             # tensor never exists in HBM (one read + one write of the block's intermediate less)
             sc, sh = self.o.groupnorm_scale_shift(t, self.par[p + ".block.1.weight"], self.par[p + ".block.1.bias"])

@@ -301,6 +301,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     winograd = bool(kw16.pop("winograd", False))          # fp32: the Winograd F(2x2,3x3) form where the layer qualifies (winograd_ok)
     winograd4 = bool(kw16.pop("winograd4", True))         # ... and the F(4x4,3x3) form where `pc.wino4` is packed (winograd4_ok)
     direct7 = bool(kw16.pop("direct7", False))            # fp32: keep the direct form of a 7x7 layer that has F(2, 7) weights packed (A/B, tests)
+    a_affine32 = kw16.pop("a_affine", None) if precision == "fp32" else None   # fp32: (scale, shift, relu) tables folded into the F(4x4) form's input transform
     cos_with = kw16.pop("cos_with", None)                  # fp32: patch cosine of the result against this tensor, result not stored
     if cos_with is not None:
         return _conv2d_cosine(srcs, pc, act, cos_with, tag, winograd=winograd, winograd4=winograd4)
@@ -420,6 +421,11 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         if winograd4 and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and winograd4_ok(srcs, pc, residual, pixmul):
             d.transposed, d.weight = 5, pc.wino4.data_ptr()     # 36 multiplies per 4x4 outputs instead of 144 (csrc/conv_wino4.hip)
             executed = flops * 36.0 / 144.0
+    if a_affine32 is not None:
+        assert int(d.transposed) == 5 and conv_affine_source_ok32(srcs, pc, act, residual, pixmul), "a_affine: only the F(4x4,3x3) form folds a source GroupNorm (conv_affine_source_ok32)"
+        sc, sh, relu = a_affine32
+        assert relu and sc.numel() == n * srcs[0].c and sh.numel() == n * srcs[0].c and sc.dtype == torch.float32
+        d.a_scale, d.a_shift, d.a_relu = sc.data_ptr(), sh.data_ptr(), 1
     if (gn_stats and precision == "fp32" and act == ACT_NONE and residual is None and pixmul is None and not pc.transposed and not pc.pixel_shuffle
             and pc.cout % 4 == 0 and out.ld % 4 == 0 and out.ptr % 16 == 0 and (pc.b is None or pc.b.data_ptr() % 16 == 0)
             # the partial-sum epilogue exists only in the LDS-DMA instantiations (conv_mfma.hip: GP_REQUIRE(dma && BN >= 32)): sources it
@@ -456,6 +462,15 @@ def winograd4_ok(srcs, pc: "PackedConv", residual: Optional["Act"] = None, pixmu
     if pc.wino4 is None or pc.cout % 64 != 0 or (pixmul is not None and residual is None):
         return False
     return not pc.pixel_shuffle or (pc.cout % 256 == 0 and residual is None and pixmul is None)
+
+
+def conv_affine_source_ok32(srcs, pc: "PackedConv", act: int = ACT_NONE, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
+    """fp32 path: can ``conv2d(..., winograd=True, a_affine=...)`` fold the GroupNorm + ReLU of its source?  One fp32 source, no activation /
+    residual / multiplier / PixelShuffle, and the layer runs in the F(4x4,3x3) form (winograd_ok and winograd4_ok)."""
+    if isinstance(srcs, Act):
+        srcs = [srcs]
+    return (len(srcs) == 1 and act == ACT_NONE and residual is None and pixmul is None and not pc.pixel_shuffle
+            and winograd_ok(srcs, pc) and winograd4_ok(srcs, pc))
 
 
 def winograd7_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
@@ -1193,12 +1208,25 @@ def conv_affine_source_ok(x: Act, pc: PackedConv) -> bool:
 
 
 def groupnorm_scale_shift(x: Act, gamma: torch.Tensor, beta: torch.Tensor, groups: int = 32, eps: float = 1e-6):
-    """GroupNorm(groups, eps, affine) of the bf16 tensor ``x`` as per-(image, channel) scale / shift tables [n][c] (fp32):
-    normalised = scale * x + shift.  Statistics from the producing convolution's epilogue (``x.gn``) or one pass over x."""
+    """GroupNorm(groups, eps, affine) of the tensor ``x`` (bf16, or fp32 on the exact path) as per-(image, channel) scale / shift tables
+    [n][c] (fp32): normalised = scale * x + shift.  Statistics from the producing convolution's epilogue (``x.gn``) or one pass over x."""
     lib = _abi.load()
     _require_gpu(x)
-    assert x.bf16
     hw, dev = x.h * x.w, x.buf.device
+    if not x.bf16:
+        parts = max(1, min(64, hw // 64))
+        ws = torch.empty(x.n * parts * x.c * 2 + x.n * groups * 2, dtype=torch.float32, device=dev)
+        mr = ws[x.n * parts * x.c * 2:]
+        if x.gn is not None:
+            gws, gparts = x.gn
+            _abi.check(lib.gpemsr_groupnorm_finish(gws.data_ptr(), x.n, hw, x.c, groups, gparts, eps, mr.data_ptr(), _stream()), "groupnorm_finish")
+        else:
+            _abi.check(lib.gpemsr_groupnorm_stats(x.ptr, x.n, hw, x.c, x.ld, groups, eps, ws.data_ptr(), parts, mr.data_ptr(), _stream()), "groupnorm_stats")
+        ss = torch.empty(2, x.n * x.c, dtype=torch.float32, device=dev)
+        _abi.check(lib.gpemsr_groupnorm_scale_shift(mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), x.n, x.c, groups, ss[0].data_ptr(), ss[1].data_ptr(),
+                                                    _stream()), "groupnorm_scale_shift")
+        x.gn = None
+        return ss[0], ss[1]
     if x.gn is not None:
         ws, parts = x.gn
     else:

@@ -115,6 +115,12 @@ typedef struct {
                                       16x16-patch cosine of two VGG relu1_2 maps (R:model/GPEMSR.py:387-395) without the second map in
                                       memory: [n][h/4][w/16][4] floats, then gpemsr_patch_cosine_finish.  33..64 output channels, h % 16 == 0,
                                       w % 32 == 0.  NULL = none */
+  const float* a_scale;            /* optional (transposed = 5 only, one source): the source is read as relu(a_scale[n][c] x + a_shift[n][c]) -- the
+                                      GroupNorm + ReLU of the producing layer (R:model/blocks.py:5-29: block.1 / block.2 of a ResidualBlock) folded
+                                      into the consuming convolution's input transform; tables from gpemsr_groupnorm_scale_shift; padding stays
+                                      zero.  NULL = the source as stored */
+  const float* a_shift;            /* with a_scale */
+  int32_t a_relu;                  /* with a_scale: must be 1 */
 } gpemsr_conv_desc;
 
 int gpemsr_conv2d(const gpemsr_conv_desc* d, void* stream);

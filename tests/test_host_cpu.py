@@ -177,7 +177,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.gpemsr_abi_version() == 1
     lib.gpemsr_last_error.restype = ctypes.c_char_p
     assert lib.gpemsr_conv2d(None, None) == -1 and b"null descriptor" in lib.gpemsr_last_error()   # validation only, no compute
-    assert ctypes.sizeof(_abi.ConvDesc) == 224        # matches the C struct layout (static_assert in conv_mfma.hip)
+    assert ctypes.sizeof(_abi.ConvDesc) == 248        # matches the C struct layout (static_assert in conv_mfma.hip)
     assert ctypes.sizeof(_abi.ConvDesc16) == 272      # static_assert in conv_bf16.hip
     assert lib.gpemsr_conv2d_bf16(None, None) == -1
 

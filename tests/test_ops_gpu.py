@@ -929,6 +929,38 @@ def test_conv2d_winograd_f4x4_form(case):
         assert torch.equal(ops.conv2d(srcs, pc, ops.ACT_NONE, gn_stats=True, winograd=True).gn[0], sums), "partial sums not bit-stable"
 
 
+@pytest.mark.parametrize("n,c,cout,h,w", [(2, 128, 128, 32, 64), (3, 64, 64, 37, 70), (1, 512, 512, 16, 32), (2, 256, 64, 48, 33)])
+def test_groupnorm_relu_folded_into_the_f4x4_input_transform(n, c, cout, h, w):
+    """gpemsr_conv_desc.a_scale / a_shift with transposed = 5 (csrc/conv_wino4.hip, W4_AFF): conv(relu(GroupNorm(t))) without the normalised
+    tensor in memory (the first Normalize + ReLU of a VQGAN ResidualBlock, R:model/blocks.py:5-29) -- against fp64, against apply + convolution,
+    with ragged edge tiles (padding must stay zero: relu(shift) is not), the GroupNorm sums of its own epilogue, bit-stable."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd, pack_winograd4
+    dev = _dev()
+    t = _rand(n, c, h, w, seed=41) * 2.0 + 0.3
+    g = (1.0 + 0.2 * _rand(c, seed=42)).to(dev); be = (0.2 * _rand(c, seed=43)).to(dev)
+    wt = _rand(cout, c, 3, 3, seed=44, scale=1.0 / np.sqrt(c * 9)); b = _rand(cout, seed=45, scale=0.1)
+    pc = pack_conv(wt, b, dev)
+    pc.wino = pack_winograd(wt, dev)
+    pc.wino4 = pack_winograd4(wt, dev)
+    ta = _to_act(t, dev)
+    assert ops.conv_affine_source_ok32(ta, pc)
+    sc, sh = ops.groupnorm_scale_shift(ta, g, be)
+    got = ops.conv2d([ta], pc, ops.ACT_NONE, winograd=True, gn_stats=True, a_affine=(sc, sh, True))
+    assert got.gn is not None
+    sums = got.gn[0].clone()
+    norm64 = torch.relu(F.group_norm(t.double(), 32, g.double().cpu(), be.double().cpu(), 1e-6))
+    want = F.conv2d(norm64, wt.double(), b.double(), 1, 1)
+    _close(got.nchw(), want, 6e-5, "folded GroupNorm + ReLU -> F(4x4) conv vs fp64")
+    tn = ops.groupnorm_relu(_to_act(t, dev), g, be, True)
+    ref = ops.conv2d([tn], pc, ops.ACT_NONE, winograd=True, gn_stats=True)
+    _close(got.nchw(), ref.nchw(), 2e-5, "folded vs apply + convolution")
+    _close(sums, ref.gn[0], 2e-5, "GroupNorm sums of the folded launch")
+    again = ops.conv2d([ta], pc, ops.ACT_NONE, winograd=True, gn_stats=True, a_affine=(sc, sh, True))
+    assert torch.equal(again.nchw(), got.nchw()) and torch.equal(again.gn[0], sums), "not bit-stable"
+    assert float((ta.nchw() - t.to(dev)).abs().max()) == 0.0                       # the source is left as stored
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 16, 32), (1, 13, 21)])
 def test_conv2d_winograd_form_pixel_shuffle(n, h, w):
     """upconv1-3 (R:model/GPEMSR.py:304-316,442-448: conv 64 -> 256 + PixelShuffle(2) + LeakyReLU) in the Winograd form: the store map
