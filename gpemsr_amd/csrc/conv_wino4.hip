@@ -56,7 +56,8 @@ struct W4Params {
   int ld[GPEMSR_MAX_SRC];
   int c[GPEMSR_MAX_SRC];
   int nsrc;
-  int n, h, w, cout;
+  int n, h, w, cout;              // cout: channels stored; the weights hold cout_pad = 64 ceil(cout / 64) (zero rows behind cout)
+  int cout_pad;
   const float* weight;            // U [cin / 8][36][2 quads][cout][4]
   const float* bias; int act;
   float* out; int out_ld;
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     }
   };
   // ---- U fragments of this wave's three positions: lane (li = cout, lh = quad), [chunk][p][quad][cout][4]: a uniform base + ONE per-lane offset ----
-  const unsigned u_off = (unsigned)(lh * P.cout + li) * 4u;                       // floats
+  const unsigned u_off = (unsigned)(lh * P.cout_pad + li) * 4u;                   // floats
   auto load_u = [&](int chunk, int j, float4 (&U)[2]) {
-    const float* ub = P.weight + ((long long)(chunk * 36 + 3 * wave + j) * 2 * P.cout + n0) * 4;     // wave-uniform
+    const float* ub = P.weight + ((long long)(chunk * 36 + 3 * wave + j) * 2 * P.cout_pad + n0) * 4; // wave-uniform
     U[0] = *reinterpret_cast<const float4*>(ub + u_off);
     U[1] = *reinterpret_cast<const float4*>(ub + u_off + 32 * 4);
   };
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   const unsigned e_moff = 4u * (unsigned)(4 * e_br * P.w + 4 * e_bc);
   float e_bias[4];                                             // all four passes' biases up front: a load inside a pass would wait (vmcnt) for the
 #pragma unroll                                                 // previous pass's stores
-  for (int k = 0; k < 4; ++k) e_bias[k] = P.bias && tid < 512 ? P.bias[n0 + 16 * k + e_cc] : 0.f;
+  for (int k = 0; k < 4; ++k) e_bias[k] = P.bias && tid < 512 && n0 + 16 * k + e_cc < P.cout ? P.bias[n0 + 16 * k + e_cc] : 0.f;
   // activation as arithmetic, max(v, slope v) + 0 with slope 0 / 0.1 for RELU / LRELU (checked on the host; the + 0 turns RELU's -0 into
   // +0): written as a select, the compiler built control flow around every store -- 1,200 instructions and 150 branches per item and pass
   const float slope = act == GPEMSR_ACT_LRELU ? 0.1f : 0.f;   // (W4_ACT instantiations only)
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   for (int k = 0; k < ((W4_SKIP & 64) ? 0 : 4); ++k) {
     const int nt = k >> 1, half = k & 1;
     if (k < 3) e_write(k + 1);                                 // (the buffer pass k - 1 was read from: every reader passed the barrier below)
-    if (tid < 512) {
+    if (tid < 512 && n0 + (nt * 32 + 16 * half) + e_cc < P.cout) {   // (a last cout block may be partly padding: cout % 64 != 0)
       const int cq = nt * 32 + 16 * half;                     // first cout of this pass within the block
       const float bias = e_bias[k];
       const float* er = E + (k & 1) * (W4_E_BYTES / 4) + e_b * W4_EPIX + e_cc;
@@ -496,7 +497,8 @@ static int launch_wino4(const W4Params& P, hipStream_t st) {
 // descriptor.transposed == 5: called from gpemsr_conv2d (conv_mfma.hip); parts_only != NULL: only report the GroupNorm records per image
 int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap, int* parts_only) {
   GP_REQUIRE(d->ksize == 3 && d->stride == 1 && d->weight_image_stride == 0, "conv2d (F(4x4,3x3) form): 3x3, stride 1, one weight set");
-  GP_REQUIRE(d->cout % 64 == 0, "conv2d (F(4x4,3x3) form): cout %% 64 == 0 (got %d)", d->cout);
+  const bool padded = d->cout % 64 != 0;           // weights packed with zero rows up to the next multiple of 64: plain store / residual only
+  GP_REQUIRE(!padded || (!d->pixel_shuffle && !d->cos_partials && !d->gn_partials && !parts_only), "conv2d (F(4x4,3x3) form): cout %% 64 != 0 (%d) takes the plain / residual epilogues only", d->cout);
   GP_REQUIRE(d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU, "conv2d (F(4x4,3x3) form): act NONE / RELU / LRELU (got %d)", d->act);
   int mode = 0;
   if (d->cos_partials) {
@@ -533,12 +535,12 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
   }
   GP_REQUIRE((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->out) & 3) == 0 && (long long)d->h * d->w < (1ll << 31),
              "conv2d (F(4x4,3x3) form): weight alignment / image size");
-  P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cout = d->cout;
+  P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cout = d->cout; P.cout_pad = cdiv(d->cout, 64) * 64;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.out = d->out; P.out_ld = d->out_ld;
   P.gn_ws = d->gn_partials; P.gn_parts = cdiv(d->h, 16) * cdiv(d->w, 32);
   P.residual = d->residual; P.res_ld = d->res_ld; P.pixmul = d->pixmul; P.cq = d->cout / 4; P.cos_ws = d->cos_partials;
   P.a_scale = d->a_scale; P.a_shift = d->a_shift;
-  P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, 16); P.tiles_n = d->cout / 64;
+  P.tiles_x = cdiv(d->w, 32); P.tiles_y = cdiv(d->h, 16); P.tiles_n = cdiv(d->cout, 64);
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (F(4x4,3x3) form): grid too large");
   P.nblocks = (int)nb;

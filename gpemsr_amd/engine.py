@@ -229,6 +229,10 @@ class Engine:
                 self.pc[name].w16 = pack_conv_split(self.pc[name], w, dev, pixel_shuffle=name in ps)
             if self.bf16 and all(c % 16 == 0 for c in self.pc[name].splits):
                 self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
+            if (self.winograd and self.winograd4 != "0" and self._wino_layer(name) and kk == 3 and w.shape[0] % 32 != 0 and w.shape[0] >= 128 and name not in ps
+                    and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "64")) and all(c % 8 == 0 for c in self.pc[name].splits)):
+                # cout % 32 != 0 (the DCN packs' 216-channel offset convolutions): no F(2x2) form, but the F(4x4) one through zero-padded weights
+                self.pc[name].wino4 = pack_winograd4(w, dev)
             if (self.winograd and self._wino_layer(name) and kk == 3 and w.shape[0] % 32 == 0 and (name not in ps or w.shape[0] % 64 == 0)
                     and all(c % 8 == 0 for c in self.pc[name].splits)):
                 self.pc[name].wino = pack_winograd(w, dev, pixel_shuffle=name in ps)      # Winograd form of the 3x3 stride-1 layers (fp32 path)
@@ -294,7 +298,7 @@ class Engine:
     def conv(self, srcs, name, act=ACT_NONE, **kw) -> Act:
         kw.setdefault("precision", self.precision)
         pc = self.pc[name]
-        if self.winograd and kw["precision"] == "fp32" and pc.wino is not None \
+        if self.winograd and kw["precision"] == "fp32" and (pc.wino is not None or pc.wino4 is not None) \
                 and self.wino_geometry_ok(srcs if isinstance(srcs, Act) else srcs[0], pc.cout):
             kw.setdefault("winograd", True)
             x0 = srcs if isinstance(srcs, Act) else srcs[0]

@@ -421,6 +421,10 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         if winograd4 and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and winograd4_ok(srcs, pc, residual, pixmul):
             d.transposed, d.weight = 5, pc.wino4.data_ptr()     # 36 multiplies per 4x4 outputs instead of 144 (csrc/conv_wino4.hip)
             executed = flops * 36.0 / 144.0
+    if (winograd and winograd4 and int(d.transposed) == 0 and precision == "fp32" and pc.wino4 is not None and pc.cout % 64 != 0 and act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+            and winograd4_padded_ok(srcs, pc, stride, out, residual, pixmul) and weight_image_stride == 0 and src_image_stride is None):
+        d.transposed, d.weight = 5, pc.wino4.data_ptr()         # cout % 64 != 0 (the 216-channel offset convs of the DCN packs): zero rows in U, no store
+        executed = flops * 36.0 / 144.0 * (-(-pc.cout // 64) * 64) / pc.cout
     if a_affine32 is not None:
         assert int(d.transposed) == 5 and conv_affine_source_ok32(srcs, pc, act, residual, pixmul), "a_affine: only the F(4x4,3x3) form folds a source GroupNorm (conv_affine_source_ok32)"
         sc, sh, relu = a_affine32
@@ -460,8 +464,18 @@ def winograd4_ok(srcs, pc: "PackedConv", residual: Optional["Act"] = None, pixmu
     channels), cout % 64 == 0; plain store, + residual (+ pixel multiplier), or PixelShuffle (cout % 256 == 0, nothing else).  (Whether a small
     map is worth its 16 x 32 pixel tiles is the caller's call: `winograd4=False`.)"""
     if pc.wino4 is None or pc.cout % 64 != 0 or (pixmul is not None and residual is None):
-        return False
+        return False                                        # (cout % 64 != 0: winograd4_padded_ok)
     return not pc.pixel_shuffle or (pc.cout % 256 == 0 and residual is None and pixmul is None)
+
+
+def winograd4_padded_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
+    """Layers with cout % 64 != 0 the F(4x4, 3x3) form takes through zero-padded weights (`pc.wino4` packed): 3x3 stride 1, fp32 sources of
+    c % 8 == 0 with 16-byte aligned rows, plain store or + residual."""
+    if pc.wino4 is None or pc.ksize != 3 or stride != 1 or pc.transposed or pc.pixel_shuffle or pixmul is not None:
+        return False
+    if any(s_.bf16 or s_.c % 8 != 0 or s_.ld % 4 != 0 or s_.ptr % 16 != 0 for s_ in srcs):
+        return False
+    return (out is None or not out.bf16) and (residual is None or not residual.bf16)
 
 
 def conv_affine_source_ok32(srcs, pc: "PackedConv", act: int = ACT_NONE, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:

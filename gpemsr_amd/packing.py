@@ -77,11 +77,15 @@ WINO4_AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 
 
 def pack_winograd4(w: torch.Tensor, device, pixel_shuffle: bool = False) -> torch.Tensor:
     """Conv2d(3x3) weight OIHW fp32 (cin % 8 == 0) -> U = G g G^T for the Winograd F(4x4, 3x3) form of gpemsr_conv2d (descriptor.transposed
-    = 5; csrc/conv_wino4.hip): [cin / 8][position p = 6 xi + nu][quad][cout][4] fp32, folded in float64.  A wave's fragment of one position
-    (32 couts x one quad) is 512 consecutive bytes: the kernel reads it straight into registers."""
+    = 5; csrc/conv_wino4.hip): [cin / 8][position p = 6 xi + nu][quad][cout_pad][4] fp32, folded in float64; cout_pad = 64 ceil(cout / 64), zero rows
+    behind cout (the kernel does not store them).  A wave's fragment of one position (32 couts x one quad) is 512 consecutive bytes: the kernel
+    reads it straight into registers."""
     cout, cin, kh, kw = w.shape
-    assert kh == 3 and kw == 3 and cin % 8 == 0
+    assert kh == 3 and kw == 3 and cin % 8 == 0 and not (pixel_shuffle and cout % 256)
     g = w.detach().to(torch.float64).cpu()
+    if cout % 64:
+        g = torch.cat([g, torch.zeros(64 - cout % 64, cin, 3, 3, dtype=torch.float64)])
+        cout = g.shape[0]
     if pixel_shuffle:                                                    # the same row permutation as pack_conv: (2i + j) * C/4 + c
         cq = cout // 4
         g = g[torch.tensor([4 * c + q for q in range(4) for c in range(cq)], dtype=torch.long)]

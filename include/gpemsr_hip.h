@@ -89,7 +89,8 @@ typedef struct {
                                       5 = WINOGRAD F(4x4, 3x3) form of a 3x3 stride-1 convolution (same result to fp32 rounding -- ~2e-5 of
                                       the result's scale at 512 channels --, 36/144 of the multiplies; csrc/conv_wino4.hip; the VQGAN prior's
                                       128-512-channel convolutions, R:model/blocks.py:5-29, and the 64-channel fusion / reconstruction /
-                                      VGG layers): every source c % 8 == 0, cout % 64 == 0, act NONE / RELU / LRELU; epilogues: plain store
+                                      VGG layers): every source c % 8 == 0, cout % 64 == 0 (or any cout with U zero-padded to the next multiple of 64:
+                                      plain store / residual only), act NONE / RELU / LRELU; epilogues: plain store
                                       (+ gn_partials), residual (+ pixmul), pixel_shuffle (cout % 256 == 0, alone), cos_partials (cout == 64,
                                       h % 16 == 0, w % 32 == 0, operand map in `residual`); weight = U[cin/8][36 positions][2][cout][4] = G g G^T
                                       (gpemsr_amd/packing.py::pack_winograd4) */

@@ -929,6 +929,39 @@ def test_conv2d_winograd_f4x4_form(case):
         assert torch.equal(ops.conv2d(srcs, pc, ops.ACT_NONE, gn_stats=True, winograd=True).gn[0], sums), "partial sums not bit-stable"
 
 
+@pytest.mark.parametrize("n,cins,cout,h,w,act,use_res", [(2, (64, 64), 216, 32, 64, 0, False), (1, (128,), 216, 37, 70, 2, True), (3, (64,), 72, 16, 32, 1, False)])
+def test_conv2d_winograd_f4x4_form_with_padded_couts(n, cins, cout, h, w, act, use_res):
+    """cout % 64 != 0 (the 216-channel offset convolutions of the DCN packs, R:model/GPEMSR.py:98-140 via basicsr DCNv2Pack): U carries zero rows
+    up to the next multiple of 64 and the kernel stores only the real channels -- against fp64 and the direct kernel, neighbours of the output
+    slice untouched."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd4
+    dev = _dev()
+    cin = sum(cins)
+    x = _rand(n, cin, h, w, seed=51)
+    wt = _rand(cout, cin, 3, 3, seed=52, scale=1.0 / np.sqrt(cin * 9)); b = _rand(cout, seed=53, scale=0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    want = F.relu(want) if act == 1 else F.leaky_relu(want, 0.1) if act == 2 else want
+    res = _rand(n, cout, h, w, seed=54) if use_res else None
+    if res is not None:
+        want = want + res.double()
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(_to_act(x[:, o:o + c], dev)); o += c
+    pc = pack_conv(wt, b, dev, cins)
+    pc.wino4 = pack_winograd4(wt, dev)
+    assert tuple(pc.wino4.shape) == (cin // 8, 36, 2, -(-cout // 64) * 64, 4) and not ops.winograd_ok(srcs, pc) and ops.winograd4_padded_ok(srcs, pc)
+    r_act = None if res is None else _to_act(res, dev, ld=cout + 4, off=4)
+    out = _to_act(torch.zeros(n, cout, h, w), dev, ld=cout + 12, off=4)
+    got = ops.conv2d(srcs, pc, act, residual=r_act, out=out, winograd=True)
+    _close(got.nchw(), want, 6e-5, "padded-cout F(4x4) vs fp64")
+    buf = out.buf.view(n, h, w, cout + 12)
+    assert float((buf[..., :4] - 7.0).abs().max()) == 0.0 and float((buf[..., 4 + cout:] - 7.0).abs().max()) == 0.0      # nothing stored beside the slice
+    direct = ops.conv2d(srcs, pc, act, residual=r_act)
+    _close(got.nchw(), direct.nchw(), 6e-5, "padded-cout F(4x4) vs direct")
+    assert not torch.equal(got.nchw(), direct.nchw())
+
+
 @pytest.mark.parametrize("n,c,cout,h,w", [(2, 128, 128, 32, 64), (3, 64, 64, 37, 70), (1, 512, 512, 16, 32), (2, 256, 64, 48, 33)])
 def test_groupnorm_relu_folded_into_the_f4x4_input_transform(n, c, cout, h, w):
     """gpemsr_conv_desc.a_scale / a_shift with transposed = 5 (csrc/conv_wino4.hip, W4_AFF): conv(relu(GroupNorm(t))) without the normalised
