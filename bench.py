@@ -252,6 +252,15 @@ def pmc_traffic(tag: str, kernel_name: str, launches_per_step: float, fam_launch
         src["family_mfma_util_pmc"] = round(fam.get("mfma_util", 0.0), 4)
     base = kernel_name.split("<")[0]
     k_traffic = None
+    if kernel_name.endswith("<*>"):       # every instantiation of one kernel template (epilogue flavours of one main loop): counters summed
+        ds = [d for nm, d in doc.get("per_kernel", {}).items() if nm.split("<")[0] == base]
+        if ds and abs(sum(d.get("dispatches_per_step", 0) for d in ds) - launches_per_step) < 0.01:
+            k_traffic = round(1e9 * sum(d["hbm_read_GB_per_step"] + d["hbm_write_GB_per_step"] for d in ds) / max(launches_per_step, 1e-9))
+            src["kernel_counter_name"] = base + "<*> (%d instantiations)" % len(ds)
+            gui = sum(d.get("gui_active", 0.0) for d in ds)
+            if gui:
+                src["kernel_mfma_util_pmc"] = round((sum(d.get("mfma_busy_cycles", 0.0) for d in ds) / 1024.0) / (gui / 8.0), 4)
+        return k_traffic, fam_traffic, src
     for nm, d in doc.get("per_kernel", {}).items():
         if nm.split("<")[0] == base and abs(d.get("dispatches_per_step", -1) - launches_per_step) < 0.01:
             k_traffic = round(1e9 * (d["hbm_read_GB_per_step"] + d["hbm_write_GB_per_step"]) / max(launches_per_step, 1e-9))
@@ -263,9 +272,12 @@ def pmc_traffic(tag: str, kernel_name: str, launches_per_step: float, fam_launch
     return k_traffic, fam_traffic, src
 
 
+FLAVOURED = ("conv_wino4_f32_kernel",)     # kernel templates whose parameters only select the epilogue
+
 FAMILIES = {
-    "fp32": (("conv_mfma",), "fp32 MFMA family (v_mfma_f32_32x32x2_f32): conv_mfma_kernel (implicit-GEMM conv / GEMM, direct form) + conv_wino_f32_kernel "
-             "(3x3 stride-1 layers in the Winograd F(2x2,3x3) form: 16/36 of the multiplies, fp32 arithmetic); per kernel: `kernels`", PEAK_F32_MATRIX_TFLOPS),
+    "fp32": (("conv_mfma",), "fp32 MFMA family (v_mfma_f32_32x32x2_f32): conv_wino4_f32_kernel (3x3 stride-1 layers in the Winograd F(4x4,3x3) form: 1/4 of the "
+             "multiplies, fp32 arithmetic; its template parameter selects the epilogue), conv_wino2*_f32_kernel (F(2x2,3x3): 16/36), conv7_wino_f32_kernel "
+             "(7x7 rows in F(2,7): 8/14), conv_mfma_kernel (implicit-GEMM conv / GEMM, direct form); per kernel: `kernels`", PEAK_F32_MATRIX_TFLOPS),
     "bf16": (("conv_bf16", "vgg_mask"),
              "bf16 MFMA family (v_mfma_f32_32x32x16_bf16 / 16x16x32): conv_bf16_kernel / conv64_resident2_kernel / convt64_resident_kernel (implicit-GEMM "
              "conv / 1x1 / transposed), conv7_c32_cout16_kernel + conv7_c8_cout32_kernel (SpyNet 7x7), flash_attn512_kernel (q.k^T + online softmax + P.v "
@@ -293,15 +305,28 @@ def build_roofline(args, prof, dtp, psteps, B, s, precision):
     fam = _family(summ, fam_names)
     steps = max(psteps, 1)
     fam_lps = fam["launches"] // steps
-    # the dominant kernel: most time among the family's instantiations
-    dom_name, dom = max(((k, v) for k, v in by_name.items() if v["family"] in fam_names), key=lambda kv: kv[1]["ms"], default=("?", None))
+    # the dominant kernel: most time among the family's instantiations.  Instantiations of a template in FLAVOURED differ only in their epilogue
+    # (store / residual / PixelShuffle / GroupNorm sums / patch cosine around ONE main loop): they count as one kernel, `kernel` = "<name><*>"
+    cand = {}
+    for k, v in by_name.items():
+        if v["family"] not in fam_names:
+            continue
+        base = k.split("<")[0]
+        key = base + "<*>" if base in FLAVOURED else k
+        if key in cand:
+            for f in ("launches", "ms", "flops", "bytes", "executed"):
+                cand[key][f] += v[f]
+            cand[key]["instantiations"].append(k)
+        else:
+            cand[key] = {**{f: v[f] for f in ("launches", "ms", "flops", "bytes", "executed")}, "family": v["family"], "instantiations": [k]}
+    dom_name, dom = max(cand.items(), key=lambda kv: kv[1]["ms"], default=("?", None))
     if dom is None:
         dom = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "executed": 0.0}
     dom_lps = dom["launches"] / steps
     k_traffic, fam_traffic, traffic_src = pmc_traffic(precision, dom_name, dom_lps, fam_lps)
     nl = max(dom["launches"], 1)
     r = {
-        "bound": "mfma", "kernel": dom_name,
+        "bound": "mfma", "kernel": dom_name, "kernel_instantiations": sorted(dom.get("instantiations", [dom_name])),
         "achieved": round(_etf(dom), 2), "peak": peak, "unit": "TFLOP/s", "frac": round(_etf(dom) / peak, 4),
         "achieved_is": "EXECUTED matrix FLOPs per launch / average launch duration (HIP events on the launch stream, second pass of "
                        f"{steps} steps; the official `value` is timed in a pass without events)",

@@ -450,7 +450,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
         executed = flops * 8.0 / 14.0
     if PROFILER is not None:
         nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32", n, h, w, tuple((s_.c, s_.ld % 4, s_.ptr % 16) for s_ in srcs), pc.cout, k, stride, int(d.transposed),
-                                                             int(pc.pixel_shuffle), bool(d.gn_partials), out.ld % 4, residual is not None))
+                                                             int(pc.pixel_shuffle), bool(d.gn_partials), out.ld % 4, residual is not None, pixmul is not None, act, a_affine32 is not None))
         wimgs = n if weight_image_stride != 0 else 1
         nb = _layer_bytes(srcs, src_image_stride, n * OH * OW * oc, 4, int(wimgs * pc.cout * pc.cin * taps), 4, residual, pixmul)
         PROFILER.run("conv_mfma", tag, flops, lambda: _abi.check(lib.gpemsr_conv2d(C.byref(d), _stream()), "conv2d"), name=nm, nbytes=nb, executed=executed)
