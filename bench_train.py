@@ -206,8 +206,9 @@ def run(args, root: str, effective_cores):
         torch.cuda.synchronize()
         dw = time.perf_counter() - tq
         extras_w = {"value": round(B * args.steps / dw, 3), "unit": "samples/s", "ms_per_step": round(1e3 * dw / args.steps, 2),
-                    "dtype": "f32; frozen 3x3 stride-1 layers (forward and data gradients) in the Winograd F(2x2,3x3) form on the f32 matrix "
-                             "pipe: gradient distance to float64 2.2e-4 median instead of 1.5e-5 (the reference's own: 1.4e-4)",
+                    "dtype": "f32; frozen 3x3 stride-1 layers (forward and data gradients) in the Winograd forms (F(4x4,3x3) / F(2x2,3x3)) on the f32 "
+                             "matrix pipe: median gradient distance to float64 on the two goldens 2.1e-4 / 6.8e-5 (direct forms: 5.9e-4 / 1.5e-5; "
+                             "the reference's own: 3.6e-5 / 1.4e-4; profiles/r05_winograd_training_distance.log)",
                     "losses_last_step": {"rec": float(ow["rec_loss"].item()), "ref": float(ow["ref_loss"].item())},
                     "speedup_vs_fp32_step": round((dt / args.steps) / (dw / args.steps), 3)}
         del tw, mw
