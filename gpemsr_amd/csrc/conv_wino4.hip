@@ -446,7 +446,8 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
                 if (MODE & W4_RES) t += rv[jx];
                 if (MODE & W4_MUL) { asm volatile("" : "+v"(mo)); t *= *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t_mul + (long long)i * P.w + jx) + mo); }
                 asm volatile("" : "+v"(oo));
-                if (!(W4_SKIP & 32) || t == 12345.678f) *reinterpret_cast<float*>(reinterpret_cast<char*>(op + jx * o_col) + oo) = t;
+                if (!(W4_SKIP & 32) || t == 12345.678f)     // (probe builds: the never-true test keeps the arithmetic alive without the stores)
+                  *reinterpret_cast<float*>(reinterpret_cast<char*>(op + jx * o_col) + oo) = t;
               }
             }
           }
