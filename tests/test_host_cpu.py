@@ -465,3 +465,22 @@ def test_winograd_f4x4_transforms_are_an_exact_identity():
             out[:, 4 * by:4 * by + 4, 4 * bx:4 * bx + 4] = torch.einsum("ix,xyo,jy->oij", WINO4_AT, M, WINO4_AT)
     ref = F.conv2d(x, wt, None, 1, 1)[0]
     assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
+def test_winograd_f4x4_packing_pads_couts_and_permutes_pixel_shuffle_rows():
+    """packing.pack_winograd4: cout % 64 != 0 -> zero rows up to the next multiple of 64 (the kernel never stores them); PixelShuffle layers ->
+    the row permutation of pack_conv ((2 i + j) C / 4 + c), so that a cout block of 64 lands in ONE sub-pixel."""
+    import torch
+    from gpemsr_amd.packing import WINO4_G, pack_winograd4
+    g = torch.Generator().manual_seed(3)
+    wt = torch.rand(216, 16, 3, 3, generator=g) - 0.5
+    U = pack_winograd4(wt, "cpu")
+    assert tuple(U.shape) == (2, 36, 2, 256, 4) and float(U[:, :, :, 216:].abs().max()) == 0.0
+    ref = torch.einsum("xa,ocab,yb->xyoc", WINO4_G, wt.double(), WINO4_G).float()          # [xi][nu][cout][cin]
+    got = U.permute(1, 3, 0, 2, 4).reshape(6, 6, 256, 16)[:, :, :216]
+    assert float((got - ref).abs().max()) < 1e-6
+    wp = torch.rand(256, 8, 3, 3, generator=g) - 0.5
+    Up = pack_winograd4(wp, "cpu", pixel_shuffle=True).permute(1, 3, 0, 2, 4).reshape(6, 6, 256, 8)
+    refp = torch.einsum("xa,ocab,yb->xyoc", WINO4_G, wp.double(), WINO4_G).float()
+    perm = torch.tensor([4 * c + q for q in range(4) for c in range(64)])
+    assert float((Up - refp[:, :, perm]).abs().max()) < 1e-6
