@@ -76,6 +76,8 @@ def parse_args(argv=None):
                     help="launcher self-test (tests/test_bench_launcher_cpu.py): a per-tile stand-in model on the CPU with "
                          "--backend gloo; exercises spawn, rendezvous, barrier, all-gather and max-over-ranks timing only")
     ap.add_argument("--rank-timeout", type=float, default=3000.0, help="seconds the launcher waits for its ranks")
+    ap.add_argument("--detail", type=str, default="bench_detail.json",
+                    help="file that receives the FULL measurement document (per-kernel tables, full legs, extras, prose); the ONE stdout line stays compact")
     ap.add_argument("--gather", type=str, default="f32", choices=("f32", "u8"),
                     help="what the step's all-gather exchanges: the fp32 HR slabs (default; 4 MiB per 1024^2 tile, the north_star's slabs) or the "
                          "8-bit image the last kernel writes (1 MiB per tile: what output_GPEMSR.py saves)")
@@ -451,6 +453,79 @@ def run_precision_leg(args, opt, x, rank, world, dev, mode, sync, scale=None, st
     return leg_entry(args, d3, largs.steps, world, B, opix, roof, phases), m3, o3
 
 
+MAX_LINE_BYTES = 8192              # the ONE stdout line; round 5's 34.7 KB line came back from the driver unparsed (BENCH_r05.parsed = null)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_roofline(r):
+    """The contract's `roofline` object of the stdout line: the dominant kernel's figures + the family's, no prose and no tables
+    (those are in the --detail document)."""
+    if not r:
+        return None
+    c = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches_per_step",
+                  "executed_gflop_per_launch", "algorithmic_gflop_per_launch", "algorithmic_bytes_per_launch", "effective_frac",
+                  "time_share_of_step", "whole_path_tflops_essential", "algorithmic_bytes_per_step", "counter_bytes_per_step_all_kernels",
+                  "counter_over_algorithmic_bytes"))
+    c.setdefault("traffic", None)
+    src = r.get("traffic_source") or {}
+    if src:
+        c["traffic_source"] = src.get("file")
+        if src.get("kernel_mfma_util_pmc") is not None:
+            c["mfma_util_pmc"] = src["kernel_mfma_util_pmc"]
+    fam = r.get("family") or {}
+    c["family"] = _pick(fam, ("achieved", "frac", "effective_frac", "launches_per_step", "avg_launch_us", "traffic", "time_share_of_step"))
+    if r.get("legs"):
+        c["legs"] = r["legs"]
+    return c
+
+
+def compact_line(d):
+    """The ONE stdout line: the contract's keys, the compact `roofline` / `cpu_baseline`, the other BASELINE configurations as
+    value_* / ms_per_step_* pairs.  Everything else stays in the --detail document."""
+    legs = d.get("legs") or {}
+    bf = ((d.get("extras") or {}).get("bf16") or {}) if isinstance(d.get("extras"), dict) else {}
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "rccl_world", "dist_backend", "steps", "warmup", "ms_per_step",
+                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "gather")}
+    line["dtype"] = str(line["dtype"]).split(" ")[0]
+    line["config"] = _pick(d.get("config") or {}, ("workload", "tiles_per_gpu", "global_tiles", "lr", "scale", "parallelism"))
+    roof = compact_roofline(d.get("roofline"))
+    compact = {k: (compact_leg(v) if k != "train" else _pick(v, ("value", "unit", "ms_per_step", "steps", "n_gpus", "kernel", "frac", "family_frac")))
+               for k, v in legs.items()}
+    if bf:
+        compact["x8_bf16"] = compact_leg(bf)
+    if roof is not None and compact:
+        roof["legs"] = compact              # inside the contract's `roofline` object: survives a driver that drops unknown top-level keys
+    line["roofline"] = roof
+    cb = d.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "gpu_vs_cpu_rel_err_free_running")) if cb else None
+    ph = d.get("rank_phases")
+    if ph:
+        line["rank_phases"] = _pick(ph, ("forward_ms_max", "forward_ms_min", "gather_ms_max", "gather_ms_min", "steps_recorded"))
+    if bf:
+        line["value_bf16"], line["ms_per_step_bf16"] = bf.get("value"), bf.get("ms_per_step")
+        rb = bf.get("roofline") or {}
+        if rb:
+            line["roofline_bf16"] = {**_pick(rb, ("kernel", "achieved", "peak", "frac", "traffic", "avg_launch_us", "launches_per_step", "time_share_of_step")),
+                                     "family": _pick(rb.get("family") or {}, ("frac", "launches_per_step", "time_share_of_step"))}
+        if bf.get("rank_phases"):
+            line["rank_phases_bf16"] = _pick(bf["rank_phases"], ("forward_ms_max", "forward_ms_min", "gather_ms_max", "gather_ms_min"))
+        for k in ("rel_err_vs_fp32_path_teacher_forced_2_windows", "code_index_agreement_free_running_2_windows", "free_running_dpsnr"):
+            if k in bf:
+                line.setdefault("bf16_fidelity", {})[k] = float(f"{bf[k]:.4g}")
+    for name in ("x16_fp32", "x16_bf16", "train"):
+        if name in legs:
+            line["value_" + name], line["ms_per_step_" + name] = legs[name].get("value"), legs[name].get("ms_per_step")
+    vol = (d.get("extras") or {}).get("volume_mode") if isinstance(d.get("extras"), dict) else None
+    if vol:
+        line["value_volume_fp32"] = vol.get("value")
+        if bf.get("volume_mode_value") is not None:
+            line["value_volume_bf16"] = bf["volume_mode_value"]
+    return line
+
+
 def compact_leg(entry):
     """The few figures of a leg that ride at the top level of the line (and inside `roofline.legs`, which a driver that keeps only the
     contract's keys still keeps): value, ms/step, the dominant kernel and its executed fraction, the family's."""
@@ -572,8 +647,8 @@ def run_cpu_baseline(args, model_sd, x, out):
     cdt = sum(times) / len(times)
     cpu_mp = (args.cpu_lr * s) ** 2 / 1e6 / cdt
     cb = {"value": round(cpu_mp, 5), "unit": "output megapixels/s", "cores": torch.get_num_threads(), "kind": "port",
-          "sample": f"1 window [1,5,1,{args.cpu_lr},{args.cpu_lr}] -> {args.cpu_lr * s}^2: same-size warm-up pass + 2 timed passes "
-                    f"({times[0]:.1f} s, {times[1]:.1f} s) of oracle/gpemsr_oracle.py (torch CPU fp32; SpyNet de-duplicated, VGG slice1 only)"}
+          "sample": f"1 window [1,5,1,{args.cpu_lr},{args.cpu_lr}] -> {args.cpu_lr * s}^2: warm-up pass + 2 timed passes "
+                    f"({times[0]:.1f} s, {times[1]:.1f} s) of oracle/gpemsr_oracle.py (torch CPU fp32)"}
     if args.cpu_lr == lr and args.precision == "fp32" and out.dtype == torch.float32:
         err = float((out[:1].cpu() - o_cpu).abs().max() / o_cpu.abs().max())
         cb["gpu_vs_cpu_rel_err_free_running"] = float(f"{err:.3e}")
@@ -583,6 +658,15 @@ def run_cpu_baseline(args, model_sd, x, out):
 def run_forward(args) -> int:
     import torch
     from gpemsr_amd import dist as gdist
+
+    t_start = time.perf_counter()
+    wall = {}
+
+    def lap(name):                      # wall seconds of each section of the command (the default line has to fit the driver's run)
+        nonlocal t_start
+        now = time.perf_counter()
+        wall[name] = round(now - t_start, 1)
+        t_start = now
 
     rank, world, local = gdist.init_from_env(backend=args.backend or None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -616,6 +700,7 @@ def run_forward(args) -> int:
         out, _ = gdist.forward_sharded(model, x, rank, world, already_local=True, gather=True, gather_u8=args.gather == "u8", timing=timing)
         return out
 
+    lap("setup")
     for _ in range(args.warmup):
         step()
     if timing is not None:
@@ -627,6 +712,7 @@ def run_forward(args) -> int:
     rccl_world = torch.distributed.get_world_size() if world > 1 else 1           # the group the all-gathers above ran on
     dist_backend = torch.distributed.get_backend() if world > 1 else None         # "nccl" = RCCL on ROCm; "gloo" in rehearsals / self-tests
 
+    lap("headline")
     opix = out.shape[-1] * out.shape[-2]
     mp_per_step = world * B * opix / 1e6
     value = mp_per_step * args.steps / dt
@@ -641,10 +727,13 @@ def run_forward(args) -> int:
         if not args.no_extras:
             extras = run_extras(args, model, opt, x, out, dt, dev, rank, world, sync)
         del model
+        lap("extras")
         if not args.no_extras and not args.no_config_legs and s == 8 and args.precision == "fp32" and args.gather == "f32":
             legs = run_config_legs(args, rank, world, dev, sync)
+            lap("config_legs")
         if model_sd is not None:
             cpu_baseline = run_cpu_baseline(args, model_sd, x, out)
+            lap("cpu_baseline")
 
     io_edges = None
     if not args.stub and rank == 0 and world == 1 and not args.no_extras:
@@ -656,18 +745,13 @@ def run_forward(args) -> int:
                  "bf16x3": "bf16x3 (fp32 activations; convs as 3 split hi+lo bf16 MFMA products, fp32 accumulate)",
                  "bf16op": "bf16 operands rounded in the kernel (fp32 activations in HBM), fp32 accumulate"}[args.precision]
         bf = ((extras or {}).get("bf16") or {}) if isinstance(extras, dict) else {}
-        compact = {k: (compact_leg(v) if k != "train" else v) for k, v in (legs or {}).items()}
-        if bf:
-            compact["x8_bf16"] = compact_leg(bf)
-        if roofline is not None and compact:
-            roofline["legs"] = compact          # inside the contract's `roofline` object: survives a driver that drops unknown top-level keys
-        line = {
+        detail = {
             "metric": "output megapixels/sec, 8x EMSR 128->1024 tiles" if s == 8 else "output megapixels/sec, 16x EMSR 64->1024 tiles",
             "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "rccl_world": rccl_world, "dist_backend": dist_backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "timed_region": "barrier + synchronize, steps x (forward of this rank's tiles + all-gather of the " +
                             ("uint8 HR images" if args.gather == "u8" else "fp32 HR slabs") + " at N > 1), synchronize + barrier; max over ranks; "
-                            "no per-launch events in this pass (the roofline tables come from a second pass)",
+                            "no per-launch events in this pass (the roofline tables come from a second pass; at N > 1 three phase marks per step)",
             "gather": args.gather,
             "vs_baseline": None, "dtype": "stub" if args.stub else dtype, "data": "synthetic",
             "config": {"workload": ("launcher self-test (stub model, CPU, gloo)" if args.stub else
@@ -678,19 +762,24 @@ def run_forward(args) -> int:
                        "parallelism": f"tiles sharded over {world} GPU(s), one process per GPU, RCCL all-gather of HR slabs" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "rank_phases": rank_phases,
-            # the other BASELINE configurations at the TOP level: configs[2] (bf16 leg), configs[3] (x16, both precisions), configs[4] (training step)
-            "roofline_bf16": bf.get("roofline"),
-            "value_bf16": bf.get("value"), "ms_per_step_bf16": bf.get("ms_per_step"),
-            "value_x16_fp32": ((legs or {}).get("x16_fp32") or {}).get("value"), "ms_per_step_x16_fp32": ((legs or {}).get("x16_fp32") or {}).get("ms_per_step"),
-            "value_x16_bf16": ((legs or {}).get("x16_bf16") or {}).get("value"), "ms_per_step_x16_bf16": ((legs or {}).get("x16_bf16") or {}).get("ms_per_step"),
-            "value_train": ((legs or {}).get("train") or {}).get("value"), "ms_per_step_train": ((legs or {}).get("train") or {}).get("ms_per_step"),
             "legs": legs,
-            "kernels": (roofline or {}).get("kernels"),
-            "algorithmic_bytes_per_step": (roofline or {}).get("algorithmic_bytes_per_step"),
             "io_edges": io_edges,
             "extras": extras,
+            "wall_s_by_section": wall,
         }
-        print(json.dumps(line), flush=True)
+        line = compact_line(detail)
+        line["detail"] = args.detail or None
+        text = json.dumps(line, separators=(",", ":"))
+        assert len(text) < MAX_LINE_BYTES, f"bench line is {len(text)} bytes (limit {MAX_LINE_BYTES}): the driver could not parse a 34.7 KB line in round 5"
+        detail["line_bytes"] = len(text)
+        if args.detail:
+            try:
+                with open(os.path.join(ROOT, args.detail) if not os.path.isabs(args.detail) else args.detail, "w") as f:
+                    json.dump(detail, f, indent=1)
+                print(f"[bench] full measurement document: {args.detail} ({len(text)}-byte line on stdout)", file=sys.stderr, flush=True)
+            except OSError as e:
+                print(f"[bench] could not write {args.detail}: {e}", file=sys.stderr, flush=True)
+        print(text, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0

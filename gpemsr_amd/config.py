@@ -41,6 +41,12 @@ def build_model(opt: dict, load_prior_files: bool = True, **extra):
     ip = net.get("indexer_precision") or opt.get("indexer_precision")
     if ip and "indexer_precision" not in extra:
         extra["indexer_precision"] = str(ip)
+    # additive: `winograd: f4x4 | decoder_f4x4 | f2x2 | off` (fp32 path: which 3x3 stride-1 layers run in a Winograd form; default f4x4)
+    wg = net.get("winograd") if net.get("winograd") is not None else opt.get("winograd")
+    if wg is False:                     # YAML reads a bare `off` as a boolean
+        wg = "off"
+    if wg and "winograd" not in extra:
+        extra["winograd"] = str(wg)
     return GPEMSR(ref_path_G=net["ref_path_G"] if load_prior_files else None,
                   ref_path_Indexer=net["ref_path_Indexer"] if load_prior_files else None,
                   argref=net["argref"], nf=net["nf"], nframes=net["nframes"], groups=net["groups"],

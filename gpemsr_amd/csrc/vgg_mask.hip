@@ -34,6 +34,13 @@ __device__ unsigned long long g_vstamps[256 * 16 * 8];
 #define VSEG_FLUSH
 #endif
 
+// timing hooks exist only in a probe build (-DGPEMSR_VGG_PROBE; either of them makes the masks wrong on purpose)
+#ifdef GPEMSR_VGG_PROBE
+#define VGG_DBG(P) ((P).dbg)
+#else
+#define VGG_DBG(P) 0
+#endif
+
 struct VggParams {
   const float* ref; const float* lr;       // [n][H][W] prior image, [n][h][w] LR slice
   int n, H, W, h, w;
@@ -43,7 +50,7 @@ struct VggParams {
   float* out;                                // [n][H/16][W/16]
   int tiles_x, tiles_y, ns;
   unsigned mg_x, mg_y;                       // floor((2^32 - 1) / tiles_*) for xdivmod
-  int dbg;                                   // timing experiments only (GPEMSR_VGG_DBG): 1 = producers idle, 2 = no conv1_2
+  int dbg;                                   // timing experiments only, compiled in with -DGPEMSR_VGG_PROBE (GPEMSR_VGG_DBG): 1 = producers idle, 2 = no conv1_2
   int hr2;                                   // `lr` is already at the HR size (scale == 1): both images are read the same way
 };
 
@@ -479,7 +486,7 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
     end_interval();                                                       // weights, constants and item 0 are in LDS
     VSEG(3);
     for (int i = 0; i <= NWI; ++i) {
-      if (i + 1 < NWI && !(P.dbg == 1 && i >= 2)) {
+      if (i + 1 < NWI && !(VGG_DBG(P) == 1 && i >= 2)) {
         convert(i + 1);                                                   // windows fetched during the previous interval
         VSEG(1);
         if (i + 2 < NWI) fetch(i + 2);
@@ -519,7 +526,7 @@ __global__ __launch_bounds__((8 + NPROD) * 64, NPROD == 8 ? 4 : 3) void vgg_mask
         }
       const unsigned bufo = (unsigned)((i & 1) * 2 * A_BYTES);
 #pragma unroll 1
-      for (int chunk = 0; chunk < (P.dbg == 2 ? 0 : 2); ++chunk) {
+      for (int chunk = 0; chunk < (VGG_DBG(P) == 2 ? 0 : 2); ++chunk) {
         const unsigned A = vsm_lds + bufo + (unsigned)(chunk * A_BYTES);
         const unsigned B = vsm_lds + b_frag + (unsigned)(chunk * (9 * 4 * 1024));
         bf16x8 fa[2], fb[2][2];
@@ -618,7 +625,11 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
       return fail(GPEMSR_ELAUNCH, "vgg_mask_bf16: cannot raise the dynamic LDS limit");
     dev_once_done(attr);
   }
+#ifdef GPEMSR_VGG_PROBE
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("GPEMSR_VGG_DBG"); dbg = e ? atoi(e) : 0; } P.dbg = dbg; }
+#else
+  P.dbg = 0;                            // the shipped library cannot idle the producers or skip conv1_2 (either makes the masks wrong on purpose)
+#endif
   static int form = -1;                 // GPEMSR_VGG_FORM=1 selects the lockstep kernel (A/B measurements)
   if (form < 0) { const char* e = getenv("GPEMSR_VGG_FORM"); form = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 3); }      // 3: 8 producer waves
   static int cus = 0;

@@ -51,7 +51,7 @@ class Engine:
 
     def __init__(self, sd: Dict[str, torch.Tensor], device, scale: int, nframes: int = 5, groups: int = 8,
                  nf: int = 64, dec_num_res_blocks: int = 1, frame_chunk: int = 80, tile_chunk: int = 16,
-                 precision: str = "fp32", indexer_precision: str = "bf16"):
+                 precision: str = "fp32", indexer_precision: str = "bf16", winograd: str = None):
         assert scale in (8, 16)
         assert nf == 64, "kernels are specialised for nf=64 (every shipped option file)"
         self.sd = sd
@@ -83,7 +83,7 @@ class Engine:
         self._idx_engine = None
         if self.bf16 and self.indexer_precision == "fp32:all":
             sub = {k: v for k, v in sd.items() if k.startswith("refmodel.indexer.")}
-            self._idx_engine = Engine(sub, device, scale, nframes, groups, nf, dec_num_res_blocks, frame_chunk, tile_chunk, precision="fp32")
+            self._idx_engine = Engine(sub, device, scale, nframes, groups, nf, dec_num_res_blocks, frame_chunk, tile_chunk, precision="fp32", winograd=winograd)
         elif self.bf16 and self.indexer_precision != "bf16":
             mode, _, cnt = self.indexer_precision.partition(":")
             assert mode in ("bf16x3", "fp32") and (cnt == "" or cnt.isdigit()), f"indexer_precision {indexer_precision!r}: bf16 | bf16x3:N | fp32:N | fp32:all"
@@ -91,22 +91,33 @@ class Engine:
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
         self.fold_gn32 = os.environ.get("GPEMSR_FOLD_GN32", "1") != "0"  # fp32 path: the same, in the input transform of the F(4x4) Winograd form
         self.flash_attn = os.environ.get("GPEMSR_FLASH_ATTN", "1") != "0"   # bf16 path: NonLocalBlock products + softmax as one kernel (C = 512, T % 128 == 0)
-        # exact-fp32 path: 3x3 stride-1 layers in the Winograd F(2x2,3x3) form (16 instead of 36 multiplies per 2x2 outputs, fp32 arithmetic,
-        # ~1e-6 of the result; csrc/conv_wino.hip).  The training engines use it for their FROZEN layers only (`_wino_layer`: the transformed
-        # weights of a trainable layer are not a permutation of its master weights, so the one-gather repack cannot refresh them).
-        # GPEMSR_WINOGRAD=0: the direct form everywhere.
-        self.winograd = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD", "1") != "0"
-        # exact-fp32 path: 7x7 stride-1 layers with cin >= 32 (% 8 == 0) and cout % 32 == 0 (SpyNet 32 -> 64, 64 -> 32; the one-chunk 8 -> 32 stems measured
-        # no faster: 4.9 vs 5.0 ms, GPEMSR_WINOGRAD7_MIN_CIN=8 enables them) in the 1-D Winograd
-        # F(2, 7) row form (8 instead of 14 multiplies per output pair and filter row, fp32 arithmetic; csrc/conv7_wino.hip).  GPEMSR_WINOGRAD7=0: direct form.
-        self.winograd7 = precision == "fp32" and os.environ.get("GPEMSR_WINOGRAD7", "1") != "0"
-        # exact-fp32 path: 3x3 stride-1 layers with >= GPEMSR_WINOGRAD4_MIN_CIN (128) input channels and cout % 64 == 0 in the F(4x4,3x3) form (36
-        # instead of 144 multiplies per 4x4 outputs; logits of the full-size golden tile within 2.9e-6 of the reference's, every code equal;
-        # csrc/conv_wino4.hip; 64-channel layers measured slower than on F(2x2): 8 chunks do not amortise a tile's fixed cost).
-        # GPEMSR_WINOGRAD4 = "all" (default): every such layer; "decoder": all but the indexer's (its arg-max decides codebook entries:
-        # this keeps the tighter F(2x2) rounding there, at +17 ms per step); "0": F(2x2) everywhere.
-        self.winograd4 = os.environ.get("GPEMSR_WINOGRAD4", "all") if self.winograd else "0"
-        assert self.winograd4 in ("0", "decoder", "all"), f"GPEMSR_WINOGRAD4={self.winograd4!r}: 0 | decoder | all"
+        # exact-fp32 path, option key `winograd` (`None` = the default "f4x4"):
+        #   "f4x4"          3x3 stride-1 layers with >= 64 input channels (% 8) and cout % 64 == 0 (or >= 128 couts through zero-padded weights:
+        #                   the DCN packs' 216-channel offset convolutions) in the F(4x4,3x3) form (36 instead of 144 multiplies per 4x4 outputs,
+        #                   ~2e-5 of the result; csrc/conv_wino4.hip; 64-channel layers included: 7.2 -> 4.9 ms on a 1024^2 map), the other 3x3
+        #                   stride-1 layers in F(2x2,3x3) (16 instead of 36, ~5e-6; csrc/conv_wino.hip), SpyNet's 32 <-> 64 7x7 layers in the 1-D
+        #                   F(2,7) row form (8 of 14, csrc/conv7_wino.hip);
+        #   "decoder_f4x4"  the same, but the indexer's layers stay on F(2x2): its arg-max decides codebook entries, this keeps the tighter
+        #                   rounding there (+17 ms per 16-window step);
+        #   "f2x2"          F(2x2) for every 3x3 layer, F(2,7) for SpyNet;
+        #   "off"           the direct form everywhere (3e-6 per layer).
+        # The training engines use the Winograd forms for their FROZEN layers only (`_wino_layer`: the transformed weights of a trainable layer
+        # are not a permutation of its master weights, so the one-gather repack cannot refresh them).
+        # Development switches (A/B scripts; the option key wins): GPEMSR_WINOGRAD=0, GPEMSR_WINOGRAD4=0|decoder|all, GPEMSR_WINOGRAD7=0.
+        if winograd is None:
+            w2 = os.environ.get("GPEMSR_WINOGRAD", "1") != "0"
+            w4 = os.environ.get("GPEMSR_WINOGRAD4", "all")
+            assert w4 in ("0", "decoder", "all"), f"GPEMSR_WINOGRAD4={w4!r}: 0 | decoder | all"
+            winograd = "off" if not w2 else {"0": "f2x2", "decoder": "decoder_f4x4", "all": "f4x4"}[w4]
+            w7 = os.environ.get("GPEMSR_WINOGRAD7", "1") != "0"
+        else:
+            w7 = True
+        assert winograd in ("f4x4", "decoder_f4x4", "f2x2", "off"), f"winograd: {winograd!r} (f4x4 | decoder_f4x4 | f2x2 | off)"
+        self.winograd_form = winograd
+        self.winograd = precision == "fp32" and winograd != "off"
+        self.winograd7 = self.winograd and w7
+        self.winograd4 = {"f4x4": "all", "decoder_f4x4": "decoder"}.get(winograd, "0") if self.winograd else "0"
+        self.winograd4_min_cin = int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "64"))
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
         self.fuse_vgg = True            # bf16 path: gpemsr_vgg_mask_bf16 (tests switch it off to compare with the layer-by-layer form)
         self.fuse_dcn = os.environ.get("GPEMSR_FUSE_DCN", "1") != "0"     # bf16 path: DCN sampling + contraction in one kernel (gpemsr_dcn_conv_bf16)
@@ -230,13 +241,13 @@ class Engine:
             if self.bf16 and all(c % 16 == 0 for c in self.pc[name].splits):
                 self.pc[name].wb = pack_conv_bf16(w, dev, self.pc[name].splits, pixel_shuffle=name in ps)
             if (self.winograd and self.winograd4 != "0" and self._wino_layer(name) and kk == 3 and w.shape[0] % 32 != 0 and w.shape[0] >= 128 and name not in ps
-                    and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "64")) and all(c % 8 == 0 for c in self.pc[name].splits)):
+                    and w.shape[1] >= self.winograd4_min_cin and all(c % 8 == 0 for c in self.pc[name].splits)):
                 # cout % 32 != 0 (the DCN packs' 216-channel offset convolutions): no F(2x2) form, but the F(4x4) one through zero-padded weights
                 self.pc[name].wino4 = pack_winograd4(w, dev)
             if (self.winograd and self._wino_layer(name) and kk == 3 and w.shape[0] % 32 == 0 and (name not in ps or w.shape[0] % 64 == 0)
                     and all(c % 8 == 0 for c in self.pc[name].splits)):
                 self.pc[name].wino = pack_winograd(w, dev, pixel_shuffle=name in ps)      # Winograd form of the 3x3 stride-1 layers (fp32 path)
-                if (self.winograd4 != "0" and w.shape[0] % (256 if name in ps else 64) == 0 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "64"))
+                if (self.winograd4 != "0" and w.shape[0] % (256 if name in ps else 64) == 0 and w.shape[1] >= self.winograd4_min_cin
                         and (self.winograd4 == "all" or not name.startswith("refmodel.indexer."))):
                     self.pc[name].wino4 = pack_winograd4(w, dev, pixel_shuffle=name in ps)     # F(4x4,3x3) form
             if (self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1

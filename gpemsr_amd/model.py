@@ -44,13 +44,16 @@ class GPEMSR(nn.Module):
                    checkpoint is loaded (the reference's files are Google-Drive only);
       frame_chunk / tile_chunk   batching granularity of the two halves of the forward;
       precision    "fp32" (default: exact fp32 MFMA), "bf16x3" (3x3 convs on the bf16 matrix pipe with split hi+lo
-                   operands, fp32-grade: ~1e-5 per op) or "bf16" (plain bf16 operands, fp32 accumulate).
+                   operands, fp32-grade: ~1e-5 per op) or "bf16" (plain bf16 operands, fp32 accumulate);
+      indexer_precision   bf16 path: "bf16" | "bf16x3:N" | "fp32:N" | "fp32:all" (how much of the indexer runs above bf16);
+      winograd     fp32 path: "f4x4" (default) | "decoder_f4x4" | "f2x2" | "off" -- which 3x3 layers take a Winograd form
+                   (option key `winograd`).
     """
 
     def __init__(self, ref_path_G, ref_path_Indexer, argref, nf=64, nframes=5, groups=8, front_RBs=5, back_RBs=10,
                  w_ref=True, ref_fusion_feat_RBs=3, align_mode='POD', fusion_mode='ThreeDA', mode='16to1', scale=16,
                  init_seed: int = 0, frame_chunk: int = 80, tile_chunk: int = 16, precision: str = "fp32",
-                 indexer_precision: str = "bf16"):
+                 indexer_precision: str = "bf16", winograd: str = None):
         super().__init__()
         if not (w_ref and align_mode == 'POD' and fusion_mode == 'ThreeDA'):
             raise NotImplementedError("gpemsr_amd implements the shipped configuration: w_ref=True, POD, ThreeDA")
@@ -63,6 +66,7 @@ class GPEMSR(nn.Module):
         self._chunks = (frame_chunk, tile_chunk)
         self.precision = precision
         self.indexer_precision = indexer_precision       # bf16 path: "bf16" | "bf16x3:N" | "fp32:N" (gpemsr_amd/engine.py)
+        self.winograd = winograd                         # fp32 path: None (= "f4x4") | "f4x4" | "decoder_f4x4" | "f2x2" | "off" (gpemsr_amd/engine.py)
         self._specs = param_specs(argref=argref, nf=nf, nframes=nframes, groups=groups, front_RBs=front_RBs,
                                   back_RBs=back_RBs, w_ref=w_ref, ref_fusion_feat_RBs=ref_fusion_feat_RBs,
                                   align_mode=align_mode, fusion_mode=fusion_mode, mode=mode, scale=scale)
@@ -137,7 +141,7 @@ class GPEMSR(nn.Module):
             sd = {k: v.detach() for k, v in live.items()}
             self._engine = Engine(sd, device, self.scale, self.nframes, self.groups, self.nf, self._dec_nrb,
                                   frame_chunk=self._chunks[0], tile_chunk=self._chunks[1], precision=self.precision,
-                                  indexer_precision=self.indexer_precision)
+                                  indexer_precision=self.indexer_precision, winograd=self.winograd)
         else:
             # validation between optimizer steps (R:train_stage3.py:197-312), torch optimizers on the autograd path,
             # model.refmodel.indexer.load_state_dict(...): repack whatever changed since the packs were made
