@@ -46,6 +46,9 @@ inline void dev_once_done(dev_once_t& m) {
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) m.fetch_or(1ull << dev, std::memory_order_release);
 }
 
+// CUs of the CURRENT device, cached per device id (common.hip): grids of the persistent kernels
+int device_cus();
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // gpemsr_conv_desc.transposed == 3: the Winograd F(2x2, 3x3) form (conv_wino.hip); name_buf != NULL: write the kernel's name, launch nothing

@@ -11,6 +11,17 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+int device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (dev >= 0 && dev < 64) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
 }  // namespace gpemsr
 
 extern "C" int gpemsr_abi_version(void) { return GPEMSR_ABI_VERSION; }

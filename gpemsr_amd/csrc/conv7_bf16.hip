@@ -351,12 +351,7 @@ extern "C" int gpemsr_conv7_c32_cout16_bf16(const void* x, int n, int h, int w, 
       return fail(GPEMSR_ELAUNCH, "conv7_c32_cout16_bf16: cannot raise the dynamic LDS limit");
     dev_once_done(attr);
   }
-  int dev = 0; hipDeviceProp_t prop;
-  static int cus = 0;
-  if (cus == 0) {
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(GPEMSR_ELAUNCH, "conv7_c32_cout16_bf16: device query failed");
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cus();
   const int grid = P.ntiles < cus ? P.ntiles : cus;    // persistent: one workgroup per CU (157 KB of LDS)
   const size_t lds = (size_t)C7_WBYTES + 2 * (size_t)C7_ABYTES;
   hipLaunchKernelGGL(conv7_c32_cout16_kernel, dim3(grid), dim3(768), lds, reinterpret_cast<hipStream_t>(stream), P);
@@ -385,12 +380,7 @@ extern "C" int gpemsr_conv7_c8_cout32_bf16(const void* x, int n, int h, int w, i
       return fail(GPEMSR_ELAUNCH, "conv7_c8_cout32_bf16: cannot raise the dynamic LDS limit");
     dev_once_done(attr);
   }
-  int dev = 0; hipDeviceProp_t prop;
-  static int cus = 0;
-  if (cus == 0) {
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(GPEMSR_ELAUNCH, "conv7_c8_cout32_bf16: device query failed");
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cus();
   const int grid = P.ntiles < cus ? P.ntiles : cus;
   const size_t lds = (size_t)C8_WBYTES + 3 * (size_t)C8_ABYTES;
   hipLaunchKernelGGL(conv7_c8_cout32_kernel, dim3(grid), dim3(768), lds, reinterpret_cast<hipStream_t>(stream), P);

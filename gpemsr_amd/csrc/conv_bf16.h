@@ -57,7 +57,6 @@ __device__ __forceinline__ void x_stage_bias(const XParams& P, float* bias_lds, 
 }
 
 
-int device_cus();                            // CUs of the current device (cached; conv_bf16.hip)
 // kernels of the family that live outside conv_bf16.hip
 int launch_convt64_resident(const XParams& P, size_t lds, hipStream_t st);                // convt_bf16.hip
 int launch_gemm_direct(const XParams& P, bool lean, bool rowmax, size_t lds, hipStream_t st);      // gemm_bf16.hip: 1x1 / Linear / matrix products, activations straight into registers

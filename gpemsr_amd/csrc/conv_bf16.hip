@@ -1301,12 +1301,7 @@ static int launch_x(const XParams& P, size_t lds, hipStream_t st) {
   }
   // persistent workgroups: as many as the chip holds at once (two per CU when the LDS footprint allows), each walking
   // tiles blockIdx.x, +gridDim.x, ...
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(GPEMSR_ELAUNCH, "conv2d_bf16: device query failed");
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cus();
   constexpr int NTH = (WM * WN + NL) * 64;
   const int slots = cus * ((NTH == 256 && lds <= 80 * 1024) ? 2 : 1);
   const int grid = P.nblocks < slots ? P.nblocks : slots;
@@ -1607,16 +1602,6 @@ extern "C" int gpemsr_conv2d_bf16_kernel_name(const gpemsr_conv16_desc* d, char*
              L.tr ? (L.tcomp ? "CONVT,TCOMP" : "CONVT") : (L.gemm ? (d->rowmax ? "GEMM,ROWMAX" : "GEMM") : (d->stride == 2 ? "S2" : "CONV")), L.NL, L.axf ? ",AXF" : "");
   }
   return GPEMSR_OK;
-}
-
-int gpemsr::device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  return cus;
 }
 
 extern "C" int gpemsr_conv2d_bf16(const gpemsr_conv16_desc* d, void* stream) {

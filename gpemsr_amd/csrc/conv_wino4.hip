@@ -14,25 +14,31 @@
 // layers (8 chunks per tile: 7.2 -> 4.9 ms on a 1024^2 map) once the epilogue was free of scratch and control flow.
 //
 //   * workgroup = 12 waves (three per SIMD, 168 registers), output tile 16 x 32 pixels = 32 blocks of 4x4 (one MFMA row tile) x 64 couts;
-//     wave w owns the positions p = 3 w .. 3 w + 2 (p = 6 xi + nu): 3 x 2 accumulator tiles = 96 registers;
-//   * NO weights in LDS: a position is multiplied by exactly one wave, so its U rows go global -> registers (U is packed
+//     wave w owns ONE ROW of the transformed tile, xi = w / 2 (positions p = 6 xi + nu, all six nu), for the 32 couts of half nt = w & 1:
+//     6 accumulator tiles = 96 registers.  (Round 5: three positions x both cout halves.  Holding all six nu of a row is what lets the wave
+//     apply the first output transform to its own accumulators, see the epilogue; the price is that a V fragment is read by two waves.)
+//   * NO weights in LDS: a (position, cout half) is multiplied by exactly one wave, so its U rows go global -> registers (U is packed
 //     [cin / 8][36][quad][cout][4]: a wave's fragment is 512 consecutive bytes per quad), one chunk ahead, into the registers the
 //     previous chunk's fragments have just left; the raw halo image goes global -> LDS by DMA three chunks ahead (ring of three);
 //   * software pipeline over chunks: while a wave multiplies chunk c (24 MFMAs from V[c & 1] and the register-held U) it also does its share of
 //     the transforms of chunk c + 1 -- (T1) the row transform B^T along x of the 18 x 34 halo image into X[row][nu][quad][block column] (576
-//     items of one channel pair) under positions 0-1, barrier, (T2) the column transform into V[(c + 1) & 1][xi][nu][quad][block] (768 items)
-//     under position 2, barrier.  Measured before the pipeline (phases one after the other, three barriers; profiles/r05_wino4_phase_probe_v1.log,
+//     items of one channel pair) under the wave's positions nu = 0-3, barrier, (T2) the column transform into V[(c + 1) & 1][xi][nu][quad][block] (768 items)
+//     under nu = 4-5 (k-steps of two positions interleaved: no MFMA waits on the previous one's accumulator), barrier.  Measured before the pipeline (phases one after the other, three barriers; profiles/r05_wino4_phase_probe_v1.log,
 //     512 -> 512 at 80 x 64^2): 5.06 ms = 0.78 fixed + 2.9 MFMA + 0.7 transforms + 0.65 loads -- nothing overlapped.  Pair-sized items keep the
 //     transform's transient registers at 24 beside the 96 accumulators;
 //   * raw image in LDS as [column mod 4][row][column / 4][quad]: the six columns an item reads for consecutive block columns are consecutive
 //     16-byte slots (a pixel-major image would be read at a 64-byte stride);
-//   * epilogue: the 36 sums of every (block, cout) meet through LDS in four passes of 16 couts, two 72 KB exchange buffers (pass k + 1 is
-//     written while pass k is transformed: one barrier per pass), A^T . A in registers (10 + 10 additions per row / column pass), bias,
-//     GroupNorm partial sums (conv + bias, per tile and channel, fixed order), activation, residual / multiplier / PixelShuffle store or
-//     patch-cosine sums.
+//   * epilogue (round 6): every wave applies A^T over nu to its six accumulator tiles IN REGISTERS (packed on register pairs: 80 instructions
+//     per wave), leaving four output-column tiles; two passes (cout half 0 / 1, written by the six waves that own it) through ONE 96 KB
+//     exchange buffer E[xi][column][block][32 couts]; an item = one block x one cout PAIR: A^T over xi one column at a time (10 packed
+//     additions), bias, GroupNorm partial sums (conv + bias, per tile and channel, fixed order), activation, residual / multiplier /
+//     PixelShuffle as 8-byte stores, or patch-cosine sums.  Round 5's form (four passes of 16 couts, scalar items doing both transforms on
+//     36 exchanged sums, half the lanes masked in every exchange write) issued more than twice the vector instructions: a tile's fixed
+//     cost fell from 13.5 to 6.8 us (64 -> 64 at 16 x 1024^2: 4.91 -> 4.63 ms; the step 467.2 -> 458.2 ms, profiles/r06_ab_wino4_epilogue.log).
 //
 // Replaces gpemsr_conv2d's direct form (descriptor.transposed = 5; weight = packing.pack_winograd4) for 3x3 stride-1 layers whose sources are
-// multiples of 8 channels, cout % 64 == 0, activation NONE / RELU / LRELU; epilogue flavours: plain (+ GroupNorm sums), + residual (+ pixel
+// multiples of 8 channels, cout % 64 == 0 (even couts >= 128 through zero-padded weights), 8-byte aligned output / residual rows, activation
+// NONE / RELU / LRELU; epilogue flavours: plain (+ GroupNorm sums), + residual (+ pixel
 // multiplier), PixelShuffle(2) (cout % 256 == 0), patch-cosine sums against `residual` instead of a store (cout == 64).
 #include "common.h"
 #include "conv_wino.h"
@@ -78,12 +84,13 @@ constexpr int W4_X_BYTES = 18 * 6 * 2 * 8 * 16;                          // X[ro
 constexpr int W4_V_BYTES = 36 * 2 * 32 * 16;                             // V[p][quad][block]: 36,864, two buffers
 constexpr int W4_X_OFF = 3 * W4_RAW_BYTES, W4_V_OFF = W4_X_OFF + W4_X_BYTES;
 constexpr int W4_MAIN_LDS = W4_V_OFF + 2 * W4_V_BYTES;                   // 163,584: the main loop's map
-constexpr int W4_EPIX = 16;                                              // floats per (position, block) row of an exchange buffer: the 16 couts of a pass (an item
-                                                                         // wave reads 4 blocks x 64 bytes = 256 consecutive bytes: conflict-free without padding)
-constexpr int W4_E_BYTES = 36 * 32 * W4_EPIX * 4;                        // 73,728; TWO buffers (pass k + 1 is written while pass k is transformed), over the main map
-constexpr int W4_RED_OFF = 2 * W4_E_BYTES;                               // GroupNorm sums [32 blocks][64 couts][2]: 16,384
-constexpr int W4_LDS = W4_RED_OFF + 16384;                               // 163,840 = all of the CU's LDS
-static_assert(W4_MAIN_LDS <= W4_LDS && W4_LDS <= 160 * 1024, "LDS map");
+constexpr int W4_EPIX = 32;                                              // floats per (row xi, output column j, block) line of the exchange buffer: the 32 couts of a
+                                                                         // pass (an item wave reads 4 blocks x 128 bytes = 512 consecutive bytes: conflict-free)
+constexpr int W4_E_BYTES = 6 * 4 * 32 * W4_EPIX * 4;                     // 98,304: E[xi][j][block][cout], ONE buffer over the main loop's map, written and read twice
+constexpr int W4_RED_OFF = W4_E_BYTES;                                   // GroupNorm sums [32 blocks][64 couts][2]: 16,384
+constexpr int W4_EPI_LDS = W4_RED_OFF + 16384;                           // 114,688: the epilogue's map
+constexpr int W4_LDS = 160 * 1024;                                       // 163,840 = all of the CU's LDS
+static_assert(W4_MAIN_LDS <= W4_LDS && W4_EPI_LDS <= W4_LDS, "LDS map");
 
 // X[row][nu][quad][block column] byte offset of a channel pair.  The four block rows a T2 wave reads are 4 rows = 6,144 bytes apart -- the same 32
 // banks, a 4-way conflict; swapping the two 128-byte halves (the quad bit) on every other group of four rows puts them on alternating halves.
@@ -188,21 +195,20 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
       f_c0 = 0; ++f_src;
     }
   };
-  // ---- U fragments of this wave's three positions: lane (li = cout, lh = quad), [chunk][p][quad][cout][4]: a uniform base + ONE per-lane offset ----
-  const unsigned u_off = (unsigned)(lh * P.cout_pad + li) * 4u;                   // floats
-  auto load_u = [&](int chunk, int j, float4 (&U)[2]) {
-    const float* ub = P.weight + ((long long)(chunk * 36 + 3 * wave + j) * 2 * P.cout_pad + n0) * 4; // wave-uniform
-    U[0] = *reinterpret_cast<const float4*>(ub + u_off);
-    U[1] = *reinterpret_cast<const float4*>(ub + u_off + 32 * 4);
+  // ---- U fragments of this wave's six positions (row xi = wave / 2, all six nu) x its 32 couts (half nt = wave & 1): lane (li = cout, lh = quad),
+  //      [chunk][p][quad][cout][4]: a uniform base + ONE per-lane offset ----
+  const int w_xi = wave >> 1, w_nt = wave & 1;
+  const unsigned u_off = (unsigned)(lh * P.cout_pad + li + 32 * w_nt) * 4u;       // floats
+  auto load_u = [&](int chunk, int j, float4& U) {
+    const float* ub = P.weight + ((long long)(chunk * 36 + 6 * w_xi + j) * 2 * P.cout_pad + n0) * 4; // wave-uniform
+    U = *reinterpret_cast<const float4*>(ub + u_off);
   };
 
-  f32x16 acc[3][2];
+  f32x16 acc[6];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < 6; ++j)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // transform items: one channel PAIR of a quad (8 bytes).  (T1) row transform along x, item (row, quad, block column, pair), waves 0-8;
   // (T2) column transform along y, item (nu, quad, block row, block column, pair), (nu, quad) wave-uniform, every thread one item.
@@ -274,12 +280,12 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
   };
 
   // ---- prologue: raw images of chunks 0-2, U fragments of chunk 0, V of chunk 0 ----
-  float4 U[3][2];
+  float4 U[6];
   issue_raw(0);
   if (nchunks > 1) issue_raw(1);
   if (nchunks > 2) issue_raw(2);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) load_u(0, j, U[j]);
+  for (int j = 0; j < 6; ++j) load_u(0, j, U[j]);
   wn_wait_vmcnt(0);
   __syncthreads();
   {
@@ -294,41 +300,48 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
 
   // ---- main loop: iteration c multiplies chunk c (V[c & 1], U in registers) and transforms chunk c + 1 (raw image (c + 1) % 3 -> X ->
   //      V[(c + 1) & 1]), fetches the U fragments of chunk c + 1 and starts the DMA of raw image c + 3.  Two barriers per chunk.
-  const int a_v = W4_V_OFF + (3 * wave) * 1024 + lane * 16;  // V[.][p][lh][li]
+  const int a_v = W4_V_OFF + (6 * w_xi) * 1024 + lane * 16;  // V[.][p][lh][li]
   int rb1 = 1;                                               // ring slot of raw image c + 1; image c + 3 goes to the slot of image c = (rb1 + 2) % 3
   if (W4_SKIP & 128) nchunks = 1;
   for (int c = 0; c < nchunks; ++c) {
     const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U: no branch around the loads)
     const bool more = c + 1 < nchunks;
     const char* vb = wsm + a_v + (c & 1) * W4_V_BYTES;
-    auto mma = [&](int j, int nt, const float4& vf, int k0, int k1) {
+    // two positions at a time, their k-steps interleaved: consecutive MFMAs never wait on each other's accumulator
+    auto mma2 = [&](int j, const float4& va, const float4& vb2, int k0, int k1) {
       if (W4_SKIP & 4) return;
-      const float v[4] = {vf.x, vf.y, vf.z, vf.w};
-      const float u[4] = {U[j][nt].x, U[j][nt].y, U[j][nt].z, U[j][nt].w};
+      const float a[4] = {va.x, va.y, va.z, va.w}, b[4] = {vb2.x, vb2.y, vb2.z, vb2.w};
+      const float ua[4] = {U[j].x, U[j].y, U[j].z, U[j].w}, ub[4] = {U[j + 1].x, U[j + 1].y, U[j + 1].z, U[j + 1].w};
 #pragma unroll
-      for (int k = k0; k < k1; ++k) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[j][nt], 0, 0, 0);
+      for (int k = k0; k < k1; ++k) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], ua[k], acc[j], 0, 0, 0);
+        acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[k], ub[k], acc[j + 1], 0, 0, 0);
+      }
     };
     float2 d[6];
-    // ---- phase A: positions 0 and 1, T1 of the next chunk between them ----
+    // ---- phase A: positions nu = 0-3, T1 of the next chunk between them ----
     const bool do_t1 = more && wave < 9 && !(W4_SKIP & 1);
     float4 vf = *reinterpret_cast<const float4*>(vb);
+    float4 vg = *reinterpret_cast<const float4*>(vb + 1024);
     if (do_t1) t1_load(rb1, d);
-    mma(0, 0, vf, 0, 4); mma(0, 1, vf, 0, 4);
-    if (!(W4_SKIP & 8)) load_u(cn, 0, U[0]);
+    mma2(0, vf, vg, 0, 4);
+    if (!(W4_SKIP & 8)) { load_u(cn, 0, U[0]); load_u(cn, 1, U[1]); }
     if (do_t1) t1_store(d);
     if (MODE & W4_AFF) aff_load(c + 2 < nchunks ? c + 2 : c);     // (clamped: no branch around a load)
-    vf = *reinterpret_cast<const float4*>(vb + 1024);
-    mma(1, 0, vf, 0, 4); mma(1, 1, vf, 0, 4);
-    if (!(W4_SKIP & 8)) load_u(cn, 1, U[1]);
-    __syncthreads();
-    // ---- phase B: position 2 and T2 of the next chunk; the DMA of raw image c + 3 behind the last wait for this chunk's U ----
-    const bool do_t2 = more && !(W4_SKIP & 2);
     vf = *reinterpret_cast<const float4*>(vb + 2048);
+    vg = *reinterpret_cast<const float4*>(vb + 3072);
+    mma2(2, vf, vg, 0, 4);
+    if (!(W4_SKIP & 8)) { load_u(cn, 2, U[2]); load_u(cn, 3, U[3]); }
+    __syncthreads();
+    // ---- phase B: positions nu = 4, 5 and T2 of the next chunk; the DMA of raw image c + 3 behind the last wait for this chunk's U ----
+    const bool do_t2 = more && !(W4_SKIP & 2);
+    vf = *reinterpret_cast<const float4*>(vb + 4096);
+    vg = *reinterpret_cast<const float4*>(vb + 5120);
     if (do_t2) t2_load(d);
-    mma(2, 0, vf, 0, 2); mma(2, 1, vf, 0, 2);
-    // The DMA goes out behind the last wait for this chunk's U and ahead of the load of U[2] -- at a different point of that window in each
-    // of a SIMD's three waves (role = wave / 4): 21 gather instructions of 32 cache lines each, issued by all twelve waves at the same program
-    // point, fill the address queue and hold every wave (in-order issue: its MFMAs too) until they drain.
+    mma2(4, vf, vg, 0, 2);
+    // The DMA goes out behind the last wait for this chunk's U and ahead of the loads of U[4], U[5] -- at a different point of that window in
+    // each of a SIMD's three waves (role = wave / 4): 21 gather instructions of 32 cache lines each, issued by all twelve waves at the same
+    // program point, fill the address queue and hold every wave (in-order issue: its MFMAs too) until they drain.
     const bool dma = c + 3 < nchunks && !(W4_SKIP & 16);
     const int role = wave >> 2, rbi = rb1 == 0 ? 2 : rb1 - 1;
     __builtin_amdgcn_sched_barrier(0);
@@ -338,131 +351,145 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     __builtin_amdgcn_sched_barrier(0);
     if (dma && role == 1) issue_raw(rbi);
     __builtin_amdgcn_sched_barrier(0);
-    mma(2, 0, vf, 2, 4); mma(2, 1, vf, 2, 4);
+    mma2(4, vf, vg, 2, 4);
     __builtin_amdgcn_sched_barrier(0);
     if (dma && role == 2) issue_raw(rbi);
     asm volatile("" ::: "memory");
-    if (!(W4_SKIP & 8)) load_u(cn, 2, U[2]);                 // (younger than the DMA: the compiler's wait for it next iteration covers the DMA)
+    if (!(W4_SKIP & 8)) { load_u(cn, 4, U[4]); load_u(cn, 5, U[5]); }   // (younger than the DMA: the compiler's waits for them next iteration cover the DMA)
     rb1 = rb1 == 2 ? 0 : rb1 + 1;
     __syncthreads();
   }
 
-  // ---- epilogue: four passes of 16 couts through the exchange buffer (fully unrolled: static accumulator indices, nothing in scratch -- a
-  //      scratch reload waits on vmcnt, i.e. for every output store before it) ----
+  // ---- epilogue.  A wave holds ALL SIX nu of its row xi for its 32 couts, so the first output transform (A^T over nu: six sums -> four output
+  //      columns) runs on its accumulators in registers, packed on register pairs, before anything is exchanged: 2/3 of the round-5 exchange volume
+  //      and no first transform in the items.  Then TWO passes (cout half nt = 0, 1; the waves owning that half write E[xi][j][block][cout]), an
+  //      item = one block x one cout PAIR: the second transform (A^T over xi, one output column at a time), statistics, activation and stores
+  //      are packed / 8-byte operations.  Round 5's form (four passes of 16 couts, scalar items doing both transforms, half the lanes masked in
+  //      every exchange write) issued more than twice the vector instructions -- and every one of them is matrix time on this chip.  Fully
+  //      unrolled: static accumulator indices, nothing in scratch (a scratch reload waits on vmcnt, i.e. for every output store before it) ----
+#define W4_AT2(m, y) do { /* A^T of F(4, 3) on a pair: six sums -> four outputs */                                      \
+    const float2 s12 = W4_ADD(m[1], m[2]), d12 = W4_SUB(m[1], m[2]), s34 = W4_ADD(m[3], m[4]), d34 = W4_SUB(m[3], m[4]); \
+    y[0] = W4_ADD(W4_ADD(m[0], s12), s34);                                                                              \
+    y[1] = W4_LIN2(d34, 2.f, d12);                                                                                      \
+    y[2] = W4_LIN2(s34, 4.f, s12);                                                                                      \
+    y[3] = W4_ADD(W4_LIN2(d34, 8.f, d12), m[5]);                                                                        \
+  } while (0)
+  if (!(W4_SKIP & 64)) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {                          // in place: acc[j] (j < 4) <- output column j of row xi
+      const float2 m[6] = {make_float2(acc[0][r], acc[0][r + 1]), make_float2(acc[1][r], acc[1][r + 1]), make_float2(acc[2][r], acc[2][r + 1]),
+                           make_float2(acc[3][r], acc[3][r + 1]), make_float2(acc[4][r], acc[4][r + 1]), make_float2(acc[5][r], acc[5][r + 1])};
+      float2 y[4];
+      W4_AT2(m, y);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j][r] = y[j].x; acc[j][r + 1] = y[j].y; }
+    }
+  }
   float* E = reinterpret_cast<float*>(wsm);
   float* red = reinterpret_cast<float*>(wsm + W4_RED_OFF);
   const int act = P.act;
   const bool inside = oy0 + 16 <= P.h && ox0 + 32 <= P.w;     // (uniform) the whole tile is image: no per-pixel tests
-  const int e_cc = tid & 15, e_b = tid >> 4;                   // item of a pass: (cout of the pass, block), threads 0-511
+  const int e_cp = tid & 15, e_b = tid >> 4;                   // item of a pass: (cout pair of the pass, block), threads 0-511
   const int e_br = e_b >> 3, e_bc = e_b & 7;
-  // addresses = a UNIFORM base (tile, pass, pixel of the block: scalar registers) + ONE per-lane 32-bit element offset per tensor: sixteen
+  // addresses = a UNIFORM base (tile, pass, pixel of the block: scalar registers) + ONE per-lane 32-bit byte offset per tensor: sixteen
   // 64-bit per-lane addresses per tensor went to scratch beside the accumulators (and a scratch reload waits on vmcnt, i.e. on the stores)
   const long long t_pix = ((long long)img * P.h + oy0) * P.w + ox0;                        // first pixel of the tile
   float* t_out = (MODE & W4_PS) ? P.out + (((long long)img * 2 * P.h + 2 * oy0) * (2 * P.w) + 2 * ox0) * P.out_ld : P.out + t_pix * P.out_ld + n0;
   const float* t_res = (MODE & (W4_RES | W4_COS)) ? P.residual + t_pix * P.res_ld + n0 : nullptr;
   const float* t_mul = (MODE & W4_MUL) ? P.pixmul + t_pix : nullptr;
   // (BYTE offsets added to a char pointer: "uniform pointer + zero-extended 32-bit register" is the pattern of the scalar-base addressing mode)
-  const unsigned e_ooff = 4u * ((MODE & W4_PS) ? (unsigned)((8 * e_br * (2 * P.w) + 8 * e_bc) * P.out_ld + e_cc)
-                                               : (unsigned)((4 * e_br * P.w + 4 * e_bc) * P.out_ld + e_cc));
-  const unsigned e_roff = 4u * (unsigned)((4 * e_br * P.w + 4 * e_bc) * P.res_ld + e_cc);
+  const unsigned e_ooff = 4u * ((MODE & W4_PS) ? (unsigned)((8 * e_br * (2 * P.w) + 8 * e_bc) * P.out_ld + 2 * e_cp)
+                                               : (unsigned)((4 * e_br * P.w + 4 * e_bc) * P.out_ld + 2 * e_cp));
+  const unsigned e_roff = 4u * (unsigned)((4 * e_br * P.w + 4 * e_bc) * P.res_ld + 2 * e_cp);
   const unsigned e_moff = 4u * (unsigned)(4 * e_br * P.w + 4 * e_bc);
-  float e_bias[4];                                             // all four passes' biases up front: a load inside a pass would wait (vmcnt) for the
+  float2 e_bias[2];                                            // both passes' biases up front: a load inside a pass would wait (vmcnt) for the
 #pragma unroll                                                 // previous pass's stores
-  for (int k = 0; k < 4; ++k) e_bias[k] = P.bias && tid < 512 && n0 + 16 * k + e_cc < P.cout ? P.bias[n0 + 16 * k + e_cc] : 0.f;
+  for (int k = 0; k < 2; ++k) {
+    const int ch = n0 + 32 * k + 2 * e_cp;                     // (cout is even: checked on the host)
+    const bool ok = P.bias && tid < 512 && ch < P.cout;
+    e_bias[k] = make_float2(ok ? P.bias[ch] : 0.f, ok ? P.bias[ch + 1] : 0.f);
+  }
   // activation as arithmetic, max(v, slope v) + 0 with slope 0 / 0.1 for RELU / LRELU (checked on the host; the + 0 turns RELU's -0 into
   // +0): written as a select, the compiler built control flow around every store -- 1,200 instructions and 150 branches per item and pass
   const float slope = act == GPEMSR_ACT_LRELU ? 0.1f : 0.f;   // (W4_ACT instantiations only)
-  float cab = 0.f, caa = 0.f, cbb = 0.f;                       // W4_COS: this thread's sums over its block and the four passes
-  auto e_write = [&](int k) {                                  // this wave's three positions x 32 blocks x the 16 couts of pass k -> E[k & 1]
-    const int nt = k >> 1, half = k & 1;
-    if ((li >> 4) == half) {
-      float* ew = E + (k & 1) * (W4_E_BYTES / 4) + ((3 * wave) * 32 + 4 * lh) * W4_EPIX + (li & 15);
+  float cab = 0.f, caa = 0.f, cbb = 0.f;                       // W4_COS: this thread's sums over its block and both passes
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+  for (int k = 0; k < ((W4_SKIP & 64) ? 0 : 2); ++k) {
+    if (w_nt == k) {                                           // the six waves holding cout half k: 4 output columns x 32 blocks x 32 couts of row xi (every lane writes)
+      float* ew = E + ((4 * w_xi) * 32 + 4 * lh) * W4_EPIX + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ew[(j * 32 + (r & 3) + 8 * (r >> 2)) * W4_EPIX] = nt == 0 ? acc[j][0][r] : acc[j][1][r];   // register r = block (r & 3) + 8 (r >> 2) + 4 lh
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ew[(j * 32 + (r & 3) + 8 * (r >> 2)) * W4_EPIX] = acc[j][r];   // register r = block (r & 3) + 8 (r >> 2) + 4 lh
     }
-  };
-  if (!(W4_SKIP & 64)) e_write(0);
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < ((W4_SKIP & 64) ? 0 : 4); ++k) {
-    const int nt = k >> 1, half = k & 1;
-    if (k < 3) e_write(k + 1);                                 // (the buffer pass k - 1 was read from: every reader passed the barrier below)
-    if (tid < 512 && n0 + (nt * 32 + 16 * half) + e_cc < P.cout) {   // (a last cout block may be partly padding: cout % 64 != 0)
-      const int cq = nt * 32 + 16 * half;                     // first cout of this pass within the block
-      const float bias = e_bias[k];
-      const float* er = E + (k & 1) * (W4_E_BYTES / 4) + e_b * W4_EPIX + e_cc;
-      float gs = 0.f, gq = 0.f;
-      auto rows = [&](auto guarded) {
+    __syncthreads();
+    const int cq = 32 * k;                                    // first cout of this pass within the block
+    if (tid < 512 && n0 + cq + 2 * e_cp < P.cout) {           // (a last cout block may be partly padding: cout % 64 != 0)
+      const float* er = E + e_b * W4_EPIX + 2 * e_cp;
+      float2 gs = make_float2(0.f, 0.f), gq = make_float2(0.f, 0.f);
+      auto cols = [&](auto guarded) {
         constexpr bool G = decltype(guarded)::value;
         // (the lane offsets are made opaque before every access: otherwise "base + offset" is formed once as a 64-bit per-lane pointer and every
         //  access becomes that pointer + a uniform step -- sixteen register pairs per tensor instead of one register and scalar bases)
         unsigned oo = e_ooff, ro = e_roff, mo = e_moff;
-        // residual / cosine operand: one row of four pixels at a time, requested one row ahead (all sixteen up front did not fit beside the
-        // accumulators: scratch, whose reloads wait on vmcnt, i.e. on the stores)
-        auto load_row = [&](int i, float (&r)[4]) {
+        // residual / cosine operand: one column of four pixels at a time, requested one column ahead (all sixteen up front did not fit beside
+        // the accumulators: scratch, whose reloads wait on vmcnt, i.e. on the stores)
+        auto load_col = [&](int jx, float2 (&r)[4]) {
 #pragma unroll
-          for (int jx = 0; jx < 4; ++jx) {
-            r[jx] = 0.f;
-            if (!G || (oy0 + 4 * e_br + i < P.h && ox0 + 4 * e_bc + jx < P.w)) { asm volatile("" : "+v"(ro)); r[jx] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t_res + ((long long)i * P.w + jx) * P.res_ld + cq) + ro); }
+          for (int i = 0; i < 4; ++i) {
+            r[i] = make_float2(0.f, 0.f);
+            if (!G || (oy0 + 4 * e_br + i < P.h && ox0 + 4 * e_bc + jx < P.w)) { asm volatile("" : "+v"(ro)); r[i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(t_res + ((long long)i * P.w + jx) * P.res_ld + cq) + ro); }
           }
         };
-        float rv[4], rn[4];
-        if (MODE & (W4_RES | W4_COS)) load_row(0, rv);
-        float z[6][4];                                        // A^T over xi for every nu: z[nu][i]
-#pragma unroll
-        for (int nu = 0; nu < 6; ++nu) {
-          float m[6];
-#pragma unroll
-          for (int xi = 0; xi < 6; ++xi) m[xi] = er[((xi * 6 + nu) * 32) * W4_EPIX];
-          w4_at(m, z[nu]);
-        }
-        // the bias rides the second transform: A^T e_1 = (1, 1, 1, 1), so b added to z[1][i] is b added to the four outputs of row i
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[1][i] += bias;
+        float2 rv[4], rn[4];
+        if (MODE & (W4_RES | W4_COS)) load_col(0, rv);
         float* op = t_out + cq;                               // uniform; + the row / column step below; [e_ooff] per lane
-        if (MODE & W4_PS) {                                    // channels n0 + cq .. + 15 of the permuted cout order lie in ONE sub-pixel q = ch / (cout / 4)
+        if (MODE & W4_PS) {                                    // channels n0 + cq .. + 31 of the permuted cout order lie in ONE sub-pixel q = ch / (cout / 4)
           const int ch0 = n0 + cq, q = ch0 / P.cq;
           op = t_out + ((long long)(q >> 1) * (2 * P.w) + (q & 1)) * P.out_ld + (ch0 - q * P.cq);
         }
         const long long o_row = (MODE & W4_PS) ? (long long)4 * P.w * P.out_ld : (long long)P.w * P.out_ld;   // one input row down
         const int o_col = (MODE & W4_PS) ? 2 * P.out_ld : P.out_ld;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                          // A^T over nu, bias, statistics, activation, (residual, multiplier,) store -- row by row
-          const float m[6] = {z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i]};
-          float y[4];
-          w4_at(m, y);
-          if ((MODE & (W4_RES | W4_COS)) && i < 3) load_row(i + 1, rn);
+        for (int jx = 0; jx < 4; ++jx) {                       // output column jx of the block: A^T over xi, bias, statistics, activation, (residual, multiplier,) store
+          float2 m[6];
 #pragma unroll
-          for (int jx = 0; jx < 4; ++jx) {
-            const float v = y[jx];
+          for (int xi = 0; xi < 6; ++xi) m[xi] = *reinterpret_cast<const float2*>(er + ((xi * 4 + jx) * 32) * W4_EPIX);
+          m[1] = W4_ADD(m[1], e_bias[k]);                      // the bias rides the transform: A^T e_1 = (1, 1, 1, 1)
+          float2 y[4];
+          W4_AT2(m, y);
+          if ((MODE & (W4_RES | W4_COS)) && jx < 3) load_col(jx + 1, rn);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float2 v = y[i];
             if (!G || (oy0 + 4 * e_br + i < P.h && ox0 + 4 * e_bc + jx < P.w)) {
-              if (MODE & W4_GN) { gs += v; gq = fmaf(v, v, gq); }
-              float t = (MODE & W4_ACT) ? fmaxf(v, slope * v) + 0.f : v;
+              if (MODE & W4_GN) { gs = W4_ADD(gs, v); gq = make_float2(fmaf(v.x, v.x, gq.x), fmaf(v.y, v.y, gq.y)); }
+              float2 t = v;
+              if (MODE & W4_ACT) t = make_float2(fmaxf(v.x, slope * v.x) + 0.f, fmaxf(v.y, slope * v.y) + 0.f);
               if (MODE & W4_COS) {
-                cab = fmaf(rv[jx], t, cab); caa = fmaf(rv[jx], rv[jx], caa); cbb = fmaf(t, t, cbb);
+                cab = fmaf(rv[i].x, t.x, cab); caa = fmaf(rv[i].x, rv[i].x, caa); cbb = fmaf(t.x, t.x, cbb);
+                cab = fmaf(rv[i].y, t.y, cab); caa = fmaf(rv[i].y, rv[i].y, caa); cbb = fmaf(t.y, t.y, cbb);
               } else {
-                if (MODE & W4_RES) t += rv[jx];
-                if (MODE & W4_MUL) { asm volatile("" : "+v"(mo)); t *= *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t_mul + (long long)i * P.w + jx) + mo); }
+                if (MODE & W4_RES) t = W4_ADD(t, rv[i]);
+                if (MODE & W4_MUL) { asm volatile("" : "+v"(mo)); const float pm = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(t_mul + (long long)i * P.w + jx) + mo); t.x *= pm; t.y *= pm; }
                 asm volatile("" : "+v"(oo));
-                if (!(W4_SKIP & 32) || t == 12345.678f)     // (probe builds: the never-true test keeps the arithmetic alive without the stores)
-                  *reinterpret_cast<float*>(reinterpret_cast<char*>(op + jx * o_col) + oo) = t;
+                if (!(W4_SKIP & 32) || t.x == 12345.678f)   // (probe builds: the never-true test keeps the arithmetic alive without the stores)
+                  *reinterpret_cast<float2*>(reinterpret_cast<char*>(op + i * o_row + jx * o_col) + oo) = t;
               }
             }
           }
-          op += o_row;
           if (MODE & (W4_RES | W4_COS)) {
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) rv[jx] = rn[jx];
+            for (int i = 0; i < 4; ++i) rv[i] = rn[i];
           }
         }
       };
-      if (inside) rows(std::false_type{}); else rows(std::true_type{});
-      if (MODE & W4_GN) { red[(e_b * 64 + cq + e_cc) * 2] = gs; red[(e_b * 64 + cq + e_cc) * 2 + 1] = gq; }
+      if (inside) cols(std::false_type{}); else cols(std::true_type{});
+      if (MODE & W4_GN) *reinterpret_cast<float4*>(red + (e_b * 64 + cq + 2 * e_cp) * 2) = make_float4(gs.x, gq.x, gs.y, gq.y);
     }
     __syncthreads();
   }
+#undef W4_AT2
   if (MODE & W4_COS) {
     // R:model/GPEMSR.py:387-395 without the second relu1_2 map in memory: one record per 4-row strip and 16-pixel patch column (the layout of
     // the direct kernel's XEPI = 2 epilogue, four strips make a patch: gpemsr_patch_cosine_finish).  Waves 0-7 hold the items of blocks
@@ -534,8 +561,11 @@ int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, in
                "conv2d (F(4x4,3x3) form): source %d misaligned, or an image beyond the 32-bit byte offsets (24-bit pixel index) of the LDS-DMA", s);
     cin += d->src[s].c;
   }
-  GP_REQUIRE((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->out) & 3) == 0 && (long long)d->h * d->w < (1ll << 31),
-             "conv2d (F(4x4,3x3) form): weight alignment / image size");
+  GP_REQUIRE((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0 && (long long)d->h * d->w < (1ll << 31), "conv2d (F(4x4,3x3) form): weight alignment / image size");
+  // the epilogue's items are cout PAIRS: 8-byte stores and residual loads
+  GP_REQUIRE(d->cout % 2 == 0 && (d->cos_partials || ((reinterpret_cast<uintptr_t>(d->out) & 7) == 0 && d->out_ld % 2 == 0)) &&
+             (!d->residual || ((reinterpret_cast<uintptr_t>(d->residual) & 7) == 0 && d->res_ld % 2 == 0)),
+             "conv2d (F(4x4,3x3) form): even cout, 8-byte aligned output / residual rows (out_ld, res_ld even)");
   P.nsrc = d->nsrc; P.n = d->n; P.h = d->h; P.w = d->w; P.cout = d->cout; P.cout_pad = cdiv(d->cout, 64) * 64;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.out = d->out; P.out_ld = d->out_ld;
   P.gn_ws = d->gn_partials; P.gn_parts = cdiv(d->h, 16) * cdiv(d->w, 32);

@@ -376,11 +376,7 @@ int launch_wino2_persistent(const WinoParams& P, hipStream_t st) {
       return fail(GPEMSR_ELAUNCH, "conv2d (Winograd form): cannot raise the dynamic LDS limit");
     dev_once_done(attr);
   }
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cus();          // (one process per GPU: dev_once above makes the same assumption)
   const int grid = P.nblocks < cus ? P.nblocks : cus;
   hipLaunchKernelGGL(conv_wino2p_f32_kernel, dim3(grid), dim3(512), WP_LDS, st, P);
   return check_launch("conv_wino2p_f32_kernel");

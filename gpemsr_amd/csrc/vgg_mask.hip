@@ -632,11 +632,7 @@ extern "C" int gpemsr_vgg_mask_bf16(const float* ref_img, const float* lr, int n
 #endif
   static int form = -1;                 // GPEMSR_VGG_FORM=1 selects the lockstep kernel (A/B measurements)
   if (form < 0) { const char* e = getenv("GPEMSR_VGG_FORM"); form = (e && e[0] == '1') ? 1 : ((e && e[0] == '2') ? 2 : 3); }      // 3: 8 producer waves
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cus();
   const int grid = P.ns < cus ? P.ns : cus;
   if (form == 2) {
     hipLaunchKernelGGL(vgg_mask2_kernel<4>, dim3(grid), dim3(768), lds2, reinterpret_cast<hipStream_t>(stream), P);

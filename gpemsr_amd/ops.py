@@ -270,7 +270,7 @@ def _conv2d_cosine(srcs, pc: "PackedConv", act: int, a: "Act", tag: str, winogra
     if winograd and pc.wino is not None and pc.cout == 64 and s0.c % 8 == 0 and h % 16 == 0 and w % 32 == 0:
         d.transposed, d.weight = 3, pc.wino.data_ptr()          # the Winograd form leaves the same records (csrc/conv_wino.hip)
         executed = flops * 16.0 / 36.0
-        if winograd4 and pc.wino4 is not None and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and _wino4_addressable([s0]):
+        if winograd4 and pc.wino4 is not None and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and _wino4_addressable([s0], a):
             d.transposed, d.weight = 5, pc.wino4.data_ptr()     # ... and so does the F(4x4) form (csrc/conv_wino4.hip)
             executed = flops * 36.0 / 144.0
     if PROFILER is not None:
@@ -418,7 +418,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     if winograd and precision == "fp32" and winograd_ok(srcs, pc, stride, out, residual) and weight_image_stride == 0 and src_image_stride is None:
         d.transposed, d.weight = 3, pc.wino.data_ptr()          # 16 multiplies per 2x2 outputs instead of 36 (csrc/conv_wino.hip)
         executed = flops * 16.0 / 36.0
-        if winograd4 and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and winograd4_ok(srcs, pc, residual, pixmul):
+        if winograd4 and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and winograd4_ok(srcs, pc, residual, pixmul, out):
             d.transposed, d.weight = 5, pc.wino4.data_ptr()     # 36 multiplies per 4x4 outputs instead of 144 (csrc/conv_wino4.hip)
             executed = flops * 36.0 / 144.0
     if (winograd and winograd4 and int(d.transposed) == 0 and precision == "fp32" and pc.wino4 is not None and pc.cout % 64 != 0 and act in (ACT_NONE, ACT_RELU, ACT_LRELU)
@@ -459,24 +459,28 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
     return out
 
 
-def winograd4_ok(srcs, pc: "PackedConv", residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
+def winograd4_ok(srcs, pc: "PackedConv", residual: Optional["Act"] = None, pixmul: Optional["Act"] = None, out: Optional["Act"] = None) -> bool:
     """Layers (among those winograd_ok accepts) the F(4x4, 3x3) form takes: `pc.wino4` packed (the engine packs it for layers of >= 64 input
-    channels), cout % 64 == 0; plain store, + residual (+ pixel multiplier), or PixelShuffle (cout % 256 == 0, nothing else).  (Whether a small
-    map is worth its 16 x 32 pixel tiles is the caller's call: `winograd4=False`.)"""
-    if pc.wino4 is None or pc.cout % 64 != 0 or (pixmul is not None and residual is None) or not _wino4_addressable(srcs):
+    channels), cout % 64 == 0 (a padded form exists for other couts >= 128: winograd4_padded_ok); plain store, + residual (+ pixel
+    multiplier), or PixelShuffle (cout % 256 == 0, nothing else); output / residual rows 8-byte aligned.  (Whether a small map is worth its
+    16 x 32 pixel tiles is the caller's call: `winograd4=False`.)"""
+    if pc.wino4 is None or pc.cout % 64 != 0 or (pixmul is not None and residual is None) or not _wino4_addressable(srcs, out, residual):
         return False                                        # (cout % 64 != 0: winograd4_padded_ok)
     return not pc.pixel_shuffle or (pc.cout % 256 == 0 and residual is None and pixmul is None)
 
 
-def _wino4_addressable(srcs) -> bool:
-    """The F(4x4) kernel's image DMA uses 32-bit byte offsets and a 24-bit pixel index per source image (csrc/conv_wino4.hip: GP_REQUIRE)."""
-    return all(s_.h * s_.w < (1 << 24) and s_.ld < (1 << 22) and s_.h * s_.w * s_.ld * 4 < (1 << 32) for s_ in srcs)
+def _wino4_addressable(srcs, *pair_tensors) -> bool:
+    """The F(4x4) kernel's image DMA uses 32-bit byte offsets and a 24-bit pixel index per source image; its epilogue stores (and reads the
+    residual in) cout PAIRS: 8-byte aligned rows for `pair_tensors` = output / residual (csrc/conv_wino4.hip: GP_REQUIRE)."""
+    return (all(s_.h * s_.w < (1 << 24) and s_.ld < (1 << 22) and s_.h * s_.w * s_.ld * 4 < (1 << 32) for s_ in srcs)
+            and all(t is None or (t.ld % 2 == 0 and t.ptr % 8 == 0) for t in pair_tensors))
 
 
 def winograd4_padded_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None) -> bool:
     """Layers with cout % 64 != 0 the F(4x4, 3x3) form takes through zero-padded weights (`pc.wino4` packed): 3x3 stride 1, fp32 sources of
     c % 8 == 0 with 16-byte aligned rows, plain store or + residual."""
-    if pc.wino4 is None or pc.ksize != 3 or stride != 1 or pc.transposed or pc.pixel_shuffle or pixmul is not None or not _wino4_addressable(srcs):
+    if (pc.wino4 is None or pc.ksize != 3 or stride != 1 or pc.transposed or pc.pixel_shuffle or pixmul is not None or pc.cout % 2 != 0
+            or not _wino4_addressable(srcs, out, residual)):
         return False
     if any(s_.bf16 or s_.c % 8 != 0 or s_.ld % 4 != 0 or s_.ptr % 16 != 0 for s_ in srcs):
         return False

@@ -77,12 +77,13 @@ def parse_chunks(data: bytes) -> Tuple[int, int, int, int, int, bytes]:
     while pos + 12 <= len(data):
         (n,) = struct.unpack(">I", data[pos:pos + 4])
         kind = data[pos + 4:pos + 8]
-        body = data[pos + 8:pos + 8 + n]
         if pos + 12 + n > len(data):
             raise ValueError(f"PNG chunk {kind!r}: truncated")
+        body = data[pos + 8:pos + 8 + n]
         (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
-        # critical chunks only: libpng (cv2, the reference's reader) merely warns about a bad CRC on an ancillary chunk and reads the file
-        if kind in (b"IHDR", b"IDAT") and crc != (zlib.crc32(kind + body) & 0xFFFFFFFF):
+        # libpng's default CRC action (cv2.imread, the reference's reader): an error on every CRITICAL chunk (upper-case first letter: IHDR, PLTE,
+        # IDAT, IEND), a warning only on ancillary ones
+        if kind[:1].isupper() and crc != (zlib.crc32(kind + body) & 0xFFFFFFFF):
             raise ValueError(f"PNG chunk {kind!r}: CRC mismatch")
         if kind == b"IHDR":
             hdr = struct.unpack(">IIBBBBB", body)

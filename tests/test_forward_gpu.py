@@ -426,6 +426,38 @@ def test_full_size_tiles_match_the_reference_golden(tag, precision, golden_dir):
     assert dpsnr_free < 0.01, f"free-running |dPSNR| {dpsnr_free:.4f} dB"
 
 
+def test_winograd_option_key_default_and_direct_form_agree_at_full_tile_size(golden_dir):
+    """the fp32 default (`winograd: f4x4`) and `winograd: off` (direct form everywhere) on the reference's full-size golden
+    tile, FREE-RUNNING: every code index equal to the reference's and to each other, `out` within 1e-4 of each other (each is within 1e-3 of
+    the golden by the test above); `decoder_f4x4` and `f2x2` select what their names say."""
+    from gpemsr_amd.config import build_model, load_options
+    d = np.load(os.path.join(golden_dir, "full_x8_lr128.npz"))
+    x = torch.from_numpy(d["x"]).cuda()
+    opt = load_options(os.path.join(ROOT, "option", "output_GPEMSR_x8.yml"))
+    outs, idxs, forms = {}, {}, {}
+    for form in ("f4x4", "off", "decoder_f4x4", "f2x2"):
+        o = dict(opt)
+        o["winograd"] = form
+        m = build_model(o, load_prior_files=False).eval().cuda()
+        tr = {}
+        out, _ = m(x, trace=tr)
+        torch.cuda.synchronize()
+        eng = m._engine
+        forms[form] = (eng.winograd_form, sum(pc.wino4 is not None for pc in eng.pc.values()), sum(pc.wino is not None for pc in eng.pc.values()),
+                       sum(pc.wino4 is not None for k, pc in eng.pc.items() if k.startswith("refmodel.indexer.")))
+        outs[form], idxs[form] = out.float().cpu(), torch.cat(tr["code_idx"]).cpu().numpy()
+        del m
+        torch.cuda.empty_cache()
+    assert forms["off"][1:] == (0, 0, 0) and forms["f2x2"][1] == 0 and forms["f2x2"][2] > 50
+    assert forms["f4x4"][1] > 50 and forms["f4x4"][3] > 0 and forms["decoder_f4x4"][3] == 0 and forms["decoder_f4x4"][1] > 30
+    for form in outs:
+        assert (idxs[form] == d["code_idx"]).all(), f"winograd: {form}: {int((idxs[form] != d['code_idx']).sum())} code indices differ from the reference's"
+    ref = outs["off"]
+    rep = {f: float((outs[f] - ref).abs().max() / ref.abs().max()) for f in outs if f != "off"}
+    print("winograd forms vs the direct form, free-running out:", {k: f"{v:.1e}" for k, v in rep.items()})
+    assert max(rep.values()) <= 1e-4, rep
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_forward_volume_matches_the_reference_window_by_window(precision, golden_dir):
     """SURVEY section 8(f)1 against the REFERENCE (not against ourselves): a 7-slice volume through forward_volume with the

@@ -95,6 +95,29 @@ def test_option_files_accepted_like_the_reference():
     assert nd["zzz"] is None and nd["a"]["nope"] is None and nd["a"]["b"] == 1
 
 
+def test_additive_option_keys_reach_the_model():
+    """`precision`, `indexer_precision` and `winograd` are option keys a reference user finds in the YAML, under `network:`
+    or at the top level; a bare YAML `off` (which the loader reads as False) still means the direct form."""
+    import copy
+    from gpemsr_amd.config import build_model
+    base = _opt(8)
+    m = build_model(copy.deepcopy(base), load_prior_files=False)
+    assert (m.precision, m.indexer_precision, m.winograd) == ("fp32", "bf16", None)       # None = the engine's default, "f4x4"
+    for where in ("top", "network"):
+        o = copy.deepcopy(base)
+        tgt = o if where == "top" else o["network"]
+        tgt["winograd"], tgt["precision"], tgt["indexer_precision"] = "decoder_f4x4", "bf16", "fp32:all"
+        m = build_model(o, load_prior_files=False)
+        assert (m.precision, m.indexer_precision, m.winograd) == ("bf16", "fp32:all", "decoder_f4x4")
+    o = copy.deepcopy(base)
+    o["winograd"] = False
+    assert build_model(o, load_prior_files=False).winograd == "off"
+    # the keyword wins over the file (bench.py passes precision=...)
+    o = copy.deepcopy(base)
+    o["winograd"] = "f2x2"
+    assert build_model(o, load_prior_files=False, winograd="off").winograd == "off"
+
+
 def _unpack_conv(pc, splits):
     """Inverse of packing: [tap][cout][cin_pad] -> OIHW (drops the per-source zero padding)."""
     k = pc.ksize
