@@ -23,7 +23,7 @@
 //   * software pipeline over chunks: while a wave multiplies chunk c (24 MFMAs from V[c & 1] and the register-held U) it also does its share of
 //     the transforms of chunk c + 1 -- (T1) the row transform B^T along x of the 18 x 34 halo image into X[row][nu][quad][block column] (576
 //     items of one channel pair) under the wave's positions nu = 0-3, barrier, (T2) the column transform into V[(c + 1) & 1][xi][nu][quad][block] (768 items)
-//     under nu = 4-5 (k-steps of two positions interleaved: no MFMA waits on the previous one's accumulator), barrier.  Measured before the pipeline (phases one after the other, three barriers; profiles/r05_wino4_phase_probe_v1.log,
+//     under nu = 4-5, barrier.  Measured before the pipeline (phases one after the other, three barriers; profiles/r05_wino4_phase_probe_v1.log,
 //     512 -> 512 at 80 x 64^2): 5.06 ms = 0.78 fixed + 2.9 MFMA + 0.7 transforms + 0.65 loads -- nothing overlapped.  Pair-sized items keep the
 //     transform's transient registers at 24 beside the 96 accumulators;
 //   * raw image in LDS as [column mod 4][row][column / 4][quad]: the six columns an item reads for consecutive block columns are consecutive
@@ -307,16 +307,15 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U: no branch around the loads)
     const bool more = c + 1 < nchunks;
     const char* vb = wsm + a_v + (c & 1) * W4_V_BYTES;
-    // two positions at a time, their k-steps interleaved: consecutive MFMAs never wait on each other's accumulator
-    auto mma2 = [&](int j, const float4& va, const float4& vb2, int k0, int k1) {
+    // one position at a time (four dependent k-steps; the SIMD's other two waves fill the gaps).  Interleaving the k-steps of two positions was
+    // measured SLOWER (256 -> 256 at 80 x 128^2: 4.35 -> 4.65 ms, profiles/r06_ab_wino4_epilogue.log): the pair needs both V fragments and both U
+    // fragments before its first MFMA.
+    auto mma = [&](int j, const float4& vf, int k0, int k1) {
       if (W4_SKIP & 4) return;
-      const float a[4] = {va.x, va.y, va.z, va.w}, b[4] = {vb2.x, vb2.y, vb2.z, vb2.w};
-      const float ua[4] = {U[j].x, U[j].y, U[j].z, U[j].w}, ub[4] = {U[j + 1].x, U[j + 1].y, U[j + 1].z, U[j + 1].w};
+      const float v[4] = {vf.x, vf.y, vf.z, vf.w};
+      const float u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
 #pragma unroll
-      for (int k = k0; k < k1; ++k) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], ua[k], acc[j], 0, 0, 0);
-        acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[k], ub[k], acc[j + 1], 0, 0, 0);
-      }
+      for (int k = k0; k < k1; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[j], 0, 0, 0);
     };
     float2 d[6];
     // ---- phase A: positions nu = 0-3, T1 of the next chunk between them ----
@@ -324,24 +323,30 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     float4 vf = *reinterpret_cast<const float4*>(vb);
     float4 vg = *reinterpret_cast<const float4*>(vb + 1024);
     if (do_t1) t1_load(rb1, d);
-    mma2(0, vf, vg, 0, 4);
-    if (!(W4_SKIP & 8)) { load_u(cn, 0, U[0]); load_u(cn, 1, U[1]); }
+    mma(0, vf, 0, 4);
+    if (!(W4_SKIP & 8)) load_u(cn, 0, U[0]);
+    mma(1, vg, 0, 4);
+    if (!(W4_SKIP & 8)) load_u(cn, 1, U[1]);
     if (do_t1) t1_store(d);
     if (MODE & W4_AFF) aff_load(c + 2 < nchunks ? c + 2 : c);     // (clamped: no branch around a load)
     vf = *reinterpret_cast<const float4*>(vb + 2048);
     vg = *reinterpret_cast<const float4*>(vb + 3072);
-    mma2(2, vf, vg, 0, 4);
-    if (!(W4_SKIP & 8)) { load_u(cn, 2, U[2]); load_u(cn, 3, U[3]); }
+    mma(2, vf, 0, 4);
+    if (!(W4_SKIP & 8)) load_u(cn, 2, U[2]);
+    mma(3, vg, 0, 4);
+    if (!(W4_SKIP & 8)) load_u(cn, 3, U[3]);
     __syncthreads();
     // ---- phase B: positions nu = 4, 5 and T2 of the next chunk; the DMA of raw image c + 3 behind the last wait for this chunk's U ----
     const bool do_t2 = more && !(W4_SKIP & 2);
     vf = *reinterpret_cast<const float4*>(vb + 4096);
     vg = *reinterpret_cast<const float4*>(vb + 5120);
     if (do_t2) t2_load(d);
-    mma2(4, vf, vg, 0, 2);
-    // The DMA goes out behind the last wait for this chunk's U and ahead of the loads of U[4], U[5] -- at a different point of that window in
-    // each of a SIMD's three waves (role = wave / 4): 21 gather instructions of 32 cache lines each, issued by all twelve waves at the same
-    // program point, fill the address queue and hold every wave (in-order issue: its MFMAs too) until they drain.
+    mma(4, vf, 0, 4);
+    if (!(W4_SKIP & 8)) load_u(cn, 4, U[4]);
+    mma(5, vg, 0, 2);
+    // The DMA goes out behind the last wait for this chunk's U and ahead of the load of U[5] -- at a different point of that window in each
+    // of a SIMD's three waves (role = wave / 4): 21 gather instructions of 32 cache lines each, issued by all twelve waves at the same program
+    // point, fill the address queue and hold every wave (in-order issue: its MFMAs too) until they drain.
     const bool dma = c + 3 < nchunks && !(W4_SKIP & 16);
     const int role = wave >> 2, rbi = rb1 == 0 ? 2 : rb1 - 1;
     __builtin_amdgcn_sched_barrier(0);
@@ -351,11 +356,11 @@ __global__ __launch_bounds__(W4_NT, 3) void conv_wino4_f32_kernel(W4Params P) {
     __builtin_amdgcn_sched_barrier(0);
     if (dma && role == 1) issue_raw(rbi);
     __builtin_amdgcn_sched_barrier(0);
-    mma2(4, vf, vg, 2, 4);
+    mma(5, vg, 2, 4);
     __builtin_amdgcn_sched_barrier(0);
     if (dma && role == 2) issue_raw(rbi);
     asm volatile("" ::: "memory");
-    if (!(W4_SKIP & 8)) { load_u(cn, 4, U[4]); load_u(cn, 5, U[5]); }   // (younger than the DMA: the compiler's waits for them next iteration cover the DMA)
+    if (!(W4_SKIP & 8)) load_u(cn, 5, U[5]);                 // (younger than the DMA: the compiler's wait for it next iteration covers the DMA)
     rb1 = rb1 == 2 ? 0 : rb1 + 1;
     __syncthreads();
   }
