@@ -78,15 +78,18 @@ class Engine:
         # "bf16" (default): everything on the bf16 data path, logits GEMM as three products (always).
         self.indexer_precision = indexer_precision or "bf16"
         self._hp_mode, self._hp_n = None, 0
-        # "fp32:all": the WHOLE indexer (R:model/indexer.py:63-102) on the exact-fp32 kernels -- a second, indexer-only Engine over the same
+        # "fp32:all" / "bf16x3:all": the WHOLE indexer (R:model/indexer.py:63-102) on the exact-fp32 / split-bf16 kernels -- a second, indexer-only Engine over the same
         # weights picks the code indices, the rest of the path stays bf16 (the setting with ~100 % code agreement; cost: the fp32 indexer)
         self._idx_engine = None
-        if self.bf16 and self.indexer_precision == "fp32:all":
+        if self.bf16 and self.indexer_precision in ("fp32:all", "bf16x3:all"):
+            # ("bf16x3:all": the same second engine with its convolutions as three split hi + lo bf16 products on fp32 activations -- fp32-grade
+            #  logits from the bf16 matrix pipe; measured in profiles/r06_indexer_precision_sweep.log)
             sub = {k: v for k, v in sd.items() if k.startswith("refmodel.indexer.")}
-            self._idx_engine = Engine(sub, device, scale, nframes, groups, nf, dec_num_res_blocks, frame_chunk, tile_chunk, precision="fp32", winograd=winograd)
+            self._idx_engine = Engine(sub, device, scale, nframes, groups, nf, dec_num_res_blocks, frame_chunk, tile_chunk,
+                                      precision=self.indexer_precision.split(":")[0], winograd=winograd)
         elif self.bf16 and self.indexer_precision != "bf16":
             mode, _, cnt = self.indexer_precision.partition(":")
-            assert mode in ("bf16x3", "fp32") and (cnt == "" or cnt.isdigit()), f"indexer_precision {indexer_precision!r}: bf16 | bf16x3:N | fp32:N | fp32:all"
+            assert mode in ("bf16x3", "fp32") and (cnt == "" or cnt.isdigit()), f"indexer_precision {indexer_precision!r}: bf16 | bf16x3:N | fp32:N | bf16x3:all | fp32:all"
             self._hp_mode, self._hp_n = mode, int(cnt or 1)
         self.fold_gn = os.environ.get("GPEMSR_FOLD_GN", "1") != "0"     # bf16 path: first GroupNorm apply of a VQGAN block inside the consuming conv
         self.fold_gn32 = os.environ.get("GPEMSR_FOLD_GN32", "1") != "0"  # fp32 path: the same, in the input transform of the F(4x4) Winograd form

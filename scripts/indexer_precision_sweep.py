@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """free-running fidelity of precision="bf16" against the cost of running the indexer's tail at a higher precision.
 For every setting of `indexer_precision` (bf16 | bf16x3:N | fp32:N, N = trailing units of R:model/indexer.py:89-96's output_layer; fp32:all =
-the whole indexer on the exact-fp32 kernels):
+the whole indexer on the exact-fp32 kernels; bf16x3:all = the whole indexer as split-bf16 products on fp32 activations):
   * code-index agreement and free-running relative error / |dPSNR| against the REFERENCE's own vectors (tests/golden/full_x8_lr128.npz,
     full_x16_lr64.npz: one 5-frame window each, emitted by the unmodified reference; oracle/gen_golden_full.py);
   * ms per step of the bench workload (16 windows of 5 x 1 x 128 x 128, x8), interleaved rounds in one process.
@@ -25,7 +25,7 @@ from gpemsr_amd.synth import synth_lr_tiles  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--modes", type=str, default="bf16,bf16x3:1,bf16x3:4,fp32:4,fp32:all")
+    ap.add_argument("--modes", type=str, default="bf16,bf16x3:4,bf16x3:all,fp32:all")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     modes = args.modes.split(",")
