@@ -29,7 +29,7 @@ SYMBOLS = [
     "gpemsr_cx_rows", "gpemsr_cx_reduce",
     # stage-3 training step: backward + optimizer
     "gpemsr_conv2d_wgrad_workspace", "gpemsr_conv2d_wgrad", "gpemsr_act_bwd", "gpemsr_bias_grad", "gpemsr_axpy", "gpemsr_mul_pix",
-    "gpemsr_mul_pix_bwd", "gpemsr_bilinear_bwd", "gpemsr_dcn_columns_bwd", "gpemsr_temporal_gate_bwd", "gpemsr_frame_mix_lrelu_bwd",
+    "gpemsr_mul_pix_bwd", "gpemsr_bilinear_bwd", "gpemsr_dcn_columns_bwd", "gpemsr_dcn_columns_bwd_det", "gpemsr_temporal_gate_bwd", "gpemsr_frame_mix_lrelu_bwd",
     "gpemsr_pool3s2_maxavg_bwd", "gpemsr_threeda_combine_bwd", "gpemsr_maxpool2_bwd", "gpemsr_scatter_add_images", "gpemsr_l1_loss",
     "gpemsr_cx_backward", "gpemsr_cx_center_normalize_bwd", "gpemsr_gray_normalize3", "gpemsr_gray_normalize3_bwd",
     "gpemsr_transpose_images", "gpemsr_adam_step",
@@ -160,6 +160,7 @@ def load():
     lib.gpemsr_mul_pix_bwd.argtypes = [p, i32, p, i32, p, i64, i32, p, i32, p, p]
     lib.gpemsr_bilinear_bwd.argtypes = [p, i32, i32, i32, i32, i32, i32, i32, i32, f32, p, i32, p]
     lib.gpemsr_dcn_columns_bwd.argtypes = [p, i32, i32, i32, i32, i32, p, i32, i32, p, p, i32, p, i32, p]
+    lib.gpemsr_dcn_columns_bwd_det.argtypes = [p, i32, i32, i32, i32, i32, p, i32, i32, p, p, p, p, i32, p, i32, p]
     lib.gpemsr_temporal_gate_bwd.argtypes = [p, p, p, p, i32, i32, i32, i32, p, p, p, p]
     lib.gpemsr_frame_mix_lrelu_bwd.argtypes = [p, p, p, i64, i32, i32, p, p, p, p, p, i64, p]
     lib.gpemsr_pool3s2_maxavg_bwd.argtypes = [p, i32, i32, i32, i32, i32, p, i32, p, i32, p]

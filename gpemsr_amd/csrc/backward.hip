@@ -4,8 +4,9 @@
 // re-packed weights), weight gradients are in wgrad.hip.
 //
 // Convention: a gradient output marked "+=" is ACCUMULATED into a zero-initialised buffer (a tensor with several
-// consumers receives one contribution per consumer).  Everything here is deterministic (fixed summation order)
-// except gpemsr_dcn_columns_bwd's scatter into dx, which uses float atomics.
+// consumers receives one contribution per consumer).  Everything here is deterministic: fixed summation order, and the one scatter
+// (the deformable sampling's input gradient) accumulates in 64-bit fixed point with integer atomics (gpemsr_dcn_columns_bwd_det;
+// gpemsr_dcn_columns_bwd is the older float-atomic form, kept for A/B).
 #include "common.h"
 
 namespace gpemsr {
@@ -320,6 +321,111 @@ __global__ __launch_bounds__(256) void dcn_columns_bwd_tiled_kernel(const float*
     const int yy = wy0 + wp / DCN_WW, xx = wx0 + wp % DCN_WW;
     if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
     unsafeAtomicAdd(dx + (((long long)img * h + yy) * w + xx) * dx_ld + ch, v);
+  }
+}
+
+// BIT-STABLE flavour of the same backward (deterministic reductions).  Float addition is not associative, so a scatter
+// through float atomics depends on the order in which the hardware retires them.  Here every contribution wts * m * dcol is turned into a
+// 64-bit FIXED-POINT integer -- scale 2^(38 - e), e = exponent of max |dcol| (a device scalar from a deterministic max reduction; |contribution|
+// <= max |dcol|, so 2^24 of them still fit) -- and accumulated with INTEGER atomics (ds_add_u64 in the tile's LDS window, global_atomic_add_x2
+// outside it and for the window's flush): integer addition is associative, the sum is exact whatever the order; resolution 2^-38 of the largest
+// column gradient, i.e. far below fp32's own rounding of the result.  gpemsr_dcn_fix_finish then adds the converted sums into dx in a fixed
+// order (one writer per element).  dom as above (one writer per element).
+__device__ __forceinline__ float dcn_fix_scale(const float* absmax) {
+  const float a = *absmax;
+  if (!(a > 0.f) || !isfinite(a)) return 1.f;
+  int e; frexpf(a, &e);                                    // a = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 38 - e);
+}
+template <bool WINDOW>
+__global__ __launch_bounds__(256) void dcn_columns_bwd_fix_kernel(const float* x, int n, int h, int w, int c, int ld, const float* om,
+                                                                  int om_ld, int groups, const float* dcol, const float* absmax,
+                                                                  unsigned long long* dx_fix, float* dom, int dom_ld, int tiles_x, int tiles_y) {
+  extern __shared__ unsigned long long winq[];            // WINDOW: [DCN_WW][DCN_WW][c]
+  const int cg = c / groups, K = 9;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, img = blockIdx.x / (tiles_x * tiles_y);
+  const int y0t = ty * DCN_T, x0t = tx * DCN_T;
+  const int wy0 = y0t - DCN_M, wx0 = x0t - DCN_M;
+  const float scale = dcn_fix_scale(absmax);
+  if (WINDOW) {
+    for (int e = threadIdx.x; e < DCN_WW * DCN_WW * c; e += 256) winq[e] = 0ull;
+    __syncthreads();
+  }
+  const int items = DCN_T * DCN_T * K * groups;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int g = it % groups;
+    const int k = (it / groups) % K;
+    const int lp = it / (groups * K);
+    const int yq = y0t + lp / DCN_T, xq = x0t + lp % DCN_T;
+    if (yq >= h || xq >= w) continue;
+    const long long pix = ((long long)img * h + yq) * w + xq;
+    const float* o = om + pix * om_ld;
+    const float dy = o[g * 2 * K + 2 * k], dxo = o[g * 2 * K + 2 * k + 1];
+    const float ml = o[2 * groups * K + g * K + k];
+    const float m = 1.f / (1.f + expf(-ml));
+    const float py = (float)(yq - 1 + k / 3) + dy, px = (float)(xq - 1 + k % 3) + dxo;
+    const float* dc = dcol + pix * (long long)(K * c) + k * c + g * cg;
+    const float4 d0 = *reinterpret_cast<const float4*>(dc), d1 = *reinterpret_cast<const float4*>(dc + 4);
+    const float dcv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    float g_m = 0.f, g_py = 0.f, g_px = 0.f;
+    if (py > -1.f && py < (float)h && px > -1.f && px < (float)w) {
+      const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+      const float ly = py - y0, lx = px - x0;
+      const float wts[4] = {(1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx};
+      const float wdy[4] = {-(1.f - lx), -lx, (1.f - lx), lx};
+      const float wdx[4] = {-(1.f - ly), (1.f - ly), -ly, ly};
+      const int ys[4] = {y0, y0, y0 + 1, y0 + 1}, xs[4] = {x0, x0 + 1, x0, x0 + 1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (ys[q] >= 0 && ys[q] <= h - 1 && xs[q] >= 0 && xs[q] <= w - 1) {
+          const long long sp = ((long long)img * h + ys[q]) * w + xs[q];
+          const float* xp = x + sp * ld + g * cg;
+          const float4 a = *reinterpret_cast<const float4*>(xp), b = *reinterpret_cast<const float4*>(xp + 4);
+          const float xv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          float dot = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) dot += dcv[r] * xv[r];
+          g_m += wts[q] * dot; g_py += wdy[q] * dot; g_px += wdx[q] * dot;
+          if (dx_fix) {
+            const float wm = wts[q] * m * scale;             // (a power of two: the product with it is exact)
+            const int wy = ys[q] - wy0, wx = xs[q] - wx0;
+            unsigned long long* tp = (WINDOW && wy >= 0 && wy < DCN_WW && wx >= 0 && wx < DCN_WW) ? winq + (wy * DCN_WW + wx) * c + g * cg
+                                                                                                    : dx_fix + sp * c + g * cg;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const long long qv = __float2ll_rn(wm * dcv[r]);
+              if (qv != 0) atomicAdd(tp + r, (unsigned long long)qv);      // two's complement: the wrapped unsigned sum is the signed sum
+            }
+          }
+        }
+      }
+    }
+    if (dom) {
+      float* dq = dom + pix * dom_ld;
+      dq[g * 2 * K + 2 * k] += g_py * m;
+      dq[g * 2 * K + 2 * k + 1] += g_px * m;
+      dq[2 * groups * K + g * K + k] += g_m * m * (1.f - m);
+    }
+  }
+  if (!WINDOW || !dx_fix) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < DCN_WW * DCN_WW * c; e += 256) {
+    const unsigned long long v = winq[e];
+    if (v == 0ull) continue;
+    const int ch = e % c, wp = e / c;
+    const int yy = wy0 + wp / DCN_WW, xx = wx0 + wp % DCN_WW;
+    if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+    atomicAdd(dx_fix + (((long long)img * h + yy) * w + xx) * c + ch, v);
+  }
+}
+// dx[pixel][ch] += fixed-point sum / scale; one thread per element, 64-bit -> double -> float (one rounding)
+__global__ __launch_bounds__(256) void dcn_fix_finish_kernel(const unsigned long long* dx_fix, const float* absmax, long long pixels, int c,
+                                                             float* dx, int dx_ld) {
+  const double inv = 1.0 / (double)dcn_fix_scale(absmax);
+  const long long total = pixels * c;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long q = (long long)dx_fix[e];
+    if (q != 0) dx[(e / c) * dx_ld + (e % c)] += (float)((double)q * inv);
   }
 }
 
@@ -665,6 +771,39 @@ extern "C" int gpemsr_dcn_columns_bwd(const float* x, int n, int h, int w, int c
   hipLaunchKernelGGL(dcn_columns_bwd_kernel, dim3(bgrid((long long)n * h * w * groups * 9)), dim3(256), 0, ST(stream), x, n, h, w, c, ld,
                      om, om_ld, groups, dcol, dx, dx_ld, dom, dom_ld);
   return check_launch("dcn_columns_bwd");
+}
+
+extern "C" int gpemsr_dcn_columns_bwd_det(const float* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
+                                          const float* dcol, const float* dcol_absmax, long long* dx_fix, float* dx, int dx_ld,
+                                          float* dom, int dom_ld, void* stream) {
+  GP_REQUIRE(x && om && dcol && dcol_absmax, "dcn_columns_bwd_det: null pointer");
+  GP_REQUIRE((dx == nullptr) == (dx_fix == nullptr), "dcn_columns_bwd_det: dx and its fixed-point workspace come together");
+  GP_REQUIRE(groups > 0 && c % groups == 0 && c / groups == 8 && ld % 4 == 0, "dcn_columns_bwd_det: needs 8 channels per deformable group");
+  GP_REQUIRE(om_ld >= 3 * groups * 9 && (!dom || dom_ld >= 3 * groups * 9), "dcn_columns_bwd_det: om_ld too small");
+  const int tiles_x = (w + DCN_T - 1) / DCN_T, tiles_y = (h + DCN_T - 1) / DCN_T;
+  const long long tiles = (long long)n * tiles_x * tiles_y;
+  GP_REQUIRE(tiles > 0 && tiles < (1ll << 31), "dcn_columns_bwd_det: grid too large");
+  const size_t lds = (size_t)DCN_WW * DCN_WW * c * sizeof(unsigned long long);
+  unsigned long long* fix = reinterpret_cast<unsigned long long*>(dx_fix);
+  if (dx && lds <= 144 * 1024) {
+    static dev_once_t attr{0};
+    if (dev_once_begin(attr)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_columns_bwd_fix_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+        return fail(GPEMSR_ELAUNCH, "dcn_columns_bwd_det: cannot raise the dynamic LDS limit");
+      dev_once_done(attr);
+    }
+    hipLaunchKernelGGL(dcn_columns_bwd_fix_kernel<true>, dim3((unsigned)tiles), dim3(256), lds, ST(stream), x, n, h, w, c, ld, om, om_ld, groups, dcol,
+                       dcol_absmax, fix, dom, dom_ld, tiles_x, tiles_y);
+  } else {
+    hipLaunchKernelGGL(dcn_columns_bwd_fix_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, ST(stream), x, n, h, w, c, ld, om, om_ld, groups, dcol,
+                       dcol_absmax, fix, dom, dom_ld, tiles_x, tiles_y);
+  }
+  if (check_launch("dcn_columns_bwd_det") != GPEMSR_OK) return GPEMSR_ELAUNCH;
+  if (dx) {
+    hipLaunchKernelGGL(dcn_fix_finish_kernel, dim3(bgrid((long long)n * h * w * c)), dim3(256), 0, ST(stream), fix, dcol_absmax, (long long)n * h * w, c, dx, dx_ld);
+    return check_launch("dcn_fix_finish");
+  }
+  return GPEMSR_OK;
 }
 
 extern "C" int gpemsr_temporal_gate_bwd(const float* aligned, const float* emb, const float* emb_ref, const float* daf, int b, int t,

@@ -910,8 +910,19 @@ def bilinear_bwd(dy: Act, dx: Act, align_corners: bool = False, mul: float = 1.0
                                                dx.ptr, dx.ld, _stream()), "bilinear_bwd")
 
 
-def dcn_columns_bwd(x: Act, om: Act, groups: int, dcol: Act, dx: Optional[Act], dom: Optional[Act]):
+def dcn_columns_bwd(x: Act, om: Act, groups: int, dcol: Act, dx: Optional[Act], dom: Optional[Act], deterministic: bool = True):
+    """torchvision deform_conv2d backward w.r.t. input / offsets / mask logits.  deterministic (default): the scatter into dx accumulates
+    64-bit fixed-point integers (gpemsr_dcn_columns_bwd_det: bit-stable run to run); False: float atomics (the round-2 form, for A/B)."""
     assert dcol.ld == dcol.c == 9 * x.c
+    if deterministic:
+        absmax = dcol.buf.abs().amax().reshape(1)                  # device scalar, no host sync; amax is order-independent
+        fix = torch.zeros(x.n * x.h * x.w * x.c, dtype=torch.int64, device=x.buf.device) if dx is not None else None
+        _abi.check(_abi.load().gpemsr_dcn_columns_bwd_det(x.ptr, x.n, x.h, x.w, x.c, x.ld, om.ptr, om.ld, groups, dcol.ptr, absmax.data_ptr(),
+                                                          fix.data_ptr() if fix is not None else None,
+                                                          dx.ptr if dx is not None else None, dx.ld if dx is not None else 0,
+                                                          dom.ptr if dom is not None else None, dom.ld if dom is not None else 0, _stream()),
+                   "dcn_columns_bwd_det")
+        return
     _abi.check(_abi.load().gpemsr_dcn_columns_bwd(x.ptr, x.n, x.h, x.w, x.c, x.ld, om.ptr, om.ld, groups, dcol.ptr,
                                                   dx.ptr if dx is not None else None, dx.ld if dx is not None else 0,
                                                   dom.ptr if dom is not None else None, dom.ld if dom is not None else 0, _stream()),

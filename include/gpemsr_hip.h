@@ -486,6 +486,13 @@ int gpemsr_bilinear_bwd(const float* dy, int dy_ld, int n, int h, int w, int c, 
  * (dom += in the conv_offset channel layout); dcol is the gradient of gpemsr_dcn_columns' output */
 int gpemsr_dcn_columns_bwd(const float* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
                            const float* dcol, float* dx, int dx_ld, float* dom, int dom_ld, void* stream);
+/* the same, BIT-STABLE: the scatter into dx accumulates 64-bit fixed-point integers with integer atomics (associative: the sum does not
+ * depend on the order), scale 2^(38 - exponent of *dcol_absmax) with dcol_absmax = max |dcol| as a DEVICE scalar (e.g. torch's
+ * deterministic amax); dx_fix: zero-initialised int64 workspace [n*h*w*c] (NULL together with dx); a second kernel adds the converted
+ * sums into dx (+=, one writer per element).  What loss.backward() through torchvision.ops.deform_conv2d does with float atomics. */
+int gpemsr_dcn_columns_bwd_det(const float* x, int n, int h, int w, int c, int ld, const float* om, int om_ld, int groups,
+                               const float* dcol, const float* dcol_absmax, long long* dx_fix, float* dx, int dx_ld,
+                               float* dom, int dom_ld, void* stream);
 /* ThreeDA pieces (model/GPEMSR.py:179-221), all +=, dense c == 64 tensors */
 int gpemsr_temporal_gate_bwd(const float* aligned, const float* emb, const float* emb_ref, const float* daf, int b, int t,
                              int hw, int c, float* d_aligned, float* d_emb, float* d_emb_ref, void* stream);
