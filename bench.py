@@ -227,7 +227,7 @@ def _tf(d):
     return d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
 
 
-PMC_ROUNDS = ("r05", "r04")         # profiles/<round>_<precision>_pmc_summary.json, newest first: the counter summary taken on THIS tree
+PMC_ROUNDS = ("r06", "r05")         # profiles/<round>_<precision>_pmc_summary.json, newest first: the counter summary taken on THIS tree
 
 
 def _pmc_doc(tag: str):
