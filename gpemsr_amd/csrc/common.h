@@ -56,5 +56,7 @@ int conv2d_winograd(const gpemsr_conv_desc* d, void* stream, char* name_buf, int
 // gpemsr_conv_desc.transposed == 4: the 1-D Winograd F(2, 7) form of a 7x7 stride-1 convolution (conv7_wino.hip)
 int conv2d_winograd7(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap);
 int conv2d_winograd4(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap, int* parts_only = nullptr);
+// gpemsr_conv_desc.transposed == 6: the 2-D Winograd F(2x2, 7x7) form of a 7x7 stride-1 convolution (conv7_wino2d.hip)
+int conv2d_winograd77(const gpemsr_conv_desc* d, void* stream, char* name_buf, int name_cap);
 
 }  // namespace gpemsr

@@ -784,6 +784,10 @@ static int conv2d_impl(const gpemsr_conv_desc* d, void* stream, int* parts_only,
     GP_REQUIRE(parts_only == nullptr, "conv2d (F(2,7) form): no GroupNorm partial sums");
     return conv2d_winograd7(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0);
   }
+  if (d->transposed == 6) {          // 2-D Winograd F(2x2, 7x7) form of a 7x7 stride-1 convolution (conv7_wino2d.hip)
+    GP_REQUIRE(parts_only == nullptr, "conv2d (F(2x2,7x7) form): no GroupNorm partial sums");
+    return conv2d_winograd77(d, stream, name_only ? name_only->buf : nullptr, name_only ? name_only->cap : 0);
+  }
   ConvParams P{};
   const bool tr = d->transposed == 1;
   const bool rowpair = d->transposed == 2;

@@ -30,7 +30,7 @@ import torch
 from . import ops
 from .ops import ACT_LRELU, ACT_LRELU_SIGMOID, ACT_NONE, ACT_RELU, Act
 from .packing import (pack_conv, pack_conv_bf16, pack_dcn_rows_bf16, pack_conv_split, pack_convT, pack_convT_bf16, pack_convT_split, pack_dcn, pack_linear, pack_linear_bf16x3, pack_rowpair7,
-                      pack_vgg_first, pack_cout1_taps, pack_winograd, pack_winograd4, pack_winograd7, pack_conv7_c32_cout16, pack_conv7_c8_cout32, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
+                      pack_vgg_first, pack_cout1_taps, pack_winograd, pack_winograd4, pack_winograd7, pack_winograd77, pack_conv7_c32_cout16, pack_conv7_c8_cout32, pack_upconv_out, pack_rowsum7, pack_cout1_taps_f32, pack_upconv_out_f32, pack_rowsum7_f32)
 
 _SPY_MEAN = (0.485, 0.456, 0.406)
 _SPY_STD = (0.229, 0.224, 0.225)
@@ -119,6 +119,7 @@ class Engine:
         self.winograd_form = winograd
         self.winograd = precision == "fp32" and winograd != "off"
         self.winograd7 = self.winograd and w7
+        self.winograd77 = self.winograd7 and winograd != "f2x2" and os.environ.get("GPEMSR_WINOGRAD77", "1") != "0"   # (2-D form of the same 7x7 layers; A/B switch)
         self.winograd4 = {"f4x4": "all", "decoder_f4x4": "decoder"}.get(winograd, "0") if self.winograd else "0"
         self.winograd4_min_cin = int(os.environ.get("GPEMSR_WINOGRAD4_MIN_CIN", "64"))
         self.fuse_argmax = os.environ.get("GPEMSR_FUSE_ARGMAX", "1") != "0"   # bf16 path: codebook arg-max inside the logits GEMM (no logits tensor)
@@ -256,6 +257,8 @@ class Engine:
             if (self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1
                     and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32"))):
                 self.pc[name].wino7 = pack_winograd7(w, dev)          # 1-D Winograd F(2, 7) form of SpyNet's 32 <-> 64 7x7 layers (fp32 path)
+                if self.winograd77:
+                    self.pc[name].wino77 = pack_winograd77(w, dev)    # ... and the 2-D form F(2x2, 7x7): 64 instead of 112 multiplies per 2x2 outputs
             if self.bf16 and tuple(w.shape) == (1, 64, 3, 3):
                 self.pc[name].wtap = pack_cout1_taps(w, dev)            # 64 -> 1 on the matrix cores (csrc/tap_sum.hip)
             if not self.bf16 and tuple(w.shape) == (1, 64, 3, 3) and getattr(self, "fuse_tail_f32", True):

@@ -217,6 +217,7 @@ class PackedConv:
     wino: Optional[torch.Tensor] = None    # fp32, 3x3 stride 1: Winograd F(2x2,3x3) weights U[16][cout][cin] (packing.pack_winograd; descriptor.transposed = 3)
     wpair7: Optional[torch.Tensor] = None  # fp32, cin -> 16 7x7: row-pair form weights (packing.pack_rowpair7; descriptor.transposed = 2)
     wino4: Optional[torch.Tensor] = None   # fp32, 3x3 stride 1, >= 64 input channels: Winograd F(4x4,3x3) weights U[cin/8][36][2][cout][4] (packing.pack_winograd4; descriptor.transposed = 5)
+    wino77: Optional[torch.Tensor] = None  # fp32, 7x7 stride 1: 2-D Winograd F(2x2, 7x7) weights U[cin/8][64][2][cout][4] (packing.pack_winograd77; descriptor.transposed = 6)
     wino7: Optional[torch.Tensor] = None   # fp32, 7x7 stride 1: 1-D Winograd F(2, 7) weights U[cin/8][7][8][2][cout][4] (packing.pack_winograd7; descriptor.transposed = 4)
     wrows: Optional[torch.Tensor] = None   # bf16 data path, DCN 64 -> 64: plain rows [cout][9 taps][64 channels] bf16 (packing.pack_dcn_rows_bf16; csrc/dcn_bf16.hip)
     algo_cin: Optional[int] = None         # input channels of the ALGORITHMIC product when the packed form multiplies more (three-product linear):
@@ -448,6 +449,10 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             and src_image_stride is None and not d.gn_partials):
         d.transposed, d.weight = 4, pc.wino7.data_ptr()         # 8 multiplies per output pair and filter row instead of 14 (csrc/conv7_wino.hip)
         executed = flops * 8.0 / 14.0
+    if (pc.wino77 is not None and not direct7 and precision == "fp32" and int(d.transposed) in (0, 4) and winograd77_ok(srcs, pc, stride, out, residual, pixmul, act)
+            and weight_image_stride == 0 and src_image_stride is None and not d.gn_partials):
+        d.transposed, d.weight = 6, pc.wino77.data_ptr()        # 64 multiplies per 2x2 outputs instead of 196 (csrc/conv7_wino2d.hip)
+        executed = flops * 64.0 / 196.0
     if PROFILER is not None:
         nm = _kernel_name(lib.gpemsr_conv2d_kernel_name, d, ("f32", n, h, w, tuple((s_.c, s_.ld % 4, s_.ptr % 16) for s_ in srcs), pc.cout, k, stride, int(d.transposed),
                                                              int(pc.pixel_shuffle), bool(d.gn_partials), out.ld % 4, residual is not None, pixmul is not None, act, a_affine32 is not None))
@@ -505,6 +510,21 @@ def winograd7_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] =
     if s_.bf16 or s_.c % 8 != 0 or s_.ld % 4 != 0 or s_.ptr % 16 != 0 or s_.w < 64 or residual is not None or pixmul is not None:
         return False
     return out is None or not out.bf16
+
+
+def winograd77_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None,
+                  act: int = ACT_NONE) -> bool:
+    """Layers the 2-D F(2x2, 7x7) form of gpemsr_conv2d takes: 7x7, stride 1, ONE fp32 source of c % 8 == 0 channels with 16-byte aligned rows,
+    cout % 32 == 0, act NONE / RELU / LRELU, plain store into 8-byte aligned rows, a map that fills at least 2/3 of its 8 x 16 pixel tiles;
+    `pc.wino77` packed."""
+    if pc.wino77 is None or pc.ksize != 7 or stride != 1 or pc.transposed or pc.pixel_shuffle or pc.cout % 32 != 0 or len(srcs) != 1:
+        return False
+    s_ = srcs[0]
+    if s_.bf16 or s_.c % 8 != 0 or s_.ld % 4 != 0 or s_.ptr % 16 != 0 or residual is not None or pixmul is not None or act not in (ACT_NONE, ACT_RELU, ACT_LRELU):
+        return False
+    if 3 * s_.h * s_.w < 2 * (-(-s_.h // 8) * 8) * (-(-s_.w // 16) * 16) or s_.h * s_.w * s_.ld * 4 >= (1 << 32):
+        return False
+    return out is None or (not out.bf16 and out.ld % 2 == 0 and out.ptr % 8 == 0)
 
 
 def winograd_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None) -> bool:

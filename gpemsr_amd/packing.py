@@ -166,6 +166,16 @@ def pack_winograd7(w: torch.Tensor, device) -> torch.Tensor:
     return u.to(torch.float32).contiguous().to(device)
 
 
+def pack_winograd77(w: torch.Tensor, device) -> torch.Tensor:
+    """Weights of a 7x7 stride-1 convolution [cout][cin][7][7] (cin % 8 == 0) in the 2-D F(2x2, 7x7) form of gpemsr_conv2d (descriptor.transposed
+    = 6): U[cin/8][64 = 8 xi + nu][quad][cout][4] fp32 with U[xi][nu] = sum_(ky, kx) G[xi][ky] w[ky][kx] G[nu][kx], folded in float64."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 7 and kw == 7 and cin % 8 == 0
+    u = torch.einsum("ay,ocyx,bx->ocab", WINO7_G, w.detach().to(torch.float64).cpu(), WINO7_G)   # [cout][cin][xi][nu]
+    u = u.reshape(cout, cin // 8, 2, 4, 64).permute(1, 4, 2, 0, 3)                                # [chunk][p][quad][cout][4]
+    return u.to(torch.float32).contiguous().to(device)
+
+
 def pack_dcn_rows_bf16(w: torch.Tensor, device) -> torch.Tensor:
     """DCN weight [cout][cin][3][3] as plain bf16 rows [cout][tap][cin] -- the K order of the column rows gpemsr_dcn_conv_bf16 builds in LDS
     (tap-major, channel fastest: the same order as the stand-alone column tensor of gpemsr_dcn_columns_bf16)."""

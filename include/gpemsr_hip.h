@@ -93,7 +93,12 @@ typedef struct {
                                       plain store / residual only), act NONE / RELU / LRELU; epilogues: plain store
                                       (+ gn_partials), residual (+ pixmul), pixel_shuffle (cout % 256 == 0, alone), cos_partials (cout == 64,
                                       h % 16 == 0, w % 32 == 0, operand map in `residual`); weight = U[cin/8][36 positions][2][cout][4] = G g G^T
-                                      (gpemsr_amd/packing.py::pack_winograd4) */
+                                      (gpemsr_amd/packing.py::pack_winograd4).
+                                      6 = 2-D WINOGRAD F(2x2, 7x7) form of a 7x7 stride-1 convolution (the same SpyNet layers as form 4; same
+                                      result to fp32 rounding -- ~5e-6 of the result's scale --, 64/196 of the multiplies;
+                                      csrc/conv7_wino2d.hip): ONE source with c % 8 == 0, cout % 32 == 0, act NONE / RELU / LRELU, plain store
+                                      with 8-byte aligned rows; weight = U[cin/8][64 positions = 8 xi + nu][2][cout][4] = G g G^T
+                                      (gpemsr_amd/packing.py::pack_winograd77) */
   const float* weight;             /* packed [tap][cout][cin_pad], tap = ky*k+kx, cin fastest, cin padded per source to 8
                                       (k>=3) or 32 (k=1).  transposed: [tap = 2*dy+dx][n' = (co/32)*128 + q*32 + co%32][cin_pad],
                                       q = 2*py+px, the phase-stacked 2x2-tap form (gpemsr_amd/packing.py::pack_convT) */

@@ -448,6 +448,34 @@ def test_winograd_f27_transforms_are_an_exact_identity():
     assert float((out - ref).abs().max() / ref.abs().max()) < 1e-6
 
 
+def test_winograd_f2x2_7x7_packing_is_an_exact_identity():
+    """The 2-D form F(2x2, 7x7) of the same layers (csrc/conv7_wino2d.hip, packing.pack_winograd77): Y = A^T [(G g G^T) (.) (B^T d B)] A with the
+    1-D form's matrices in both directions; a whole convolution assembled from the packed U tensor exactly as the kernel indexes it -- tile of
+    4 x 8 blocks of 2 x 2 outputs, 8 x 8 patch starting at (2 br, 2 bc) of the pad-3 halo, position p = 8 xi + nu, chunk / quad / element of a
+    channel -- equals F.conv2d (U is rounded to fp32 on the way: 1e-6)."""
+    import torch
+    import torch.nn.functional as F
+    from gpemsr_amd.packing import WINO7_AT, pack_winograd77, wino7_bt
+    g = torch.Generator().manual_seed(9)
+    cin, cout, h, w = 16, 32, 8, 16
+    x = torch.rand(1, cin, h, w, generator=g, dtype=torch.float64) * 2 - 1
+    wt = (torch.rand(cout, cin, 7, 7, generator=g, dtype=torch.float64) * 2 - 1) / (7 * cin ** 0.5)
+    U = pack_winograd77(wt, "cpu").double()
+    assert tuple(U.shape) == (cin // 8, 64, 2, cout, 4)
+    bt, at = wino7_bt(), WINO7_AT
+    xp = F.pad(x, (3, 3, 3, 3))[0]
+    out = torch.zeros(cout, h, w, dtype=torch.float64)
+    for br in range(4):
+        for bc in range(8):
+            V = torch.einsum("ai,cij,bj->cab", bt, xp[:, 2 * br:2 * br + 8, 2 * bc:2 * bc + 8], bt)        # [cin][xi][nu]
+            M = torch.zeros(8, 8, cout, dtype=torch.float64)
+            for ch in range(cin):
+                M += V[ch][:, :, None] * U[ch // 8, :, (ch % 8) // 4, :, ch % 4].reshape(8, 8, cout)
+            out[:, 2 * br:2 * br + 2, 2 * bc:2 * bc + 2] = torch.einsum("ia,abo,jb->oij", at, M, at)
+    ref = F.conv2d(x, wt, None, 1, 3)[0]
+    assert float((out - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
 def test_winograd_f4x4_transforms_are_an_exact_identity():
     """The Winograd F(4x4, 3x3) form of the many-channel fp32 layers (csrc/conv_wino4.hip, packing.pack_winograd4): with G (host, float64), the
     integer B^T the kernel evaluates as sums (w4_bt) and A^T (w4_at), Y = A^T [(G g G^T) (.) (B^T d B)] A is the 4x4 block of the pad-1

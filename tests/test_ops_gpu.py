@@ -629,6 +629,40 @@ def test_conv7_winograd_row_form(n, cin, cout, h, w, act):
     assert torch.equal(got.buf, again.buf)
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,act", [(2, 32, 64, 16, 64, 1), (1, 64, 32, 37, 130, 1), (3, 32, 32, 8, 16, 0), (1, 8, 64, 13, 70, 2), (4, 8, 32, 64, 64, 1), (2, 64, 64, 64, 128, 1),
+                                                (1, 32, 64, 7, 200, 1), (2, 24, 64, 19, 45, 2)])
+def test_conv7_winograd_2d_form(n, cin, cout, h, w, act):
+    """gpemsr_conv2d with descriptor.transposed = 6 (csrc/conv7_wino2d.hip, packing.pack_winograd77): Conv2d(cin -> cout, 7x7, pad 3) + bias +
+    activation in the 2-D Winograd F(2x2, 7x7) form (SpyNet's 32 -> 64 / 64 -> 32 layers, basicsr BasicModule via R:model/GPEMSR.py:67,98-100)
+    == the float64 convolution to 4e-5 of the result and the direct fp32 kernel to the same; ragged heights / widths (not multiples of the
+    8 x 16 tile), one to eight chunks (the raw-image ring wraps beyond three), one or two cout blocks, a strided output slice, run-to-run
+    bit-stable."""
+    from gpemsr_amd import ops
+    from gpemsr_amd.packing import pack_conv, pack_winograd77
+    dev = _dev()
+    x = _rand(n, cin, h, w, seed=950 + h)
+    wt = _rand(cout, cin, 7, 7, seed=951, scale=1.0 / (7 * cin ** 0.5)); b = _rand(cout, seed=952)
+    pc = pack_conv(wt, b, dev)
+    pc.wino77 = pack_winograd77(wt, dev)
+    assert tuple(pc.wino77.shape) == (cin // 8, 64, 2, cout, 4)
+    xa = _to_act(x, dev)
+    assert ops.winograd77_ok([xa], pc, act=act)
+    direct = ops.conv2d([xa], pc, act, direct7=True).nchw().clone()
+    nm = []
+    got = ops.conv2d([xa], pc, act)
+    want = F.conv2d(x.double(), wt.double(), b.double(), 1, 3)
+    want = {0: want, 1: torch.relu(want), 2: F.leaky_relu(want, 0.1)}[act]
+    _close(got.nchw(), want.float(), tol=4e-5, what="F(2x2,7x7) form vs fp64")
+    _close(got.nchw(), direct, tol=4e-5, what="F(2x2,7x7) form vs the direct kernel")
+    again = ops.conv2d([xa], pc, act)
+    assert torch.equal(got.buf, again.buf)
+    # into a channel slice of a wider buffer (the neighbouring channels stay untouched)
+    wide = ops.Act(torch.full((n, h, w, cout + 16), 7.0, device=dev), n, h, w, cout, cout + 16, 8)
+    ops.conv2d([xa], pc, act, out=wide)
+    assert torch.equal(wide.nchw(), got.nchw())
+    assert float((wide.buf[..., :8] - 7.0).abs().max()) == 0.0 and float((wide.buf[..., cout + 8:] - 7.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n,cin,cout,k,h,w", [(2, 64, 64, 3, 37, 70), (1, 128, 256, 3, 20, 36), (3, 64, 512, 1, 16, 16), (1, 32, 128, 3, 64, 64), (2, 64, 32, 3, 9, 50)])
 def test_groupnorm_statistics_from_the_fp32_conv_epilogue(n, cin, cout, k, h, w):
     """gpemsr_conv_desc.gn_partials: the conv output is unchanged (bit for bit) and groupnorm_relu on it -- now finish + apply, no
