@@ -15,12 +15,19 @@
 //     [cin / 8][64][quad][cout][4]); the raw halo image (14 x 22 pixels x 8 channels) goes global -> LDS by DMA three chunks ahead (ring of 3);
 //   * per chunk of 8 input channels: (M) 32 MFMAs per wave from V and the register-held U, with (T1) of the NEXT chunk -- the row transform B^T
 //     along x of the 14 halo rows into X[row][nu][quad][block column], 448 items of one channel pair -- between them; barrier; (T2) the column
-//     transform of the next chunk into V[xi][nu][quad][block], one float4 item per thread; barrier.  ONE V buffer (64 KB: two do not fit), so
+//     transform of the next chunk into V[xi][nu][quad][block], two pair-sized items per thread; barrier.  ONE V buffer (64 KB: two do not fit), so
 //     T2 is not overlapped with MFMAs;
 //   * raw image in LDS as [quad][column parity][row][column / 2]: the eight columns an item reads for consecutive block columns are
 //     consecutive 16-byte slots;
 //   * epilogue: A^T over nu in registers (8 -> 2 columns), one exchange E[xi][column][block][cout] through LDS, an item = one block x one cout
-//     PAIR: A^T over xi (8 -> 2 rows), bias, activation, 8-byte stores.
+//     PAIR: A^T over xi (8 -> 2 rows), bias, activation, 8-byte stores;
+//   * persistent workgroups (one per CU), the next tile's first raw images / U fragments / bias requested during the last chunk of this one.
+//
+// Measured (profiles/r06_ab_winograd77.log; 80 frames): 64 -> 32 at 512^2 24.7 -> 18.2 ms, 32 -> 64 at 512^2 21.9 -> 20.0 ms (two cout blocks =
+// two workgroups, each with its own transforms), the fp32 step 458.3 -> 446.6 ms.  Per tile 2.8 us fixed (4.4 before the persistent form) + 3.2 us
+// per 8-channel chunk against 2.0 us of pure MFMA time: ~150 vector instructions per wave and chunk (the 8-point transforms are 30 operations
+// per 8 outputs, twice) beside 32 MFMAs, and on this chip they are matrix time.  k-steps of two positions interleaved
+// (-DW77_PAIR=1): 1.4 % slower.
 //
 // Replaces gpemsr_conv2d's direct form (descriptor.transposed = 6; weight = packing.pack_winograd77) for 7x7 stride-1 layers with one fp32
 // source of c % 8 == 0 channels, cout % 32 == 0, plain store (8-byte aligned rows), activation NONE / RELU / LRELU.
@@ -38,6 +45,9 @@ struct W77Params {
   int tiles_x, tiles_y, tiles_n, nblocks;
 };
 
+#ifndef W77_PAIR
+#define W77_PAIR 0               // main loop: k-steps of two positions interleaved (A/B: profiles/r06_ab_winograd77.log)
+#endif
 constexpr int W77_NT = 512;
 constexpr int W77_ROWS = 14, W77_C2 = 11;                                  // halo rows; columns per parity ((16 + 6) / 2)
 constexpr int W77_RAW_SLOTS = 2 * 2 * W77_ROWS * W77_C2;                   // 616 16-byte slots: [quad][parity][row][col / 2]
@@ -88,37 +98,45 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
 
-  int bid = blockIdx.x;
-  {   // XCD-aware (bijective): consecutive logical blocks -- the cout blocks and neighbouring pixel tiles of one image -- share an L2
-    const int nwg = P.nblocks, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
-  int t = bid;
-  const int tn = t % P.tiles_n; t /= P.tiles_n;
-  const int tx0 = t % P.tiles_x; t /= P.tiles_x;
-  const int ty0 = t % P.tiles_y; t /= P.tiles_y;
-  const int img = t;
-  const int oy0 = ty0 * 8, ox0 = tx0 * 16, n0 = tn * 32;
-  int nchunks = P.cin / 8;
-
+  // PERSISTENT workgroups (one per CU: 121 KB of LDS): a tile's fixed cost -- the launch gap, the latency of its first raw images and U
+  // fragments -- was 4.4 us of the 16.6 us a 4-chunk tile took; the NEXT tile's raw images and U fragments are requested during this tile's
+  // last chunk.  Round k gives the 32 workgroups of XCD x the logical tiles [(8 k + x) 32, + 32): the two cout blocks and the neighbouring
+  // pixel tiles of an image share that XCD's L2 (workgroup b runs on XCD b % 8; the grid is a multiple of 8).
+  const int per_xcd = gridDim.x >> 3;
+  const int tile_step = per_xcd * 8;
+  int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  int img = 0, oy0 = 0, ox0 = 0, n0 = 0;
+  const int nchunks = P.cin / 8;
   // ---- raw halo image: slots tid and tid + 512 of [quad][parity][row][col / 2]; byte offset of the slot's 16 bytes in the image, or ~0u outside.
   //      Global -> LDS by DMA (inline asm: invisible to the compiler's vmcnt counts, see conv_wino4.hip for the wait discipline copied here) ----
-  unsigned r_off[2];
+  int s_desc[2];                                              // this thread's two slots: halo row | halo column << 8 | quad << 16 (tile-independent)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int s = tid + i * W77_NT;
-    r_off[i] = ~0u;
-    if (s < W77_RAW_SLOTS) {
-      const int c2 = s % W77_C2, r1 = s / W77_C2;
-      const int row = r1 % W77_ROWS, r2 = r1 / W77_ROWS;
-      const int par = r2 & 1, qd = r2 >> 1;
-      const int iy = oy0 - 3 + row, ix = ox0 - 3 + 2 * c2 + par;
-      if (iy >= 0 && iy < P.h && ix >= 0 && ix < P.w) r_off[i] = (unsigned)(iy * P.w + ix) * ((unsigned)P.ld * 4u) + 16u * (unsigned)qd;
-    }
+    const int c2 = s % W77_C2, r1 = s / W77_C2;
+    const int row = r1 % W77_ROWS, r2 = r1 / W77_ROWS;
+    s_desc[i] = row | ((2 * c2 + (r2 & 1)) << 8) | (((r2 >> 1) & 1) << 16);
   }
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm + (unsigned)wave * 1024u);
-  const float* src_img = P.src + (long long)img * P.img_stride;
+  unsigned r_off[2];
+  const float* src_img = nullptr;
   int f_chunk = 0;                                            // chunk whose raw image is issued next
+  auto set_tile = [&](int tl) {                               // decode logical tile tl: cout block fastest, then pixel tiles of one image
+    int t = tl;
+    const int tn = t % P.tiles_n; t /= P.tiles_n;
+    const int tx0 = t % P.tiles_x; t /= P.tiles_x;
+    const int ty0 = t % P.tiles_y; t /= P.tiles_y;
+    img = t; oy0 = ty0 * 8; ox0 = tx0 * 16; n0 = tn * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int iy = oy0 - 3 + (s_desc[i] & 255), ix = ox0 - 3 + ((s_desc[i] >> 8) & 255);
+      r_off[i] = ~0u;
+      if (tid + i * W77_NT < W77_RAW_SLOTS && iy >= 0 && iy < P.h && ix >= 0 && ix < P.w)
+        r_off[i] = (unsigned)(iy * P.w + ix) * ((unsigned)P.ld * 4u) + 16u * (unsigned)(s_desc[i] >> 16);
+    }
+    src_img = P.src + (long long)img * P.img_stride;
+    f_chunk = 0;
+  };
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wsm + (unsigned)wave * 1024u);
   auto issue_raw = [&](int buf) {
     const float* sp = src_img + f_chunk * 8;
     const unsigned la = lds0 + (unsigned)(W77_RAW_OFF + buf * W77_RAW_BYTES);
@@ -147,13 +165,13 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // ---- transform items.  (T1) row transform along x: item (row, quad, block column, channel pair), threads 0-447 (waves 0-6);
-  //      (T2) column transform along y: item (nu = wave, quad, block row, block column) of a whole quad (float4), every thread one item ----
+  //      (T2) column transform along y: item (nu = wave, quad, block row, block column, channel pair), two per thread (block rows br, br + 2) ----
   const int t1_hb = (tid & 1) * 8, t1_bc = (tid >> 1) & 7, t1_q = (tid >> 4) & 1, t1_row = tid >> 5;
   const int a_t1l = ((t1_q * 2) * W77_ROWS + t1_row) * W77_C2 * 16 + t1_bc * 16 + t1_hb;        // + ((i & 1) * 14 * 11 + (i >> 1)) * 16 + raw image
   const int a_t1s = W77_X_OFF + (((t1_row * 8) * 2 + t1_q) * 8 + t1_bc) * 16 + t1_hb;           // + nu * 256
-  const int t2_bc = lane & 7, t2_q = (lane >> 3) & 1, t2_br = lane >> 4;
-  const int a_t2l = W77_X_OFF + ((((2 * t2_br) * 8 + wave) * 2 + t2_q) * 8 + t2_bc) * 16;       // + i * 2048 (rows 2 br + i)
-  const int a_t2s = W77_V_OFF + (((wave) * 2 + t2_q) * 32 + t2_br * 8 + t2_bc) * 16;            // + xi * 8192
+  const int t2_br = lane >> 5;                                                                   // (and + 2: two items per thread)
+  const int a_t2l = W77_X_OFF + ((((2 * t2_br) * 8 + wave) * 2 + t1_q) * 8 + t1_bc) * 16 + t1_hb;  // + i * 2048 (rows 2 br + i), + 8192 for br + 2
+  const int a_t2s = W77_V_OFF + (((wave) * 2 + t1_q) * 32 + t2_br * 8 + t1_bc) * 16 + t1_hb;       // + xi * 8192, + 256 for br + 2
   auto t1_load = [&](int buf, float2 (&d)[8]) {
     const char* rb = wsm + W77_RAW_OFF + buf * W77_RAW_BYTES + a_t1l;
 #pragma unroll
@@ -165,23 +183,41 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
 #pragma unroll
     for (int nu = 0; nu < 8; ++nu) *reinterpret_cast<float2*>(wsm + a_t1s + nu * 256) = tt[nu];
   };
-  auto t2_run = [&]() {
-    float4 d[8], tt[8];
+  auto t2_run = [&]() {                                       // two pair-sized items per thread (block rows br, br + 2): a float4 item's 64 transient
+#pragma unroll                                                // registers did not fit beside the accumulators and the prefetched U
+    for (int it = 0; it < 2; ++it) {
+      float2 d[8], tt[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = *reinterpret_cast<const float4*>(wsm + a_t2l + i * 2048);
-    w77_bt(d, tt);
+      for (int i = 0; i < 8; ++i) d[i] = *reinterpret_cast<const float2*>(wsm + a_t2l + it * 8192 + i * 2048);
+      w77_bt(d, tt);
 #pragma unroll
-    for (int xi = 0; xi < 8; ++xi) *reinterpret_cast<float4*>(wsm + a_t2s + xi * 8192) = tt[xi];
+      for (int xi = 0; xi < 8; ++xi) *reinterpret_cast<float2*>(wsm + a_t2s + it * 256 + xi * 8192) = tt[xi];
+    }
   };
 
-  // ---- prologue: raw images of chunks 0-2, U fragments of chunk 0, X and V of chunk 0 ----
+  // ---- a tile's first requests: raw images of chunks 0-2 (DMA), then the U fragments of chunk 0 (younger than the DMA: the compiler's wait
+  //      for them is also the wait for the images) ----
   float4 U[8];
-  issue_raw(0);
-  if (nchunks > 1) issue_raw(1);
-  if (nchunks > 2) issue_raw(2);
+  float2 bias_req = make_float2(0.f, 0.f);                    // the bias pair of this thread's epilogue item, requested WITH the tile (a load inside
+  auto request_tile = [&]() {                                  // the epilogue would be younger than the next tile's requests: its wait would drain them)
+    issue_raw(0);
+    if (nchunks > 1) issue_raw(1);
+    if (nchunks > 2) issue_raw(2);
+    asm volatile("" ::: "memory");
 #pragma unroll
-  for (int j = 0; j < 8; ++j) load_u(0, j, U[j]);
-  wn_wait_vmcnt(0);
+    for (int j = 0; j < 8; ++j) load_u(0, j, U[j]);
+    if (P.bias) bias_req = *reinterpret_cast<const float2*>(P.bias + n0 + 2 * (tid & 15));
+  };
+  if (tile >= P.nblocks) return;
+  set_tile(tile);
+  request_tile();
+
+  for (;;) {
+  // ---- prologue of this tile: its requests were issued before the previous tile's epilogue (or just above); X and V of chunk 0 ----
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(U[j].x), "v"(U[j].y), "v"(U[j].z), "v"(U[j].w));   // (the compiler's wait for the U loads lands here)
+  const float2 bias = bias_req;
+  asm volatile("" :: "v"(bias.x), "v"(bias.y) : "memory");
   __syncthreads();
   {
     float2 d[8];
@@ -190,14 +226,30 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     t2_run();
     __syncthreads();
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // ---- main loop: iteration c multiplies chunk c (V, U in registers), runs T1 of chunk c + 1 between the MFMAs (raw image (c + 1) % 3 -> X),
   //      fetches the U fragments of chunk c + 1 and starts the DMA of raw image c + 3; barrier; T2 of chunk c + 1 (X -> V); barrier ----
   const int a_v = W77_V_OFF + (8 * wave) * 1024 + lane * 16;  // V[p][lh][li]
   int rb1 = 1;                                               // ring slot of raw image c + 1; image c + 3 goes to the slot of image c = (rb1 + 2) % 3
+  int e_img = 0, e_oy0 = 0, e_ox0 = 0, e_n0 = 0;              // this tile's coordinates, for its epilogue
+  bool have_next = false;
   for (int c = 0; c < nchunks; ++c) {
-    const int cn = c + 1 < nchunks ? c + 1 : c;              // (the last chunk re-reads its own U: no branch around the loads)
     const bool more = c + 1 < nchunks;
+    int cn = c + 1;
+    if (!more) {
+      // The LAST chunk's iteration belongs to the next tile as far as memory is concerned: the U prefetch "of chunk c + 1" fetches the next
+      // tile's chunk 0 and the DMA window starts its raw images 0-2 (the ring is free: the last T1 ran an iteration ago) -- nothing of the
+      // next tile waits behind this tile's epilogue, and no stale U re-read stands between the compiler's waits and the DMA.
+      e_img = img; e_oy0 = oy0; e_ox0 = ox0; e_n0 = n0;
+      tile += tile_step;
+      have_next = tile < P.nblocks;                           // (uniform)
+      if (have_next) set_tile(tile);                          // img / oy0 / ox0 / n0 / r_off / src_img describe the NEXT tile from here on
+      cn = have_next ? 0 : c;                                 // (no next tile: the loads re-read this chunk's U -- no branch around them)
+    }
     const char* vb = wsm + a_v;
     auto mma = [&](int j, const float4& vf, int k0, int k1) {
       const float v[4] = {vf.x, vf.y, vf.z, vf.w};
@@ -205,11 +257,38 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
 #pragma unroll
       for (int k = k0; k < k1; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[j], 0, 0, 0);
     };
+    // two positions at a time, k-steps interleaved (W77_PAIR; two waves per SIMD leave a single dependent chain exposed whenever the partner
+    // wave is in its transform or waiting) -- or one position at a time
+    auto mma2 = [&](int j, const float4& va, const float4& vb2, int k0, int k1) {
+      const float a[4] = {va.x, va.y, va.z, va.w}, b[4] = {vb2.x, vb2.y, vb2.z, vb2.w};
+      const float ua[4] = {U[j].x, U[j].y, U[j].z, U[j].w}, ub[4] = {U[j + 1].x, U[j + 1].y, U[j + 1].z, U[j + 1].w};
+#pragma unroll
+      for (int k = k0; k < k1; ++k) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], ua[k], acc[j], 0, 0, 0);
+        acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[k], ub[k], acc[j + 1], 0, 0, 0);
+      }
+    };
     float2 d[8];
     const bool do_t1 = more && wave < 7;
     float4 vf = *reinterpret_cast<const float4*>(vb);
     float4 vg = *reinterpret_cast<const float4*>(vb + 1024);
     if (do_t1) t1_load(rb1, d);
+#if W77_PAIR
+    mma2(0, vf, vg, 0, 4);
+    load_u(cn, 0, U[0]); load_u(cn, 1, U[1]);
+    vf = *reinterpret_cast<const float4*>(vb + 2048);
+    vg = *reinterpret_cast<const float4*>(vb + 3072);
+    if (do_t1) t1_store(d);
+    mma2(2, vf, vg, 0, 4);
+    load_u(cn, 2, U[2]); load_u(cn, 3, U[3]);
+    vf = *reinterpret_cast<const float4*>(vb + 4096);
+    vg = *reinterpret_cast<const float4*>(vb + 5120);
+    mma2(4, vf, vg, 0, 4);
+    load_u(cn, 4, U[4]); load_u(cn, 5, U[5]);
+    vf = *reinterpret_cast<const float4*>(vb + 6144);
+    vg = *reinterpret_cast<const float4*>(vb + 7168);
+    mma2(6, vf, vg, 0, 2);
+#else
     mma(0, vf, 0, 4);
     load_u(cn, 0, U[0]);
     mma(1, vg, 0, 4);
@@ -232,25 +311,36 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     mma(6, vf, 0, 4);
     load_u(cn, 6, U[6]);
     mma(7, vg, 0, 2);
+#endif
     // the DMA goes out behind the last wait for this chunk's U and ahead of the load of U[7] (the compiler's wait for that load, one iteration
     // later, is then also the wait for the DMA); the two waves of a SIMD issue it at different points of the window
     const bool dma = c + 3 < nchunks;
+    const bool roll = !more && have_next;                     // (uniform) the next tile's raw images 0-2
     const int role = wave >> 2, rbi = rb1 == 0 ? 2 : rb1 - 1;
     __builtin_amdgcn_sched_barrier(0);
-    if (dma && role == 0) issue_raw(rbi);
+    if (role == 0) { if (dma) issue_raw(rbi); else if (roll) { issue_raw(0); if (nchunks > 1) issue_raw(1); if (nchunks > 2) issue_raw(2); } }
     __builtin_amdgcn_sched_barrier(0);
+#if W77_PAIR
+    mma2(6, vf, vg, 2, 4);
+#else
     mma(7, vg, 2, 4);
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    if (dma && role == 1) issue_raw(rbi);
+    if (role == 1) { if (dma) issue_raw(rbi); else if (roll) { issue_raw(0); if (nchunks > 1) issue_raw(1); if (nchunks > 2) issue_raw(2); } }
     asm volatile("" ::: "memory");
+#if W77_PAIR
+    load_u(cn, 6, U[6]);
+#endif
     load_u(cn, 7, U[7]);
+    if (roll && P.bias) bias_req = *reinterpret_cast<const float2*>(P.bias + n0 + 2 * (tid & 15));
     rb1 = rb1 == 2 ? 0 : rb1 + 1;
     __syncthreads();
     if (more) t2_run();
     __syncthreads();
   }
 
-  // ---- epilogue: A^T over nu on the wave's own accumulators (registers, packed on register pairs): acc[0], acc[1] <- the two output columns ----
+  // ---- epilogue, first part: A^T over nu on the wave's own accumulators (registers, packed on register pairs): acc[0], acc[1] <- the two output
+  //      columns ----
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
     const float2 m[8] = {make_float2(acc[0][r], acc[0][r + 1]), make_float2(acc[1][r], acc[1][r + 1]), make_float2(acc[2][r], acc[2][r + 1]),
@@ -272,13 +362,12 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
   {
     const int e_cp = tid & 15, e_b = tid >> 4;                 // item: (cout pair, block)
     const int e_br = e_b >> 3, e_bc = e_b & 7;
-    const int ch = n0 + 2 * e_cp;
-    const float2 bias = P.bias ? make_float2(P.bias[ch], P.bias[ch + 1]) : make_float2(0.f, 0.f);
+    const int ch = e_n0 + 2 * e_cp;
     const float slope = P.act == GPEMSR_ACT_LRELU ? 0.1f : 0.f;
     const bool has_act = P.act != GPEMSR_ACT_NONE;
     const float* er = E + e_b * 32 + 2 * e_cp;
-    const int oy = oy0 + 2 * e_br, ox = ox0 + 2 * e_bc;
-    float* op = P.out + (((long long)img * P.h + oy) * P.w + ox) * P.out_ld + ch;
+    const int oy = e_oy0 + 2 * e_br, ox = e_ox0 + 2 * e_bc;
+    float* op = P.out + (((long long)e_img * P.h + oy) * P.w + ox) * P.out_ld + ch;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float2 m[8];
@@ -295,6 +384,8 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
       }
     }
   }
+  if (!have_next) break;
+  }   // persistent tile loop (the barrier at the top of the next tile's prologue also separates the items' E reads from its T2)
 }
 
 // descriptor.transposed == 6: called from gpemsr_conv2d (conv_mfma.hip)
@@ -305,7 +396,8 @@ int conv2d_winograd77(const gpemsr_conv_desc* d, void* stream, char* name_buf, i
   GP_REQUIRE(d->cout % 32 == 0 && d->src[0].c % 8 == 0 && d->src[0].ld % 4 == 0 && d->src[0].ld >= d->src[0].c &&
              (reinterpret_cast<uintptr_t>(d->src[0].ptr) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0,
              "conv2d (F(2x2,7x7) form): cout %% 32 == 0, source c %% 8 == 0 with 16-byte aligned rows");
-  GP_REQUIRE((reinterpret_cast<uintptr_t>(d->out) & 7) == 0 && d->out_ld % 2 == 0, "conv2d (F(2x2,7x7) form): 8-byte aligned output rows");
+  GP_REQUIRE((reinterpret_cast<uintptr_t>(d->out) & 7) == 0 && d->out_ld % 2 == 0 && (!d->bias || (reinterpret_cast<uintptr_t>(d->bias) & 7) == 0),
+             "conv2d (F(2x2,7x7) form): 8-byte aligned output rows and bias");
   if (name_buf) { snprintf(name_buf, (size_t)name_cap, "conv7_wino2d_f32_kernel"); return GPEMSR_OK; }
   W77Params P{};
   P.src = d->src[0].ptr; P.ld = d->src[0].ld; P.cin = d->src[0].c;
@@ -323,7 +415,10 @@ int conv2d_winograd77(const gpemsr_conv_desc* d, void* stream, char* name_buf, i
       return fail(GPEMSR_ELAUNCH, "conv2d (F(2x2,7x7) form): cannot raise the dynamic LDS limit to %d bytes", W77_LDS);
     dev_once_done(done);
   }
-  hipLaunchKernelGGL(conv7_wino2d_f32_kernel, dim3(P.nblocks), dim3(W77_NT), W77_LDS, reinterpret_cast<hipStream_t>(stream), P);
+  int grid = device_cus();                                     // persistent: one workgroup per CU, a multiple of 8 (one share per XCD)
+  if ((long long)grid > nb) grid = (int)nb;
+  grid = grid < 8 ? 8 : grid & ~7;
+  hipLaunchKernelGGL(conv7_wino2d_f32_kernel, dim3(grid), dim3(W77_NT), W77_LDS, reinterpret_cast<hipStream_t>(stream), P);
   return check_launch("conv7_wino2d_f32_kernel");
 }
 
