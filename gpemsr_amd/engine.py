@@ -98,11 +98,11 @@ class Engine:
         #   "f4x4"          3x3 stride-1 layers with >= 64 input channels (% 8) and cout % 64 == 0 (or >= 128 couts through zero-padded weights:
         #                   the DCN packs' 216-channel offset convolutions) in the F(4x4,3x3) form (36 instead of 144 multiplies per 4x4 outputs,
         #                   ~2e-5 of the result; csrc/conv_wino4.hip; 64-channel layers included: 7.2 -> 4.9 ms on a 1024^2 map), the other 3x3
-        #                   stride-1 layers in F(2x2,3x3) (16 instead of 36, ~5e-6; csrc/conv_wino.hip), SpyNet's 32 <-> 64 7x7 layers in the 1-D
-        #                   F(2,7) row form (8 of 14, csrc/conv7_wino.hip);
+        #                   stride-1 layers in F(2x2,3x3) (16 instead of 36, ~5e-6; csrc/conv_wino.hip), SpyNet's 8 -> 32 and 32 <-> 64 7x7 layers in
+        #                   the 2-D form F(2x2,7x7) (64 of 196 multiplies, ~5e-6; csrc/conv7_wino2d.hip);
         #   "decoder_f4x4"  the same, but the indexer's layers stay on F(2x2): its arg-max decides codebook entries, this keeps the tighter
         #                   rounding there (+17 ms per 16-window step);
-        #   "f2x2"          F(2x2) for every 3x3 layer, F(2,7) for SpyNet;
+        #   "f2x2"          F(2x2) for every 3x3 layer, the 1-D row form F(2,7) (8 of 14, csrc/conv7_wino.hip) for SpyNet's 32 <-> 64 layers;
         #   "off"           the direct form everywhere (3e-6 per layer).
         # The training engines use the Winograd forms for their FROZEN layers only (`_wino_layer`: the transformed weights of a trainable layer
         # are not a permutation of its master weights, so the one-gather repack cannot refresh them).
@@ -254,11 +254,13 @@ class Engine:
                 if (self.winograd4 != "0" and w.shape[0] % (256 if name in ps else 64) == 0 and w.shape[1] >= self.winograd4_min_cin
                         and (self.winograd4 == "all" or not name.startswith("refmodel.indexer."))):
                     self.pc[name].wino4 = pack_winograd4(w, dev, pixel_shuffle=name in ps)     # F(4x4,3x3) form
-            if (self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1
-                    and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32"))):
-                self.pc[name].wino7 = pack_winograd7(w, dev)          # 1-D Winograd F(2, 7) form of SpyNet's 32 <-> 64 7x7 layers (fp32 path)
-                if self.winograd77:
-                    self.pc[name].wino77 = pack_winograd77(w, dev)    # ... and the 2-D form F(2x2, 7x7): 64 instead of 112 multiplies per 2x2 outputs
+            if self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1:
+                if w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32")):
+                    self.pc[name].wino7 = pack_winograd7(w, dev)      # 1-D Winograd F(2, 7) form of SpyNet's 32 <-> 64 7x7 layers (fp32 path)
+                if self.winograd77 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD77_MIN_CIN", "8")):
+                    # the 2-D form F(2x2, 7x7): 64 instead of 112 (1-D) / 196 (direct) multiplies per 2x2 outputs; also the one-chunk 8 -> 32 stems
+                    # (447.2 -> 445.4 ms per step, profiles/r06_ab_winograd77.log)
+                    self.pc[name].wino77 = pack_winograd77(w, dev)
             if self.bf16 and tuple(w.shape) == (1, 64, 3, 3):
                 self.pc[name].wtap = pack_cout1_taps(w, dev)            # 64 -> 1 on the matrix cores (csrc/tap_sum.hip)
             if not self.bf16 and tuple(w.shape) == (1, 64, 3, 3) and getattr(self, "fuse_tail_f32", True):
