@@ -278,8 +278,8 @@ FLAVOURED = ("conv_wino4_f32_kernel",)     # kernel templates whose parameters o
 
 FAMILIES = {
     "fp32": (("conv_mfma",), "fp32 MFMA family (v_mfma_f32_32x32x2_f32): conv_wino4_f32_kernel (3x3 stride-1 layers in the Winograd F(4x4,3x3) form: 1/4 of the "
-             "multiplies, fp32 arithmetic; its template parameter selects the epilogue), conv_wino2*_f32_kernel (F(2x2,3x3): 16/36), conv7_wino_f32_kernel "
-             "(7x7 rows in F(2,7): 8/14), conv_mfma_kernel (implicit-GEMM conv / GEMM, direct form); per kernel: `kernels`", PEAK_F32_MATRIX_TFLOPS),
+             "multiplies, fp32 arithmetic; its template parameter selects the epilogue), conv_wino2*_f32_kernel (F(2x2,3x3): 16/36), conv7_wino2d_f32_kernel "
+             "(7x7 in F(2x2,7x7): 64/196), conv_mfma_kernel (implicit-GEMM conv / GEMM, direct form); per kernel: `kernels`", PEAK_F32_MATRIX_TFLOPS),
     "bf16": (("conv_bf16", "vgg_mask"),
              "bf16 MFMA family (v_mfma_f32_32x32x16_bf16 / 16x16x32): conv_bf16_kernel / conv64_resident2_kernel / convt64_resident_kernel (implicit-GEMM "
              "conv / 1x1 / transposed), conv7_c32_cout16_kernel + conv7_c8_cout32_kernel (SpyNet 7x7), flash_attn512_kernel (q.k^T + online softmax + P.v "
