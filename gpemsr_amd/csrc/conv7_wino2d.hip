@@ -26,13 +26,15 @@
 // Measured (profiles/r06_ab_winograd77.log; 80 frames): 64 -> 32 at 512^2 24.7 -> 18.2 ms, 32 -> 64 at 512^2 21.9 -> 20.0 ms (two cout blocks =
 // two workgroups, each with its own transforms), the fp32 step 458.3 -> 446.6 ms.  Per tile 2.8 us fixed (4.4 before the persistent form) + 3.2 us
 // per 8-channel chunk against 2.0 us of pure MFMA time: ~150 vector instructions per wave and chunk (the 8-point transforms are 30 operations
-// per 8 outputs, twice) beside 32 MFMAs, and on this chip they are matrix time.  k-steps of two positions interleaved
-// (-DW77_PAIR=1): 1.4 % slower.
+// per 8 outputs, twice) beside 32 MFMAs, and on this chip they are matrix time.  k-steps of two positions interleaved:
+// measured 1.4 % slower, removed.  <16>: SpyNet's 32 -> 16 layers (the direct row-pair form before: 99 TFLOP/s) on v_mfma_f32_16x16x4_f32 --
+// 16 couts per workgroup, two 16-block tiles per position, the same V: the step 443.4 -> 440.6 ms.
 //
 // Replaces gpemsr_conv2d's direct form (descriptor.transposed = 6; weight = packing.pack_winograd77) for 7x7 stride-1 layers with one fp32
-// source of c % 8 == 0 channels, cout % 32 == 0, plain store (8-byte aligned rows), activation NONE / RELU / LRELU.
+// source of c % 8 == 0 channels, cout % 16 == 0, plain store (8-byte aligned rows), activation NONE / RELU / LRELU.
 #include "common.h"
 #include "conv_wino.h"
+#include <type_traits>
 
 namespace gpemsr {
 
@@ -45,9 +47,6 @@ struct W77Params {
   int tiles_x, tiles_y, tiles_n, nblocks;
 };
 
-#ifndef W77_PAIR
-#define W77_PAIR 0               // main loop: k-steps of two positions interleaved (A/B: profiles/r06_ab_winograd77.log)
-#endif
 constexpr int W77_NT = 512;
 constexpr int W77_ROWS = 14, W77_C2 = 11;                                  // halo rows; columns per parity ((16 + 6) / 2)
 constexpr int W77_RAW_SLOTS = 2 * 2 * W77_ROWS * W77_C2;                   // 616 16-byte slots: [quad][parity][row][col / 2]
@@ -93,7 +92,14 @@ __device__ __forceinline__ void w77_at(const float2 (&m)[8], float2& y0, float2&
   y1 = w77_add(w77_add(w77_fma(2.f, w77_sub(m[3], m[4]), w77_sub(m[1], m[2])), w77_mul(0.5f, w77_sub(m[5], m[6]))), m[7]);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// CO = couts per workgroup: 32 (v_mfma_f32_32x32x2_f32, one 32 x 32 tile per position) or 16 (SpyNet's 32 -> 16 layers: v_mfma_f32_16x16x4_f32,
+// two 16-block x 16-cout tiles per position -- a 32-cout tile would be half empty; same V, same transforms, half the multiplies)
+template <int CO>
 __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P) {
+  constexpr bool C16 = CO == 16;
+  static_assert(CO == 32 || CO == 16, "couts per workgroup");
   extern __shared__ __attribute__((aligned(16))) char wsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     const int tn = t % P.tiles_n; t /= P.tiles_n;
     const int tx0 = t % P.tiles_x; t /= P.tiles_x;
     const int ty0 = t % P.tiles_y; t /= P.tiles_y;
-    img = t; oy0 = ty0 * 8; ox0 = tx0 * 16; n0 = tn * 32;
+    img = t; oy0 = ty0 * 8; ox0 = tx0 * 16; n0 = tn * CO;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int iy = oy0 - 3 + (s_desc[i] & 255), ix = ox0 - 3 + ((s_desc[i] >> 8) & 255);
@@ -151,18 +157,20 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     }
     ++f_chunk;
   };
-  // ---- U fragments of this wave's eight positions (row xi = wave): lane (li = cout, lh = quad): a uniform base + ONE per-lane offset ----
-  const unsigned u_off = (unsigned)(lh * P.cout + li) * 4u;                        // floats
-  auto load_u = [&](int chunk, int j, float4& U) {
+  // ---- U fragments of this wave's eight positions (row xi = wave): a uniform base + ONE per-lane offset.  CO = 32: lane (li = cout, lh = quad),
+  //      a float4 = the quad's four channels = four k-steps.  CO = 16: lane (cout = lane % 16, channel = lane / 16 of a quad), one float per quad ----
+  const unsigned u_off = C16 ? (unsigned)((lane & 15) * 4 + (lane >> 4)) : (unsigned)(lh * P.cout + li) * 4u;      // floats
+  typedef typename std::conditional<C16, float2, float4>::type UT;
+  auto load_u = [&](int chunk, int j, UT& U) {
     const float* ub = P.weight + ((long long)(chunk * 64 + 8 * wave + j) * 2 * P.cout + n0) * 4;   // wave-uniform
-    U = *reinterpret_cast<const float4*>(ub + u_off);
+    if constexpr (C16) { U.x = ub[u_off]; U.y = ub[u_off + 4 * P.cout]; }
+    else U = *reinterpret_cast<const float4*>(ub + u_off);
   };
 
-  f32x16 acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  typedef typename std::conditional<C16, f32x4, f32x16>::type AccT;
+  constexpr int NACC = C16 ? 16 : 8;                           // CO = 16: acc[2 j + half], half = blocks 16 half .. + 15
+  constexpr int AR = C16 ? 4 : 16;
+  AccT acc[NACC];
 
   // ---- transform items.  (T1) row transform along x: item (row, quad, block column, channel pair), threads 0-447 (waves 0-6);
   //      (T2) column transform along y: item (nu = wave, quad, block row, block column, channel pair), two per thread (block rows br, br + 2) ----
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
 
   // ---- a tile's first requests: raw images of chunks 0-2 (DMA), then the U fragments of chunk 0 (younger than the DMA: the compiler's wait
   //      for them is also the wait for the images) ----
-  float4 U[8];
+  UT U[8];
   float2 bias_req = make_float2(0.f, 0.f);                    // the bias pair of this thread's epilogue item, requested WITH the tile (a load inside
   auto request_tile = [&]() {                                  // the epilogue would be younger than the next tile's requests: its wait would drain them)
     issue_raw(0);
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 8; ++j) load_u(0, j, U[j]);
-    if (P.bias) bias_req = *reinterpret_cast<const float2*>(P.bias + n0 + 2 * (tid & 15));
+    if (P.bias) bias_req = *reinterpret_cast<const float2*>(P.bias + n0 + 2 * (tid & (CO / 2 - 1)));
   };
   if (tile >= P.nblocks) return;
   set_tile(tile);
@@ -215,7 +223,10 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
   for (;;) {
   // ---- prologue of this tile: its requests were issued before the previous tile's epilogue (or just above); X and V of chunk 0 ----
 #pragma unroll
-  for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(U[j].x), "v"(U[j].y), "v"(U[j].z), "v"(U[j].w));   // (the compiler's wait for the U loads lands here)
+  for (int j = 0; j < 8; ++j) {                                // (the compiler's wait for the U loads lands here)
+    if constexpr (C16) asm volatile("" :: "v"(U[j].x), "v"(U[j].y));
+    else asm volatile("" :: "v"(U[j].x), "v"(U[j].y), "v"(U[j].z), "v"(U[j].w));
+  }
   const float2 bias = bias_req;
   asm volatile("" :: "v"(bias.x), "v"(bias.y) : "memory");
   __syncthreads();
@@ -227,9 +238,9 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < NACC; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int r = 0; r < AR; ++r) acc[j][r] = 0.f;
 
   // ---- main loop: iteration c multiplies chunk c (V, U in registers), runs T1 of chunk c + 1 between the MFMAs (raw image (c + 1) % 3 -> X),
   //      fetches the U fragments of chunk c + 1 and starts the DMA of raw image c + 3; barrier; T2 of chunk c + 1 (X -> V); barrier ----
@@ -251,67 +262,45 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
       cn = have_next ? 0 : c;                                 // (no next tile: the loads re-read this chunk's U -- no branch around them)
     }
     const char* vb = wsm + a_v;
-    auto mma = [&](int j, const float4& vf, int k0, int k1) {
-      const float v[4] = {vf.x, vf.y, vf.z, vf.w};
-      const float u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
+    // position j, k-steps k0 .. k1 - 1 of 4.  CO = 32: the V fragment (a float4: lane = (block, quad)) is read here, element k is k-step k.
+    // CO = 16: k-steps 2 q, 2 q + 1 stand for quad q: one 16x16x4 MFMA per block half, the lane's A value is channel lane / 16 of the quad.
+    auto mma = [&](int j, int k0, int k1) {
+      if constexpr (C16) {
+        const char* v16 = wsm + W77_V_OFF + (8 * wave + j) * 1024 + (lane & 15) * 16 + (lane >> 4) * 4;
 #pragma unroll
-      for (int k = k0; k < k1; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[j], 0, 0, 0);
-    };
-    // two positions at a time, k-steps interleaved (W77_PAIR; two waves per SIMD leave a single dependent chain exposed whenever the partner
-    // wave is in its transform or waiting) -- or one position at a time
-    auto mma2 = [&](int j, const float4& va, const float4& vb2, int k0, int k1) {
-      const float a[4] = {va.x, va.y, va.z, va.w}, b[4] = {vb2.x, vb2.y, vb2.z, vb2.w};
-      const float ua[4] = {U[j].x, U[j].y, U[j].z, U[j].w}, ub[4] = {U[j + 1].x, U[j + 1].y, U[j + 1].z, U[j + 1].w};
+        for (int q = k0 / 2; q < k1 / 2; ++q) {
+          const float a0 = *reinterpret_cast<const float*>(v16 + q * 512), a1 = *reinterpret_cast<const float*>(v16 + q * 512 + 256);
+          const float u = q == 0 ? U[j].x : U[j].y;
+          acc[2 * j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, u, acc[2 * j], 0, 0, 0);
+          acc[2 * j + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, u, acc[2 * j + 1], 0, 0, 0);
+        }
+      } else {
+        const float4 vf = *reinterpret_cast<const float4*>(vb + j * 1024);
+        const float v[4] = {vf.x, vf.y, vf.z, vf.w};
+        const float u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
 #pragma unroll
-      for (int k = k0; k < k1; ++k) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], ua[k], acc[j], 0, 0, 0);
-        acc[j + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[k], ub[k], acc[j + 1], 0, 0, 0);
+        for (int k = k0; k < k1; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[k], u[k], acc[j], 0, 0, 0);
       }
     };
     float2 d[8];
     const bool do_t1 = more && wave < 7;
-    float4 vf = *reinterpret_cast<const float4*>(vb);
-    float4 vg = *reinterpret_cast<const float4*>(vb + 1024);
     if (do_t1) t1_load(rb1, d);
-#if W77_PAIR
-    mma2(0, vf, vg, 0, 4);
-    load_u(cn, 0, U[0]); load_u(cn, 1, U[1]);
-    vf = *reinterpret_cast<const float4*>(vb + 2048);
-    vg = *reinterpret_cast<const float4*>(vb + 3072);
-    if (do_t1) t1_store(d);
-    mma2(2, vf, vg, 0, 4);
-    load_u(cn, 2, U[2]); load_u(cn, 3, U[3]);
-    vf = *reinterpret_cast<const float4*>(vb + 4096);
-    vg = *reinterpret_cast<const float4*>(vb + 5120);
-    mma2(4, vf, vg, 0, 4);
-    load_u(cn, 4, U[4]); load_u(cn, 5, U[5]);
-    vf = *reinterpret_cast<const float4*>(vb + 6144);
-    vg = *reinterpret_cast<const float4*>(vb + 7168);
-    mma2(6, vf, vg, 0, 2);
-#else
-    mma(0, vf, 0, 4);
+    mma(0, 0, 4);
     load_u(cn, 0, U[0]);
-    mma(1, vg, 0, 4);
+    mma(1, 0, 4);
     load_u(cn, 1, U[1]);
-    vf = *reinterpret_cast<const float4*>(vb + 2048);
-    vg = *reinterpret_cast<const float4*>(vb + 3072);
     if (do_t1) t1_store(d);
-    mma(2, vf, 0, 4);
+    mma(2, 0, 4);
     load_u(cn, 2, U[2]);
-    mma(3, vg, 0, 4);
+    mma(3, 0, 4);
     load_u(cn, 3, U[3]);
-    vf = *reinterpret_cast<const float4*>(vb + 4096);
-    vg = *reinterpret_cast<const float4*>(vb + 5120);
-    mma(4, vf, 0, 4);
+    mma(4, 0, 4);
     load_u(cn, 4, U[4]);
-    mma(5, vg, 0, 4);
+    mma(5, 0, 4);
     load_u(cn, 5, U[5]);
-    vf = *reinterpret_cast<const float4*>(vb + 6144);
-    vg = *reinterpret_cast<const float4*>(vb + 7168);
-    mma(6, vf, 0, 4);
+    mma(6, 0, 4);
     load_u(cn, 6, U[6]);
-    mma(7, vg, 0, 2);
-#endif
+    mma(7, 0, 2);
     // the DMA goes out behind the last wait for this chunk's U and ahead of the load of U[7] (the compiler's wait for that load, one iteration
     // later, is then also the wait for the DMA); the two waves of a SIMD issue it at different points of the window
     const bool dma = c + 3 < nchunks;
@@ -320,59 +309,64 @@ __global__ __launch_bounds__(W77_NT, 1) void conv7_wino2d_f32_kernel(W77Params P
     __builtin_amdgcn_sched_barrier(0);
     if (role == 0) { if (dma) issue_raw(rbi); else if (roll) { issue_raw(0); if (nchunks > 1) issue_raw(1); if (nchunks > 2) issue_raw(2); } }
     __builtin_amdgcn_sched_barrier(0);
-#if W77_PAIR
-    mma2(6, vf, vg, 2, 4);
-#else
-    mma(7, vg, 2, 4);
-#endif
+    mma(7, 2, 4);
     __builtin_amdgcn_sched_barrier(0);
     if (role == 1) { if (dma) issue_raw(rbi); else if (roll) { issue_raw(0); if (nchunks > 1) issue_raw(1); if (nchunks > 2) issue_raw(2); } }
     asm volatile("" ::: "memory");
-#if W77_PAIR
-    load_u(cn, 6, U[6]);
-#endif
     load_u(cn, 7, U[7]);
-    if (roll && P.bias) bias_req = *reinterpret_cast<const float2*>(P.bias + n0 + 2 * (tid & 15));
+    if (roll && P.bias) bias_req = *reinterpret_cast<const float2*>(P.bias + n0 + 2 * (tid & (CO / 2 - 1)));
     rb1 = rb1 == 2 ? 0 : rb1 + 1;
     __syncthreads();
     if (more) t2_run();
     __syncthreads();
   }
 
-  // ---- epilogue, first part: A^T over nu on the wave's own accumulators (registers, packed on register pairs): acc[0], acc[1] <- the two output
-  //      columns ----
+  // ---- epilogue, first part: A^T over nu on the wave's own accumulators (registers, packed on register pairs): the two output columns land in
+  //      the accumulators of nu = 0, 1 ----
+  constexpr int NH = C16 ? 2 : 1;                              // accumulator tiles per position
 #pragma unroll
-  for (int r = 0; r < 16; r += 2) {
-    const float2 m[8] = {make_float2(acc[0][r], acc[0][r + 1]), make_float2(acc[1][r], acc[1][r + 1]), make_float2(acc[2][r], acc[2][r + 1]),
-                         make_float2(acc[3][r], acc[3][r + 1]), make_float2(acc[4][r], acc[4][r + 1]), make_float2(acc[5][r], acc[5][r + 1]),
-                         make_float2(acc[6][r], acc[6][r + 1]), make_float2(acc[7][r], acc[7][r + 1])};
-    float2 y0, y1;
-    w77_at(m, y0, y1);
-    acc[0][r] = y0.x; acc[0][r + 1] = y0.y; acc[1][r] = y1.x; acc[1][r + 1] = y1.y;
-  }
+  for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+    for (int r = 0; r < AR; r += 2) {
+      float2 m[8];
+#pragma unroll
+      for (int nu = 0; nu < 8; ++nu) m[nu] = make_float2(acc[NH * nu + hf][r], acc[NH * nu + hf][r + 1]);
+      float2 y0, y1;
+      w77_at(m, y0, y1);
+      acc[hf][r] = y0.x; acc[hf][r + 1] = y0.y; acc[NH + hf][r] = y1.x; acc[NH + hf][r + 1] = y1.y;
+    }
+  // ---- exchange E[xi][column j][block][cout] (CO floats per line), then an item = one block x one cout PAIR ----
   float* E = reinterpret_cast<float*>(wsm + W77_V_OFF);       // (every wave is past the loop's last barrier: V is free)
-  {
-    float* ew = E + ((2 * wave) * 32 + 4 * lh) * 32 + li;
+  if constexpr (C16) {
+    float* ew = E + ((2 * wave) * 32 + 4 * (lane >> 4)) * CO + (lane & 15);      // register r of half hf = block 16 hf + 4 (lane / 16) + r, lane % 16 = cout
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ew[(j * 32 + (r & 3) + 8 * (r >> 2)) * 32] = acc[j][r];    // register r = block (r & 3) + 8 (r >> 2) + 4 lh
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ew[(j * 32 + 16 * hf + r) * CO] = acc[NH * j + hf][r];
+  } else {
+    float* ew = E + ((2 * wave) * 32 + 4 * lh) * CO + li;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ew[(j * 32 + (r & 3) + 8 * (r >> 2)) * CO] = acc[j][r];    // register r = block (r & 3) + 8 (r >> 2) + 4 lh
   }
   __syncthreads();
-  {
-    const int e_cp = tid & 15, e_b = tid >> 4;                 // item: (cout pair, block)
+  if (tid < 32 * (CO / 2)) {
+    const int e_cp = tid & (CO / 2 - 1), e_b = tid / (CO / 2);  // item: (cout pair, block)
     const int e_br = e_b >> 3, e_bc = e_b & 7;
     const int ch = e_n0 + 2 * e_cp;
     const float slope = P.act == GPEMSR_ACT_LRELU ? 0.1f : 0.f;
     const bool has_act = P.act != GPEMSR_ACT_NONE;
-    const float* er = E + e_b * 32 + 2 * e_cp;
+    const float* er = E + e_b * CO + 2 * e_cp;
     const int oy = e_oy0 + 2 * e_br, ox = e_ox0 + 2 * e_bc;
     float* op = P.out + (((long long)e_img * P.h + oy) * P.w + ox) * P.out_ld + ch;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float2 m[8];
 #pragma unroll
-      for (int xi = 0; xi < 8; ++xi) m[xi] = *reinterpret_cast<const float2*>(er + ((xi * 2 + j) * 32) * 32);
+      for (int xi = 0; xi < 8; ++xi) m[xi] = *reinterpret_cast<const float2*>(er + ((xi * 2 + j) * 32) * CO);
       m[1] = w77_add(m[1], bias);                              // the bias rides the transform: A^T e_1 = (1, 1)
       float2 y[2];
       w77_at(m, y[0], y[1]);
@@ -393,32 +387,36 @@ int conv2d_winograd77(const gpemsr_conv_desc* d, void* stream, char* name_buf, i
   GP_REQUIRE(d->ksize == 7 && d->stride == 1 && d->weight_image_stride == 0 && d->nsrc == 1, "conv2d (F(2x2,7x7) form): 7x7, stride 1, one source, one weight set");
   GP_REQUIRE(!d->residual && !d->pixmul && !d->pixel_shuffle && !d->gn_partials && !d->cos_partials && !d->a_scale, "conv2d (F(2x2,7x7) form): plain store only");
   GP_REQUIRE(d->act == GPEMSR_ACT_NONE || d->act == GPEMSR_ACT_RELU || d->act == GPEMSR_ACT_LRELU, "conv2d (F(2x2,7x7) form): act NONE / RELU / LRELU (got %d)", d->act);
-  GP_REQUIRE(d->cout % 32 == 0 && d->src[0].c % 8 == 0 && d->src[0].ld % 4 == 0 && d->src[0].ld >= d->src[0].c &&
+  GP_REQUIRE(d->cout % 16 == 0 && d->src[0].c % 8 == 0 && d->src[0].ld % 4 == 0 && d->src[0].ld >= d->src[0].c &&
              (reinterpret_cast<uintptr_t>(d->src[0].ptr) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0,
-             "conv2d (F(2x2,7x7) form): cout %% 32 == 0, source c %% 8 == 0 with 16-byte aligned rows");
+             "conv2d (F(2x2,7x7) form): cout %% 16 == 0, source c %% 8 == 0 with 16-byte aligned rows");
   GP_REQUIRE((reinterpret_cast<uintptr_t>(d->out) & 7) == 0 && d->out_ld % 2 == 0 && (!d->bias || (reinterpret_cast<uintptr_t>(d->bias) & 7) == 0),
              "conv2d (F(2x2,7x7) form): 8-byte aligned output rows and bias");
-  if (name_buf) { snprintf(name_buf, (size_t)name_cap, "conv7_wino2d_f32_kernel"); return GPEMSR_OK; }
+  const int co = d->cout % 32 == 0 ? 32 : 16;                  // couts per workgroup (16: the 16x16x4 MFMA form, no half-empty 32-cout tile)
+  if (name_buf) { snprintf(name_buf, (size_t)name_cap, co == 32 ? "conv7_wino2d_f32_kernel<32>" : "conv7_wino2d_f32_kernel<16>"); return GPEMSR_OK; }
   W77Params P{};
   P.src = d->src[0].ptr; P.ld = d->src[0].ld; P.cin = d->src[0].c;
   P.img_stride = d->src_image_stride[0] < 0 ? (long long)d->h * d->w * d->src[0].ld : d->src_image_stride[0];
   GP_REQUIRE(P.img_stride % 4 == 0 && (long long)d->h * d->w * P.ld * 4 < (1ll << 32), "conv2d (F(2x2,7x7) form): source too large / misaligned");
   P.n = d->n; P.h = d->h; P.w = d->w; P.cout = d->cout;
   P.weight = d->weight; P.bias = d->bias; P.act = d->act; P.out = d->out; P.out_ld = d->out_ld;
-  P.tiles_x = cdiv(d->w, 16); P.tiles_y = cdiv(d->h, 8); P.tiles_n = d->cout / 32;
+  P.tiles_x = cdiv(d->w, 16); P.tiles_y = cdiv(d->h, 8); P.tiles_n = d->cout / co;
   const long long nb = (long long)d->n * P.tiles_y * P.tiles_x * P.tiles_n;
   GP_REQUIRE(nb > 0 && nb < (1ll << 31), "conv2d (F(2x2,7x7) form): grid too large");
   P.nblocks = (int)nb;
   static dev_once_t done{0};
   if (dev_once_begin(done)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv7_wino2d_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W77_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv7_wino2d_f32_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, W77_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv7_wino2d_f32_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, W77_LDS) != hipSuccess)
       return fail(GPEMSR_ELAUNCH, "conv2d (F(2x2,7x7) form): cannot raise the dynamic LDS limit to %d bytes", W77_LDS);
     dev_once_done(done);
   }
   int grid = device_cus();                                     // persistent: one workgroup per CU, a multiple of 8 (one share per XCD)
   if ((long long)grid > nb) grid = (int)nb;
   grid = grid < 8 ? 8 : grid & ~7;
-  hipLaunchKernelGGL(conv7_wino2d_f32_kernel, dim3(grid), dim3(W77_NT), W77_LDS, reinterpret_cast<hipStream_t>(stream), P);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (co == 32) hipLaunchKernelGGL(conv7_wino2d_f32_kernel<32>, dim3(grid), dim3(W77_NT), W77_LDS, st, P);
+  else hipLaunchKernelGGL(conv7_wino2d_f32_kernel<16>, dim3(grid), dim3(W77_NT), W77_LDS, st, P);
   return check_launch("conv7_wino2d_f32_kernel");
 }
 

@@ -254,10 +254,11 @@ class Engine:
                 if (self.winograd4 != "0" and w.shape[0] % (256 if name in ps else 64) == 0 and w.shape[1] >= self.winograd4_min_cin
                         and (self.winograd4 == "all" or not name.startswith("refmodel.indexer."))):
                     self.pc[name].wino4 = pack_winograd4(w, dev, pixel_shuffle=name in ps)     # F(4x4,3x3) form
-            if self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 32 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1:
-                if w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32")):
+            if self.winograd7 and self._wino_layer(name) and kk == 7 and w.shape[0] % 16 == 0 and w.shape[1] % 8 == 0 and len(self.pc[name].splits) == 1:
+                if w.shape[0] % 32 == 0 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD7_MIN_CIN", "32")):
                     self.pc[name].wino7 = pack_winograd7(w, dev)      # 1-D Winograd F(2, 7) form of SpyNet's 32 <-> 64 7x7 layers (fp32 path)
-                if self.winograd77 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD77_MIN_CIN", "8")):
+                if (self.winograd77 and w.shape[1] >= int(os.environ.get("GPEMSR_WINOGRAD77_MIN_CIN", "8"))
+                        and (w.shape[0] % 32 == 0 or os.environ.get("GPEMSR_WINOGRAD77_C16", "1") != "0")):
                     # the 2-D form F(2x2, 7x7): 64 instead of 112 (1-D) / 196 (direct) multiplies per 2x2 outputs; also the one-chunk 8 -> 32 stems
                     # (447.2 -> 445.4 ms per step, profiles/r06_ab_winograd77.log)
                     self.pc[name].wino77 = pack_winograd77(w, dev)

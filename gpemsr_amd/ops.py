@@ -449,7 +449,7 @@ def _conv2d(srcs, pc: PackedConv, act: int = ACT_NONE, stride: int = 1, residual
             and src_image_stride is None and not d.gn_partials):
         d.transposed, d.weight = 4, pc.wino7.data_ptr()         # 8 multiplies per output pair and filter row instead of 14 (csrc/conv7_wino.hip)
         executed = flops * 8.0 / 14.0
-    if (pc.wino77 is not None and not direct7 and precision == "fp32" and int(d.transposed) in (0, 4) and winograd77_ok(srcs, pc, stride, out, residual, pixmul, act)
+    if (pc.wino77 is not None and not direct7 and precision == "fp32" and int(d.transposed) in (0, 2, 4) and winograd77_ok(srcs, pc, stride, out, residual, pixmul, act)
             and weight_image_stride == 0 and src_image_stride is None and not d.gn_partials):
         d.transposed, d.weight = 6, pc.wino77.data_ptr()        # 64 multiplies per 2x2 outputs instead of 196 (csrc/conv7_wino2d.hip)
         executed = flops * 64.0 / 196.0
@@ -515,9 +515,10 @@ def winograd7_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] =
 def winograd77_ok(srcs, pc: "PackedConv", stride: int = 1, out: Optional["Act"] = None, residual: Optional["Act"] = None, pixmul: Optional["Act"] = None,
                   act: int = ACT_NONE) -> bool:
     """Layers the 2-D F(2x2, 7x7) form of gpemsr_conv2d takes: 7x7, stride 1, ONE fp32 source of c % 8 == 0 channels with 16-byte aligned rows,
-    cout % 32 == 0, act NONE / RELU / LRELU, plain store into 8-byte aligned rows, a map that fills at least 2/3 of its 8 x 16 pixel tiles;
+    cout % 16 == 0 (32 couts per workgroup, or 16 on the 16x16x4 MFMA shape), act NONE / RELU / LRELU, plain store into 8-byte aligned rows, a
+    map that fills at least 2/3 of its 8 x 16 pixel tiles;
     `pc.wino77` packed."""
-    if pc.wino77 is None or pc.ksize != 7 or stride != 1 or pc.transposed or pc.pixel_shuffle or pc.cout % 32 != 0 or len(srcs) != 1:
+    if pc.wino77 is None or pc.ksize != 7 or stride != 1 or pc.transposed or pc.pixel_shuffle or pc.cout % 16 != 0 or len(srcs) != 1:
         return False
     s_ = srcs[0]
     if s_.bf16 or s_.c % 8 != 0 or s_.ld % 4 != 0 or s_.ptr % 16 != 0 or residual is not None or pixmul is not None or act not in (ACT_NONE, ACT_RELU, ACT_LRELU):

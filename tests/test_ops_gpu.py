@@ -630,12 +630,13 @@ def test_conv7_winograd_row_form(n, cin, cout, h, w, act):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,act", [(2, 32, 64, 16, 64, 1), (1, 64, 32, 37, 130, 1), (3, 32, 32, 8, 16, 0), (1, 8, 64, 13, 70, 2), (4, 8, 32, 64, 64, 1), (2, 64, 64, 64, 128, 1),
-                                                (1, 32, 64, 7, 200, 1), (2, 24, 64, 19, 45, 2), (3, 32, 64, 72, 200, 1), (5, 16, 32, 100, 90, 0)])
+                                                (1, 32, 64, 7, 200, 1), (2, 24, 64, 19, 45, 2), (3, 32, 64, 72, 200, 1), (5, 16, 32, 100, 90, 0), (2, 32, 16, 40, 64, 1), (3, 16, 48, 21, 50, 2), (4, 32, 16, 96, 160, 1)])
 def test_conv7_winograd_2d_form(n, cin, cout, h, w, act):
     """gpemsr_conv2d with descriptor.transposed = 6 (csrc/conv7_wino2d.hip, packing.pack_winograd77): Conv2d(cin -> cout, 7x7, pad 3) + bias +
     activation in the 2-D Winograd F(2x2, 7x7) form (SpyNet's 32 -> 64 / 64 -> 32 layers, basicsr BasicModule via R:model/GPEMSR.py:67,98-100)
     == the float64 convolution to 4e-5 of the result and the direct fp32 kernel to the same; ragged heights / widths (not multiples of the
-    8 x 16 tile), one to eight chunks (the raw-image ring wraps beyond three), one or two cout blocks, up to four tiles per persistent workgroup, a strided output slice, run-to-run
+    8 x 16 tile), one to eight chunks (the raw-image ring wraps beyond three), one or two 32-cout blocks or one to three 16-cout blocks (the
+    16x16x4 MFMA form of SpyNet's 32 -> 16 layers), up to four tiles per persistent workgroup, a strided output slice, run-to-run
     bit-stable."""
     from gpemsr_amd import ops
     from gpemsr_amd.packing import pack_conv, pack_winograd77
