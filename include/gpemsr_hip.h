@@ -96,7 +96,8 @@ typedef struct {
                                       (gpemsr_amd/packing.py::pack_winograd4).
                                       6 = 2-D WINOGRAD F(2x2, 7x7) form of a 7x7 stride-1 convolution (the same SpyNet layers as form 4; same
                                       result to fp32 rounding -- ~5e-6 of the result's scale --, 64/196 of the multiplies;
-                                      csrc/conv7_wino2d.hip): ONE source with c % 8 == 0, cout % 32 == 0, act NONE / RELU / LRELU, plain store
+                                      csrc/conv7_wino2d.hip): ONE source with c % 8 == 0, cout % 16 == 0 (32 couts per workgroup, or 16 on
+                                      v_mfma_f32_16x16x4_f32 when cout % 32 != 0), act NONE / RELU / LRELU, plain store
                                       with 8-byte aligned rows; weight = U[cin/8][64 positions = 8 xi + nu][2][cout][4] = G g G^T
                                       (gpemsr_amd/packing.py::pack_winograd77) */
   const float* weight;             /* packed [tap][cout][cin_pad], tap = ky*k+kx, cin fastest, cin padded per source to 8
